@@ -1,0 +1,141 @@
+"""Checkpoint tensor grammar of the NCSNv2Deepest score network, seed-derived
+weights, and the packing the MFMA convolution kernels consume.
+
+The key names / shapes mirror what ``NCSNv2Deepest.state_dict()`` produces
+(``ncsnv2/models/ncsnv2.py:198-262`` with the blocks of
+``ncsnv2/models/layers.py:62-134,165-249,291-313,401-441`` and
+``ncsnv2/models/normalization.py:150-162``) so that a real ``final_model.pt``
+(``train_score.py:211-216``) loads unchanged.  The pretrained blobs are not
+shipped with the reference, so tests and the benchmark use weights drawn from a
+fixed numpy bit-generator ("seed-derived weights").
+"""
+import numpy as np
+
+
+def _residual_block(prefix, cin, cout, resample, dilation):
+    """Tensor list of one ResidualBlock, in ``state_dict`` order (layers.py:401-441)."""
+    down = resample == 'down'
+    pooled = down and dilation is None            # ConvMeanPool wraps the conv in ``.conv``
+    c1_out = cin if down else cout
+    t = [(prefix + 'conv1.weight', (c1_out, cin, 3, 3)), (prefix + 'conv1.bias', (c1_out,))]
+    t += [(prefix + 'normalize2.' + k, (c1_out,)) for k in ('alpha', 'gamma', 'beta')]
+    c2 = prefix + ('conv2.conv.' if pooled else 'conv2.')
+    t += [(c2 + 'weight', (cout, c1_out, 3, 3)), (c2 + 'bias', (cout,))]
+    if cin != cout or resample is not None:
+        sc = prefix + ('shortcut.conv.' if pooled else 'shortcut.')
+        k = 1 if pooled else 3
+        t += [(sc + 'weight', (cout, cin, k, k)), (sc + 'bias', (cout,))]
+    t += [(prefix + 'normalize1.' + k, (cin,)) for k in ('alpha', 'gamma', 'beta')]
+    return t
+
+
+def _refine_block(prefix, in_planes, features, start=False, end=False):
+    """Tensor list of one RefineBlock (layers.py:214-232): RCU adapt, RCU out, MSF, CRP."""
+    t = []
+    for i, c in enumerate(in_planes):
+        for blk in (1, 2):
+            for stage in (1, 2):
+                t.append((prefix + 'adapt_convs.%d.%d_%d_conv.weight' % (i, blk, stage), (c, c, 3, 3)))
+    for blk in range(1, (3 if end else 1) + 1):
+        for stage in (1, 2):
+            t.append((prefix + 'output_convs.%d_%d_conv.weight' % (blk, stage), (features, features, 3, 3)))
+    if not start:
+        for i, c in enumerate(in_planes):
+            t.append((prefix + 'msf.convs.%d.weight' % i, (features, c, 3, 3)))
+            t.append((prefix + 'msf.convs.%d.bias' % i, (features,)))
+    for i in range(2):
+        t.append((prefix + 'crp.convs.%d.weight' % i, (features, features, 3, 3)))
+    return t
+
+
+def state_dict_spec(ngf=32, channels=2, num_classes=2311):
+    """Ordered ``[(name, shape)]`` of every tensor in the reference ``state_dict``."""
+    t = [('sigmas', (num_classes,)),
+         ('begin_conv.weight', (ngf, channels, 3, 3)), ('begin_conv.bias', (ngf,))]
+    t += [('normalizer.' + k, (ngf,)) for k in ('alpha', 'gamma', 'beta')]
+    t += [('end_conv.weight', (channels, ngf, 3, 3)), ('end_conv.bias', (channels,))]
+    stages = [('res1', ngf, ngf, None, None, ngf, None),
+              ('res2', ngf, 2 * ngf, 'down', None, 2 * ngf, None),
+              ('res3', 2 * ngf, 2 * ngf, 'down', None, 2 * ngf, None),
+              ('res31', 2 * ngf, 2 * ngf, 'down', None, 2 * ngf, None),
+              ('res4', 2 * ngf, 4 * ngf, 'down', 2, 4 * ngf, 2),
+              ('res5', 4 * ngf, 4 * ngf, 'down', 4, 4 * ngf, 4)]
+    for name, cin, cout, resample, dil, _, _ in stages:
+        t += _residual_block(name + '.0.', cin, cout, resample, dil)
+        t += _residual_block(name + '.1.', cout, cout, None, dil)
+    t += _refine_block('refine1.', [4 * ngf], 4 * ngf, start=True)
+    t += _refine_block('refine2.', [4 * ngf, 4 * ngf], 2 * ngf)
+    t += _refine_block('refine3.', [2 * ngf, 2 * ngf], 2 * ngf)
+    t += _refine_block('refine31.', [2 * ngf, 2 * ngf], 2 * ngf)
+    t += _refine_block('refine4.', [2 * ngf, 2 * ngf], ngf)
+    t += _refine_block('refine5.', [ngf, ngf], ngf, end=True)
+    return t
+
+
+def get_sigmas(config):
+    """Geometric noise schedule: float64 ``exp(linspace(log s1, log sL, L))`` rounded to
+    float32 (``ncsnv2/models/__init__.py:4-8``)."""
+    m = config.model
+    if m.sigma_dist != 'geometric':
+        raise NotImplementedError('only the geometric sigma schedule is on the hot path')
+    return np.exp(np.linspace(np.log(m.sigma_begin), np.log(m.sigma_end),
+                              m.num_classes)).astype(np.float32)
+
+
+def seeded_state_dict(config, seed=2024):
+    """Deterministic stand-in for the missing pretrained weights.
+
+    Convolutions: U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weight and bias (the
+    distribution ``nn.Conv2d`` starts from); InstanceNorm++ ``alpha, gamma ~ N(1, 0.02)``
+    (``normalization.py:158-159``), ``beta ~ N(0, 0.05)`` (non-zero so the term is exercised).
+    Drawn tensor by tensor, in ``state_dict_spec`` order, from ``PCG64(seed)``.
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = {}
+    for name, shape in state_dict_spec(config.model.ngf, config.data.channels,
+                                       config.model.num_classes):
+        if name == 'sigmas':
+            sd[name] = get_sigmas(config)
+        elif name.endswith('.weight'):
+            fan_in = shape[1] * shape[2] * shape[3]
+            b = 1.0 / np.sqrt(fan_in)
+            sd[name] = rng.uniform(-b, b, size=shape).astype(np.float32)
+        elif name.endswith('.bias'):
+            wshape = sd[name[:-4] + 'weight'].shape
+            b = 1.0 / np.sqrt(wshape[1] * wshape[2] * wshape[3])
+            sd[name] = rng.uniform(-b, b, size=shape).astype(np.float32)
+        elif name.endswith('.beta'):
+            sd[name] = (0.05 * rng.standard_normal(shape)).astype(np.float32)
+        else:  # alpha, gamma
+            sd[name] = (1.0 + 0.02 * rng.standard_normal(shape)).astype(np.float32)
+    return sd
+
+
+def check_state_dict(sd, config):
+    """Raise ``KeyError``/``ValueError`` like ``load_state_dict(strict=True)`` would."""
+    spec = state_dict_spec(config.model.ngf, config.data.channels, config.model.num_classes)
+    missing = [n for n, _ in spec if n not in sd]
+    unexpected = [n for n in sd if n not in dict(spec)]
+    if missing or unexpected:
+        raise KeyError('state_dict mismatch: missing %s, unexpected %s' % (missing[:5], unexpected[:5]))
+    for n, shape in spec:
+        if tuple(sd[n].shape) != tuple(shape):
+            raise ValueError('size mismatch for %s: %s vs %s' % (n, tuple(sd[n].shape), shape))
+
+
+def pack_conv_weight(w):
+    """Re-order an ``[O, C, k, k]`` convolution weight into MFMA B-operand fragments.
+
+    Result ``[k*k, C/8, O/32, 64, 4]`` float32: for tap ``t = kh*k + kw``, channel group
+    ``g`` and output block ``n``, lane ``l`` of a wavefront holds the four values
+    ``w[n*32 + (l & 31), g*8 + 4*(l >> 5) + j, kh, kw]``, ``j = 0..3`` -- i.e. one 16-byte load
+    per lane feeds four ``v_mfma_f32_32x32x2_f32`` issues (lanes 0-31 supply k-row 0, lanes
+    32-63 k-row 1 of each).  Requires ``C % 8 == 0`` and ``O % 32 == 0``.
+    """
+    w = np.asarray(w, dtype=np.float32)
+    o, c, kh, kw = w.shape
+    if c % 8 or o % 32:
+        raise ValueError('pack_conv_weight needs C %% 8 == 0 and O %% 32 == 0, got %s' % (w.shape,))
+    a = w.reshape(o // 32, 32, c // 8, 2, 4, kh * kw)     # [nb, l31, g, half, j, tap]
+    a = a.transpose(5, 2, 0, 3, 1, 4)                      # [tap, g, nb, half, l31, j]
+    return np.ascontiguousarray(a).reshape(kh * kw, c // 8, o // 32, 64, 4)

@@ -1,0 +1,34 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name), allow_pickle=False) as f:
+        return {k: f[k] for k in f.files}
+
+
+@pytest.fixture(scope='session')
+def weights64():
+    from score_based_channels_amd.config import default_config
+    from score_based_channels_amd.weights import seeded_state_dict
+    cfg = default_config()
+    return cfg, seeded_state_dict(cfg, 2024)
+
+
+def rel_err(a, b):
+    ctype = np.complex128 if (np.iscomplexobj(a) or np.iscomplexobj(b)) else np.float64
+    a = np.asarray(a, ctype)
+    b = np.asarray(b, ctype)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30))

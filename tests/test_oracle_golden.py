@@ -1,0 +1,104 @@
+"""Pin the CPU oracle (oracle/) against fixtures produced by the reference itself
+(tests/gen_golden.py).  CPU only; no HIP code is exercised here."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden, rel_err
+from oracle import ald_oracle, ncsnv2_oracle
+from score_based_channels_amd.noise import HostNoise
+from score_based_channels_amd.weights import state_dict_spec
+
+
+def test_state_dict_grammar_matches_reference():
+    with open(os.path.join(GOLDEN, 'state_dict_keys.json')) as f:
+        ref = [(k, tuple(s)) for k, s in json.load(f)]
+    assert [(k, tuple(s)) for k, s in state_dict_spec()] == ref
+
+
+def test_conv_flops_match_survey():
+    assert ncsnv2_oracle.conv_flops_per_sample(32, 64, 16) == 820772864
+    assert ncsnv2_oracle.conv_flops_per_sample(32, 256, 64) == 13132365824
+
+
+def test_forward_matches_reference(weights64):
+    _, sd = weights64
+    g = load_golden('forward_64x16.npz')
+    for i, lv in enumerate(g['levels']):
+        out = ncsnv2_oracle.score_forward(sd, g['x'], np.full((4,), lv))
+        assert rel_err(out, g['out'][i]) < 2e-5, lv
+
+
+def test_forward_stages_match_reference(weights64):
+    _, sd = weights64
+    g = load_golden('forward_64x16.npz')
+    _, st = ncsnv2_oracle.score_forward(sd, g['x'][:1], np.array([1155]), return_stages=True)
+    names = {'begin_conv': 'begin'}
+    for k in [k for k in g if k.startswith('stage_')]:
+        name = k[len('stage_'):]
+        assert rel_err(st[names.get(name, name)], g[k]) < 2e-5, name
+
+
+def _oracle_ald(sd, cfg, g, snr_idx):
+    noise = HostNoise(int(g['seed']))
+    H, P = g['H'], g['P']
+    local_noise = ald_oracle.snr_to_noise(g['snr_db'], H.shape[1])[snr_idx]
+    Y = ald_oracle.make_measurements(P, H, local_noise, noise.measurement(snr_idx, g['Y'][snr_idx].shape))
+    X, log = ald_oracle.ald_run(
+        lambda x, lab: ncsnv2_oracle.score_forward(sd, x, lab), sd['sigmas'], cfg.model.sigma_end,
+        P, Y, H, noise.init(H.shape), noise.step_stream(snr_idx, H.shape), local_noise,
+        alpha_step=float(g['alpha_step']), beta_noise=float(g['beta_noise']),
+        steps_each=int(g['steps_each']), levels=[int(v) for v in g['levels']])
+    return Y, X, log
+
+
+@pytest.mark.parametrize('name', ['ald_plumbing_level0.npz', 'ald_plumbing_3levels.npz'])
+def test_ald_plumbing_matches_reference(weights64, name):
+    cfg, sd = weights64
+    g = load_golden(name)
+    Y, X, log = _oracle_ald(sd, cfg, g, 0)
+    assert rel_err(Y, g['Y'][0]) < 1e-6
+    assert np.max(np.abs(log / g['nmse_log'][0] - 1)) < 1e-5
+    assert rel_err(X, g['X_final'][0]) < 1e-5
+
+
+def test_ald_truncated_schedule_matches_reference(weights64):
+    """Every 77th noise level + the last one (31 levels x 3 steps), non-default (alpha, beta) cell."""
+    cfg, sd = weights64
+    g = load_golden('ald_trunc_cell.npz')
+    _, X, log = _oracle_ald(sd, cfg, g, 0)
+    assert np.max(np.abs(log / g['nmse_log'][0] - 1)) < 1e-5
+    assert rel_err(X, g['X_final'][0]) < 1e-5
+
+
+def test_big_array_forward_matches_reference():
+    from score_based_channels_amd.config import default_config
+    from score_based_channels_amd.weights import seeded_state_dict
+    cfg = default_config(image_size=(64, 256))
+    sd = seeded_state_dict(cfg, 2024)
+    g = load_golden('big_256x64.npz')
+    out = ncsnv2_oracle.score_forward(sd, g['x'], np.array([int(g['level'])]))
+    assert rel_err(out, g['out']) < 2e-5
+
+
+def test_loader_pieces_match_reference():
+    g = load_golden('loader.npz')
+    ch, mean, std, pil = ald_oracle.channels_dataset(g['output_h'], 64, 38, 'global',
+                                                     legacy_seed=int(g['legacy_seed']))
+    assert mean == 0. and abs(std - float(g['std'])) < 1e-7
+    assert np.array_equal(pil.astype(np.complex64), g['pilots'])
+    for idx in (0, 5):
+        it = ald_oracle.channels_item(ch, mean, std, pil, idx)
+        assert np.array_equal(it['H_herm'], g['H_herm%d' % idx])
+        assert np.array_equal(it['H'], g['H%d' % idx])
+        assert np.array_equal(it['P'], g['P%d' % idx])
+
+
+def test_tune_postprocessing_matches_reference():
+    g = load_golden('tune_post.npz')
+    avg, best = ald_oracle.reduce_nmse(g['nmse_log'])
+    assert np.array_equal(avg, g['avg_nmse']) and np.array_equal(best, g['best_nmse'])
+    ba, bb = ald_oracle.tune_select(best, g['alpha_step_range'], g['beta_noise_range'])
+    assert np.array_equal(ba, g['best_alpha_snr']) and np.array_equal(bb, g['best_beta_snr'])
