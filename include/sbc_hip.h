@@ -1,0 +1,175 @@
+/* sbc_hip.h -- C ABI of libsbc_hip.so: the annealed-Langevin MIMO channel-estimation hot path of
+ * utcsilab/score-based-channels as hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * The reference has no FFI of its own: its operator boundary is the PyTorch call
+ *     score = diffuser(current_real, labels)                 (src/score_based_channels/test_score.py:151)
+ * on an NCSNv2Deepest nn.Module (ncsnv2/models/ncsnv2.py:198-300) plus the tensor expressions of the
+ * sampling loop around it (test_score.py:118-171, copied in tune_hparams_score.py:100-148).  This
+ * library replaces exactly that: the host side (Python, score_based_channels_amd/) builds a *plan* -- an
+ * ordered list of fused operator launches over NHWC float32 device buffers it owns -- and the library
+ * executes it on a HIP stream.  One plan = one score evaluation, optionally followed by the
+ * data-consistency + Langevin update + NMSE of one step, so that a whole trajectory is
+ * sbc_plan_run(plan, stream, n_steps) with no host synchronisation (the reference syncs every step,
+ * test_score.py:137,170).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer borrowed for the duration of the
+ *     call / the lifetime of the plan (buffers stay owned by the caller, normally torch tensors);
+ *   - activations are NHWC float32: x[n][h][w][c]; a complex64 [B][Nt][Nr] tensor IS a 2-channel NHWC
+ *     tensor (re, im interleaved), which removes the reference's real/complex view copies
+ *     (test_score.py:149,153-154);
+ *   - every function returns 0 on success or a negative sbc_status; sbc_last_error() gives the message of
+ *     the calling thread's last failure.  Nothing throws across the ABI.  Launches are asynchronous on the
+ *     given stream (pass torch.cuda.current_stream().cuda_stream); no hidden device synchronisation
+ *     except in the functions documented as synchronising.
+ */
+#ifndef SBC_HIP_H
+#define SBC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SBC_ABI_VERSION 1
+
+typedef enum sbc_status {
+    SBC_OK = 0,
+    SBC_ERR_INVALID = -1,      /* bad argument / unsupported shape */
+    SBC_ERR_HIP = -2,          /* a HIP runtime call failed (message has hipGetErrorString) */
+    SBC_ERR_UNSUPPORTED = -3   /* no kernel instantiation for this (cin, cout, ksize) */
+} sbc_status;
+
+/* Operator kinds.  Reference counterparts (file:line under /root/reference): */
+typedef enum sbc_op_kind {
+    SBC_OP_BEGIN_CONV = 1,   /* h = 2x-1; begin_conv 2->ngf 3x3 + bias          ncsnv2.py:270-275            */
+    SBC_OP_INORM_STATS = 2,  /* InstanceNorm2dPlus statistics -> (mu, scale, shift) normalization.py:163-176 */
+    SBC_OP_CONV = 3,         /* nn.Conv2d 1x1 / 3x3 / dilated 3x3 with fused prologue+epilogue  layers.py:28-60,
+                                ResidualBlock :443-456, RCUBlock :126-134, CRPBlock :76-83, MSFBlock :178-184,
+                                ConvMeanPool :309-313                                                        */
+    SBC_OP_MAXPOOL5 = 4,     /* nn.MaxPool2d(5, stride 1, pad 2) (+ELU of the input)  layers.py:69,77-80      */
+    SBC_OP_END_CONV = 5,     /* normalizer -> ELU -> end_conv ngf->2 -> / sigma   ncsnv2.py:291-298           */
+    SBC_OP_LANGEVIN = 6,     /* P^H(PX-Y), noise, Langevin update, NMSE           test_score.py:156-170       */
+    SBC_OP_STEP_INC = 7,     /* advance the device-side step counter (trailing_idx, test_score.py:171)        */
+    SBC_OP_MEASURE = 8       /* Y = P H + sqrt(noise) n                           test_score.py:122-124       */
+} sbc_op_kind;
+
+/* sbc_op.flags for SBC_OP_CONV / SBC_OP_MAXPOOL5 */
+#define SBC_PRO_ELU      0x001  /* apply ELU to the input while staging it                                  */
+#define SBC_PRO_NORM     0x002  /* apply (x - mu) * scale + shift from `stats` first (InstanceNorm++)       */
+#define SBC_EPI_RES1_ELU 0x010  /* ELU the res1 operand before adding (CRP: x = act(x))                    */
+#define SBC_EPI_POOL     0x020  /* 2x2 mean pool of (conv + bias), then + res1 (ConvMeanPool)               */
+#define SBC_EPI_UP       0x040  /* + bilinear(align_corners) resize of `up` [B][up_h][up_w][cout] (MSF)     */
+
+/* One fused launch.  Unused fields are 0 / NULL.  Tensor shapes per kind:
+ *   BEGIN_CONV  in [B][H][W][2], weight [cout][2][3][3] (torch layout), bias [cout], out [B][H][W][cout]
+ *   INORM_STATS in [B][H][W][cin], weight = alpha|gamma|beta [3][cin], out = stats [B][3][cin]
+ *   CONV        in [B][H][W][cin], weight = sbc_pack layout [k*k][cin/8][cout/32][64][4], bias [cout] or
+ *               NULL, stats [B][3][cin] (PRO_NORM), res1/res2 [B][Ho][Wo][cout] or NULL, up (EPI_UP),
+ *               out [B][Ho][Wo][cout] with Ho,Wo = H,W or H/2,W/2 (EPI_POOL).
+ *               epilogue:  v = conv + bias;  [POOL: v = mean2x2(v)]
+ *                          r = res1 [ELU];  if res2: r = res2 + r;  v = v + r;  [UP: v = v + resize(up)]
+ *   MAXPOOL5    in/out [B][H][W][cin]; PRO_ELU applies ELU (monotone, so pooled after or before is equal)
+ *   END_CONV    in [B][H][W][cin], stats, weight [2][cin][3][3] (torch layout), bias [2], out [B][H][W][2];
+ *               divides by sigmas[labels[b]] if labels != NULL else by sigma_of_step[*step]
+ *   LANGEVIN    see sbc_langevin below (passed through `ext`)
+ */
+typedef struct sbc_op {
+    int32_t kind, flags;
+    int32_t B, H, W;
+    int32_t cin, cout, ksize, dil;
+    int32_t up_h, up_w;
+    int32_t tag;                 /* free label; sbc_plan_profile times all ops carrying a given tag */
+    const void* in;
+    void* out;
+    const void* weight;
+    const void* bias;
+    const void* stats;
+    const void* res1;
+    const void* res2;
+    const void* up;
+    const void* ext;             /* kind-specific extension struct (sbc_langevin / sbc_endconv), host memory,
+                                    copied at sbc_plan_create / read during sbc_op_launch */
+} sbc_op;
+
+/* Extension of SBC_OP_END_CONV: where the noise level comes from (ncsnv2.py:295-298). */
+typedef struct sbc_endconv {
+    const float* sigmas;         /* [num_classes] device, float32 (models/__init__.py:4-8) */
+    const int64_t* labels;       /* [B] device or NULL */
+    const float* sigma_of_step;  /* [n_steps] device: sigma of the level walked at step k (if labels NULL) */
+    const int32_t* step;         /* device step counter */
+} sbc_endconv;
+
+/* Extension of SBC_OP_LANGEVIN and SBC_OP_MEASURE.  All complex tensors are interleaved float32 pairs.
+ *   X      [B][Nt][Nr]  current estimate, updated in place            (test_score.py:164-165)
+ *   score  [B][Nt][Nr]  output of the score plan                       (:150-154)
+ *   P      [nP][Np][Nt] conj-transposed pilots, sample b uses P[p_index[b]] (b if p_index NULL)   (:109-111)
+ *   Y      [B][Np][Nr]  measurements                                   (:122-124)
+ *   Htrue  [nH][Nt][Nr] ground truth, sample b uses Htrue[h_index[b]]  (:112-113,131)
+ *   sched  [G][n_steps][4] float32 (alpha, dc_div, noise_scale, unused) of group `group[b]` at step k,
+ *          i.e. the float64 python scalars of :143-144,160,165 rounded to float32
+ *   noise  [n_steps][B][Nt][Nr] CN(0,1) draws or NULL -> in-kernel Philox4x32-10 keyed by
+ *          (seed, traj_id[b], step, element)                            (:160-161)
+ *   nmse   [n_steps][B] float32 log, row *step is written               (:168-170)
+ * MEASURE uses X as H input?  no: it reads Htrue/P and writes Y; `noise` is then [B][Np][Nr] and
+ * `meas_scale[b]` = float32(sqrt(local_noise)).
+ */
+typedef struct sbc_langevin {
+    float* X;
+    const float* score;
+    const float* P;
+    const int32_t* p_index;
+    float* Y;
+    const float* Htrue;
+    const int32_t* h_index;
+    const float* sched;
+    const int32_t* group;
+    const float* noise;
+    float* nmse;
+    const int32_t* step;
+    const int64_t* traj_id;
+    const float* meas_scale;
+    uint64_t seed;
+    int32_t n_steps, Nt, Nr, Np;
+} sbc_langevin;
+
+typedef struct sbc_plan sbc_plan;
+
+/* --- library ----------------------------------------------------------------------------------- */
+int sbc_abi_version(void);
+const char* sbc_last_error(void);
+/* number of visible HIP devices, or a negative sbc_status (does not initialise a device context) */
+int sbc_device_count(void);
+
+/* --- single operator (unit tests, ad-hoc use) ---------------------------------------------------- */
+/* Launch one fused operator asynchronously on `stream` (a hipStream_t, may be NULL = default stream). */
+int sbc_op_launch(const sbc_op* op, void* stream);
+
+/* --- plans ---------------------------------------------------------------------------------------
+ * sbc_plan_create copies `ops` (and their `ext` structs); the device buffers they point to must outlive the
+ * plan.  sbc_plan_run executes the whole op list `n_iters` times in order on `stream`.  With
+ * use_graph != 0 the op list is captured once into a hipGraph (on first use for that stream) and replayed;
+ * this is legal because nothing in a plan depends on host state -- step-dependent scalars are read from
+ * device tables through the device step counter. */
+int sbc_plan_create(const sbc_op* ops, int32_t n_ops, sbc_plan** out_plan);
+int sbc_plan_run(sbc_plan* plan, void* stream, int32_t n_iters, int32_t use_graph);
+void sbc_plan_destroy(sbc_plan* plan);
+
+/* Per-kernel timing for the roofline report: while enabled (tag >= 0), every launch of an op whose
+ * `tag` matches is bracketed by a hipEvent pair on the launch stream (eager runs only).  sbc_plan_profile_read
+ * synchronises on the recorded events, returns the summed kernel time and launch count since enabling, and
+ * resets the accumulators. */
+int sbc_plan_profile(sbc_plan* plan, int32_t tag);
+int sbc_plan_profile_read(sbc_plan* plan, double* total_ms, int64_t* n_launches);
+
+/* --- helpers --------------------------------------------------------------------------------------
+ * Host-side re-ordering of a torch-layout convolution weight [cout][cin][k][k] into the MFMA B-operand
+ * fragment order consumed by SBC_OP_CONV: [k*k][cin/8][cout/32][64 lanes][4].  dst and src are HOST
+ * pointers; cin % 8 == 0, cout % 32 == 0. */
+int sbc_pack_conv_weight(const float* src, int32_t cout, int32_t cin, int32_t ksize, float* dst);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBC_HIP_H */

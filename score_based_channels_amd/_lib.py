@@ -1,0 +1,110 @@
+"""ctypes binding of ``libsbc_hip.so`` (C ABI declared in ``include/sbc_hip.h``).
+
+There is no fallback: if the shared library is missing or a call fails, an exception is raised -- the
+product path never routes around the HIP kernels.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsbc_hip.so')
+ABI_VERSION = 1
+
+EXPORTS = ('sbc_abi_version', 'sbc_last_error', 'sbc_device_count', 'sbc_op_launch', 'sbc_plan_create',
+           'sbc_plan_run', 'sbc_plan_destroy', 'sbc_plan_profile', 'sbc_plan_profile_read',
+           'sbc_pack_conv_weight')
+
+
+class SbcError(RuntimeError):
+    pass
+
+
+class sbc_op(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('flags', C.c_int32),
+                ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
+                ('cin', C.c_int32), ('cout', C.c_int32), ('ksize', C.c_int32), ('dil', C.c_int32),
+                ('up_h', C.c_int32), ('up_w', C.c_int32), ('tag', C.c_int32),
+                ('in_', C.c_void_p), ('out', C.c_void_p), ('weight', C.c_void_p), ('bias', C.c_void_p),
+                ('stats', C.c_void_p), ('res1', C.c_void_p), ('res2', C.c_void_p), ('up', C.c_void_p),
+                ('ext', C.c_void_p)]
+
+
+class sbc_endconv(C.Structure):
+    _fields_ = [('sigmas', C.c_void_p), ('labels', C.c_void_p), ('sigma_of_step', C.c_void_p),
+                ('step', C.c_void_p)]
+
+
+class sbc_langevin(C.Structure):
+    _fields_ = [('X', C.c_void_p), ('score', C.c_void_p), ('P', C.c_void_p), ('p_index', C.c_void_p),
+                ('Y', C.c_void_p), ('Htrue', C.c_void_p), ('h_index', C.c_void_p), ('sched', C.c_void_p),
+                ('group', C.c_void_p), ('noise', C.c_void_p), ('nmse', C.c_void_p), ('step', C.c_void_p),
+                ('traj_id', C.c_void_p), ('meas_scale', C.c_void_p), ('seed', C.c_uint64),
+                ('n_steps', C.c_int32), ('Nt', C.c_int32), ('Nr', C.c_int32), ('Np', C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    """Load the library once; raise ``SbcError`` with a build hint if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SbcError('%s not found: build it with `make -C %s` (or `python -c "import __graft_entry__ as g; '
+                       'g.build()"`); there is no CPU fallback' % (LIB_PATH, os.path.join(_HERE, 'csrc')))
+    h = C.CDLL(LIB_PATH)
+    h.sbc_abi_version.restype = C.c_int
+    h.sbc_last_error.restype = C.c_char_p
+    h.sbc_device_count.restype = C.c_int
+    h.sbc_op_launch.argtypes = [C.POINTER(sbc_op), C.c_void_p]
+    h.sbc_plan_create.argtypes = [C.POINTER(sbc_op), C.c_int32, C.POINTER(C.c_void_p)]
+    h.sbc_plan_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+    h.sbc_plan_destroy.argtypes = [C.c_void_p]
+    h.sbc_plan_destroy.restype = None
+    h.sbc_plan_profile.argtypes = [C.c_void_p, C.c_int32]
+    h.sbc_plan_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    h.sbc_pack_conv_weight.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    if h.sbc_abi_version() != ABI_VERSION:
+        raise SbcError('libsbc_hip.so ABI %d != expected %d' % (h.sbc_abi_version(), ABI_VERSION))
+    _lib = h
+    return h
+
+
+def check(rc):
+    if rc != 0:
+        raise SbcError('libsbc_hip: %s (status %d)' % (lib().sbc_last_error().decode(), rc))
+
+
+class Plan:
+    """Owner of an ``sbc_plan*``.  ``keepalive`` holds whatever owns the device buffers the ops point to."""
+
+    def __init__(self, ops, keepalive=None):
+        arr = (sbc_op * len(ops))(*ops)
+        handle = C.c_void_p()
+        check(lib().sbc_plan_create(arr, len(ops), C.byref(handle)))
+        self._h = handle
+        self._keep = keepalive
+        self.n_ops = len(ops)
+
+    def run(self, stream, n_iters=1, use_graph=False):
+        check(lib().sbc_plan_run(self._h, C.c_void_p(stream), int(n_iters), 1 if use_graph else 0))
+
+    def profile(self, tag):
+        check(lib().sbc_plan_profile(self._h, int(tag)))
+
+    def profile_read(self):
+        ms, n = C.c_double(), C.c_int64()
+        check(lib().sbc_plan_profile_read(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def close(self):
+        if self._h:
+            lib().sbc_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,176 @@
+"""Annealed-Langevin channel estimation on the HIP path: the counterpart of the sampling loop in
+``src/score_based_channels/test_score.py:118-171`` (= ``tune_hparams_score.py:100-148``).
+
+The reference walks the 17 SNR points (and, in the tuner, the (alpha, beta) cells) one after another with a
+batch of 100 channels and synchronises with the host after every step.  All of those trajectories follow the
+same noise-level schedule in lock-step, so here they are ONE batch of ``T`` trajectories with per-trajectory
+scalars: trajectory ``t`` estimates channel ``h_index[t]`` observed through pilots ``p_index[t]`` at noise
+``local_noise[t]`` with hyper-parameters ``(alpha_step[t], beta_noise[t])``.  One ``sbc_plan`` holds a complete
+Langevin step (score network + data-consistency/update/NMSE kernel + step counter), and a whole schedule is a
+single ``plan.run(n_steps)``: per-step scalars come from device tables indexed by the device step counter, the
+NMSE log stays on the device until it is read.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import plan as P
+from .scorenet import _ptr
+
+
+def snr_to_noise(snr_db, nt):
+    """``noise_range = 10 ** (-snr_range / 10.) * config.data.image_size[1]`` (test_score.py:72-75)."""
+    return 10 ** (-np.asarray(snr_db, np.float64) / 10.) * nt
+
+
+def schedule_tables(sigmas_f32, sigma_end, levels, steps_each, alpha_step, beta_noise, local_noise):
+    """Per-step scalars of the loop, computed in float64 exactly like the python code of
+    test_score.py:137-165 and rounded to float32 where they meet a complex64 tensor.
+
+    ``alpha_step``, ``beta_noise``, ``local_noise``: float64 arrays of equal length G (one row per distinct
+    scalar group).  Returns (``sched`` float32 ``[G, n_steps, 4]`` = (alpha, dc_div, noise_scale, 0),
+    ``sigma_of_step`` float32 ``[n_steps]``)."""
+    levels = np.asarray(levels, np.int64)
+    sig = np.asarray(sigmas_f32, np.float32)[levels].astype(np.float64)        # .item() of a float32 tensor
+    alpha = np.asarray(alpha_step, np.float64)[:, None] * (sig[None, :] / float(sigma_end)) ** 2     # :143-144
+    nscale = np.sqrt(2 * alpha * np.asarray(beta_noise, np.float64)[:, None])                        # :160
+    dc_div = np.asarray(local_noise, np.float64)[:, None] / 2. + sig[None, :] ** 2                   # :165
+    per_level = np.stack((alpha, dc_div, nscale, np.zeros_like(alpha)), axis=-1).astype(np.float32)
+    sched = np.repeat(per_level, steps_each, axis=1)
+    sigma_of_step = np.repeat(np.asarray(sigmas_f32, np.float32)[levels], steps_each)
+    return np.ascontiguousarray(sched), np.ascontiguousarray(sigma_of_step)
+
+
+def _as_c64(t, device):
+    t = torch.as_tensor(t)
+    if not t.is_complex():
+        raise TypeError('expected a complex tensor')
+    return t.to(device=device, dtype=torch.complex64).contiguous()
+
+
+class AldBatch:
+    """``T`` lock-step annealed-Langevin trajectories on one GPU.
+
+    Htrue ``[nH, Nt, Nr]`` complex64 (normalised Hermitian channels, ``val_H`` of test_score.py:112-113),
+    P ``[nP, Np, Nt]`` complex64 (conj-transposed pilots, ``val_P`` of :109-111).  Per-trajectory arrays
+    (length T): ``h_index``, ``p_index``, ``local_noise``, ``alpha_step``, ``beta_noise`` (scalars broadcast).
+    ``levels``: noise-level indices to walk (default: the full schedule), ``steps_each``: Langevin steps per
+    level (test_score.py:56).  Noise: ``seed`` keys the in-kernel Philox stream of trajectory ``traj_id[t]``
+    (independent of batching / world size); pass ``step_noise`` ``[n_steps, T, Nt, Nr]`` complex64 to replay
+    externally drawn noise instead (parity runs).
+    """
+
+    def __init__(self, net, Htrue, P_pilots, h_index, p_index, local_noise, alpha_step=3e-11, beta_noise=0.01,
+                 levels=None, steps_each=3, seed=0, traj_id=None, step_noise=None):
+        dev = net.device
+        self.net = net
+        self.H = _as_c64(Htrue, dev)
+        self.P = _as_c64(P_pilots, dev)
+        _, self.nt, self.nr = self.H.shape
+        self.np_ = self.P.shape[1]
+        if self.P.shape[2] != self.nt:
+            raise ValueError('P must be [nP, Np, Nt=%d], got %s' % (self.nt, tuple(self.P.shape)))
+        h_index = np.asarray(h_index, np.int32)
+        T = self.T = int(h_index.shape[0])
+        p_index = np.broadcast_to(np.asarray(p_index, np.int32), (T,))
+        if h_index.min() < 0 or h_index.max() >= self.H.shape[0] or p_index.min() < 0 or p_index.max() >= self.P.shape[0]:
+            raise IndexError('h_index / p_index out of range')
+        ln = np.broadcast_to(np.asarray(local_noise, np.float64), (T,))
+        a0 = np.broadcast_to(np.asarray(alpha_step, np.float64), (T,))
+        be = np.broadcast_to(np.asarray(beta_noise, np.float64), (T,))
+        self.local_noise = ln
+        self.levels = np.arange(net.num_classes) if levels is None else np.asarray(levels, np.int64)
+        self.steps_each = int(steps_each)
+        self.n_steps = len(self.levels) * self.steps_each
+        rows, group = np.unique(np.stack((a0, be, ln), axis=1), axis=0, return_inverse=True)
+        sched, sig_step = schedule_tables(net._sigmas_np, net.config.model.sigma_end, self.levels, self.steps_each,
+                                          rows[:, 0], rows[:, 1], rows[:, 2])
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.d_sched = torch.from_numpy(sched).to(dev)
+        self.d_sigma_of_step = torch.from_numpy(sig_step).to(dev)
+        self.d_group = torch.from_numpy(group.reshape(-1).astype(np.int32)).to(dev)
+        self.d_hidx = torch.from_numpy(np.ascontiguousarray(h_index)).to(dev)
+        self.d_pidx = torch.from_numpy(np.ascontiguousarray(p_index)).to(dev)
+        tid = np.arange(T, dtype=np.int64) if traj_id is None else np.asarray(traj_id, np.int64)
+        self.d_traj = torch.from_numpy(np.ascontiguousarray(tid)).to(dev)
+        self.d_meas_scale = torch.from_numpy(np.sqrt(ln).astype(np.float32)).to(dev)     # :124
+        self.d_step = torch.zeros(1, **i32)
+        self.d_nmse = torch.zeros(self.n_steps, T, dtype=torch.float32, device=dev)
+        self.Y = torch.zeros(T, self.np_, self.nr, dtype=torch.complex64, device=dev)
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self._done = 0
+        self.step_noise = None
+        if step_noise is not None:
+            self.step_noise = _as_c64(step_noise, dev)
+            if tuple(self.step_noise.shape) != (self.n_steps, T, self.nt, self.nr):
+                raise ValueError('step_noise must be [n_steps=%d, T=%d, Nt, Nr]' % (self.n_steps, T))
+        # score network bound to this batch: its input buffer IS the current estimate X (complex64 view)
+        self.bound = net.bind(T, self.nt, self.nr, step=self.d_step, sigma_of_step=self.d_sigma_of_step,
+                              use_labels=False)
+        self.X = torch.view_as_complex(self.bound.x)                    # [T, Nt, Nr] complex64, in place
+        self._lang = _lib.sbc_langevin(
+            X=_ptr(self.bound.x), score=_ptr(self.bound.out), P=_ptr(torch.view_as_real(self.P)),
+            p_index=_ptr(self.d_pidx), Y=_ptr(torch.view_as_real(self.Y)), Htrue=_ptr(torch.view_as_real(self.H)),
+            h_index=_ptr(self.d_hidx), sched=_ptr(self.d_sched), group=_ptr(self.d_group),
+            noise=_ptr(torch.view_as_real(self.step_noise)) if self.step_noise is not None else None,
+            nmse=_ptr(self.d_nmse), step=_ptr(self.d_step), traj_id=_ptr(self.d_traj),
+            meas_scale=_ptr(self.d_meas_scale), seed=self.seed, n_steps=self.n_steps, Nt=self.nt, Nr=self.nr,
+            Np=self.np_)
+        lang = _lib.sbc_op(kind=P.LANGEVIN, B=T, ext=C.cast(C.pointer(self._lang), C.c_void_p))
+        inc = _lib.sbc_op(kind=P.STEP_INC, B=1, out=_ptr(self.d_step))
+        self.plan = _lib.Plan(list(self.bound.ops) + [lang, inc], keepalive=self)
+        self.score_plan = _lib.Plan(list(self.bound.ops), keepalive=self)
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.net.device).cuda_stream
+
+    # --- inputs -------------------------------------------------------------------------------------
+    def set_init(self, X0):
+        """``current = init_val_H.clone()`` (test_score.py:115,126); ``X0`` ``[T, Nt, Nr]`` complex64."""
+        self.X.copy_(_as_c64(X0, self.net.device))
+        self.d_step.zero_()
+        self._done = 0
+
+    def set_measurements(self, Y):
+        self.Y.copy_(_as_c64(Y, self.net.device))
+
+    def synthesize_measurements(self, noise=None):
+        """``val_Y = P H + sqrt(local_noise) * randn`` (test_score.py:122-124) on the device.  ``noise``
+        ``[T, Np, Nr]`` complex64 replays an external draw; otherwise Philox keyed by (seed, traj_id)."""
+        nz = _as_c64(noise, self.net.device) if noise is not None else None
+        ext = _lib.sbc_langevin(**{f: getattr(self._lang, f) for f, _ in _lib.sbc_langevin._fields_})
+        ext.noise = _ptr(torch.view_as_real(nz)) if nz is not None else None
+        op = _lib.sbc_op(kind=P.MEASURE, B=self.T, ext=C.cast(C.pointer(ext), C.c_void_p))
+        _lib.check(_lib.lib().sbc_op_launch(C.byref(op), C.c_void_p(self._stream())))
+        torch.cuda.current_stream(self.net.device).synchronize()       # ext / nz go out of scope
+        return self.Y
+
+    # --- execution ----------------------------------------------------------------------------------
+    def run(self, n_steps=None, use_graph=False):
+        """Advance every trajectory by ``n_steps`` Langevin steps (default: the rest of the schedule).
+        Asynchronous: returns once the launches are queued on the current stream."""
+        done = self._done
+        n = self.n_steps - done if n_steps is None else int(n_steps)
+        if n < 0 or done + n > self.n_steps:
+            raise ValueError('schedule has %d steps, %d already done, %d requested' % (self.n_steps, done, n))
+        self.plan.run(self._stream(), n, use_graph)
+        self._done = done + n
+
+    def steps_done(self):
+        return self._done
+
+    def rewind(self):
+        """Reset the step counter without touching X (benchmark loops re-walk the first steps)."""
+        self.d_step.zero_()
+        self._done = 0
+
+    def score_only(self):
+        """One evaluation of the score network on the current estimate (no update); benchmark helper."""
+        self.score_plan.run(self._stream(), 1, False)
+        return torch.view_as_complex(self.bound.out)
+
+    def nmse_log(self):
+        """``[n_steps, T]`` float32 device tensor: row k = NMSE after Langevin step k (test_score.py:168-170)."""
+        return self.d_nmse

@@ -1,0 +1,212 @@
+// C ABI of libsbc_hip.so (include/sbc_hip.h): error reporting, single-op launch, plans (eager or hipGraph
+// replay), per-tag kernel timing, host-side weight packing.
+#include <stdarg.h>
+#include <string.h>
+#include <vector>
+#include "common.h"
+
+namespace sbc {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct PlanOp {
+    sbc_op op;
+    sbc_langevin lang;     // valid for LANGEVIN / MEASURE
+    sbc_endconv endc;      // valid for END_CONV
+};
+
+static int dispatch(const sbc_op& op, const sbc_langevin* lang, const sbc_endconv* endc, hipStream_t s) {
+    switch (op.kind) {
+        case SBC_OP_BEGIN_CONV: return launch_begin_conv(op, s);
+        case SBC_OP_INORM_STATS: return launch_inorm_stats(op, s);
+        case SBC_OP_CONV: return launch_conv(op, s);
+        case SBC_OP_MAXPOOL5: return launch_maxpool5(op, s);
+        case SBC_OP_END_CONV:
+            SBC_REQUIRE(endc, "end_conv: ext (sbc_endconv) must be set");
+            return launch_end_conv(op, *endc, s);
+        case SBC_OP_LANGEVIN:
+            SBC_REQUIRE(lang, "langevin: ext (sbc_langevin) must be set");
+            return launch_langevin(op, *lang, s);
+        case SBC_OP_MEASURE:
+            SBC_REQUIRE(lang, "measure: ext (sbc_langevin) must be set");
+            return launch_measure(op, *lang, s);
+        case SBC_OP_STEP_INC: return launch_step_inc(op, s);
+        default: set_error("unknown op kind %d", op.kind); return SBC_ERR_INVALID;
+    }
+}
+
+}  // namespace sbc
+
+struct sbc_plan {
+    std::vector<sbc::PlanOp> ops;
+    // hipGraph replay
+    hipGraphExec_t exec = nullptr;
+    hipStream_t graph_stream = nullptr;
+    // per-tag timing
+    int prof_tag = -1;
+    std::vector<hipEvent_t> ev_pool;     // pairs
+    size_t ev_used = 0;
+    double prof_ms = 0.0;
+    int64_t prof_n = 0;
+};
+
+using namespace sbc;
+
+static int drain_events(sbc_plan* plan) {
+    for (size_t i = 0; i + 1 < plan->ev_used; i += 2) {
+        SBC_CHECK_HIP(hipEventSynchronize(plan->ev_pool[i + 1]));
+        float ms = 0.f;
+        SBC_CHECK_HIP(hipEventElapsedTime(&ms, plan->ev_pool[i], plan->ev_pool[i + 1]));
+        plan->prof_ms += ms;
+        plan->prof_n += 1;
+    }
+    plan->ev_used = 0;
+    return SBC_OK;
+}
+
+static int run_eager(sbc_plan* plan, hipStream_t s) {
+    for (auto& po : plan->ops) {
+        const bool timed = plan->prof_tag >= 0 && po.op.tag == plan->prof_tag;
+        if (timed) {
+            if (plan->ev_used + 2 > plan->ev_pool.size()) {
+                if (plan->ev_pool.size() >= 8192) {       // bounded pool: fold what is recorded so far
+                    const int rc = drain_events(plan);
+                    if (rc) return rc;
+                } else {
+                    hipEvent_t a, b;
+                    SBC_CHECK_HIP(hipEventCreate(&a));
+                    SBC_CHECK_HIP(hipEventCreate(&b));
+                    plan->ev_pool.push_back(a);
+                    plan->ev_pool.push_back(b);
+                }
+            }
+            SBC_CHECK_HIP(hipEventRecord(plan->ev_pool[plan->ev_used], s));
+        }
+        const int rc = dispatch(po.op, &po.lang, &po.endc, s);
+        if (rc) return rc;
+        if (timed) {
+            SBC_CHECK_HIP(hipEventRecord(plan->ev_pool[plan->ev_used + 1], s));
+            plan->ev_used += 2;
+        }
+    }
+    return SBC_OK;
+}
+
+extern "C" {
+
+int sbc_abi_version(void) { return SBC_ABI_VERSION; }
+
+const char* sbc_last_error(void) { return g_err; }
+
+int sbc_device_count(void) {
+    int n = 0;
+    SBC_CHECK_HIP(hipGetDeviceCount(&n));
+    return n;
+}
+
+int sbc_op_launch(const sbc_op* op, void* stream) {
+    SBC_REQUIRE(op, "sbc_op_launch: op is NULL");
+    return dispatch(*op, (const sbc_langevin*)op->ext, (const sbc_endconv*)op->ext, (hipStream_t)stream);
+}
+
+int sbc_plan_create(const sbc_op* ops, int32_t n_ops, sbc_plan** out_plan) {
+    SBC_REQUIRE(ops && n_ops > 0 && out_plan, "sbc_plan_create: bad arguments");
+    sbc_plan* plan = new sbc_plan();
+    plan->ops.resize(n_ops);
+    for (int i = 0; i < n_ops; ++i) {
+        PlanOp& po = plan->ops[i];
+        po.op = ops[i];
+        memset(&po.lang, 0, sizeof(po.lang));
+        memset(&po.endc, 0, sizeof(po.endc));
+        if (ops[i].kind == SBC_OP_LANGEVIN || ops[i].kind == SBC_OP_MEASURE) {
+            if (!ops[i].ext) { delete plan; set_error("op %d: ext (sbc_langevin) is NULL", i); return SBC_ERR_INVALID; }
+            po.lang = *(const sbc_langevin*)ops[i].ext;
+        } else if (ops[i].kind == SBC_OP_END_CONV) {
+            if (!ops[i].ext) { delete plan; set_error("op %d: ext (sbc_endconv) is NULL", i); return SBC_ERR_INVALID; }
+            po.endc = *(const sbc_endconv*)ops[i].ext;
+        }
+        po.op.ext = nullptr;
+    }
+    *out_plan = plan;
+    return SBC_OK;
+}
+
+int sbc_plan_run(sbc_plan* plan, void* stream, int32_t n_iters, int32_t use_graph) {
+    SBC_REQUIRE(plan && n_iters >= 0, "sbc_plan_run: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (!use_graph || plan->prof_tag >= 0) {
+        for (int it = 0; it < n_iters; ++it) {
+            const int rc = run_eager(plan, s);
+            if (rc) return rc;
+        }
+        return SBC_OK;
+    }
+    SBC_REQUIRE(s != nullptr, "sbc_plan_run: graph replay needs a non-default stream");
+    if (!plan->exec || plan->graph_stream != s) {
+        if (plan->exec) { (void)hipGraphExecDestroy(plan->exec); plan->exec = nullptr; }
+        hipGraph_t graph = nullptr;
+        SBC_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+        const int rc = run_eager(plan, s);
+        const hipError_t e = hipStreamEndCapture(s, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        SBC_CHECK_HIP(e);
+        SBC_CHECK_HIP(hipGraphInstantiate(&plan->exec, graph, nullptr, nullptr, 0));
+        SBC_CHECK_HIP(hipGraphDestroy(graph));
+        plan->graph_stream = s;
+    }
+    for (int it = 0; it < n_iters; ++it) SBC_CHECK_HIP(hipGraphLaunch(plan->exec, s));
+    return SBC_OK;
+}
+
+void sbc_plan_destroy(sbc_plan* plan) {
+    if (!plan) return;
+    if (plan->exec) (void)hipGraphExecDestroy(plan->exec);
+    for (hipEvent_t e : plan->ev_pool) (void)hipEventDestroy(e);
+    delete plan;
+}
+
+int sbc_plan_profile(sbc_plan* plan, int32_t tag) {
+    SBC_REQUIRE(plan, "sbc_plan_profile: plan is NULL");
+    plan->prof_tag = tag;
+    plan->ev_used = 0;
+    plan->prof_ms = 0.0;
+    plan->prof_n = 0;
+    return SBC_OK;
+}
+
+int sbc_plan_profile_read(sbc_plan* plan, double* total_ms, int64_t* n_launches) {
+    SBC_REQUIRE(plan && total_ms && n_launches, "sbc_plan_profile_read: bad arguments");
+    const int rc = drain_events(plan);
+    if (rc) return rc;
+    *total_ms = plan->prof_ms;
+    *n_launches = plan->prof_n;
+    plan->prof_ms = 0.0;
+    plan->prof_n = 0;
+    return SBC_OK;
+}
+
+int sbc_pack_conv_weight(const float* src, int32_t cout, int32_t cin, int32_t ksize, float* dst) {
+    SBC_REQUIRE(src && dst, "sbc_pack_conv_weight: NULL pointer");
+    SBC_REQUIRE(cin % 8 == 0 && cout % 32 == 0 && (ksize == 1 || ksize == 3),
+                "sbc_pack_conv_weight: cin %% 8, cout %% 32, ksize in {1,3} required (got %d, %d, %d)", cin, cout, ksize);
+    const int taps = ksize * ksize, KG = cin / 8, NB = cout / 32;
+    for (int tap = 0; tap < taps; ++tap)
+        for (int g = 0; g < KG; ++g)
+            for (int nb = 0; nb < NB; ++nb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j) {
+                        const int co = nb * 32 + (lane & 31), ci = g * 8 + 4 * (lane >> 5) + j;
+                        dst[((((size_t)tap * KG + g) * NB + nb) * 64 + lane) * 4 + j] =
+                            src[((size_t)co * cin + ci) * taps + tap];
+                    }
+    return SBC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,49 @@
+// Shared declarations of libsbc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/sbc_hip.h"
+
+namespace sbc {
+
+// thread-local error text behind sbc_last_error()
+void set_error(const char* fmt, ...);
+
+#define SBC_CHECK_HIP(expr)                                                                   \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            ::sbc::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                             __LINE__);                                                       \
+            return SBC_ERR_HIP;                                                               \
+        }                                                                                     \
+    } while (0)
+
+#define SBC_REQUIRE(cond, ...)            \
+    do {                                  \
+        if (!(cond)) {                    \
+            ::sbc::set_error(__VA_ARGS__); \
+            return SBC_ERR_INVALID;       \
+        }                                 \
+    } while (0)
+
+// per-kind launchers (each validates its op, then launches asynchronously on `stream`)
+int launch_conv(const sbc_op& op, hipStream_t stream);
+int launch_begin_conv(const sbc_op& op, hipStream_t stream);
+int launch_inorm_stats(const sbc_op& op, hipStream_t stream);
+int launch_maxpool5(const sbc_op& op, hipStream_t stream);
+int launch_end_conv(const sbc_op& op, const sbc_endconv& ext, hipStream_t stream);
+int launch_langevin(const sbc_op& op, const sbc_langevin& ext, hipStream_t stream);
+int launch_measure(const sbc_op& op, const sbc_langevin& ext, hipStream_t stream);
+int launch_step_inc(const sbc_op& op, hipStream_t stream);
+
+#if defined(__HIPCC__)
+// nn.ELU(alpha=1): x > 0 ? x : exp(x) - 1   (ncsnv2/models/layers.py:12-13)
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+__device__ __forceinline__ float4 elu4(float4 v) {
+    return make_float4(elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w));
+}
+#endif
+
+}  // namespace sbc

@@ -1,0 +1,421 @@
+// The non-GEMM kernels of the annealed-Langevin hot path (gfx950): 2-channel begin/end convolutions on the
+// vector ALU, InstanceNorm++ statistics, 5x5 max pooling, and the fused data-consistency gradient + Langevin
+// update + NMSE kernel.  All activations NHWC float32; complex tensors are interleaved (re, im) pairs.
+#include "tile.h"
+
+namespace sbc {
+
+// ------------------------------------------------------------------------------------------------ begin conv
+// h = 2x - 1 (ncsnv2.py:270-273), then begin_conv: Conv2d(2 -> COUT, 3x3, pad 1) + bias (ncsnv2.py:209,275).
+// Zero padding applies to h, not x.  One thread per (pixel, output channel); the 18*COUT weights sit in LDS.
+__global__ __launch_bounds__(256) void begin_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ out,
+                                                          int B, int H, int W, int cout) {
+    extern __shared__ float wl[];   // [cout][18] torch order [co][ci][kh][kw]
+    for (int i = threadIdx.x; i < cout * 18; i += 256) wl[i] = w[i];
+    __syncthreads();
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)B * H * W * cout;
+    if (idx >= total) return;
+    const int co = idx % cout;
+    const long px = idx / cout;
+    const int wq = px % W;
+    const long row = px / W;
+    const int h = row % H;
+    float acc = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int hh = h + kh - 1;
+        if (hh < 0 || hh >= H) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int ww = wq + kw - 1;
+            if (ww < 0 || ww >= W) continue;
+            const float2 v = *reinterpret_cast<const float2*>(x + ((row + kh - 1) * W + ww) * 2);
+            acc = fmaf(wl[co * 18 + kh * 3 + kw], 2.f * v.x - 1.f, acc);
+            acc = fmaf(wl[co * 18 + 9 + kh * 3 + kw], 2.f * v.y - 1.f, acc);
+        }
+    }
+    out[idx] = acc + bias[co];
+}
+
+int launch_begin_conv(const sbc_op& op, hipStream_t stream) {
+    SBC_REQUIRE(op.in && op.out && op.weight && op.bias, "begin_conv: in/out/weight/bias must be set");
+    SBC_REQUIRE(op.cin == 2 && op.cout > 0 && op.cout <= 256, "begin_conv: cin=%d cout=%d", op.cin, op.cout);
+    const long total = (long)op.B * op.H * op.W * op.cout;
+    const int grid = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(begin_conv_kernel, dim3(grid), dim3(256), op.cout * 18 * sizeof(float), stream,
+                       (const float*)op.in, (const float*)op.weight, (const float*)op.bias, (float*)op.out, op.B,
+                       op.H, op.W, op.cout);
+    SBC_CHECK_HIP(hipGetLastError());
+    return SBC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ IN++ stats
+// InstanceNorm2dPlus (normalization.py:163-176), one workgroup per sample:
+//   mu_c = mean_HW(x), var_c = biased variance (two-pass), m = mean_C(mu), v = unbiased var_C(mu),
+//   out = gamma * ((x - mu_c)/sqrt(var_c + 1e-5) + (mu_c - m)/sqrt(v + 1e-5) * alpha) + beta
+// is stored as (mu, scale = gamma * rstd, shift = gamma * mhat * alpha + beta) so consumers apply
+// (x - mu) * scale + shift while staging.
+template <int C>
+__global__ __launch_bounds__(256) void inorm_stats_kernel(const float* __restrict__ x, const float* __restrict__ agb,
+                                                           float* __restrict__ stats, int HW) {
+    constexpr int C4 = C / 4;
+    constexpr int J = 256 / C4;              // pixel lanes per channel quad
+    __shared__ float4 red[256];
+    __shared__ float mean_s[C], var_s[C];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int c4 = tid % C4, j = tid / C4;
+    const float* base = x + (size_t)n * HW * C + c4 * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int px = j; px < HW; px += J) {
+        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)px * C);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    red[tid] = s;
+    __syncthreads();
+    for (int st = J / 2; st > 0; st >>= 1) {
+        if (j < st) {
+            const float4 o = red[tid + st * C4];
+            float4 m = red[tid];
+            m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
+            red[tid] = m;
+        }
+        __syncthreads();
+    }
+    const float inv = 1.f / (float)HW;
+    if (j == 0) {
+        const float4 m = red[tid];
+        mean_s[c4 * 4 + 0] = m.x * inv; mean_s[c4 * 4 + 1] = m.y * inv;
+        mean_s[c4 * 4 + 2] = m.z * inv; mean_s[c4 * 4 + 3] = m.w * inv;
+    }
+    __syncthreads();
+    const float4 mu = make_float4(mean_s[c4 * 4], mean_s[c4 * 4 + 1], mean_s[c4 * 4 + 2], mean_s[c4 * 4 + 3]);
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int px = j; px < HW; px += J) {
+        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)px * C);
+        const float dx = v.x - mu.x, dy = v.y - mu.y, dz = v.z - mu.z, dw = v.w - mu.w;
+        q.x = fmaf(dx, dx, q.x); q.y = fmaf(dy, dy, q.y); q.z = fmaf(dz, dz, q.z); q.w = fmaf(dw, dw, q.w);
+    }
+    __syncthreads();
+    red[tid] = q;
+    __syncthreads();
+    for (int st = J / 2; st > 0; st >>= 1) {
+        if (j < st) {
+            const float4 o = red[tid + st * C4];
+            float4 m = red[tid];
+            m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
+            red[tid] = m;
+        }
+        __syncthreads();
+    }
+    if (j == 0) {
+        const float4 m = red[tid];
+        var_s[c4 * 4 + 0] = m.x * inv; var_s[c4 * 4 + 1] = m.y * inv;
+        var_s[c4 * 4 + 2] = m.z * inv; var_s[c4 * 4 + 3] = m.w * inv;
+    }
+    __syncthreads();
+    if (tid < C) {
+        float m = 0.f;
+        for (int c = 0; c < C; ++c) m += mean_s[c];
+        m *= 1.f / (float)C;
+        float v = 0.f;
+        for (int c = 0; c < C; ++c) { const float d = mean_s[c] - m; v = fmaf(d, d, v); }
+        v *= 1.f / (float)(C - 1);
+        const float mhat = (mean_s[tid] - m) / sqrtf(v + 1e-5f);
+        const float rstd = 1.f / sqrtf(var_s[tid] + 1e-5f);
+        const float alpha = agb[tid], gamma = agb[C + tid], beta = agb[2 * C + tid];
+        float* o = stats + (size_t)n * 3 * C;
+        o[tid] = mean_s[tid];
+        o[C + tid] = gamma * rstd;
+        o[2 * C + tid] = fmaf(gamma, mhat * alpha, beta);
+    }
+}
+
+int launch_inorm_stats(const sbc_op& op, hipStream_t stream) {
+    SBC_REQUIRE(op.in && op.out && op.weight, "inorm_stats: in/out/weight must be set");
+    const int HW = op.H * op.W;
+    const float* x = (const float*)op.in;
+    const float* agb = (const float*)op.weight;
+    float* st = (float*)op.out;
+    switch (op.cin) {
+        case 32: hipLaunchKernelGGL(inorm_stats_kernel<32>, dim3(op.B), dim3(256), 0, stream, x, agb, st, HW); break;
+        case 64: hipLaunchKernelGGL(inorm_stats_kernel<64>, dim3(op.B), dim3(256), 0, stream, x, agb, st, HW); break;
+        case 128: hipLaunchKernelGGL(inorm_stats_kernel<128>, dim3(op.B), dim3(256), 0, stream, x, agb, st, HW); break;
+        default: set_error("inorm_stats: %d channels (only 32/64/128)", op.cin); return SBC_ERR_UNSUPPORTED;
+    }
+    SBC_CHECK_HIP(hipGetLastError());
+    return SBC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ max pool
+// nn.MaxPool2d(5, stride 1, padding 2) with -inf padding (layers.py:69).  With SBC_PRO_ELU the result is
+// ELU(max) == max(ELU) because ELU is monotone (CRPBlock: x = act(x); path = maxpool(x), layers.py:77-80).
+__global__ __launch_bounds__(256) void maxpool5_kernel(const float* __restrict__ in, float* __restrict__ out, int B,
+                                                        int H, int W, int C4, int flags) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)B * H * W * C4;
+    if (idx >= total) return;
+    const int c4 = idx % C4;
+    const long px = idx / C4;
+    const int w = px % W;
+    const long row = px / W;
+    const int h = row % H;
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int dh = -2; dh <= 2; ++dh) {
+        if (h + dh < 0 || h + dh >= H) continue;
+        for (int dw = -2; dw <= 2; ++dw) {
+            if (w + dw < 0 || w + dw >= W) continue;
+            const float4 v = *reinterpret_cast<const float4*>(in + (((row + dh) * W + w + dw) * C4 + c4) * 4);
+            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+    }
+    if (flags & SBC_PRO_ELU) m = elu4(m);
+    *reinterpret_cast<float4*>(out + idx * 4) = m;
+}
+
+int launch_maxpool5(const sbc_op& op, hipStream_t stream) {
+    SBC_REQUIRE(op.in && op.out && op.cin % 4 == 0, "maxpool5: in/out must be set, channels %% 4 == 0");
+    const long total = (long)op.B * op.H * op.W * (op.cin / 4);
+    hipLaunchKernelGGL(maxpool5_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, stream, (const float*)op.in,
+                       (float*)op.out, op.B, op.H, op.W, op.cin / 4, op.flags);
+    SBC_CHECK_HIP(hipGetLastError());
+    return SBC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ end conv
+// normalizer (InstanceNorm++) -> ELU -> end_conv: Conv2d(CIN -> 2, 3x3, pad 1) + bias -> / sigma
+// (ncsnv2.py:291-298).  256-pixel tiles staged like the MFMA conv; one thread per output pixel (both channels),
+// weights [tap][c][2] in LDS (broadcast reads).
+template <int CIN>
+__global__ __launch_bounds__(256) void end_conv_kernel(const float* __restrict__ in, const float* __restrict__ stats,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                        float* __restrict__ out, sbc_endconv e, int B, int H, int W) {
+    constexpr int TM = 256, S = CIN + 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const TileGeom g = tile_geom(blockIdx.x, TM, B, H, W, 1);
+    stage_tile<CIN>(lds, in, stats, SBC_PRO_NORM | SBC_PRO_ELU, g, H, W, tid, 256);
+    float* wl = lds + (size_t)(g.nps + 1) * S;          // [9][CIN][2]
+    for (int i = tid; i < 9 * CIN * 2; i += 256) {
+        const int o = i & 1, c = (i >> 1) % CIN, tap = i / (2 * CIN);
+        wl[i] = w[(o * CIN + c) * 9 + tap];             // torch [2][CIN][3][3]
+    }
+    __syncthreads();
+    const int px = g.p0 + tid;
+    if (px >= B * H * W) return;
+    const int row = px / W, wq = px - row * W, h = row % H;
+    float a0 = 0.f, a1 = 0.f;
+    for (int tap = 0; tap < 9; ++tap) {
+        const int hh = h + tap / 3 - 1, ww = wq + tap % 3 - 1;
+        const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
+        const float* a = lds + (ok ? (row + tap / 3 - 1 - g.rs0) * W + ww : g.nps) * S;
+        const float* wt = wl + tap * CIN * 2;
+#pragma unroll
+        for (int c = 0; c < CIN; c += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(a + c);
+            a0 = fmaf(v.x, wt[2 * c + 0], a0); a1 = fmaf(v.x, wt[2 * c + 1], a1);
+            a0 = fmaf(v.y, wt[2 * c + 2], a0); a1 = fmaf(v.y, wt[2 * c + 3], a1);
+            a0 = fmaf(v.z, wt[2 * c + 4], a0); a1 = fmaf(v.z, wt[2 * c + 5], a1);
+            a0 = fmaf(v.w, wt[2 * c + 6], a0); a1 = fmaf(v.w, wt[2 * c + 7], a1);
+        }
+    }
+    const int n = px / (H * W);
+    const float sigma = e.labels ? e.sigmas[e.labels[n]] : e.sigma_of_step[*e.step];
+    float2 o;
+    o.x = (a0 + bias[0]) / sigma;
+    o.y = (a1 + bias[1]) / sigma;
+    *reinterpret_cast<float2*>(out + (size_t)px * 2) = o;
+}
+
+int launch_end_conv(const sbc_op& op, const sbc_endconv& e, hipStream_t stream) {
+    SBC_REQUIRE(op.in && op.out && op.weight && op.bias && op.stats, "end_conv: in/out/weight/bias/stats must be set");
+    SBC_REQUIRE(op.cout == 2, "end_conv: cout=%d", op.cout);
+    SBC_REQUIRE((e.labels && e.sigmas) || (e.sigma_of_step && e.step), "end_conv: no noise-level source");
+    const int HW = op.H * op.W, TM = 256;
+    SBC_REQUIRE(TM % op.W == 0 && (HW % TM == 0 || TM % HW == 0), "end_conv: image %dx%d does not tile", op.H, op.W);
+    const int total = op.B * HW;
+    const int halo_px = TM >= HW ? 0 : 2 * op.W;
+    const size_t lds = ((size_t)(TM + halo_px + 1) * (op.cin + 4) + 9 * op.cin * 2) * sizeof(float);
+    SBC_REQUIRE(lds <= 160 * 1024, "end_conv: tile needs %zu bytes of LDS", lds);
+    SBC_REQUIRE(op.cin == 32, "end_conv: %d input channels (only ngf = 32)", op.cin);
+    static size_t lds_attr = 0;
+    if (lds > lds_attr) {
+        SBC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(end_conv_kernel<32>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_attr = lds;
+    }
+    hipLaunchKernelGGL(end_conv_kernel<32>, dim3((total + TM - 1) / TM), dim3(256), lds, stream, (const float*)op.in,
+                       (const float*)op.stats, (const float*)op.weight, (const float*)op.bias, (float*)op.out, e, op.B,
+                       op.H, op.W);
+    SBC_CHECK_HIP(hipGetLastError());
+    return SBC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ Langevin
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {          // a * b
+    return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ float2 cfma(float2 a, float2 b, float2 c) {  // a * b + c
+    return make_float2(fmaf(a.x, b.x, fmaf(-a.y, b.y, c.x)), fmaf(a.x, b.y, fmaf(a.y, b.x, c.y)));
+}
+__device__ __forceinline__ float2 cfma_conj(float2 a, float2 b, float2 c) {  // conj(a) * b + c
+    return make_float2(fmaf(a.x, b.x, fmaf(a.y, b.y, c.x)), fmaf(a.x, b.y, fmaf(-a.y, b.x, c.y)));
+}
+
+// Philox4x32-10 (Salmon et al. 2011), counter (c0..c3), key (k0, k1)
+__device__ __forceinline__ uint4 philox4x32(uint4 c, uint2 k) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += 0x9E3779B9u;
+        k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+// one CN(0,1) sample (re, im each N(0, 1/2)) per (trajectory, step, element): Box-Muller on two uniforms
+__device__ __forceinline__ float2 complex_normal(uint64_t seed, int64_t traj, int step, int elem) {
+    const uint4 r = philox4x32(make_uint4((uint32_t)elem, (uint32_t)step, (uint32_t)traj, (uint32_t)((uint64_t)traj >> 32)),
+                               make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+    const float u1 = ((float)(r.x >> 8) + 0.5f) * (1.f / 16777216.f);   // (0, 1)
+    const float u2 = ((float)(r.y >> 8) + 0.5f) * (1.f / 16777216.f);
+    const float rad = sqrtf(-logf(u1));                                  // sqrt(-2 ln u1) * sqrt(1/2)
+    float s, c;
+    sincosf(6.283185307179586f * u2, &s, &c);
+    return make_float2(rad * c, rad * s);
+}
+
+// One workgroup per trajectory b:  R = P X - Y  [Np x Nr],  G = P^H R  [Nt x Nr]  (test_score.py:157-158),
+// X <- X + alpha (S - G / dc_div) + noise_scale * n  (:160-165),  nmse[step][b] = |X - H|^2 / |H|^2  (:168-170).
+// X and R live in LDS; P (per-sample pilots, L2 resident) is read through the vector cache: in both products the
+// 16 lanes that share a pilot entry read the same address.
+__global__ __launch_bounds__(256) void langevin_kernel(sbc_langevin a, int B, int x_in_lds) {
+    extern __shared__ __attribute__((aligned(16))) float2 sm[];
+    const int Nt = a.Nt, Nr = a.Nr, Np = a.Np;
+    float2* Rs = sm;                   // [Np*Nr]
+    float2* Xl = sm + Np * Nr;         // [Nt*Nr] when it fits (64x16: 8 KB); large arrays read X through L1/L2
+    __shared__ float red[2][4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int step = *a.step;
+    float2* X = reinterpret_cast<float2*>(a.X) + (size_t)b * Nt * Nr;
+    const float2* P = reinterpret_cast<const float2*>(a.P) + (size_t)(a.p_index ? a.p_index[b] : b) * Np * Nt;
+    const float2* Y = reinterpret_cast<const float2*>(a.Y) + (size_t)b * Np * Nr;
+    const float2* Ht = reinterpret_cast<const float2*>(a.Htrue) + (size_t)(a.h_index ? a.h_index[b] : b) * Nt * Nr;
+    const float2* Sc = reinterpret_cast<const float2*>(a.score) + (size_t)b * Nt * Nr;
+    if (x_in_lds) {
+        for (int e = tid; e < Nt * Nr; e += 256) Xl[e] = X[e];
+        __syncthreads();
+    }
+    const float2* Xs = x_in_lds ? Xl : X;
+    for (int o = tid; o < Np * Nr; o += 256) {
+        const int m = o / Nr, r = o - m * Nr;
+        float2 acc = make_float2(0.f, 0.f);
+        const float2* pm = P + (size_t)m * Nt;
+        for (int t = 0; t < Nt; ++t) acc = cfma(pm[t], Xs[t * Nr + r], acc);
+        const float2 y = Y[o];
+        Rs[o] = make_float2(acc.x - y.x, acc.y - y.y);
+    }
+    __syncthreads();
+    const float* sc = a.sched + ((size_t)(a.group ? a.group[b] : 0) * a.n_steps + step) * 4;
+    const float alpha = sc[0], dc_div = sc[1], nscale = sc[2];
+    const float2* ext = a.noise ? reinterpret_cast<const float2*>(a.noise) + ((size_t)step * B + b) * Nt * Nr : nullptr;
+    const int64_t traj = a.traj_id ? a.traj_id[b] : b;
+    float err = 0.f, den = 0.f;
+    for (int e = tid; e < Nt * Nr; e += 256) {
+        const int t = e / Nr, r = e - t * Nr;
+        float2 gacc = make_float2(0.f, 0.f);
+        for (int m = 0; m < Np; ++m) gacc = cfma_conj(P[(size_t)m * Nt + t], Rs[m * Nr + r], gacc);
+        const float2 s = Sc[e], x = Xs[e], h = Ht[e];
+        const float2 n = ext ? ext[e] : complex_normal(a.seed, traj, step, e);
+        float2 u;
+        u.x = x.x + alpha * (s.x - gacc.x / dc_div) + nscale * n.x;
+        u.y = x.y + alpha * (s.y - gacc.y / dc_div) + nscale * n.y;
+        X[e] = u;
+        const float dx = u.x - h.x, dy = u.y - h.y;
+        err += dx * dx + dy * dy;
+        den += h.x * h.x + h.y * h.y;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        err += __shfl_down(err, off);
+        den += __shfl_down(den, off);
+    }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = err; red[1][tid >> 6] = den; }
+    __syncthreads();
+    if (tid == 0) {
+        const float e4 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        const float d4 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        a.nmse[(size_t)step * B + b] = e4 / d4;
+    }
+}
+
+static int check_langevin(const sbc_op& op, const sbc_langevin& a, bool measure) {
+    SBC_REQUIRE(a.P && a.Y && a.Htrue, "langevin/measure: P, Y, Htrue must be set");
+    SBC_REQUIRE(a.Nt > 0 && a.Nr > 0 && a.Np > 0 && op.B > 0, "langevin/measure: bad sizes");
+    if (!measure) {
+        SBC_REQUIRE(a.X && a.score && a.sched && a.nmse && a.step && a.n_steps > 0,
+                    "langevin: X, score, sched, nmse, step must be set");
+        const size_t lds = (size_t)a.Np * a.Nr * sizeof(float2);
+        SBC_REQUIRE(lds <= 150 * 1024, "langevin: Nr=%d Np=%d needs %zu bytes of LDS", a.Nr, a.Np, lds);
+    } else {
+        SBC_REQUIRE(a.meas_scale, "measure: meas_scale must be set");
+    }
+    return SBC_OK;
+}
+
+int launch_langevin(const sbc_op& op, const sbc_langevin& a, hipStream_t stream) {
+    const int rc = check_langevin(op, a, false);
+    if (rc) return rc;
+    const size_t lds_all = (size_t)(a.Nt + a.Np) * a.Nr * sizeof(float2);
+    const int x_in_lds = lds_all <= 64 * 1024;
+    const size_t lds = x_in_lds ? lds_all : (size_t)a.Np * a.Nr * sizeof(float2);
+    static size_t lds_attr = 0;
+    if (lds > lds_attr) {
+        SBC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(langevin_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_attr = lds;
+    }
+    hipLaunchKernelGGL(langevin_kernel, dim3(op.B), dim3(256), lds, stream, a, op.B, x_in_lds);
+    SBC_CHECK_HIP(hipGetLastError());
+    return SBC_OK;
+}
+
+// Y = P H + sqrt(local_noise) * n   (test_score.py:122-124); n from `noise` [B][Np][Nr] or Philox (step = -1).
+__global__ __launch_bounds__(256) void measure_kernel(sbc_langevin a, int B) {
+    const int Nt = a.Nt, Nr = a.Nr, Np = a.Np;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float2* P = reinterpret_cast<const float2*>(a.P) + (size_t)(a.p_index ? a.p_index[b] : b) * Np * Nt;
+    const float2* Ht = reinterpret_cast<const float2*>(a.Htrue) + (size_t)(a.h_index ? a.h_index[b] : b) * Nt * Nr;
+    float2* Y = reinterpret_cast<float2*>(a.Y) + (size_t)b * Np * Nr;
+    const float2* ext = a.noise ? reinterpret_cast<const float2*>(a.noise) + (size_t)b * Np * Nr : nullptr;
+    const float sn = a.meas_scale[b];
+    const int64_t traj = a.traj_id ? a.traj_id[b] : b;
+    for (int o = tid; o < Np * Nr; o += 256) {
+        const int m = o / Nr, r = o - m * Nr;
+        float2 acc = make_float2(0.f, 0.f);
+        for (int t = 0; t < Nt; ++t) acc = cfma(P[(size_t)m * Nt + t], Ht[t * Nr + r], acc);
+        const float2 n = ext ? ext[o] : complex_normal(a.seed, traj, -1, o);
+        Y[o] = make_float2(acc.x + sn * n.x, acc.y + sn * n.y);
+    }
+}
+
+int launch_measure(const sbc_op& op, const sbc_langevin& a, hipStream_t stream) {
+    const int rc = check_langevin(op, a, true);
+    if (rc) return rc;
+    hipLaunchKernelGGL(measure_kernel, dim3(op.B), dim3(256), 0, stream, a, op.B);
+    SBC_CHECK_HIP(hipGetLastError());
+    return SBC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ step counter
+__global__ void step_inc_kernel(int* step) { *step += 1; }
+
+int launch_step_inc(const sbc_op& op, hipStream_t stream) {
+    SBC_REQUIRE(op.out, "step_inc: out (device int32 counter) must be set");
+    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, stream, (int*)op.out);
+    SBC_CHECK_HIP(hipGetLastError());
+    return SBC_OK;
+}
+
+}  // namespace sbc

@@ -1,0 +1,75 @@
+// Input-tile staging shared by the MFMA convolution and the end-conv kernel.
+//
+// A workgroup owns TM consecutive output pixels of the flattened (n, h, w) space of an NHWC tensor.  TM is
+// either a whole number of image rows inside one sample (TM < H*W, TM % W == 0) or a whole number of samples
+// (TM % (H*W) == 0).  The rows a 3x3 (dilated) stencil needs are copied to LDS once -- transformed on the way
+// (InstanceNorm++ affine, ELU) -- as [pixel][CIN + 4] floats: the +4 pad makes the pixel stride an odd number
+// of 16-byte slots, so the ds_read_b128 A-fragment reads (16 lanes = 16 consecutive pixels, same channel
+// offset) hit 16 distinct slots of the 64-bank row.  One extra all-zero pixel at index `nps` stands in for
+// every out-of-image tap (zero padding of nn.Conv2d), so no border is materialised.
+#pragma once
+#include "common.h"
+
+namespace sbc {
+
+struct TileGeom {
+    int p0;        // first output pixel (flattened n*H*W + h*W + w)
+    int rs0;       // first staged global row (n*H + h)
+    int nps;       // staged pixels; LDS pixel index nps is the zero pixel
+    int n_first;   // sample index of the first staged row
+    int multi;     // tile spans whole samples (no halo)
+};
+
+__device__ __forceinline__ TileGeom tile_geom(int tile, int TM, int B, int H, int W, int halo_rows) {
+    TileGeom g;
+    const int HW = H * W;
+    g.p0 = tile * TM;
+    const int r0 = g.p0 / W;
+    int r1 = r0 + TM / W;
+    if (r1 > B * H) r1 = B * H;
+    g.multi = TM >= HW;
+    int rs1;
+    if (g.multi) {
+        g.rs0 = r0;
+        rs1 = r1;
+    } else {
+        const int n = r0 / H;
+        g.rs0 = max(r0 - halo_rows, n * H);
+        rs1 = min(r1 + halo_rows, (n + 1) * H);
+    }
+    g.nps = (rs1 - g.rs0) * W;
+    g.n_first = g.rs0 / H;
+    return g;
+}
+
+// Copy the staged rows into LDS with the prologue applied.  stats = [B][3][CIN] (mu, scale, shift).
+template <int CIN>
+__device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__ in,
+                                           const float* __restrict__ stats, int flags, const TileGeom& g,
+                                           int H, int W, int tid, int nthreads) {
+    constexpr int S = CIN + 4;
+    constexpr int C4 = CIN / 4;
+    const float* src = in + (size_t)g.rs0 * W * CIN;
+    const int HW = H * W;
+    const int total = g.nps * C4;
+    for (int idx = tid; idx < total; idx += nthreads) {
+        const int pix = idx / C4, c4 = idx % C4;
+        float4 v = *reinterpret_cast<const float4*>(src + (size_t)pix * CIN + c4 * 4);
+        if (flags & SBC_PRO_NORM) {
+            const int n = g.n_first + (g.multi ? pix / HW : 0);
+            const float* st = stats + (size_t)n * 3 * CIN + c4 * 4;
+            const float4 mu = *reinterpret_cast<const float4*>(st);
+            const float4 sc = *reinterpret_cast<const float4*>(st + CIN);
+            const float4 sh = *reinterpret_cast<const float4*>(st + 2 * CIN);
+            v.x = (v.x - mu.x) * sc.x + sh.x;
+            v.y = (v.y - mu.y) * sc.y + sh.y;
+            v.z = (v.z - mu.z) * sc.z + sh.z;
+            v.w = (v.w - mu.w) * sc.w + sh.w;
+        }
+        if (flags & SBC_PRO_ELU) v = elu4(v);
+        *reinterpret_cast<float4*>(lds + pix * S + c4 * 4) = v;
+    }
+    for (int i = tid; i < S; i += nthreads) lds[g.nps * S + i] = 0.f;
+}
+
+}  // namespace sbc

@@ -1,0 +1,231 @@
+"""Launch plan of the NCSNv2Deepest score network (and of one full Langevin step).
+
+``NCSNv2Deepest.forward`` (``ncsnv2/models/ncsnv2.py:269-300``) issues ~700 stock kernels per call; here
+the same dataflow is expressed as ~160 fused operator records (``Op``) over NHWC buffers -- one record per
+HIP launch of ``libsbc_hip.so`` (``include/sbc_hip.h``).  This module is pure Python (no torch, no HIP): it
+only decides *what* is launched in which order and which logical tensors can share storage.  ``scorenet.py``
+binds the records to device memory; ``tests/test_plan_cpu.py`` interprets the very same records with the CPU
+oracle's primitives to prove the wiring without a GPU.
+
+Fusion rules (reference lines in brackets):
+  * InstanceNorm++ -> ELU -> conv  [layers.py:444-449]: a statistics op writes (mu, scale, shift) per
+    (sample, channel); the conv applies the affine + ELU while staging its input tile (PRO_NORM|PRO_ELU).
+  * ELU -> conv of RCU blocks [layers.py:130-131]: PRO_ELU; ``x += residual`` [:133] is the conv's res1.
+  * ResidualBlock ``shortcut + output`` [:456]: res1 of conv2; pooled blocks run the 1x1 shortcut first and
+    add it after conv2's own 2x2 mean pool [ConvMeanPool :311-312].
+  * CRP [layers.py:76-83]: ``x = act(x)`` is never materialised: maxpool(ELU(x)) == ELU(maxpool(x)), and the
+    running sum ``x = path + x`` is folded into the second conv's epilogue as path1 + (path0 + ELU(x)).
+  * MSF [layers.py:178-184]: ``sums = 0 + conv0(h0) + resize(conv1(h1))``: conv1 runs first at its own
+    resolution, conv0 adds its (bilinear, align_corners) resize in the epilogue.
+  * ``h = 2x - 1`` [ncsnv2.py:270-273] lives in the begin conv; normalizer -> ELU -> end_conv -> / sigma
+    [ncsnv2.py:291-298] is one kernel.
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+# op kinds / flags: numerically identical to include/sbc_hip.h
+BEGIN_CONV, INORM_STATS, CONV, MAXPOOL5, END_CONV, LANGEVIN, STEP_INC, MEASURE = 1, 2, 3, 4, 5, 6, 7, 8
+PRO_ELU, PRO_NORM = 0x001, 0x002
+EPI_RES1_ELU, EPI_POOL, EPI_UP = 0x010, 0x020, 0x040
+
+# profiling tag of the dominant kernel class: 3x3 convs ngf->ngf at full resolution
+TAG_CONV_TOP = 1
+
+
+@dataclass
+class Tensor:
+    """A logical per-sample NHWC tensor ``[H][W][C]`` (batch dimension implicit)."""
+    name: str
+    h: int
+    w: int
+    c: int
+    slot: int = -1            # physical buffer assigned by ``assign_slots``
+
+    @property
+    def elems(self):
+        return self.h * self.w * self.c
+
+
+@dataclass
+class Op:
+    kind: int
+    name: str
+    src: Optional[Tensor] = None
+    dst: Optional[Tensor] = None
+    weight: Optional[str] = None        # state_dict key of the conv weight / norm prefix
+    bias: Optional[str] = None
+    stats: Optional[Tensor] = None
+    res1: Optional[Tensor] = None
+    res2: Optional[Tensor] = None
+    up: Optional[Tensor] = None
+    flags: int = 0
+    ksize: int = 3
+    dil: int = 1
+    tag: int = 0
+
+    def inputs(self):
+        return [t for t in (self.src, self.stats, self.res1, self.res2, self.up) if t is not None]
+
+
+@dataclass
+class ScorePlan:
+    ops: List[Op]
+    x: Tensor                 # network input  [Nt][Nr][2]   (complex64 view of the current estimate)
+    out: Tensor               # network output [Nt][Nr][2]   (complex64 view of the score)
+    tensors: List[Tensor]
+    slot_elems: List[int] = field(default_factory=list)   # per-sample float32 elements of each physical slot
+
+
+class _Builder:
+    def __init__(self, ngf, nt, nr):
+        self.ngf, self.nt, self.nr = ngf, nt, nr
+        self.ops, self.tensors = [], []
+
+    def t(self, name, h, w, c):
+        x = Tensor(name, h, w, c)
+        self.tensors.append(x)
+        return x
+
+    def conv(self, name, src, wkey, cout, *, bias=True, flags=0, stats=None, res1=None, res2=None, up=None,
+             ksize=3, dil=1):
+        pool = bool(flags & EPI_POOL)
+        dst = self.t(name, src.h // 2 if pool else src.h, src.w // 2 if pool else src.w, cout)
+        tag = TAG_CONV_TOP if (ksize == 3 and src.c == self.ngf and cout == self.ngf and src.h == self.nt) else 0
+        self.ops.append(Op(CONV, name, src=src, dst=dst, weight=wkey + '.weight',
+                           bias=(wkey + '.bias') if bias else None, stats=stats, res1=res1, res2=res2, up=up,
+                           flags=flags | (EPI_UP if up is not None else 0), ksize=ksize, dil=dil, tag=tag))
+        return dst
+
+    def stats(self, name, src, nkey):
+        dst = self.t(name, 1, 3, src.c)
+        self.ops.append(Op(INORM_STATS, name, src=src, dst=dst, weight=nkey))
+        return dst
+
+    def maxpool(self, name, src, elu):
+        dst = self.t(name, src.h, src.w, src.c)
+        self.ops.append(Op(MAXPOOL5, name, src=src, dst=dst, flags=PRO_ELU if elu else 0))
+        return dst
+
+    # --- blocks -----------------------------------------------------------------------------------
+    def residual_block(self, p, x, cout, resample, dilation):
+        """layers.py:443-456."""
+        d = 1 if dilation is None else dilation
+        pooled = resample == 'down' and dilation is None
+        c1 = x.c if resample == 'down' else cout
+        s1 = self.stats(p + 'normalize1', x, p + 'normalize1')
+        a = self.conv(p + 'conv1', x, p + 'conv1', c1, flags=PRO_NORM | PRO_ELU, stats=s1, dil=d)
+        s2 = self.stats(p + 'normalize2', a, p + 'normalize2')
+        if pooled:
+            sc = self.conv(p + 'shortcut', x, p + 'shortcut.conv', cout, flags=EPI_POOL, ksize=1)
+            return self.conv(p + 'conv2', a, p + 'conv2.conv', cout, flags=PRO_NORM | PRO_ELU | EPI_POOL,
+                             stats=s2, res1=sc)
+        if x.c != cout or resample is not None:
+            sc = self.conv(p + 'shortcut', x, p + 'shortcut', cout, dil=d)
+        else:
+            sc = x
+        return self.conv(p + 'conv2', a, p + 'conv2', cout, flags=PRO_NORM | PRO_ELU, stats=s2, res1=sc, dil=d)
+
+    def rcu(self, p, x, n_blocks):
+        """layers.py:126-134 (n_stages = 2, no bias)."""
+        for i in range(1, n_blocks + 1):
+            t = self.conv(p + '%d_1_conv' % i, x, p + '%d_1_conv' % i, x.c, bias=False, flags=PRO_ELU)
+            x = self.conv(p + '%d_2_conv' % i, t, p + '%d_2_conv' % i, x.c, bias=False, flags=PRO_ELU, res1=x)
+        return x
+
+    def crp(self, p, x):
+        """layers.py:76-83 (two stages, max pooling)."""
+        p0 = self.maxpool(p + 'pool0', x, elu=True)
+        path0 = self.conv(p + 'convs.0', p0, p + 'convs.0', x.c, bias=False)
+        p1 = self.maxpool(p + 'pool1', path0, elu=False)
+        return self.conv(p + 'convs.1', p1, p + 'convs.1', x.c, bias=False, flags=EPI_RES1_ELU, res1=x, res2=path0)
+
+    def msf(self, p, hs, features):
+        """layers.py:178-184 for two inputs; the second may be at half resolution."""
+        t1 = self.conv(p + 'convs.1', hs[1], p + 'convs.1', features)
+        return self.conv(p + 'convs.0', hs[0], p + 'convs.0', features, up=t1)
+
+    def refine(self, p, xs, features, end=False):
+        """layers.py:234-249."""
+        hs = [self.rcu(p + 'adapt_convs.%d.' % i, x, 2) for i, x in enumerate(xs)]
+        h = self.msf(p + 'msf.', hs, features) if len(xs) > 1 else hs[0]
+        h = self.crp(p + 'crp.', h)
+        return self.rcu(p + 'output_convs.', h, 3 if end else 1)
+
+
+def build_score_plan(ngf=32, nt=64, nr=16, channels=2):
+    """Op list of one ``NCSNv2Deepest.forward`` for ``[B, 2, nt, nr]`` inputs (ncsnv2.py:269-300)."""
+    if nt % 8 or nr % 8:
+        raise ValueError('Nt and Nr must be multiples of 8 (three 2x mean-pools), got %dx%d' % (nt, nr))
+    b = _Builder(ngf, nt, nr)
+    x = b.t('x', nt, nr, channels)
+    h = b.t('begin_conv', nt, nr, ngf)
+    b.ops.append(Op(BEGIN_CONV, 'begin_conv', src=x, dst=h, weight='begin_conv.weight', bias='begin_conv.bias'))
+    stages = [('res1', ngf, None, None), ('res2', 2 * ngf, 'down', None), ('res3', 2 * ngf, 'down', None),
+              ('res31', 2 * ngf, 'down', None), ('res4', 4 * ngf, 'down', 2), ('res5', 4 * ngf, 'down', 4)]
+    layers = []
+    for name, cout, resample, dil in stages:
+        h = b.residual_block(name + '.0.', h, cout, resample, dil)
+        h = b.residual_block(name + '.1.', h, cout, None, dil)
+        layers.append(h)
+    l1, l2, l3, l31, l4, l5 = layers
+    ref1 = b.refine('refine1.', [l5], 4 * ngf)
+    ref2 = b.refine('refine2.', [l4, ref1], 2 * ngf)
+    ref31 = b.refine('refine31.', [l31, ref2], 2 * ngf)
+    ref3 = b.refine('refine3.', [l3, ref31], 2 * ngf)
+    ref4 = b.refine('refine4.', [l2, ref3], ngf)
+    ref5 = b.refine('refine5.', [l1, ref4], ngf, end=True)
+    sn = b.stats('normalizer', ref5, 'normalizer')
+    out = b.t('score', nt, nr, channels)
+    b.ops.append(Op(END_CONV, 'end_conv', src=ref5, dst=out, weight='end_conv.weight', bias='end_conv.bias',
+                    stats=sn))
+    plan = ScorePlan(b.ops, x, out, b.tensors)
+    assign_slots(plan)
+    return plan
+
+
+def assign_slots(plan):
+    """Share storage between logical tensors with disjoint lifetimes (linear-scan over the op list).
+    The network input and output keep private slots (they are caller-visible)."""
+    last_use = {}
+    for i, op in enumerate(plan.ops):
+        for t in op.inputs():
+            last_use[id(t)] = i
+    pinned = {id(plan.x), id(plan.out)}
+    free = {}                     # elems -> [slot]
+    slot_elems = []
+    live = []                     # (tensor, last use)
+
+    def alloc(t):
+        pool = free.get(t.elems, [])
+        if pool and id(t) not in pinned:
+            t.slot = pool.pop()
+        else:
+            t.slot = len(slot_elems)
+            slot_elems.append(t.elems)
+
+    alloc(plan.x)
+    for i, op in enumerate(plan.ops):
+        # outputs may not alias any input of the same op -> allocate before releasing
+        alloc(op.dst)
+        live.append(op.dst)
+        for t in list(live):
+            if id(t) in pinned:
+                continue
+            if last_use.get(id(t), -1) <= i and t is not op.dst:
+                free.setdefault(t.elems, []).append(t.slot)
+                live.remove(t)
+            elif t is op.dst and id(t) not in last_use:
+                pass                                  # dead store (never happens in this network)
+    plan.slot_elems = slot_elems
+    return plan
+
+
+def count_conv_flops(plan):
+    """2 * MACs of every convolution record, per sample (820 772 864 at 64x16)."""
+    total = 0
+    for op in plan.ops:
+        if op.kind == CONV:
+            total += 2 * op.src.h * op.src.w * op.src.c * op.dst.c * op.ksize * op.ksize
+        elif op.kind in (BEGIN_CONV, END_CONV):
+            total += 2 * op.src.h * op.src.w * op.src.c * op.dst.c * 9
+    return total

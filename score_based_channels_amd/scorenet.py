@@ -1,0 +1,182 @@
+"""``ScoreNet`` -- host-side stand-in for the reference's ``NCSNv2Deepest`` ``nn.Module``
+(``ncsnv2/models/ncsnv2.py:198-300``) whose forward runs on the HIP kernels of ``libsbc_hip.so``.
+
+Interface kept from the reference call sites (``test_score.py:59-63,137,151``):
+``ScoreNet(config)``, ``.cuda()``, ``.load_state_dict(contents['model_state'])``, ``.eval()``,
+``.sigmas`` (float32 ``[num_classes]`` device tensor) and ``net(x[B,2,Nt,Nr], labels[B]) -> [B,2,Nt,Nr]``.
+torch is used for device memory and streams only; no torch operator computes anything on this path.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import plan as P
+from .weights import check_state_dict, get_sigmas, pack_conv_weight
+
+
+def _ptr(t, offset_elems=0):
+    return C.c_void_p(t.data_ptr() + 4 * offset_elems)
+
+
+class BoundScore:
+    """A score plan bound to device buffers for a fixed batch size."""
+
+    def __init__(self, ops, x, out, slots, labels, extra_keep):
+        self.ops = ops              # list of _lib.sbc_op (ctypes); END_CONV.ext points into ``extra_keep``
+        self.x = x                  # float32 [B, Nt, Nr, 2]  (view as complex64 [B, Nt, Nr])
+        self.out = out              # float32 [B, Nt, Nr, 2]
+        self.slots = slots
+        self.labels = labels
+        self.keep = extra_keep
+
+
+class ScoreNet:
+    def __init__(self, config, device=None):
+        self.config = config
+        m, d = config.model, config.data
+        if str(m.normalization) != 'InstanceNorm++' or str(m.nonlinearity).lower() != 'elu':
+            raise NotImplementedError('the HIP path implements InstanceNorm++ / ELU (train_score.py:39-40), got %r / %r'
+                                      % (m.normalization, m.nonlinearity))
+        if d.logit_transform or d.rescaled:
+            raise NotImplementedError('only the h = 2x - 1 input map is implemented (ncsnv2.py:270-273)')
+        self.ngf = int(m.ngf)
+        self.num_classes = int(m.num_classes)
+        self.channels = int(d.channels)
+        if self.ngf != 32 or self.channels != 2:
+            raise NotImplementedError('kernels are instantiated for ngf = 32, 2 input channels')
+        self.device = torch.device(device if device is not None else 'cuda:0')
+        self._sigmas_np = get_sigmas(config)
+        self._wdev = None
+        self._woff = {}
+        self._sigmas = None
+        self._call_cache = {}
+        self._plans = {}
+
+    # --- nn.Module look-alikes ------------------------------------------------------------------
+    def cuda(self, device=None):
+        if device is not None:
+            self.device = torch.device('cuda', device) if isinstance(device, int) else torch.device(device)
+        return self
+
+    def to(self, device):
+        self.device = torch.device(device)
+        return self
+
+    def eval(self):
+        return self
+
+    @property
+    def sigmas(self):
+        if self._sigmas is None:
+            self._sigmas = torch.from_numpy(self._sigmas_np).to(self.device)
+        return self._sigmas
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Accepts the reference ``model_state`` (torch tensors) or numpy arrays; packs conv weights into
+        MFMA fragment order and uploads everything as one flat float32 device tensor."""
+        sd = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+              for k, v in state_dict.items()}
+        if strict:
+            check_state_dict(sd, self.config)
+        if 'sigmas' in sd:
+            self._sigmas_np = np.asarray(sd['sigmas'], np.float32)
+            self._sigmas = None
+        chunks, off, cur = [], {}, 0
+
+        def add(key, arr):
+            nonlocal cur
+            a = np.ascontiguousarray(arr, dtype=np.float32).ravel()
+            pad = (-cur) % 4                      # keep every tensor 16-byte aligned (float4 loads)
+            if pad:
+                chunks.append(np.zeros(pad, np.float32))
+                cur += pad
+            off[key] = cur
+            chunks.append(a)
+            cur += a.size
+
+        for name, w in sd.items():
+            if name == 'sigmas':
+                continue
+            if name.endswith('.weight') and w.ndim == 4 and name not in ('begin_conv.weight', 'end_conv.weight'):
+                add(name, pack_conv_weight(w))
+            elif name.endswith('.alpha'):
+                pre = name[:-len('.alpha')]
+                add(pre, np.concatenate([sd[pre + '.alpha'], sd[pre + '.gamma'], sd[pre + '.beta']]))
+            elif name.endswith('.gamma') or name.endswith('.beta'):
+                continue
+            else:
+                add(name, w)
+        self._wdev = torch.from_numpy(np.concatenate(chunks)).to(self.device)
+        self._woff = off
+        self._call_cache.clear()
+        self._plans.clear()
+        return self
+
+    # --- binding ----------------------------------------------------------------------------------
+    def score_plan(self, nt, nr):
+        key = (nt, nr)
+        if key not in self._plans:
+            self._plans[key] = P.build_score_plan(self.ngf, nt, nr, self.channels)
+        return self._plans[key]
+
+    def bind(self, B, nt, nr, *, step=None, sigma_of_step=None, use_labels=True):
+        """Allocate buffers for batch ``B`` and translate the plan into ``sbc_op`` records.
+        Noise level source of the end conv: per-sample ``labels`` (module-call semantics) or the device step
+        counter + ``sigma_of_step`` table (inside an ALD plan)."""
+        if self._wdev is None:
+            raise RuntimeError('load_state_dict() must be called before the network is used')
+        pl = self.score_plan(nt, nr)
+        dev = self.device
+        slots = [torch.empty(B * e, dtype=torch.float32, device=dev) for e in pl.slot_elems]
+        labels = torch.zeros(B, dtype=torch.int64, device=dev) if use_labels else None
+        ext = _lib.sbc_endconv(sigmas=_ptr(self.sigmas),
+                               labels=_ptr(labels) if use_labels else None,
+                               sigma_of_step=_ptr(sigma_of_step) if sigma_of_step is not None else None,
+                               step=_ptr(step) if step is not None else None)
+        ops = []
+        for op in pl.ops:
+            o = _lib.sbc_op()
+            o.kind, o.flags, o.B, o.H, o.W = op.kind, op.flags, B, op.src.h, op.src.w
+            o.cin, o.cout, o.ksize, o.dil, o.tag = op.src.c, op.dst.c, op.ksize, op.dil, op.tag
+            o.in_ = _ptr(slots[op.src.slot])
+            o.out = _ptr(slots[op.dst.slot])
+            if op.weight is not None:
+                o.weight = _ptr(self._wdev, self._woff[op.weight])
+            if op.bias is not None:
+                o.bias = _ptr(self._wdev, self._woff[op.bias])
+            if op.stats is not None:
+                o.stats = _ptr(slots[op.stats.slot])
+            if op.res1 is not None:
+                o.res1 = _ptr(slots[op.res1.slot])
+            if op.res2 is not None:
+                o.res2 = _ptr(slots[op.res2.slot])
+            if op.up is not None:
+                o.up, o.up_h, o.up_w = _ptr(slots[op.up.slot]), op.up.h, op.up.w
+            if op.kind == P.END_CONV:
+                o.ext = C.cast(C.pointer(ext), C.c_void_p)
+            ops.append(o)
+        x = slots[pl.x.slot].view(B, nt, nr, self.channels)
+        out = slots[pl.out.slot].view(B, nt, nr, self.channels)
+        return BoundScore(ops, x, out, slots, labels, [ext, self._wdev, self.sigmas, sigma_of_step, step])
+
+    # --- module call --------------------------------------------------------------------------------
+    def __call__(self, x, labels):
+        """``diffuser(current_real, labels)`` (test_score.py:151).  ``x``: float32 ``[B, 2, Nt, Nr]`` (any
+        strides; the permuted ``view_as_real`` of the reference is consumed without a copy kernel beyond the
+        one staging copy), ``labels``: integer ``[B]``.  Returns a fresh ``[B, 2, Nt, Nr]`` tensor (channels-last strides)."""
+        if x.dim() != 4 or x.shape[1] != self.channels:
+            raise ValueError('expected x of shape [B, %d, Nt, Nr], got %s' % (self.channels, tuple(x.shape)))
+        B, _, nt, nr = x.shape
+        key = (B, nt, nr)
+        if key not in self._call_cache:
+            bound = self.bind(B, nt, nr)
+            self._call_cache[key] = (bound, _lib.Plan(bound.ops, keepalive=bound))
+        bound, plan = self._call_cache[key]
+        bound.x.copy_(x.to(self.device, torch.float32).permute(0, 2, 3, 1))
+        bound.labels.copy_(labels.to(self.device).long())
+        plan.run(torch.cuda.current_stream(self.device).cuda_stream)
+        return bound.out.permute(0, 3, 1, 2).clone()
+
+    forward = __call__

@@ -1,0 +1,86 @@
+"""Test helper: execute a ``ScorePlan`` op list on the CPU with the oracle's numpy primitives, honouring the
+physical slot assignment, to check the wiring / fusion rules of plan.py (and the epilogue semantics documented
+in include/sbc_hip.h) against the oracle's straight-line forward.  Test infrastructure only."""
+import numpy as np
+
+from oracle import ncsnv2_oracle as O
+from score_based_channels_amd import plan as P
+
+F32 = np.float32
+
+
+def _nchw(a):
+    return np.ascontiguousarray(a.transpose(0, 3, 1, 2))
+
+
+def _nhwc(a):
+    return np.ascontiguousarray(a.transpose(0, 2, 3, 1))
+
+
+def inorm_stats(x_nhwc, alpha, gamma, beta):
+    """(mu, scale, shift) as the INORM_STATS kernel defines them (normalization.py:163-176)."""
+    x = x_nhwc.astype(F32)
+    mu = x.mean(axis=(1, 2), dtype=F32)                                      # [B, C]
+    var = ((x - mu[:, None, None, :]) ** 2).mean(axis=(1, 2), dtype=F32)
+    m = mu.mean(axis=-1, keepdims=True, dtype=F32)
+    v = mu.var(axis=-1, keepdims=True, ddof=1, dtype=F32)
+    mhat = (mu - m) / np.sqrt(v + F32(1e-5))
+    rstd = F32(1) / np.sqrt(var + F32(1e-5))
+    return np.stack((mu, gamma[None] * rstd, gamma[None] * (mhat * alpha[None]) + beta[None]), axis=1).astype(F32)
+
+
+def run_plan(plan, sd, x_nhwc, labels):
+    B = x_nhwc.shape[0]
+    slots = [None] * len(plan.slot_elems)
+
+    def get(t):
+        a = slots[t.slot]
+        assert a is not None and a.shape == (B, t.h, t.w, t.c), (t.name, None if a is None else a.shape)
+        return a
+
+    slots[plan.x.slot] = x_nhwc.astype(F32)
+    for op in plan.ops:
+        slots[op.dst.slot] = exec_op(op, sd, get, labels)
+    return get(plan.out)
+
+
+def exec_op(op, sd, get, labels):
+    """CPU result (NHWC float32) of one op record; ``get(tensor)`` returns the op's input arrays."""
+    if True:
+        src = get(op.src)
+        if op.kind == P.BEGIN_CONV:
+            out = _nhwc(O.conv2d(_nchw(F32(2) * src - F32(1)), sd[op.weight], sd[op.bias]))
+        elif op.kind == P.INORM_STATS:
+            out = inorm_stats(src, sd[op.weight + '.alpha'], sd[op.weight + '.gamma'],
+                              sd[op.weight + '.beta'])[:, None]               # [B,1,3,C]
+        elif op.kind == P.MAXPOOL5:
+            out = _nhwc(O.max_pool5(_nchw(src)))
+            if op.flags & P.PRO_ELU:
+                out = O.elu(out)
+        elif op.kind in (P.CONV, P.END_CONV):
+            v = src
+            flags = op.flags | ((P.PRO_NORM | P.PRO_ELU) if op.kind == P.END_CONV else 0)
+            if flags & P.PRO_NORM:
+                st = get(op.stats)[:, 0]
+                v = (v - st[:, None, None, 0]) * st[:, None, None, 1] + st[:, None, None, 2]
+            if flags & P.PRO_ELU:
+                v = O.elu(v)
+            out = O.conv2d(_nchw(v), sd[op.weight], sd[op.bias] if op.bias else None, op.dil)
+            if op.kind == P.END_CONV:
+                out = _nhwc(out / np.asarray(sd['sigmas'], F32)[labels].reshape(-1, 1, 1, 1))
+            else:
+                if flags & P.EPI_POOL:
+                    out = O.mean_pool2(out)
+                out = _nhwc(out)
+                if op.res1 is not None:
+                    r = get(op.res1)
+                    if flags & P.EPI_RES1_ELU:
+                        r = O.elu(r)
+                    if op.res2 is not None:
+                        r = get(op.res2) + r
+                    out = out + r
+                if op.up is not None:
+                    out = out + _nhwc(O.bilinear_align_corners(_nchw(get(op.up)), (op.dst.h, op.dst.w)))
+        else:
+            raise AssertionError(op.kind)
+        return out.astype(F32)

@@ -1,0 +1,204 @@
+"""GPU parity of every HIP operator against the CPU oracle's primitives, called through the C ABI
+(``sbc_op_launch``).  Run on the MI355X box: ``python -m pytest tests -m gpu``."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+from oracle import ncsnv2_oracle as O
+from plan_interp import inorm_stats
+
+pytestmark = pytest.mark.gpu
+
+F32 = np.float32
+TOL = 2e-5          # fp32 accumulate in a different order than the oracle's sgemm
+
+
+@pytest.fixture(scope='module')
+def gpu():
+    import torch
+    from score_based_channels_amd import _lib
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    _lib.lib()
+    return torch, _lib
+
+
+def _dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _launch(gpu, op):
+    torch, _lib = gpu
+    _lib.check(_lib.lib().sbc_op_launch(C.byref(op), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+CONV_CASES = [
+    # cin, cout, k, dil, B, H, W, flags-set
+    (32, 32, 3, 1, 3, 64, 16, 'norm_elu_res'),     # ResidualBlock conv2 at full resolution (TM=128 at B=3)
+    (32, 32, 3, 1, 130, 64, 16, 'elu_res'),        # big tile (TM=256) with a partial last wave of samples
+    (32, 32, 3, 1, 5, 32, 8, 'crp2'),              # CRP second conv: res1 with ELU + res2
+    (32, 64, 3, 1, 3, 64, 16, 'norm_elu_pool_res'),  # ConvMeanPool 3x3 + pooled shortcut
+    (32, 64, 1, 1, 3, 64, 16, 'pool'),             # ConvMeanPool 1x1 shortcut
+    (64, 64, 3, 1, 7, 32, 8, 'norm_elu_res'),
+    (64, 64, 3, 1, 600, 32, 8, 'plain'),           # TM=256 with 64 channels
+    (64, 64, 3, 1, 9, 16, 4, 'norm_elu_pool_res'),  # pooling with W=4 (pairs cross half-waves)
+    (64, 64, 1, 1, 9, 16, 4, 'pool'),
+    (64, 64, 3, 2, 21, 8, 2, 'norm_elu'),          # dilated, tiles span several samples, ragged tail
+    (64, 128, 3, 2, 21, 8, 2, 'norm_elu_res'),
+    (128, 128, 3, 4, 19, 8, 2, 'norm_elu_res'),
+    (128, 128, 3, 1, 19, 8, 2, 'crp2'),
+    (128, 64, 3, 1, 19, 8, 2, 'up_same'),          # MSF with same-size second input
+    (64, 64, 3, 1, 6, 16, 4, 'up_2x'),             # MSF with bilinear x2 resize of the second input
+    (64, 32, 3, 1, 6, 32, 8, 'up_2x'),
+    (32, 32, 3, 1, 2, 64, 16, 'up_2x'),
+    (32, 32, 3, 1, 1, 256, 64, 'norm_elu_res'),    # large-array config: row tiles with halo at W=64
+    (64, 64, 3, 1, 1100, 16, 4, 'elu_res'),        # TM=128 variant
+]
+
+
+@pytest.mark.parametrize('cin,cout,k,dil,B,H,W,mode', CONV_CASES)
+def test_conv_matches_oracle(gpu, cin, cout, k, dil, B, H, W, mode):
+    torch, _lib = gpu
+    from score_based_channels_amd import plan as P
+    from score_based_channels_amd.weights import pack_conv_weight
+    rng = np.random.default_rng(hash((cin, cout, k, dil, B, H, W)) % (2 ** 31))
+    x = rng.standard_normal((B, H, W, cin)).astype(F32) * 1.5 + 0.3
+    w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(F32)
+    bias = rng.standard_normal(cout).astype(F32) if 'crp' not in mode else None
+    pool = 'pool' in mode
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    flags = 0
+    v = x
+    stats = None
+    if 'norm' in mode:
+        flags |= P.PRO_NORM
+        stats = inorm_stats(x, (1 + 0.1 * rng.standard_normal(cin)).astype(F32),
+                            (1 + 0.1 * rng.standard_normal(cin)).astype(F32), (0.1 * rng.standard_normal(cin)).astype(F32))
+        v = (v - stats[:, None, None, 0]) * stats[:, None, None, 1] + stats[:, None, None, 2]
+    if 'elu' in mode:
+        flags |= P.PRO_ELU
+        v = O.elu(v)
+    ref = O.conv2d(v.transpose(0, 3, 1, 2), w, bias, dil)
+    if pool:
+        flags |= P.EPI_POOL
+        ref = O.mean_pool2(ref)
+    ref = ref.transpose(0, 2, 3, 1)
+    res1 = res2 = up = None
+    if 'res' in mode:
+        res1 = rng.standard_normal((B, Ho, Wo, cout)).astype(F32)
+        ref = ref + res1
+    if mode == 'crp2':
+        flags |= P.EPI_RES1_ELU
+        res1 = rng.standard_normal((B, Ho, Wo, cout)).astype(F32)
+        res2 = rng.standard_normal((B, Ho, Wo, cout)).astype(F32)
+        ref = ref + (res2 + O.elu(res1))
+    if mode.startswith('up'):
+        flags |= P.EPI_UP
+        uh, uw = (H, W) if mode == 'up_same' else (H // 2, W // 2)
+        up = rng.standard_normal((B, uh, uw, cout)).astype(F32)
+        ref = ref + O.bilinear_align_corners(up.transpose(0, 3, 1, 2), (H, W)).transpose(0, 2, 3, 1)
+
+    d = {k_: _dev(torch, a) for k_, a in dict(x=x, w=pack_conv_weight(w), bias=bias, stats=stats, res1=res1,
+                                              res2=res2, up=up).items() if a is not None}
+    out = torch.full((B, Ho, Wo, cout), float('nan'), dtype=torch.float32, device='cuda')
+    op = _lib.sbc_op(kind=P.CONV, flags=flags, B=B, H=H, W=W, cin=cin, cout=cout, ksize=k, dil=dil,
+                     in_=_p(d['x']), out=_p(out), weight=_p(d['w']))
+    for name in ('bias', 'stats', 'res1', 'res2', 'up'):
+        if name in d:
+            setattr(op, name, _p(d[name]))
+    if up is not None:
+        op.up_h, op.up_w = up.shape[1], up.shape[2]
+    _launch(gpu, op)
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert rel_err(got, ref) < TOL
+
+
+def test_conv_rejects_unsupported_shapes(gpu):
+    torch, _lib = gpu
+    from score_based_channels_amd import plan as P
+    t = torch.zeros(16, device='cuda')
+    op = _lib.sbc_op(kind=P.CONV, B=1, H=8, W=8, cin=48, cout=32, ksize=3, dil=1, in_=_p(t), out=_p(t), weight=_p(t))
+    rc = _lib.lib().sbc_op_launch(C.byref(op), None)
+    assert rc == -3 and b'no kernel' in _lib.lib().sbc_last_error()
+    op = _lib.sbc_op(kind=P.CONV, B=1, H=8, W=8, cin=32, cout=32, ksize=5, dil=1, in_=_p(t), out=_p(t), weight=_p(t))
+    assert _lib.lib().sbc_op_launch(C.byref(op), None) == -1
+
+
+@pytest.mark.parametrize('C_,B,H,W', [(32, 5, 64, 16), (64, 3, 32, 8), (64, 4, 16, 4), (128, 7, 8, 2), (32, 1, 256, 64)])
+def test_inorm_stats_matches_oracle(gpu, C_, B, H, W):
+    torch, _lib = gpu
+    from score_based_channels_amd import plan as P
+    rng = np.random.default_rng(C_ + B)
+    x = (rng.standard_normal((B, H, W, C_)) * rng.uniform(0.5, 2, C_) + rng.standard_normal(C_) * 3).astype(F32)
+    agb = np.stack(((1 + 0.1 * rng.standard_normal(C_)), (1 + 0.1 * rng.standard_normal(C_)),
+                    0.1 * rng.standard_normal(C_))).astype(F32)
+    dx, dagb = _dev(torch, x), _dev(torch, agb)
+    out = torch.zeros(B, 3, C_, device='cuda')
+    _launch(gpu, _lib.sbc_op(kind=P.INORM_STATS, B=B, H=H, W=W, cin=C_, cout=C_, in_=_p(dx), out=_p(out), weight=_p(dagb)))
+    ref = inorm_stats(x, agb[0], agb[1], agb[2])
+    got = out.cpu().numpy()
+    # applying both to the data is the meaningful comparison
+    y_ref = (x - ref[:, None, None, 0]) * ref[:, None, None, 1] + ref[:, None, None, 2]
+    y_got = (x - got[:, None, None, 0]) * got[:, None, None, 1] + got[:, None, None, 2]
+    assert rel_err(y_got, y_ref) < 1e-5
+    assert rel_err(y_ref, O.instance_norm_plus(x.transpose(0, 3, 1, 2), agb[0], agb[1], agb[2]).transpose(0, 2, 3, 1)) < 1e-5
+
+
+@pytest.mark.parametrize('C_,B,H,W,elu', [(32, 3, 64, 16, True), (64, 5, 16, 4, False), (128, 9, 8, 2, True)])
+def test_maxpool5_matches_oracle(gpu, C_, B, H, W, elu):
+    torch, _lib = gpu
+    from score_based_channels_amd import plan as P
+    x = np.random.default_rng(3).standard_normal((B, H, W, C_)).astype(F32)
+    dx = _dev(torch, x)
+    out = torch.zeros_like(dx)
+    _launch(gpu, _lib.sbc_op(kind=P.MAXPOOL5, flags=P.PRO_ELU if elu else 0, B=B, H=H, W=W, cin=C_, cout=C_,
+                             in_=_p(dx), out=_p(out)))
+    ref = O.max_pool5(x.transpose(0, 3, 1, 2)).transpose(0, 2, 3, 1)
+    ref = O.elu(ref) if elu else ref
+    assert rel_err(out.cpu().numpy(), ref) < 1e-6
+
+
+@pytest.mark.parametrize('B,H,W', [(3, 64, 16), (1, 256, 64), (5, 8, 8)])
+def test_begin_conv_matches_oracle(gpu, B, H, W):
+    torch, _lib = gpu
+    from score_based_channels_amd import plan as P
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((B, H, W, 2)).astype(F32)
+    w = (rng.standard_normal((32, 2, 3, 3)) / 4).astype(F32)
+    b = rng.standard_normal(32).astype(F32)
+    dx, dw, db = _dev(torch, x), _dev(torch, w), _dev(torch, b)
+    out = torch.zeros(B, H, W, 32, device='cuda')
+    _launch(gpu, _lib.sbc_op(kind=P.BEGIN_CONV, B=B, H=H, W=W, cin=2, cout=32, ksize=3, dil=1, in_=_p(dx), out=_p(out),
+                             weight=_p(dw), bias=_p(db)))
+    ref = O.conv2d((2 * x - 1).transpose(0, 3, 1, 2), w, b).transpose(0, 2, 3, 1)
+    assert rel_err(out.cpu().numpy(), ref) < 1e-5
+
+
+@pytest.mark.parametrize('B,H,W', [(5, 64, 16), (1, 256, 64), (40, 8, 8)])
+def test_end_conv_matches_oracle(gpu, B, H, W):
+    torch, _lib = gpu
+    from score_based_channels_amd import plan as P
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((B, H, W, 32)).astype(F32)
+    agb = np.stack(((1 + 0.1 * rng.standard_normal(32)), (1 + 0.1 * rng.standard_normal(32)),
+                    0.1 * rng.standard_normal(32))).astype(F32)
+    stats = inorm_stats(x, agb[0], agb[1], agb[2])
+    w = (rng.standard_normal((2, 32, 3, 3)) / 17).astype(F32)
+    b = rng.standard_normal(2).astype(F32)
+    sigmas = np.exp(np.linspace(np.log(39.15), np.log(3.6e-4), 50)).astype(F32)
+    labels = rng.integers(0, 50, B)
+    d = [_dev(torch, a) for a in (x, stats, w, b, sigmas, labels.astype(np.int64))]
+    out = torch.zeros(B, H, W, 2, device='cuda')
+    ext = _lib.sbc_endconv(sigmas=_p(d[4]), labels=_p(d[5]))
+    _launch(gpu, _lib.sbc_op(kind=P.END_CONV, B=B, H=H, W=W, cin=32, cout=2, ksize=3, dil=1, in_=_p(d[0]), out=_p(out),
+                             weight=_p(d[2]), bias=_p(d[3]), stats=_p(d[1]), ext=C.cast(C.pointer(ext), C.c_void_p)))
+    v = O.elu((x - stats[:, None, None, 0]) * stats[:, None, None, 1] + stats[:, None, None, 2])
+    ref = O.conv2d(v.transpose(0, 3, 1, 2), w, b).transpose(0, 2, 3, 1) / sigmas[labels][:, None, None, None]
+    assert rel_err(out.cpu().numpy(), ref) < 1e-5

@@ -1,0 +1,199 @@
+"""GPU parity of the whole hot path (score network, Langevin loop) against the golden fixtures produced by the
+reference (tests/gen_golden.py) and against the CPU oracle, through the C ABI.  ``pytest -m gpu``."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+from plan_interp import exec_op
+
+pytestmark = pytest.mark.gpu
+
+NMSE_RTOL = 1e-5      # BASELINE.json north_star: NMSE within 1e-5 relative of the reference
+
+
+@pytest.fixture(scope='module')
+def net64(weights64):
+    import torch
+    from score_based_channels_amd.scorenet import ScoreNet
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    cfg, sd = weights64
+    return ScoreNet(cfg).cuda().load_state_dict(sd).eval()
+
+
+def test_forward_every_op_matches_cpu_interpretation(net64, weights64):
+    """Run the bound plan one launch at a time; after each launch compare its output with the CPU
+    interpretation of the same record fed with the GPU's own inputs (errors cannot accumulate)."""
+    import torch
+    from score_based_channels_amd import _lib
+    _, sd = weights64
+    g = load_golden('forward_64x16.npz')
+    B = 3
+    bound = net64.bind(B, 64, 16)
+    pl = net64.score_plan(64, 16)
+    bound.x.copy_(torch.from_numpy(g['x'][:B]).permute(0, 2, 3, 1))
+    labels = np.array([0, 1155, 2310])
+    bound.labels.copy_(torch.from_numpy(labels))
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    bad = []
+    for op, rec in zip(pl.ops, bound.ops):
+        def get(t):
+            return bound.slots[t.slot].view(B, t.h, t.w, t.c).cpu().numpy()
+        ref = exec_op(op, sd, get, labels)
+        _lib.check(_lib.lib().sbc_op_launch(C.byref(rec), stream))
+        torch.cuda.synchronize()
+        got = get(op.dst)
+        err = rel_err(got, ref) if np.isfinite(got).all() else float('inf')
+        if err > 5e-5:
+            bad.append((op.name, err))
+    assert not bad, bad[:10]
+
+
+def test_forward_matches_reference_golden(net64):
+    import torch
+    g = load_golden('forward_64x16.npz')
+    x = torch.from_numpy(g['x']).cuda()
+    for i, lv in enumerate(g['levels']):
+        out = net64(x, torch.full((4,), int(lv), dtype=torch.long, device='cuda'))
+        assert tuple(out.shape) == (4, 2, 64, 16)
+        assert rel_err(out.cpu().numpy(), g['out'][i]) < 2e-5, lv
+
+
+def test_forward_accepts_reference_call_pattern(net64):
+    """test_score.py:149-154: permuted view_as_real in, permute + contiguous + view_as_complex out."""
+    import torch
+    g = load_golden('forward_64x16.npz')
+    cur = torch.from_numpy(np.ascontiguousarray(g['x'].transpose(0, 2, 3, 1))).cuda()
+    current = torch.view_as_complex(cur)
+    current_real = torch.view_as_real(current).permute(0, 3, 1, 2)
+    labels = (torch.ones(4).cuda() * 1155).long()
+    score = net64(current_real, labels)
+    score = torch.view_as_complex(score.permute(0, 2, 3, 1).contiguous())
+    ref = g['out'][1][:, 0] + 1j * g['out'][1][:, 1]
+    assert rel_err(score.cpu().numpy(), ref) < 2e-5
+    assert net64.sigmas.dtype == torch.float32 and net64.sigmas.shape == (2311,)
+    assert abs(net64.sigmas[0].item() - 39.15) < 1e-5
+
+
+def _run_golden_ald(net, g, use_graph=False):
+    """All SNR points of a golden case as one lock-step batch, replaying the golden's keyed noise."""
+    import torch
+    from score_based_channels_amd.ald import AldBatch, snr_to_noise
+    from score_based_channels_amd.noise import HostNoise
+    H, P = g['H'], g['P']
+    B, nt, nr = H.shape
+    S = len(g['snr_db'])
+    levels = [int(v) for v in g['levels']]
+    n_steps = len(levels) * int(g['steps_each'])
+    noise = HostNoise(int(g['seed']))
+    ln = np.repeat(snr_to_noise(g['snr_db'], nt), B)
+    idx = np.tile(np.arange(B), S)
+    step_noise = np.concatenate([noise.step_block(s, H.shape, n_steps) for s in range(S)], axis=1)
+    ald = AldBatch(net, H, P, idx, idx, ln, alpha_step=float(g['alpha_step']), beta_noise=float(g['beta_noise']),
+                   levels=levels, steps_each=int(g['steps_each']), step_noise=torch.from_numpy(step_noise))
+    ald.set_init(torch.from_numpy(np.tile(noise.init(H.shape), (S, 1, 1))))
+    meas = np.concatenate([noise.measurement(s, g['Y'][s].shape) for s in range(S)], axis=0)
+    Y = ald.synthesize_measurements(torch.from_numpy(meas))
+    ald.run(use_graph=use_graph)
+    torch.cuda.synchronize()
+    log = ald.nmse_log().cpu().numpy().reshape(n_steps, S, B).transpose(1, 0, 2)
+    X = ald.X.cpu().numpy().reshape(S, B, nt, nr)
+    return Y.cpu().numpy().reshape(S, B, -1, nr), X, log
+
+
+@pytest.mark.parametrize('name', ['ald_plumbing_level0.npz', 'ald_plumbing_3levels.npz', 'ald_trunc.npz',
+                                  'ald_trunc_cell.npz'])
+def test_ald_matches_reference_golden(net64, name):
+    g = load_golden(name)
+    Y, X, log = _run_golden_ald(net64, g)
+    assert rel_err(Y, g['Y']) < 1e-6
+    assert np.max(np.abs(log / g['nmse_log'] - 1)) < NMSE_RTOL
+    assert rel_err(X, g['X_final']) < 1e-5
+
+
+def test_ald_full_schedule_matches_reference_golden(net64):
+    """All 2311 x 3 = 6933 Langevin steps (BASELINE config: full noise-level schedule)."""
+    g = load_golden('ald_full.npz')
+    _, X, log = _run_golden_ald(net64, g)
+    assert log.shape[1] == 6933
+    assert np.max(np.abs(log / g['nmse_log'] - 1)) < NMSE_RTOL
+    avg = log.mean(-1)
+    assert np.max(np.abs(avg.min(-1) / g['nmse_log'].mean(-1).min(-1) - 1)) < NMSE_RTOL
+    assert rel_err(X, g['X_final']) < 1e-5
+
+
+def test_ald_graph_replay_equals_eager(net64):
+    g = load_golden('ald_trunc_cell.npz')
+    _, X0, log0 = _run_golden_ald(net64, g, use_graph=False)
+    _, X1, log1 = _run_golden_ald(net64, g, use_graph=True)
+    assert np.array_equal(log0, log1) and np.array_equal(X0, X1)
+
+
+def test_langevin_kernel_matches_oracle_step(net64):
+    """Data-consistency gradient + update + NMSE alone (score supplied), vs oracle/ald_oracle.py."""
+    import torch
+    from oracle import ald_oracle as A
+    from score_based_channels_amd import _lib, plan as P
+    rng = np.random.default_rng(12)
+    T, nt, nr, npil = 6, 64, 16, 38
+
+    def cn(*s):
+        return (rng.standard_normal(s) + 1j * rng.standard_normal(s)).astype(np.complex64)
+    X, S, H, Y, Pm, nz = cn(T, nt, nr), cn(T, nt, nr), cn(T, nt, nr), cn(T, npil, nr), cn(T, npil, nt) / 8, cn(T, nt, nr)
+    sched = np.array([[[0.3, 7.0, 0.05, 0]], [[1e-3, 0.2, 0.01, 0]]], np.float32)
+    group = np.array([0, 1, 0, 1, 1, 0], np.int32)
+    d = {k: torch.from_numpy(v).cuda() for k, v in dict(X=X, S=S, H=H, Y=Y, P=Pm, nz=nz[None], sched=sched, group=group).items()}
+    nm = torch.zeros(1, T, device='cuda')
+    step = torch.zeros(1, dtype=torch.int32, device='cuda')
+    r = torch.view_as_real
+    ext = _lib.sbc_langevin(X=r(d['X']).data_ptr(), score=r(d['S']).data_ptr(), P=r(d['P']).data_ptr(),
+                            Y=r(d['Y']).data_ptr(), Htrue=r(d['H']).data_ptr(), sched=d['sched'].data_ptr(),
+                            group=d['group'].data_ptr(), noise=r(d['nz']).data_ptr(), nmse=nm.data_ptr(),
+                            step=step.data_ptr(), n_steps=1, Nt=nt, Nr=nr, Np=npil)
+    op = _lib.sbc_op(kind=P.LANGEVIN, B=T, ext=C.cast(C.pointer(ext), C.c_void_p))
+    _lib.check(_lib.lib().sbc_op_launch(C.byref(op), None))
+    torch.cuda.synchronize()
+    for t in range(T):
+        a, dv, ns = sched[group[t], 0, :3]
+        ref = A.langevin_step(X[t:t + 1], S[t:t + 1], Pm[t:t + 1], Y[t:t + 1], a, dv, ns, nz[t:t + 1])
+        assert rel_err(d['X'][t].cpu().numpy(), ref[0]) < 1e-5
+        assert abs(nm[0, t].item() / A.nmse(ref, H[t:t + 1])[0] - 1) < 1e-5
+
+
+def test_philox_noise_statistics_and_batch_independence(net64):
+    """In-kernel noise: CN(0,1) moments, and identical draws for a trajectory wherever it sits in a batch."""
+    import torch
+    from score_based_channels_amd.ald import AldBatch
+    g = load_golden('ald_plumbing_level0.npz')
+    H, P = g['H'], g['P']
+
+    def run(order):
+        ald = AldBatch(net64, H, P, order, order, 64.0, levels=[0], steps_each=2, seed=77, traj_id=order)
+        ald.set_init(torch.zeros(len(order), 64, 16, dtype=torch.complex64))
+        ald.synthesize_measurements()
+        ald.run()
+        torch.cuda.synchronize()
+        return ald.Y.cpu().numpy(), ald.X.cpu().numpy()
+    Ya, Xa = run(np.array([0, 1, 2, 3]))
+    Yb, Xb = run(np.array([3, 1]))
+    assert np.array_equal(Ya[3], Yb[0]) and np.array_equal(Ya[1], Yb[1])
+    assert np.array_equal(Xa[3], Xb[0]) and np.array_equal(Xa[1], Xb[1])
+    n = (Ya - np.matmul(P, H)) / 8.0                       # sqrt(local_noise) = 8
+    assert abs(n.real.var() - 0.5) < 0.05 and abs(n.imag.var() - 0.5) < 0.05 and abs(n.mean()) < 0.05
+
+
+def test_big_array_forward_and_ald(weights64):
+    """256 x 64 antennas (BASELINE config 5 geometry, fp32): forward + 6 Langevin steps vs the reference."""
+    import torch
+    from score_based_channels_amd.config import default_config
+    from score_based_channels_amd.scorenet import ScoreNet
+    from score_based_channels_amd.weights import seeded_state_dict
+    cfg = default_config(image_size=(64, 256))
+    net = ScoreNet(cfg).cuda().load_state_dict(seeded_state_dict(cfg, 2024))
+    g = load_golden('big_256x64.npz')
+    out = net(torch.from_numpy(g['x']).cuda(), torch.full((1,), int(g['level']), dtype=torch.long))
+    assert rel_err(out.cpu().numpy(), g['out']) < 2e-5
+    _, X, log = _run_golden_ald(net, dict(g, steps_each=3, alpha_step=3e-11, beta_noise=0.01))
+    assert np.max(np.abs(log / g['nmse_log'] - 1)) < NMSE_RTOL
+    assert rel_err(X, g['X_final']) < 1e-5
