@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Throughput of the annealed-Langevin channel-estimation hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): CDL-C-like Nt64 x Nr16 channels, pilot fraction 0.6 (38 pilots), batch of
+100 channels x 17 SNR points (-10..30 dB) = 1700 lock-step trajectories per GPU, full schedule of
+2311 noise levels x 3 steps = 6933 Langevin steps per trajectory (test_score.py:56,72,77; train_score.py:42).
+
+A benchmark "step" is ONE Langevin step of the whole 1700-trajectory batch: score network forward (113 convs),
+data-consistency gradient, noise, update, NMSE log.  Every one of the 6933 steps of the schedule is the same
+work (the noise level only changes three scalars), so
+    channels/s = trajectories / (6933 * seconds_per_step)
+is the full-schedule rate; `--full-schedule` walks all 6933 steps instead of K to confirm it.
+
+One process per GPU (torch.distributed / RCCL when WORLD_SIZE > 1): trajectories are independent, each rank
+runs its own 1700 (weak scaling), the only collective is the final gather of the per-step NMSE curves.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+STEPS_PER_CHANNEL = 2311 * 3
+
+
+def cpu_baseline(cfg, sd, n_samples=16, n_steps=2):
+    """The numpy oracle (oracle/, a port of the reference loop) timed on this host: `n_steps` Langevin steps of
+    `n_samples` channels.  Reported, never used by the GPU path."""
+    from oracle import ald_oracle as A, ncsnv2_oracle as O
+    from score_based_channels_amd import synth
+    from score_based_channels_amd.noise import HostNoise
+    nt, nr, npil = 64, 16, 38
+    raw = synth.generate_channels('CDL-C', n_samples, nt, nr, 0.5, 1)
+    H = np.conj(np.transpose(raw / np.std(raw), (0, 2, 1))).astype(np.complex64)
+    P = np.conj(np.transpose(synth.qpsk_pilots(np.random.default_rng(2), n_samples, nt, npil), (0, 2, 1)))
+    noise = HostNoise(3)
+    Y = A.make_measurements(P, H, 64.0, noise.measurement(0, (n_samples, npil, nr)))
+    draw = noise.step_stream(0, H.shape)
+    score = lambda x, lab: O.score_forward(sd, x, lab)                      # noqa: E731
+    A.ald_run(score, sd['sigmas'], cfg.model.sigma_end, P, Y, H, noise.init(H.shape), draw, 64.0, levels=[0],
+              steps_each=1)                                                  # warm-up (BLAS threads, caches)
+    t0 = time.perf_counter()
+    A.ald_run(score, sd['sigmas'], cfg.model.sigma_end, P, Y, H, noise.init(H.shape),
+              noise.step_stream(0, H.shape), 64.0, levels=[0], steps_each=n_steps)
+    dt = (time.perf_counter() - t0) / n_steps
+    return {'value': n_samples / (STEPS_PER_CHANNEL * dt), 'unit': 'channels/s', 'cores': os.cpu_count(),
+            'kind': 'port',
+            'sample': '%d Langevin steps of %d channels with the numpy oracle (%.2f s/step), scaled to the '
+                      '6933-step schedule' % (n_steps, n_samples, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--channels', type=int, default=100, help='channel realisations per GPU (test_score.py:77)')
+    ap.add_argument('--snr-points', type=int, default=17)
+    ap.add_argument('--graph', type=int, default=0, help='replay the step as a hipGraph (no per-kernel timing)')
+    ap.add_argument('--full-schedule', action='store_true', help='time all 6933 steps instead of --steps')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+
+    from score_based_channels_amd import plan as P, synth
+    from score_based_channels_amd.ald import AldBatch, snr_to_noise
+    from score_based_channels_amd.config import default_config
+    from score_based_channels_amd.scorenet import ScoreNet
+    from score_based_channels_amd.weights import seeded_state_dict
+
+    cfg = default_config('CDL-C')
+    sd = seeded_state_dict(cfg, 2024)                     # random-init weights of the reference architecture
+    net = ScoreNet(cfg, 'cuda:%d' % local).load_state_dict(sd)
+    nt, nr, npil = 64, 16, int(np.floor(64 * 0.6))
+    nch, nsnr = args.channels, args.snr_points
+    raw = synth.generate_channels('CDL-C', nch, nt, nr, 0.5, seed=4321 + rank)       # per-rank channel batch
+    H = np.conj(np.transpose(raw / np.std(raw), (0, 2, 1))).astype(np.complex64)
+    pil = synth.qpsk_pilots(np.random.default_rng([4321, rank]), nch, nt, npil)
+    Pm = np.conj(np.transpose(pil, (0, 2, 1)))
+    snr = np.arange(-10, 32.5, 2.5)[:nsnr]
+    T = nch * len(snr)
+    idx = np.tile(np.arange(nch), len(snr))
+    ln = np.repeat(snr_to_noise(snr, nt), nch)
+    traj = rank * T + np.arange(T)
+    ald = AldBatch(net, H, Pm, idx, idx, ln, alpha_step=3e-11, beta_noise=0.01, seed=1234, traj_id=traj)
+    init = torch.randn(nch, nt, nr, dtype=torch.complex64, device=net.device,
+                       generator=torch.Generator(net.device).manual_seed(rank))
+    ald.set_init(init.repeat(len(snr), 1, 1))            # one initial estimate shared by all SNR points (:115)
+    ald.synthesize_measurements()
+
+    K = STEPS_PER_CHANNEL - args.warmup if args.full_schedule else args.steps
+    use_graph = bool(args.graph)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    ald.run(args.warmup, use_graph=use_graph)
+    if not use_graph:
+        ald.plan.profile(P.TAG_CONV_TOP)
+    sync()
+    t0 = time.perf_counter()
+    ald.run(K, use_graph=use_graph)
+    sync()
+    dt = time.perf_counter() - t0
+    kern_ms, kern_n = ald.plan.profile_read() if not use_graph else (0.0, 0)
+    ald.plan.profile(-1)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=net.device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    # the one collective of the path: gather the per-step mean NMSE curves of every rank (RCCL over xGMI)
+    curves = ald.nmse_log()[:args.warmup + K].view(-1, len(snr), nch).mean(-1)
+    t_g = time.perf_counter()
+    if world > 1:
+        gathered = [torch.empty_like(curves) for _ in range(world)]
+        dist.all_gather(gathered, curves)
+        curves = torch.stack(gathered).mean(0)
+    torch.cuda.synchronize()
+    gather_ms = (time.perf_counter() - t_g) * 1e3
+    finite = bool(torch.isfinite(curves).all().item())
+
+    if rank == 0:
+        ms_per_step = dt / K * 1e3
+        value = world * T / (STEPS_PER_CHANNEL * dt / K)
+        flops_fwd = P.count_conv_flops(net.score_plan(nt, nr)) * T          # conv FLOPs of one step on this GPU
+        out = {
+            'metric': 'channels/s full ALD inference, CDL-C Nt64xNr16', 'value': value, 'unit': 'channels/s',
+            'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic (CDL-C-like cluster channels, QPSK pilots, seed-derived random-init weights)',
+            'config': {'workload': 'CDL-C Nt64xNr16, batch=100 channels x 17 SNR points (-10..30 dB) = 1700 '
+                                   'lock-step trajectories per GPU, full 2311x3 schedule',
+                       'trajectories_per_gpu': T, 'steps_per_channel': STEPS_PER_CHANNEL, 'num_pilots': npil,
+                       'step_definition': 'one Langevin step (score forward + DC gradient + update + NMSE) of all '
+                                          'trajectories; channels/s = trajectories / (6933 * s_per_step)',
+                       'full_schedule_timed': bool(args.full_schedule), 'graph_replay': use_graph,
+                       'parallelism': 'independent trajectories sharded over %d GPU(s); one RCCL all_gather of NMSE '
+                                      'curves at the end (%.2f ms)' % (world, gather_ms),
+                       'nmse_finite': finite},
+            'step_conv_tflops': flops_fwd / (ms_per_step * 1e-3) / 1e12,
+        }
+        if kern_n:
+            per_launch = 2.0 * T * nt * nr * 9 * 32 * 32                    # 3x3 conv 32->32 at 64x16, 2*MACs
+            ach = per_launch / (kern_ms / kern_n * 1e-3) / 1e12
+            out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                               'kernel': 'conv_mfma_kernel<32,32,3,...> (3x3 ngf->ngf convs at 64x16; %d launches, '
+                                         'avg %.1f us)' % (kern_n, kern_ms / kern_n * 1e3)}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(cfg, sd)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

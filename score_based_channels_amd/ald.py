@@ -72,9 +72,9 @@ class AldBatch:
         self.np_ = self.P.shape[1]
         if self.P.shape[2] != self.nt:
             raise ValueError('P must be [nP, Np, Nt=%d], got %s' % (self.nt, tuple(self.P.shape)))
-        h_index = np.asarray(h_index, np.int32)
+        h_index = np.array(h_index, np.int32)
         T = self.T = int(h_index.shape[0])
-        p_index = np.broadcast_to(np.asarray(p_index, np.int32), (T,))
+        p_index = np.array(np.broadcast_to(np.asarray(p_index, np.int32), (T,)))
         if h_index.min() < 0 or h_index.max() >= self.H.shape[0] or p_index.min() < 0 or p_index.max() >= self.P.shape[0]:
             raise IndexError('h_index / p_index out of range')
         ln = np.broadcast_to(np.asarray(local_noise, np.float64), (T,))
@@ -101,6 +101,7 @@ class AldBatch:
         self.Y = torch.zeros(T, self.np_, self.nr, dtype=torch.complex64, device=dev)
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self._done = 0
+        self._gstream = None
         self.step_noise = None
         if step_noise is not None:
             self.step_noise = _as_c64(step_noise, dev)
@@ -155,7 +156,17 @@ class AldBatch:
         n = self.n_steps - done if n_steps is None else int(n_steps)
         if n < 0 or done + n > self.n_steps:
             raise ValueError('schedule has %d steps, %d already done, %d requested' % (self.n_steps, done, n))
-        self.plan.run(self._stream(), n, use_graph)
+        if use_graph:
+            # hipGraph capture is not allowed on the legacy default stream: replay on a private stream that is
+            # ordered after / before the caller's current stream
+            cur = torch.cuda.current_stream(self.net.device)
+            if self._gstream is None:
+                self._gstream = torch.cuda.Stream(self.net.device)
+            self._gstream.wait_stream(cur)
+            self.plan.run(self._gstream.cuda_stream, n, True)
+            cur.wait_stream(self._gstream)
+        else:
+            self.plan.run(self._stream(), n, False)
         self._done = done + n
 
     def steps_done(self):

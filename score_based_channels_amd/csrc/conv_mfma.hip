@@ -212,21 +212,30 @@ static int launch_variant(const ConvParams& p, hipStream_t stream) {
     return SBC_OK;
 }
 
-// Tile choice: as many pixels per workgroup as still leaves >= ~2 workgroups per CU (256 CUs).
+// Tile choice: as many pixels per workgroup as still leaves >= ~2 workgroups per CU (256 CUs), subject to the
+// tile fitting the image (whole rows of one sample, or whole samples) and, for pooling, holding whole 2x2 blocks.
 template <int CIN, int COUT, int KS>
 static int launch_sized(const ConvParams& p, hipStream_t stream) {
     constexpr int NB = COUT / 32;
     const int HW = p.H * p.W;
     const long px = p.total_px;
-    const bool fits256 = (256 % p.W == 0) && (HW % 256 == 0 || 256 % HW == 0);
-    const bool fits128 = (128 % p.W == 0) && (HW % 128 == 0 || 128 % HW == 0);
-    if (fits256 && px >= 256L * 512) return launch_variant<CIN, COUT, KS, 2, NB, 4, 1>(p, stream);
+    auto fits = [&](int tm) {
+        return tm % p.W == 0 && (HW % tm == 0 || tm % HW == 0) && (!(p.flags & SBC_EPI_POOL) || tm % (2 * p.W) == 0);
+    };
+    int tm = 0;
+    if (fits(256) && px >= 256L * 512) tm = 256;
+    else if (fits(128) && px >= 128L * 512) tm = 128;
+    else if (fits(64)) tm = 64;
+    else if (fits(128)) tm = 128;
+    else if (fits(256)) tm = 256;
+    SBC_REQUIRE(tm != 0, "conv: no tile of 64/128/256 pixels fits image %dx%d (flags 0x%x)", p.H, p.W, p.flags);
+    if (tm == 256) return launch_variant<CIN, COUT, KS, 2, NB, 4, 1>(p, stream);
     if constexpr (NB >= 2) {
-        if (fits128 && px >= 128L * 512) return launch_variant<CIN, COUT, KS, 2, NB / 2, 2, 2>(p, stream);
+        if (tm == 128) return launch_variant<CIN, COUT, KS, 2, NB / 2, 2, 2>(p, stream);
         if constexpr (NB >= 4) return launch_variant<CIN, COUT, KS, 2, 1, 1, 4>(p, stream);
         else return launch_variant<CIN, COUT, KS, 1, 1, 2, 2>(p, stream);
     } else {
-        if (fits128 && px >= 128L * 512) return launch_variant<CIN, COUT, KS, 1, 1, 4, 1>(p, stream);
+        if (tm == 128) return launch_variant<CIN, COUT, KS, 1, 1, 4, 1>(p, stream);
         return launch_variant<CIN, COUT, KS, 1, 1, 2, 1>(p, stream);
     }
 }
