@@ -11,38 +11,48 @@ namespace sbc {
 __global__ __launch_bounds__(256) void begin_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ out,
                                                           int B, int H, int W, int cout) {
-    extern __shared__ float wl[];   // [cout][18] torch order [co][ci][kh][kw]
-    for (int i = threadIdx.x; i < cout * 18; i += 256) wl[i] = w[i];
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [18][cout]: k = ci*9 + kh*3 + kw
+    for (int i = threadIdx.x; i < cout * 18; i += 256) {
+        const int co = i / 18, k = i - co * 18;                  // torch order [co][ci][kh][kw]
+        wl[k * cout + co] = w[i];
+    }
     __syncthreads();
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const long total = (long)B * H * W * cout;
-    if (idx >= total) return;
-    const int co = idx % cout;
-    const long px = idx / cout;
+    const int C4 = cout >> 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;       // (pixel, channel quad)
+    if (idx >= (long)B * H * W * C4) return;
+    const int c4 = idx % C4;
+    const long px = idx / C4;
     const int wq = px % W;
     const long row = px / W;
     const int h = row % H;
-    float acc = 0.f;
+    float4 acc = *reinterpret_cast<const float4*>(bias + c4 * 4);
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
-        const int hh = h + kh - 1;
-        if (hh < 0 || hh >= H) continue;
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
-            const int ww = wq + kw - 1;
-            if (ww < 0 || ww >= W) continue;
-            const float2 v = *reinterpret_cast<const float2*>(x + ((row + kh - 1) * W + ww) * 2);
-            acc = fmaf(wl[co * 18 + kh * 3 + kw], 2.f * v.x - 1.f, acc);
-            acc = fmaf(wl[co * 18 + 9 + kh * 3 + kw], 2.f * v.y - 1.f, acc);
+            const int hh = h + kh - 1, ww = wq + kw - 1;
+            float2 v = make_float2(0.f, 0.f);                    // zero padding applies to h = 2x - 1
+            if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
+                v = *reinterpret_cast<const float2*>(x + ((row + kh - 1) * W + ww) * 2);
+                v.x = 2.f * v.x - 1.f;
+                v.y = 2.f * v.y - 1.f;
+            }
+            const float4 w0 = *reinterpret_cast<const float4*>(wl + (kh * 3 + kw) * cout + c4 * 4);
+            const float4 w1 = *reinterpret_cast<const float4*>(wl + (9 + kh * 3 + kw) * cout + c4 * 4);
+            acc.x = fmaf(w0.x, v.x, fmaf(w1.x, v.y, acc.x));
+            acc.y = fmaf(w0.y, v.x, fmaf(w1.y, v.y, acc.y));
+            acc.z = fmaf(w0.z, v.x, fmaf(w1.z, v.y, acc.z));
+            acc.w = fmaf(w0.w, v.x, fmaf(w1.w, v.y, acc.w));
         }
     }
-    out[idx] = acc + bias[co];
+    *reinterpret_cast<float4*>(out + idx * 4) = acc;
 }
 
 int launch_begin_conv(const sbc_op& op, hipStream_t stream) {
     SBC_REQUIRE(op.in && op.out && op.weight && op.bias, "begin_conv: in/out/weight/bias must be set");
-    SBC_REQUIRE(op.cin == 2 && op.cout > 0 && op.cout <= 256, "begin_conv: cin=%d cout=%d", op.cin, op.cout);
-    const long total = (long)op.B * op.H * op.W * op.cout;
+    SBC_REQUIRE(op.cin == 2 && op.cout > 0 && op.cout <= 256 && op.cout % 4 == 0, "begin_conv: cin=%d cout=%d", op.cin,
+                op.cout);
+    const long total = (long)op.B * op.H * op.W * (op.cout / 4);
     const int grid = (int)((total + 255) / 256);
     hipLaunchKernelGGL(begin_conv_kernel, dim3(grid), dim3(256), op.cout * 18 * sizeof(float), stream,
                        (const float*)op.in, (const float*)op.weight, (const float*)op.bias, (float*)op.out, op.B,
@@ -117,9 +127,11 @@ __global__ __launch_bounds__(256) void inorm_stats_kernel(const float* __restric
     __syncthreads();
     if (tid < C) {
         float m = 0.f;
+#pragma unroll 8
         for (int c = 0; c < C; ++c) m += mean_s[c];
         m *= 1.f / (float)C;
         float v = 0.f;
+#pragma unroll 8
         for (int c = 0; c < C; ++c) { const float d = mean_s[c] - m; v = fmaf(d, d, v); }
         v *= 1.f / (float)(C - 1);
         const float mhat = (mean_s[tid] - m) / sqrtf(v + 1e-5f);
@@ -206,6 +218,7 @@ __global__ __launch_bounds__(256) void end_conv_kernel(const float* __restrict__
     if (px >= B * H * W) return;
     const int row = px / W, wq = px - row * W, h = row % H;
     float a0 = 0.f, a1 = 0.f;
+#pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
         const int hh = h + tap / 3 - 1, ww = wq + tap % 3 - 1;
         const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;

@@ -1,0 +1,56 @@
+"""Shared driver of the two inference scripts: shard a list of lock-step trajectories over the ranks, run
+them through ``AldBatch`` (in chunks that fit the device), gather the NMSE logs.
+
+Replaces the triple loop of ``test_score.py:118-171`` / ``tune_hparams_score.py:100-148`` (SNR point -> noise
+level -> inner step, one host synchronisation per step) by one asynchronous ``plan.run`` per chunk.
+"""
+import numpy as np
+import torch
+
+from . import shard
+from .ald import AldBatch
+
+
+def level_subset(num_classes, stride=1, num_levels=None):
+    """Noise levels to walk: all of them (reference behaviour), every ``stride``-th plus the last one, or the
+    first ``num_levels``.  Truncation is an addition of this build for quick runs; it is never applied silently."""
+    levels = list(range(0, num_classes, max(1, int(stride))))
+    if levels[-1] != num_classes - 1:
+        levels.append(num_classes - 1)
+    if num_levels is not None:
+        levels = levels[:int(num_levels)]
+    return levels
+
+
+def shared_init(n_channels, nt, nr, seed, combo):
+    """``init_val_H = torch.randn_like(val_H)`` (test_score.py:115): one CN(0,1) draw per channel, shared by all
+    SNR points of a combination.  CPU generator keyed by (seed, combo) => independent of sharding."""
+    g = torch.Generator().manual_seed((int(seed) * 1000003 + int(combo)) % (2 ** 63 - 1))
+    return torch.randn(n_channels, nt, nr, dtype=torch.complex64, generator=g)
+
+
+def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, beta_noise, levels, steps_each,
+                     seed, init, traj_base=0, max_batch=4096, use_graph=True, rank=0, world=1):
+    """Run ``T = len(h_index)`` trajectories, sharded over ``world`` ranks; returns the full NMSE log
+    ``[n_steps, T]`` (float32 numpy, identical on every rank).  ``init``: ``[nH, Nt, Nr]`` complex64 initial
+    estimates indexed by ``h_index``.  Trajectory ``t`` draws its noise from Philox stream ``traj_base + t``."""
+    h_index = np.asarray(h_index, np.int64)
+    T = len(h_index)
+    bc = lambda a: np.broadcast_to(np.asarray(a), (T,))            # noqa: E731
+    p_index, local_noise, alpha_step, beta_noise = bc(p_index), bc(local_noise), bc(alpha_step), bc(beta_noise)
+    lo, hi = shard.my_block(T, rank, world)
+    n_steps = len(levels) * steps_each
+    local = torch.zeros(n_steps, hi - lo, dtype=torch.float32, device=net.device)
+    for c0 in range(lo, hi, max_batch):
+        c1 = min(hi, c0 + max_batch)
+        sl = slice(c0, c1)
+        ald = AldBatch(net, Htrue, P, h_index[sl], p_index[sl], local_noise[sl], alpha_step[sl], beta_noise[sl],
+                       levels=levels, steps_each=steps_each, seed=seed, traj_id=traj_base + np.arange(c0, c1))
+        ald.set_init(init[torch.from_numpy(h_index[sl])])
+        ald.synthesize_measurements()
+        ald.run(use_graph=use_graph)
+        local[:, c0 - lo:c1 - lo] = ald.nmse_log()
+        del ald
+    torch.cuda.synchronize(net.device)
+    full = shard.gather_trajectory_logs(local, T, rank, world)
+    return full.cpu().numpy()

@@ -1,0 +1,62 @@
+"""Sharding of independent annealed-Langevin trajectories over the GPUs of one node.
+
+The reference is single-GPU (``CUDA_VISIBLE_DEVICES``, test_score.py:29-30).  Trajectories -- (channel, SNR
+point, (alpha, beta) cell, test profile) combinations -- never interact, so each rank runs a
+contiguous block of the flattened trajectory list with a full weight replica, and the only exchange is one
+``all_gather`` of the NMSE logs at the end (``torch.distributed``; backend ``nccl`` = RCCL over xGMI on the GPU
+box, ``gloo`` in the CPU tests).  Noise streams are keyed by global trajectory id, so results do not depend on
+the world size.
+"""
+import os
+
+import numpy as np
+
+
+def dist_info():
+    """(rank, world_size, local_rank) from the torchrun environment (1-process defaults)."""
+    return (int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1')),
+            int(os.environ.get('LOCAL_RANK', '0')))
+
+
+def init_distributed(backend=None):
+    """Initialise ``torch.distributed`` when launched with WORLD_SIZE > 1; returns (rank, world, local_rank)."""
+    rank, world, local = dist_info()
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            if backend is None:
+                backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            kw = {'device_id': torch.device('cuda', local)} if backend == 'nccl' else {}
+            dist.init_process_group(backend, **kw)
+    return rank, world, local
+
+
+def block_bounds(n_items, world):
+    """Boundaries of ``world`` contiguous, near-equal blocks of ``range(n_items)``: rank r owns
+    ``[b[r], b[r+1])``; the first ``n_items % world`` ranks get one extra item."""
+    q, r = divmod(int(n_items), int(world))
+    sizes = np.array([q + (1 if i < r else 0) for i in range(world)], np.int64)
+    return np.concatenate(([0], np.cumsum(sizes)))
+
+
+def my_block(n_items, rank, world):
+    b = block_bounds(n_items, world)
+    return int(b[rank]), int(b[rank + 1])
+
+
+def gather_trajectory_logs(local_log, n_items, rank, world):
+    """All-gather per-rank NMSE logs ``[n_steps, T_local]`` into the full ``[n_steps, n_items]`` log (every rank
+    gets it).  Blocks are padded to equal width because the collective needs equal shapes."""
+    import torch
+    if world == 1:
+        return local_log
+    import torch.distributed as dist
+    b = block_bounds(n_items, world)
+    width = int(np.max(np.diff(b)))
+    n_steps = local_log.shape[0]
+    pad = torch.zeros(n_steps, width, dtype=local_log.dtype, device=local_log.device)
+    pad[:, :local_log.shape[1]] = local_log
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    return torch.cat([parts[r][:, :int(b[r + 1] - b[r])] for r in range(world)], dim=1)

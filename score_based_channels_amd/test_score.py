@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""Score-based channel estimation over an SNR sweep -- counterpart of
+``src/score_based_channels/test_score.py`` with the sampling loop on the MI355X HIP path.
+
+    python -m score_based_channels_amd.test_score --train CDL-C --test CDL-C --spacing 0.5 --pilot_alpha 0.6
+
+Same arguments, input files (``./models/score/<train>/final_model.pt``, ``./data/*.mat``) and outputs
+(``./results/score/train-<train>_test-<test>/results.{pt,png}``, same dictionary keys and array shapes) as the
+reference (test_score.py:15-22,33-36,83,187-200).  Additions, all default-off: ``--seed`` (the reference never
+seeds its RNG), ``--levels_stride/--num_levels`` (truncated schedules), ``--num_channels``, ``--synthetic`` /
+``--synthetic_weights`` (stand-ins for the undistributed blobs), multi-GPU via ``torch.distributed.run``.
+All 17 SNR points run as one lock-step batch (they are independent: each restarts from the same initial
+estimate, test_score.py:126).
+"""
+import argparse
+import copy
+import itertools
+import os
+
+import numpy as np
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpu', type=int, default=0)
+    p.add_argument('--train', type=str, default='CDL-C')
+    p.add_argument('--test', type=str, default='CDL-C')
+    p.add_argument('--save_channels', type=int, default=0)
+    p.add_argument('--spacing', nargs='+', type=float, default=[0.5])
+    p.add_argument('--pilot_alpha', nargs='+', type=float, default=[0.6])
+    # additions of this build
+    p.add_argument('--seed', type=int, default=None, help='seed of every noise stream (default: fresh entropy)')
+    p.add_argument('--levels_stride', type=int, default=1, help='walk every k-th noise level (+ the last)')
+    p.add_argument('--num_levels', type=int, default=None, help='walk only the first n selected levels')
+    p.add_argument('--num_channels', type=int, default=100)
+    p.add_argument('--synthetic', action='store_true', help='generate CDL-like channels instead of reading ./data')
+    p.add_argument('--synthetic_weights', type=int, default=None, metavar='SEED',
+                   help='seed-derived random weights instead of ./models/score/<train>/final_model.pt')
+    p.add_argument('--no_plot', action='store_true')
+    p.add_argument('--no_graph', action='store_true', help='launch kernels eagerly instead of hipGraph replay')
+    return p.parse_args(argv)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    import torch
+    from . import shard
+    from .checkpoint import load_checkpoint
+    from .config import default_config
+    from .driver import level_subset, run_trajectories, shared_init
+    from .loaders import Channels
+    from .scorenet import ScoreNet
+    from .weights import seeded_state_dict
+
+    rank, world, local = shard.init_distributed()
+    device = 'cuda:%d' % (local if world > 1 else args.gpu)
+    torch.cuda.set_device(device)
+
+    if args.synthetic_weights is not None:
+        config = default_config(args.train)
+        model_state = seeded_state_dict(config, args.synthetic_weights)
+    else:
+        contents = load_checkpoint(os.path.join('./models/score/%s' % args.train, 'final_model.pt'))
+        config, model_state = contents['config'], contents['model_state']
+    alpha_step, beta_noise = 3e-11, 0.01                  # all profiles, test_score.py:39-54
+    config.sampling.steps_each = 3                        # :56
+    diffuser = ScoreNet(config, device).load_state_dict(model_state).eval()
+
+    seed = int.from_bytes(os.urandom(4), 'little') if args.seed is None else args.seed
+    if world > 1:                                         # every rank must use rank 0's seed
+        t = torch.tensor([seed], dtype=torch.int64, device=device)
+        torch.distributed.broadcast(t, 0)
+        seed = int(t.item())
+    np.random.seed(seed % (2 ** 32))                      # pilots come from numpy's legacy global RNG (loaders.py:52-55)
+
+    train_seed, val_seed = 1234, 4321
+    config.data.channel = args.train
+    dataset = Channels(train_seed, config, norm=config.data.norm_channels, synthetic=args.synthetic)
+
+    snr_range = np.arange(-10, 32.5, 2.5)
+    spacing_range = np.asarray(args.spacing)
+    pilot_alpha_range = np.asarray(args.pilot_alpha)
+    nt = config.data.image_size[1]
+    noise_range = 10 ** (-snr_range / 10.) * nt
+    num_channels = args.num_channels
+    levels = level_subset(config.model.num_classes, args.levels_stride, args.num_levels)
+    n_steps = len(levels) * config.sampling.steps_each
+    nmse_log = np.zeros((len(spacing_range), len(pilot_alpha_range), len(snr_range), n_steps, num_channels))
+    result_dir = './results/score/train-%s_test-%s' % (args.train, args.test)
+    if rank == 0:
+        os.makedirs(result_dir, exist_ok=True)
+
+    val_config = None
+    for meta_idx, (spacing, pilot_alpha) in enumerate(itertools.product(spacing_range, pilot_alpha_range)):
+        spacing_idx, pilot_alpha_idx = np.unravel_index(meta_idx, (len(spacing_range), len(pilot_alpha_range)))
+        val_config = copy.deepcopy(config)
+        val_config.data.channel = args.test
+        val_config.data.spacing_list = [spacing]
+        val_config.data.num_pilots = int(np.floor(nt * pilot_alpha))
+        val_dataset = Channels(val_seed, val_config, norm=[dataset.mean, dataset.std], synthetic=args.synthetic)
+        if rank == 0:
+            print('There are %d validation channels' % len(val_dataset))
+        sample = val_dataset.batch(num_channels)                        # first batch, shuffle=False (:102-108)
+        val_P = np.conj(np.transpose(sample['P'], (0, 2, 1)))           # Hermitian pilots [B, Np, Nt] (:109-111)
+        val_H = sample['H_herm'][:, 0] + 1j * sample['H_herm'][:, 1]     # [B, Nt, Nr] (:112-113)
+        nr = val_H.shape[-1]
+        init = shared_init(num_channels, nt, nr, seed, meta_idx)        # one init for all SNR points (:115,126)
+        S = len(snr_range)
+        idx = np.tile(np.arange(num_channels), S)                       # trajectory t = snr * B + channel
+        log = run_trajectories(diffuser, val_H, val_P, idx, idx, np.repeat(noise_range, num_channels), alpha_step,
+                               beta_noise, levels, config.sampling.steps_each, seed, init,
+                               traj_base=meta_idx * S * num_channels, use_graph=not args.no_graph,
+                               rank=rank, world=world)
+        nmse_log[spacing_idx, pilot_alpha_idx] = log.reshape(n_steps, S, num_channels).transpose(1, 0, 2)
+
+    avg_nmse = np.mean(nmse_log, axis=-1)                 # :174
+    best_nmse = np.min(avg_nmse, axis=-1)                 # :175  (best stopping step per SNR)
+    if rank == 0:
+        if not args.no_plot:
+            try:
+                import matplotlib
+                matplotlib.use('Agg')
+                from matplotlib import pyplot as plt
+                plt.rcParams['font.size'] = 14
+                plt.figure(figsize=(10, 10))
+                for alpha_idx, local_alpha in enumerate(pilot_alpha_range):
+                    plt.plot(snr_range, 10 * np.log10(best_nmse[0, alpha_idx]), linewidth=4,
+                             label='Alpha=%.2f' % local_alpha)
+                plt.grid(); plt.legend()
+                plt.title('Score-based channel estimation')
+                plt.xlabel('SNR [dB]'); plt.ylabel('NMSE [dB]')
+                plt.tight_layout()
+                plt.savefig(os.path.join(result_dir, 'results.png'), dpi=300, bbox_inches='tight')
+                plt.close()
+            except ImportError:
+                print('matplotlib not available: skipping results.png')
+        torch.save({'nmse_log': nmse_log, 'avg_nmse': avg_nmse, 'best_nmse': best_nmse,
+                    'spacing_range': spacing_range, 'pilot_alpha_range': pilot_alpha_range, 'snr_range': snr_range,
+                    'val_config': val_config, 'seed': seed, 'levels': np.asarray(levels)},
+                   os.path.join(result_dir, 'results.pt'))
+        print('best NMSE [dB] per SNR:', np.round(10 * np.log10(best_nmse[0, 0]), 2))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return nmse_log, avg_nmse, best_nmse
+
+
+if __name__ == '__main__':
+    main()

@@ -197,3 +197,36 @@ def test_big_array_forward_and_ald(weights64):
     _, X, log = _run_golden_ald(net, dict(g, steps_each=3, alpha_step=3e-11, beta_noise=0.01))
     assert np.max(np.abs(log / g['nmse_log'] - 1)) < NMSE_RTOL
     assert rel_err(X, g['X_final']) < 1e-5
+
+
+def test_cli_test_score_drop_in_outputs(net64, tmp_path, monkeypatch):
+    """``python -m score_based_channels_amd.test_score`` keeps the reference's result file (test_score.py:192-200)."""
+    import torch
+    from score_based_channels_amd import test_score
+    monkeypatch.chdir(tmp_path)
+    argv = ['--synthetic', '--synthetic_weights', '2024', '--num_levels', '2', '--num_channels', '4', '--seed', '3',
+            '--no_plot']
+    nmse_log, avg, best = test_score.main(argv)
+    assert nmse_log.shape == (1, 1, 17, 6, 4) and nmse_log.dtype == np.float64 and np.isfinite(nmse_log).all()
+    res = torch.load(tmp_path / 'results/score/train-CDL-C_test-CDL-C/results.pt', weights_only=False)
+    assert {'nmse_log', 'avg_nmse', 'best_nmse', 'spacing_range', 'pilot_alpha_range', 'snr_range',
+            'val_config'} <= set(res)
+    assert np.array_equal(res['best_nmse'], np.min(np.mean(nmse_log, -1), -1)) and res['val_config'].data.num_pilots == 38
+    again, _, _ = test_score.main(argv + ['--no_graph'])            # same seed => same result, graph or eager
+    assert np.array_equal(again, nmse_log)
+    # low SNR must not beat high SNR after the same number of steps on the same channels (sanity of per-SNR scalars)
+    assert not np.array_equal(nmse_log[0, 0, 0], nmse_log[0, 0, -1])
+
+
+def test_cli_tune_hparams_drop_in_outputs(net64, tmp_path, monkeypatch):
+    import torch
+    from score_based_channels_amd import tune_hparams_score
+    monkeypatch.chdir(tmp_path)
+    nmse_log, ba, bb = tune_hparams_score.main(['--synthetic', '--synthetic_weights', '2024', '--num_levels', '1',
+                                                '--num_channels', '3', '--seed', '4', '--no_plot',
+                                                '--alpha_step_range', '3e-11', '3e-10', '--beta_noise_range', '0.1', '0.01'])
+    assert nmse_log.shape == (2, 2, 17, 3, 3) and np.isfinite(nmse_log).all() and len(ba) == 17 and len(bb) == 17
+    res = torch.load(tmp_path / 'results/score/CDL-C-hyperparameters.pt', weights_only=False)
+    assert {'nmse_log', 'avg_nmse', 'best_nmse', 'best_alpha_snr', 'best_beta_snr', 'snr_range', 'alpha_step_range',
+            'beta_noise_range', 'config', 'args'} <= set(res)
+    assert set(ba) <= {3e-11, 3e-10} and set(bb) <= {0.1, 0.01}

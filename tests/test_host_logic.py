@@ -1,0 +1,197 @@
+"""CPU tests of the host side: loaders, checkpoint reader, schedule tables, sharding arithmetic, and that the
+C-ABI library loads and exports every symbol declared in include/sbc_hip.h (no compute calls: no GPU here)."""
+import os
+import pickle
+import re
+import sys
+import types
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+from oracle import ald_oracle
+from score_based_channels_amd.config import Config, default_config
+
+
+def test_library_exports_every_declared_symbol():
+    from score_based_channels_amd import _lib
+    header = open(os.path.join(ROOT, 'include', 'sbc_hip.h')).read()
+    declared = set(re.findall(r'^\s*(?:int|void|const char\*)\s+(sbc_\w+)\s*\(', header, re.M))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    h = _lib.lib()
+    for name in declared:
+        assert hasattr(h, name), name
+    assert h.sbc_abi_version() == 1
+
+
+def test_pack_conv_weight_c_matches_python():
+    from score_based_channels_amd import _lib
+    from score_based_channels_amd.weights import pack_conv_weight
+    rng = np.random.default_rng(0)
+    for (o, c, k) in [(32, 32, 3), (128, 64, 3), (64, 32, 1)]:
+        w = rng.standard_normal((o, c, k, k)).astype(np.float32)
+        dst = np.zeros(w.size, np.float32)
+        _lib.check(_lib.lib().sbc_pack_conv_weight(w.ctypes.data, o, c, k, dst.ctypes.data))
+        ref = pack_conv_weight(w)
+        assert ref.shape == (k * k, c // 8, o // 32, 64, 4)
+        assert np.array_equal(dst, ref.ravel())
+        # lane l of block (t, g, n) holds w[n*32 + l%32, g*8 + 4*(l//32) + j, kh, kw]
+        assert ref[k * k - 1, 1, 0, 37, 2] == w[5, 8 + 4 + 2, k - 1, k - 1]
+    assert _lib.lib().sbc_pack_conv_weight(w.ctypes.data, 30, 32, 3, dst.ctypes.data) == -1
+    assert b'cout % 32' in _lib.lib().sbc_last_error()
+
+
+def test_config_is_dotmap_like():
+    c = Config()
+    assert not c.data.logit_transform and not c.data.rescaled       # auto-created empty nodes are falsy
+    c.sampling.steps_each = 3
+    assert c.sampling.steps_each == 3 and c.toDict()['sampling'] == {'steps_each': 3}
+    d = default_config()
+    assert d.model.num_classes == 2311 and abs(d.model.sigma_end - 39.15 * 0.995 ** 2310) < 1e-12
+
+
+def test_channels_loader_matches_reference_golden(tmp_path):
+    from score_based_channels_amd.loaders import Channels
+    g = load_golden('loader.npz')
+    np.savez(tmp_path / 'CDL-C_Nt64_Nr16_ULA0.50_seed4321.npz', output_h=g['output_h'])
+    cfg = default_config()
+    cfg.data.num_pilots = 38
+    np.random.seed(int(g['legacy_seed']))
+    ds = Channels(4321, cfg, norm='global', data_dir=str(tmp_path))
+    assert os.path.basename(ds.filenames[0]) == os.path.basename(str(g['filename']))
+    assert ds.mean == 0. and abs(ds.std - float(g['std'])) < 1e-7 and len(ds) == 12
+    assert np.array_equal(ds.pilots.astype(np.complex64), g['pilots'])
+    for idx in (0, 5):
+        it = ds[idx]
+        for key in ('H', 'H_herm', 'P'):
+            assert np.array_equal(it[key], g['%s%d' % (key, idx)]), key
+        assert it['H_herm_cplx'].shape == (64, 16) and it['Y'].shape == (16, 38) and it['idx'] == idx
+    b = ds.batch(4)
+    assert b['H_herm'].shape == (4, 2, 64, 16) and b['P'].shape == (4, 64, 38)
+    g2 = load_golden('loader_listnorm.npz')
+    ds2 = Channels(4321, cfg, norm=[float(g2['mean']), float(g2['std'])], data_dir=str(tmp_path))
+    assert np.array_equal(ds2[3]['H_herm'], g2['H_herm3'])
+    with pytest.raises(FileNotFoundError):
+        Channels(1, cfg, norm='global', data_dir=str(tmp_path))
+    syn = Channels(7, cfg, norm='global', synthetic=True, num_synthetic=5)
+    assert syn.channels.shape == (5, 16, 64)
+
+
+def test_checkpoint_roundtrip_and_dotmap_pickle(tmp_path):
+    import torch
+    from score_based_channels_amd.checkpoint import load_checkpoint, save_checkpoint
+    from score_based_channels_amd.weights import seeded_state_dict
+    cfg = default_config()
+    sd = {k: v for k, v in list(seeded_state_dict(cfg, 1).items())[:6]}
+    save_checkpoint(tmp_path / 'a.pt', sd, cfg)
+    c = load_checkpoint(tmp_path / 'a.pt')
+    assert isinstance(c['config'], Config) and c['config'].model.ngf == 32
+    assert not c['config'].data.logit_transform
+    assert np.array_equal(c['model_state']['begin_conv.bias'].numpy(), sd['begin_conv.bias'])
+    # a checkpoint whose config is a pickled dotmap.DotMap (module not installed here): emulate its layout
+    fake = types.ModuleType('dotmap')
+
+    class DotMap(object):
+        def __init__(self):
+            from collections import OrderedDict
+            self._map, self._dynamic = OrderedDict(), True
+
+        def __getstate__(self):
+            return self.__dict__
+
+        def __setstate__(self, d):
+            self.__dict__.update(d)
+    DotMap.__module__, DotMap.__qualname__ = 'dotmap', 'DotMap'
+    fake.DotMap = DotMap
+    sys.modules['dotmap'] = fake
+    try:
+        root, model = DotMap(), DotMap()
+        model._map['ngf'] = 32
+        model._map['sigma_end'] = 1e-3
+        root._map['model'] = model
+        root._map['device'] = 'cuda:0'
+        torch.save({'model_state': {}, 'config': root}, tmp_path / 'b.pt')
+    finally:
+        del sys.modules['dotmap']
+    c = load_checkpoint(tmp_path / 'b.pt')
+    assert c['config'].model.ngf == 32 and c['config'].device == 'cuda:0' and not c['config'].data.rescaled
+    with pytest.raises(KeyError):
+        torch.save({'foo': 1}, tmp_path / 'c.pt')
+        load_checkpoint(tmp_path / 'c.pt')
+
+
+def test_schedule_tables_follow_reference_scalars():
+    from score_based_channels_amd.ald import schedule_tables, snr_to_noise
+    from score_based_channels_amd.weights import get_sigmas
+    cfg = default_config()
+    sig = get_sigmas(cfg)
+    assert sig.dtype == np.float32 and abs(sig[0] - 39.15) < 1e-5 and abs(sig[-1] / 3.6647832e-4 - 1) < 1e-6
+    levels = [0, 77, 2310]
+    ln = snr_to_noise([-10.0, 30.0], 64)
+    assert abs(ln[0] - 640.0) < 1e-9
+    sched, s_of = schedule_tables(sig, cfg.model.sigma_end, levels, 3, [3e-11, 3e-10], [0.01, 0.1], ln)
+    assert sched.shape == (2, 9, 4) and s_of.shape == (9,)
+    for g, (a0, be, l) in enumerate(zip([3e-11, 3e-10], [0.01, 0.1], ln)):
+        for li, lv in enumerate(levels):
+            a, d, n = ald_oracle.step_scalars(sig[lv], cfg.model.sigma_end, a0, be, l)
+            for k in range(3):
+                assert tuple(sched[g, 3 * li + k, :3]) == (a, d, n)
+                assert s_of[3 * li + k] == sig[lv]
+    assert abs(sched[0, 0, 0] - 0.34236) < 1e-4 and abs(sched[0, -1, 0] / 3e-11 - 1) < 1e-5
+
+
+def test_level_subset_and_shared_init():
+    from score_based_channels_amd.driver import level_subset, shared_init
+    assert level_subset(2311) == list(range(2311))
+    lv = level_subset(2311, 77)
+    assert lv[0] == 0 and lv[-1] == 2310 and len(lv) == 32 - 1
+    assert level_subset(2311, 1, 3) == [0, 1, 2]
+    a, b = shared_init(3, 64, 16, 5, 0), shared_init(3, 64, 16, 5, 0)
+    assert a.dtype.is_complex and (a == b).all() and not (a == shared_init(3, 64, 16, 5, 1)).all()
+
+
+def test_tune_selection_matches_reference_golden():
+    from score_based_channels_amd.tune_hparams_score import select_best
+    g = load_golden('tune_post.npz')
+    avg = np.mean(g['nmse_log'], axis=-1)
+    best = np.min(avg, axis=-1)
+    ba, bb = select_best(best, g['alpha_step_range'], g['beta_noise_range'])
+    assert np.array_equal(ba, g['best_alpha_snr']) and np.array_equal(bb, g['best_beta_snr'])
+
+
+def test_host_noise_streams_are_keyed_and_complex_normal():
+    from score_based_channels_amd.noise import HostNoise
+    n = HostNoise(9)
+    a = n.step_block(2, (4, 8, 2), 5)
+    draw = n.step_stream(2, (4, 8, 2))
+    assert all(np.array_equal(a[k], draw(k)) for k in range(5))
+    assert not np.array_equal(n.measurement(0, (4, 3)), n.measurement(1, (4, 3)))
+    big = n.init((200, 64, 16))
+    assert big.dtype == np.complex64 and abs(big.real.var() - 0.5) < 0.01 and abs(big.imag.var() - 0.5) < 0.01
+    with pytest.raises(ValueError):
+        draw(7)
+
+
+def test_block_bounds_cover_everything():
+    from score_based_channels_amd.shard import block_bounds, my_block
+    for n, w in [(1700, 8), (20400, 8), (5, 8), (17, 2)]:
+        b = block_bounds(n, w)
+        assert b[0] == 0 and b[-1] == n and np.all(np.diff(b) >= 0) and np.diff(b).max() - np.diff(b).min() <= 1
+        assert [my_block(n, r, w) for r in range(w)] == [(int(b[r]), int(b[r + 1])) for r in range(w)]
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'score_based_channels_amd')
+    for fn in os.listdir(pkg):
+        if fn.endswith('.py'):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r'^\s*(from|import)\s+oracle', src, re.M), fn
+
+
+def test_product_fails_loudly_without_the_library(monkeypatch):
+    from score_based_channels_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libsbc_hip.so')
+    with pytest.raises(_lib.SbcError, match='no CPU fallback'):
+        _lib.lib()
