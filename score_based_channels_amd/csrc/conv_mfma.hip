@@ -40,6 +40,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvParams p) {
     constexpr int KG = CIN / 8;
     constexpr int NBLK = COUT / 32;
     constexpr int NTHREADS = 64 * WM * WN;
+    constexpr int TAPS = KS * KS;
+    constexpr int NIT = TAPS * KG;
     static_assert(WN * NT == NBLK, "waves x blocks must cover COUT");
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvParams p) {
     const int H = p.H, W = p.W;
     const TileGeom g = tile_geom(blockIdx.x, TM, p.B, H, W, KS == 3 ? p.dil : 0);
 
-    stage_tile<CIN>(lds, p.in, p.stats, p.flags, g, H, W, tid, NTHREADS);
+    stage_tile<CIN, NTHREADS>(lds, p.in, p.stats, p.flags, g, H, W, tid);
 
     // this lane's A rows: pixel (lane & 31) of each of the wave's MT blocks
     int row[MT], hh0[MT], ww0[MT];
@@ -64,6 +66,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvParams p) {
     }
     const int khalf = 4 * (lane >> 5);
 
+    // LDS float offset of this lane's A fragment for tap `tap` (zero pixel when the tap leaves the image)
+    auto tap_offset = [&](int tap, int mi) {
+        const int dh = KS == 3 ? (tap / 3 - 1) * p.dil : 0;
+        const int dw = KS == 3 ? (tap % 3 - 1) * p.dil : 0;
+        const int hh = hh0[mi] + dh, ww = ww0[mi] + dw;
+        const bool ok = live[mi] && hh >= 0 && hh < H && ww >= 0 && ww < W;
+        return (ok ? (row[mi] + dh - g.rs0) * W + ww : g.nps) * S + khalf;
+    };
+
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
@@ -72,83 +83,60 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    __syncthreads();
-
-    for (int tap = 0; tap < KS * KS; ++tap) {
-        const int dh = KS == 3 ? (tap / 3 - 1) * p.dil : 0;
-        const int dw = KS == 3 ? (tap % 3 - 1) * p.dil : 0;
-        int aoff[MT];
+    // K loop, software-pipelined by one (tap, 8-channel group) step: the B fragment (global/L2) and the A
+    // fragment (LDS) of step it+1 are requested before the MFMAs of step it are issued.
+    const float4* wp = p.wpk + (size_t)(wn * NT) * 64 + lane;      // + it * NBLK * 64 per step
+    int aoff[MT], aoff_n[MT];
+    float4 a_cur[MT], b_cur[NT], a_nxt[MT], b_nxt[NT];
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-            const int hh = hh0[mi] + dh, ww = ww0[mi] + dw;
-            const bool ok = live[mi] && hh >= 0 && hh < H && ww >= 0 && ww < W;
-            const int lp = ok ? (row[mi] + dh - g.rs0) * W + ww : g.nps;
-            aoff[mi] = lp * S + khalf;
-        }
-        const float4* wp = p.wpk + ((size_t)tap * KG * NBLK + wn * NT) * 64 + lane;
-#pragma unroll 2
+    for (int ni = 0; ni < NT; ++ni) b_cur[ni] = wp[ni * 64];
+    __syncthreads();                                               // staged tile visible
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+        aoff[mi] = tap_offset(0, mi);
+        a_cur[mi] = *reinterpret_cast<const float4*>(lds + aoff[mi]);
+    }
+#pragma unroll 1
+    for (int tap = 0; tap < TAPS; ++tap) {
+        const int tap_n = tap + 1 < TAPS ? tap + 1 : tap;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) aoff_n[mi] = tap_offset(tap_n, mi);
+#pragma unroll
         for (int kg = 0; kg < KG; ++kg) {
-            float4 b[NT], a[MT];
+            const int it = tap * KG + kg;
+            const int it_n = it + 1 < NIT ? it + 1 : it;
 #pragma unroll
-            for (int ni = 0; ni < NT; ++ni) b[ni] = wp[(size_t)(kg * NBLK + ni) * 64];
+            for (int ni = 0; ni < NT; ++ni) b_nxt[ni] = wp[(size_t)(it_n * NBLK + ni) * 64];
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi) a[mi] = *reinterpret_cast<const float4*>(lds + aoff[mi] + kg * 8);
+            for (int mi = 0; mi < MT; ++mi)
+                a_nxt[mi] = *reinterpret_cast<const float4*>(lds + (kg + 1 < KG ? aoff[mi] + (kg + 1) * 8 : aoff_n[mi]));
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NT; ++ni) {
-                        const float av = j == 0 ? a[mi].x : j == 1 ? a[mi].y : j == 2 ? a[mi].z : a[mi].w;
-                        const float bv = j == 0 ? b[ni].x : j == 1 ? b[ni].y : j == 2 ? b[ni].z : b[ni].w;
+                        const float av = j == 0 ? a_cur[mi].x : j == 1 ? a_cur[mi].y : j == 2 ? a_cur[mi].z : a_cur[mi].w;
+                        const float bv = j == 0 ? b_cur[ni].x : j == 1 ? b_cur[ni].y : j == 2 ? b_cur[ni].z : b_cur[ni].w;
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mi][ni], 0, 0, 0);
                     }
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) a_cur[mi] = a_nxt[mi];
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) b_cur[ni] = b_nxt[ni];
         }
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) aoff[mi] = aoff_n[mi];
     }
 
     // ---------------------------------------------------------------- epilogue
-    // accumulator map (32x32 MFMA): column = lane & 31 (output channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // The accumulators (32x32 MFMA map: column = lane & 31 = output channel, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+    // go through LDS as [pixel][COUT + 4] so that every global access of the epilogue is a 16-byte access of 4
+    // consecutive channels, and all loads of a phase are issued before any is consumed.
+    constexpr int ES = COUT + 4;
+    constexpr int C4 = COUT / 4;
     const int col = lane & 31, rhalf = 4 * (lane >> 5);
-    if (p.flags & SBC_EPI_POOL) {
-        constexpr int ES = COUT + 1;
-        __syncthreads();   // every wave is done reading the staged tile
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni) {
-                const int co = (wn * NT + ni) * 32 + col;
-                const float bv = p.bias ? p.bias[co] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int pl = (wm * MT + mi) * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
-                    lds[pl * ES + co] = acc[mi][ni][r] + bv;
-                }
-            }
-        __syncthreads();
-        const int Wo = W / 2, Ho = H / 2;
-        const int r0 = g.p0 / W;                       // first global row of the tile (even)
-        for (int idx = tid; idx < (TM / 4) * COUT; idx += NTHREADS) {
-            const int co = idx % COUT, q = idx / COUT;
-            const int qr = q / Wo, qc = q - qr * Wo;
-            const int grow = r0 + 2 * qr;
-            if (grow >= p.B * H) continue;
-            const float* e = lds + ((2 * qr) * W + 2 * qc) * ES + co;
-            // ((((0 + a) + b) + c) + d) / 4 with a=[0::2,0::2] b=[1::2,0::2] c=[0::2,1::2] d=[1::2,1::2]
-            float v = (((e[0] + e[W * ES]) + e[ES]) + e[(W + 1) * ES]) * 0.25f;
-            const int n = grow / H, ho = (grow - n * H) >> 1;
-            const size_t o = ((size_t)(n * Ho + ho) * Wo + qc) * COUT + co;
-            if (p.res1) v = p.res1[o] + v;
-            p.out[o] = v;
-        }
-        return;
-    }
-
-    const int HW = H * W;
-    float sh = 0.f, sw = 0.f;
-    if (p.flags & SBC_EPI_UP) {
-        sh = H > 1 ? (float)(p.up_h - 1) / (float)(H - 1) : 0.f;
-        sw = W > 1 ? (float)(p.up_w - 1) / (float)(W - 1) : 0.f;
-    }
+    __syncthreads();   // every wave is done reading the staged tile
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -157,32 +145,131 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvParams p) {
             const float bv = p.bias ? p.bias[co] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int px = g.p0 + (wm * MT + mi) * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
-                if (px >= p.total_px) continue;
-                const size_t o = (size_t)px * COUT + co;
-                float v = acc[mi][ni][r] + bv;
-                if (p.res1) {
-                    float rr = p.res1[o];
-                    if (p.flags & SBC_EPI_RES1_ELU) rr = elu1(rr);
-                    if (p.res2) rr = p.res2[o] + rr;
-                    v = v + rr;
-                }
-                if (p.flags & SBC_EPI_UP) {
-                    const int n = px / HW, rem = px - n * HW;
-                    const int h = rem / W, w = rem - h * W;
-                    const float fh = sh * (float)h, fw = sw * (float)w;
-                    const int h0 = min((int)fh, p.up_h - 1), w0 = min((int)fw, p.up_w - 1);
-                    const int h1 = min(h0 + 1, p.up_h - 1), w1 = min(w0 + 1, p.up_w - 1);
-                    const float lh1 = fh - (float)h0, lw1 = fw - (float)w0;
-                    const float lh0 = 1.f - lh1, lw0 = 1.f - lw1;
-                    const float* u = p.up + (size_t)n * p.up_h * p.up_w * COUT + co;
-                    const float v00 = u[(size_t)(h0 * p.up_w + w0) * COUT], v01 = u[(size_t)(h0 * p.up_w + w1) * COUT];
-                    const float v10 = u[(size_t)(h1 * p.up_w + w0) * COUT], v11 = u[(size_t)(h1 * p.up_w + w1) * COUT];
-                    v = v + (lh0 * (lw0 * v00 + lw1 * v01) + lh1 * (lw0 * v10 + lw1 * v11));
-                }
-                p.out[o] = v;
+                const int pl = (wm * MT + mi) * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
+                lds[pl * ES + co] = acc[mi][ni][r] + bv;
             }
         }
+    __syncthreads();
+
+    if (p.flags & SBC_EPI_POOL) {
+        // ((((0 + a) + b) + c) + d) / 4 with a=[0::2,0::2] b=[1::2,0::2] c=[0::2,1::2] d=[1::2,1::2]  (layers.py:311-312)
+        constexpr int PTOT = (TM / 4) * C4;              // pooled 16-byte outputs of the tile
+        constexpr int PC = 4;
+        const int Wo = W / 2, Ho = H / 2;
+        const int r0 = g.p0 / W;                       // first global row of the tile (even)
+#pragma unroll 1
+        for (int base = 0; base < PTOT; base += PC * NTHREADS) {
+            float4 v[PC], rr[PC];
+            unsigned o[PC];
+            bool ok[PC];
+#pragma unroll
+            for (int i = 0; i < PC; ++i) {
+                const int idx = base + i * NTHREADS + tid;
+                const int c4 = idx % C4, q = idx / C4;
+                const int qr = q / Wo, qc = q - qr * Wo;
+                const int grow = r0 + 2 * qr;
+                ok[i] = idx < PTOT && grow < p.B * H;
+                const float* e = lds + (ok[i] ? ((2 * qr) * W + 2 * qc) * ES + c4 * 4 : 0);
+                const float4 a = *reinterpret_cast<const float4*>(e), b = *reinterpret_cast<const float4*>(e + W * ES);
+                const float4 c = *reinterpret_cast<const float4*>(e + ES), d = *reinterpret_cast<const float4*>(e + (W + 1) * ES);
+                v[i].x = (((a.x + b.x) + c.x) + d.x) * 0.25f;
+                v[i].y = (((a.y + b.y) + c.y) + d.y) * 0.25f;
+                v[i].z = (((a.z + b.z) + c.z) + d.z) * 0.25f;
+                v[i].w = (((a.w + b.w) + c.w) + d.w) * 0.25f;
+                const int n = grow / H, ho = (grow - n * H) >> 1;
+                o[i] = ((unsigned)(n * Ho + ho) * Wo + qc) * COUT + c4 * 4;
+            }
+            if (p.res1) {
+#pragma unroll
+                for (int i = 0; i < PC; ++i)
+                    if (ok[i]) rr[i] = *reinterpret_cast<const float4*>(p.res1 + o[i]);
+#pragma unroll
+                for (int i = 0; i < PC; ++i) {
+                    v[i].x = rr[i].x + v[i].x; v[i].y = rr[i].y + v[i].y;
+                    v[i].z = rr[i].z + v[i].z; v[i].w = rr[i].w + v[i].w;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < PC; ++i)
+                if (ok[i]) *reinterpret_cast<float4*>(p.out + o[i]) = v[i];
+        }
+        return;
+    }
+
+    constexpr int ITER = TM * C4 / NTHREADS;
+    static_assert(TM * C4 % NTHREADS == 0, "epilogue chunks must divide evenly");
+    constexpr int EC = ITER < 4 ? ITER : 4;            // 16-byte requests in flight per thread and phase
+    static_assert(ITER % EC == 0, "epilogue chunking");
+    const int HW = H * W;
+    const float sh = (p.flags & SBC_EPI_UP) && H > 1 ? (float)(p.up_h - 1) / (float)(H - 1) : 0.f;
+    const float sw = (p.flags & SBC_EPI_UP) && W > 1 ? (float)(p.up_w - 1) / (float)(W - 1) : 0.f;
+#pragma unroll 1
+    for (int c0 = 0; c0 < ITER; c0 += EC) {
+        float4 v[EC], rr[EC];
+        unsigned o[EC];
+        bool ok[EC];
+#pragma unroll
+        for (int i = 0; i < EC; ++i) {
+            const int idx = tid + (c0 + i) * NTHREADS;
+            const int c4 = idx % C4, pl = idx / C4;
+            v[i] = *reinterpret_cast<const float4*>(lds + pl * ES + c4 * 4);
+            ok[i] = g.p0 + pl < p.total_px;
+            o[i] = (unsigned)(g.p0 + pl) * COUT + c4 * 4;
+        }
+        if (p.res1) {
+#pragma unroll
+            for (int i = 0; i < EC; ++i)
+                if (ok[i]) rr[i] = *reinterpret_cast<const float4*>(p.res1 + o[i]);
+            if (p.flags & SBC_EPI_RES1_ELU) {
+#pragma unroll
+                for (int i = 0; i < EC; ++i) rr[i] = elu4(rr[i]);
+            }
+            if (p.res2) {
+                float4 r2[EC];
+#pragma unroll
+                for (int i = 0; i < EC; ++i)
+                    if (ok[i]) r2[i] = *reinterpret_cast<const float4*>(p.res2 + o[i]);
+#pragma unroll
+                for (int i = 0; i < EC; ++i) {
+                    rr[i].x = r2[i].x + rr[i].x; rr[i].y = r2[i].y + rr[i].y;
+                    rr[i].z = r2[i].z + rr[i].z; rr[i].w = r2[i].w + rr[i].w;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < EC; ++i) {
+                v[i].x = v[i].x + rr[i].x; v[i].y = v[i].y + rr[i].y;
+                v[i].z = v[i].z + rr[i].z; v[i].w = v[i].w + rr[i].w;
+            }
+        }
+        if (p.flags & SBC_EPI_UP) {
+            // F.interpolate(bilinear, align_corners=True) of `up` added on top (MSFBlock, layers.py:182-183)
+#pragma unroll
+            for (int i = 0; i < EC; ++i) {
+                if (!ok[i]) continue;
+                const int idx = tid + (c0 + i) * NTHREADS;
+                const int c4 = idx % C4, px = g.p0 + idx / C4;
+                const int n = px / HW, rem = px - n * HW;
+                const int h = rem / W, w = rem - h * W;
+                const float fh = sh * (float)h, fw = sw * (float)w;
+                const int h0 = min((int)fh, p.up_h - 1), w0 = min((int)fw, p.up_w - 1);
+                const int h1 = min(h0 + 1, p.up_h - 1), w1 = min(w0 + 1, p.up_w - 1);
+                const float lh1 = fh - (float)h0, lw1 = fw - (float)w0;
+                const float lh0 = 1.f - lh1, lw0 = 1.f - lw1;
+                const float* u = p.up + (size_t)n * p.up_h * p.up_w * COUT + c4 * 4;
+                const float4 v00 = *reinterpret_cast<const float4*>(u + (size_t)(h0 * p.up_w + w0) * COUT);
+                const float4 v01 = *reinterpret_cast<const float4*>(u + (size_t)(h0 * p.up_w + w1) * COUT);
+                const float4 v10 = *reinterpret_cast<const float4*>(u + (size_t)(h1 * p.up_w + w0) * COUT);
+                const float4 v11 = *reinterpret_cast<const float4*>(u + (size_t)(h1 * p.up_w + w1) * COUT);
+                v[i].x = v[i].x + (lh0 * (lw0 * v00.x + lw1 * v01.x) + lh1 * (lw0 * v10.x + lw1 * v11.x));
+                v[i].y = v[i].y + (lh0 * (lw0 * v00.y + lw1 * v01.y) + lh1 * (lw0 * v10.y + lw1 * v11.y));
+                v[i].z = v[i].z + (lh0 * (lw0 * v00.z + lw1 * v01.z) + lh1 * (lw0 * v10.z + lw1 * v11.z));
+                v[i].w = v[i].w + (lh0 * (lw0 * v00.w + lw1 * v01.w) + lh1 * (lw0 * v10.w + lw1 * v11.w));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < EC; ++i)
+            if (ok[i]) *reinterpret_cast<float4*>(p.out + o[i]) = v[i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ dispatch
@@ -197,7 +284,7 @@ static int launch_variant(const ConvParams& p, hipStream_t stream) {
         SBC_REQUIRE(p.H % 2 == 0 && p.W % 2 == 0 && TM % (2 * p.W) == 0, "mean-pool needs even H, W (%dx%d)", p.H, p.W);
     const int halo_px = (TM >= HW || KS == 1) ? 0 : 2 * p.dil * p.W;
     size_t lds = (size_t)(TM + halo_px + 1) * S * sizeof(float);
-    if (p.flags & SBC_EPI_POOL) lds = max(lds, (size_t)TM * (COUT + 1) * sizeof(float));
+    lds = max(lds, (size_t)TM * (COUT + 4) * sizeof(float));       // epilogue transposes through LDS
     SBC_REQUIRE(lds <= 160 * 1024, "conv tile needs %zu bytes of LDS (> 160 KiB)", lds);
     auto kern = conv_mfma_kernel<CIN, COUT, KS, MT, NT, WM, WN>;
     static size_t lds_attr = 0;   // per instantiation

@@ -43,33 +43,46 @@ __device__ __forceinline__ TileGeom tile_geom(int tile, int TM, int B, int H, in
 }
 
 // Copy the staged rows into LDS with the prologue applied.  stats = [B][3][CIN] (mu, scale, shift).
-template <int CIN>
+// Loads are issued in batches of UNR 16-byte requests per thread before any is consumed.
+template <int CIN, int NTHREADS>
 __device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__ in,
                                            const float* __restrict__ stats, int flags, const TileGeom& g,
-                                           int H, int W, int tid, int nthreads) {
+                                           int H, int W, int tid) {
     constexpr int S = CIN + 4;
     constexpr int C4 = CIN / 4;
+    constexpr int UNR = 4;
     const float* src = in + (size_t)g.rs0 * W * CIN;
     const int HW = H * W;
     const int total = g.nps * C4;
-    for (int idx = tid; idx < total; idx += nthreads) {
-        const int pix = idx / C4, c4 = idx % C4;
-        float4 v = *reinterpret_cast<const float4*>(src + (size_t)pix * CIN + c4 * 4);
-        if (flags & SBC_PRO_NORM) {
-            const int n = g.n_first + (g.multi ? pix / HW : 0);
-            const float* st = stats + (size_t)n * 3 * CIN + c4 * 4;
-            const float4 mu = *reinterpret_cast<const float4*>(st);
-            const float4 sc = *reinterpret_cast<const float4*>(st + CIN);
-            const float4 sh = *reinterpret_cast<const float4*>(st + 2 * CIN);
-            v.x = (v.x - mu.x) * sc.x + sh.x;
-            v.y = (v.y - mu.y) * sc.y + sh.y;
-            v.z = (v.z - mu.z) * sc.z + sh.z;
-            v.w = (v.w - mu.w) * sc.w + sh.w;
+    for (int base = 0; base < total; base += UNR * NTHREADS) {
+        float4 v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int idx = base + u * NTHREADS + tid;
+            if (idx < total) v[u] = *reinterpret_cast<const float4*>(src + (size_t)idx * 4);
         }
-        if (flags & SBC_PRO_ELU) v = elu4(v);
-        *reinterpret_cast<float4*>(lds + pix * S + c4 * 4) = v;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int idx = base + u * NTHREADS + tid;
+            if (idx >= total) continue;
+            const int pix = idx / C4, c4 = idx % C4;
+            float4 x = v[u];
+            if (flags & SBC_PRO_NORM) {
+                const int n = g.n_first + (g.multi ? pix / HW : 0);
+                const float* st = stats + (size_t)n * 3 * CIN + c4 * 4;
+                const float4 mu = *reinterpret_cast<const float4*>(st);
+                const float4 sc = *reinterpret_cast<const float4*>(st + CIN);
+                const float4 sh = *reinterpret_cast<const float4*>(st + 2 * CIN);
+                x.x = (x.x - mu.x) * sc.x + sh.x;
+                x.y = (x.y - mu.y) * sc.y + sh.y;
+                x.z = (x.z - mu.z) * sc.z + sh.z;
+                x.w = (x.w - mu.w) * sc.w + sh.w;
+            }
+            if (flags & SBC_PRO_ELU) x = elu4(x);
+            *reinterpret_cast<float4*>(lds + pix * S + c4 * 4) = x;
+        }
     }
-    for (int i = tid; i < S; i += nthreads) lds[g.nps * S + i] = 0.f;
+    for (int i = tid; i < S; i += NTHREADS) lds[g.nps * S + i] = 0.f;
 }
 
 }  // namespace sbc
