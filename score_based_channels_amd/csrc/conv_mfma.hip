@@ -15,11 +15,21 @@
 // K is walked in groups of 8 channels: within a group, lanes 0-31 supply channels g*8+0..3 and lanes 32-63
 // channels g*8+4..7 as the two k-rows of four consecutive 32x32x2 MFMAs (any K permutation is legal as long
 // as A and B agree).
+#include <stdlib.h>
 #include "tile.h"
 
 namespace sbc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Performance triage only (SBC_DEBUG_FLAGS=0x20000): per-workgroup phase timestamps (s_memtime) + hardware id.
+#define SBC_PROF_MAX 8192
+__device__ long long sbc_prof[SBC_PROF_MAX * 8];
+#define SBC_PROF(slot)                                                                             \
+    do {                                                                                           \
+        if ((p.flags & 0x20000) && threadIdx.x == 0 && blockIdx.x < SBC_PROF_MAX)                  \
+            sbc_prof[blockIdx.x * 8 + (slot)] = (long long)__builtin_readcyclecounter();           \
+    } while (0)
 
 struct ConvParams {
     const float* __restrict__ in;
@@ -43,6 +53,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvParams p) {
     constexpr int TAPS = KS * KS;
     constexpr int NIT = TAPS * KG;
     static_assert(WN * NT == NBLK, "waves x blocks must cover COUT");
+    // 16-byte staging requests in flight per thread: the whole tile + 1-row halo at W <= 16 in one batch when it is
+    // at most 10 requests, else batches of 9
+    constexpr int STAGE_NEED = ((TM + 32) * (CIN / 4) + NTHREADS - 1) / NTHREADS;
+    constexpr int STAGE_UNR = STAGE_NEED <= 10 ? STAGE_NEED : 9;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -51,7 +65,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvParams p) {
     const int H = p.H, W = p.W;
     const TileGeom g = tile_geom(blockIdx.x, TM, p.B, H, W, KS == 3 ? p.dil : 0);
 
-    stage_tile<CIN, NTHREADS>(lds, p.in, p.stats, p.flags, g, H, W, tid);
+    SBC_PROF(0);
+    if ((p.flags & 0x20000) && threadIdx.x == 0 && blockIdx.x < SBC_PROF_MAX) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        sbc_prof[blockIdx.x * 8 + 7] = ((long long)xcc << 32) | hwid;
+    }
+    if (!(p.flags & 0x1000)) stage_tile<CIN, NTHREADS, STAGE_UNR>(lds, p.in, p.stats, p.flags, g, H, W, tid);
+    SBC_PROF(1);
 
     // this lane's A rows: pixel (lane & 31) of each of the wave's MT blocks
     int row[MT], hh0[MT], ww0[MT];
@@ -83,47 +105,52 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    // K loop, software-pipelined by one (tap, 8-channel group) step: the B fragment (global/L2) and the A
-    // fragment (LDS) of step it+1 are requested before the MFMAs of step it are issued.
+    // K loop, software-pipelined by one (tap, 8-channel group) step with two statically indexed register sets:
+    // the B fragment (global/L2) and the A fragment (LDS) of step it+1 are requested, then the MFMAs of step it
+    // are issued.  sched_barrier pins that order so the waits the compiler inserts in front of the MFMAs are
+    // counted (vmcnt(NT) / lgkmcnt(MT): "everything but the requests just issued"), never a full drain.
+    static_assert(KG % 2 == 0, "two register sets alternate per 8-channel group");
     const float4* wp = p.wpk + (size_t)(wn * NT) * 64 + lane;      // + it * NBLK * 64 per step
     int aoff[MT], aoff_n[MT];
-    float4 a_cur[MT], b_cur[NT], a_nxt[MT], b_nxt[NT];
+    float4 aS[2][MT], bS[2][NT];
 #pragma unroll
-    for (int ni = 0; ni < NT; ++ni) b_cur[ni] = wp[ni * 64];
+    for (int ni = 0; ni < NT; ++ni) bS[0][ni] = wp[ni * 64];
     __syncthreads();                                               // staged tile visible
+    SBC_PROF(2);
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
         aoff[mi] = tap_offset(0, mi);
-        a_cur[mi] = *reinterpret_cast<const float4*>(lds + aoff[mi]);
+        aS[0][mi] = *reinterpret_cast<const float4*>(__builtin_assume_aligned(lds + aoff[mi], 16));
     }
 #pragma unroll 1
-    for (int tap = 0; tap < TAPS; ++tap) {
+    for (int tap = 0; tap < ((p.flags & 0x2000) ? 0 : TAPS); ++tap) {
         const int tap_n = tap + 1 < TAPS ? tap + 1 : tap;
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) aoff_n[mi] = tap_offset(tap_n, mi);
 #pragma unroll
         for (int kg = 0; kg < KG; ++kg) {
+            const int cur = kg & 1, nxt = cur ^ 1;
             const int it = tap * KG + kg;
             const int it_n = it + 1 < NIT ? it + 1 : it;
 #pragma unroll
-            for (int ni = 0; ni < NT; ++ni) b_nxt[ni] = wp[(size_t)(it_n * NBLK + ni) * 64];
+            for (int ni = 0; ni < NT; ++ni) bS[nxt][ni] = wp[(size_t)(it_n * NBLK + ni) * 64];
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi)
-                a_nxt[mi] = *reinterpret_cast<const float4*>(lds + (kg + 1 < KG ? aoff[mi] + (kg + 1) * 8 : aoff_n[mi]));
+                aS[nxt][mi] = *reinterpret_cast<const float4*>(
+                    __builtin_assume_aligned(lds + (kg + 1 < KG ? aoff[mi] + (kg + 1) * 8 : aoff_n[mi]), 16));
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NT; ++ni) {
-                        const float av = j == 0 ? a_cur[mi].x : j == 1 ? a_cur[mi].y : j == 2 ? a_cur[mi].z : a_cur[mi].w;
-                        const float bv = j == 0 ? b_cur[ni].x : j == 1 ? b_cur[ni].y : j == 2 ? b_cur[ni].z : b_cur[ni].w;
+                        const float4 a4 = aS[cur][mi], b4 = bS[cur][ni];
+                        const float av = j == 0 ? a4.x : j == 1 ? a4.y : j == 2 ? a4.z : a4.w;
+                        const float bv = j == 0 ? b4.x : j == 1 ? b4.y : j == 2 ? b4.z : b4.w;
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mi][ni], 0, 0, 0);
                     }
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi) a_cur[mi] = a_nxt[mi];
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni) b_cur[ni] = b_nxt[ni];
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) aoff[mi] = aoff_n[mi];
@@ -136,7 +163,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvParams p) {
     constexpr int ES = COUT + 4;
     constexpr int C4 = COUT / 4;
     const int col = lane & 31, rhalf = 4 * (lane >> 5);
+    SBC_PROF(3);
     __syncthreads();   // every wave is done reading the staged tile
+    SBC_PROF(4);
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -151,6 +180,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvParams p) {
         }
     __syncthreads();
 
+    if (p.flags & 0x4000) return;
     if (p.flags & SBC_EPI_POOL) {
         // ((((0 + a) + b) + c) + d) / 4 with a=[0::2,0::2] b=[1::2,0::2] c=[0::2,1::2] d=[1::2,1::2]  (layers.py:311-312)
         constexpr int PTOT = (TM / 4) * C4;              // pooled 16-byte outputs of the tile
@@ -198,7 +228,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvParams p) {
 
     constexpr int ITER = TM * C4 / NTHREADS;
     static_assert(TM * C4 % NTHREADS == 0, "epilogue chunks must divide evenly");
-    constexpr int EC = ITER < 4 ? ITER : 4;            // 16-byte requests in flight per thread and phase
+    constexpr int EC = ITER < 8 ? ITER : 8;            // 16-byte requests in flight per thread and phase
     static_assert(ITER % EC == 0, "epilogue chunking");
     const int HW = H * W;
     const float sh = (p.flags & SBC_EPI_UP) && H > 1 ? (float)(p.up_h - 1) / (float)(H - 1) : 0.f;
@@ -219,7 +249,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvParams p) {
         if (p.res1) {
 #pragma unroll
             for (int i = 0; i < EC; ++i)
-                if (ok[i]) rr[i] = *reinterpret_cast<const float4*>(p.res1 + o[i]);
+                if (ok[i]) rr[i] = ld_stream(p.res1 + o[i]);
             if (p.flags & SBC_EPI_RES1_ELU) {
 #pragma unroll
                 for (int i = 0; i < EC; ++i) rr[i] = elu4(rr[i]);
@@ -228,7 +258,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvParams p) {
                 float4 r2[EC];
 #pragma unroll
                 for (int i = 0; i < EC; ++i)
-                    if (ok[i]) r2[i] = *reinterpret_cast<const float4*>(p.res2 + o[i]);
+                    if (ok[i]) r2[i] = ld_stream(p.res2 + o[i]);
 #pragma unroll
                 for (int i = 0; i < EC; ++i) {
                     rr[i].x = r2[i].x + rr[i].x; rr[i].y = r2[i].y + rr[i].y;
@@ -268,8 +298,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvParams p) {
         }
 #pragma unroll
         for (int i = 0; i < EC; ++i)
-            if (ok[i]) *reinterpret_cast<float4*>(p.out + o[i]) = v[i];
+            if (ok[i]) st_stream(p.out + o[i], v[i]);
     }
+    SBC_PROF(5);
 }
 
 // ------------------------------------------------------------------------------------------------ dispatch
@@ -309,8 +340,10 @@ static int launch_sized(const ConvParams& p, hipStream_t stream) {
     auto fits = [&](int tm) {
         return tm % p.W == 0 && (HW % tm == 0 || tm % HW == 0) && (!(p.flags & SBC_EPI_POOL) || tm % (2 * p.W) == 0);
     };
+    static const int force = getenv("SBC_TILE") ? atoi(getenv("SBC_TILE")) : 0;
     int tm = 0;
-    if (fits(256) && px >= 256L * 512) tm = 256;
+    if (force && fits(force)) tm = force;
+    else if (fits(256) && px >= 256L * 512) tm = 256;
     else if (fits(128) && px >= 128L * 512) tm = 128;
     else if (fits(64)) tm = 64;
     else if (fits(128)) tm = 128;
@@ -322,7 +355,7 @@ static int launch_sized(const ConvParams& p, hipStream_t stream) {
         if constexpr (NB >= 4) return launch_variant<CIN, COUT, KS, 2, 1, 1, 4>(p, stream);
         else return launch_variant<CIN, COUT, KS, 1, 1, 2, 2>(p, stream);
     } else {
-        if (tm == 128) return launch_variant<CIN, COUT, KS, 1, 1, 4, 1>(p, stream);
+        if (tm == 128) return launch_variant<CIN, COUT, KS, 2, 1, 2, 1>(p, stream);
         return launch_variant<CIN, COUT, KS, 1, 1, 2, 1>(p, stream);
     }
 }
@@ -343,6 +376,8 @@ int launch_conv(const sbc_op& op, hipStream_t stream) {
     p.res1 = (const float*)op.res1; p.res2 = (const float*)op.res2; p.up = (const float*)op.up;
     p.B = op.B; p.H = op.H; p.W = op.W; p.dil = op.dil; p.flags = op.flags;
     p.up_h = op.up_h; p.up_w = op.up_w; p.total_px = op.B * op.H * op.W;
+    static const int dbg = getenv("SBC_DEBUG_FLAGS") ? (int)strtol(getenv("SBC_DEBUG_FLAGS"), nullptr, 0) : 0;
+    p.flags |= dbg & 0x27000;     // phase-skipping switches for performance triage only (results are wrong)
     const int key = op.cin * 100000 + op.cout * 100 + op.ksize;
     switch (key) {
         case 32 * 100000 + 32 * 100 + 3: return launch_sized<32, 32, 3>(p, stream);
@@ -362,3 +397,7 @@ int launch_conv(const sbc_op& op, hipStream_t stream) {
 }
 
 }  // namespace sbc
+
+extern "C" int sbc_debug_read_prof(long long* out, int n_blocks) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(sbc::sbc_prof), sizeof(long long) * 8 * n_blocks) == hipSuccess ? 0 : -2;
+}

@@ -12,6 +12,26 @@
 
 namespace sbc {
 
+// Streaming (non-temporal) 16-byte accesses for activations: each element is touched once per kernel, so it
+// should not displace the L1/L2-resident weight fragments the MFMA loops of co-resident workgroups re-read.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_stream(const float* p) {
+#ifdef SBC_NO_STREAM
+    return *reinterpret_cast<const float4*>(p);
+#else
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#endif
+}
+__device__ __forceinline__ void st_stream(float* p, float4 v) {
+#ifdef SBC_NO_STREAM
+    *reinterpret_cast<float4*>(p) = v;
+#else
+    f32x4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p));
+#endif
+}
+
 struct TileGeom {
     int p0;        // first output pixel (flattened n*H*W + h*W + w)
     int rs0;       // first staged global row (n*H + h)
@@ -44,13 +64,12 @@ __device__ __forceinline__ TileGeom tile_geom(int tile, int TM, int B, int H, in
 
 // Copy the staged rows into LDS with the prologue applied.  stats = [B][3][CIN] (mu, scale, shift).
 // Loads are issued in batches of UNR 16-byte requests per thread before any is consumed.
-template <int CIN, int NTHREADS>
+template <int CIN, int NTHREADS, int UNR = 4>
 __device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__ in,
                                            const float* __restrict__ stats, int flags, const TileGeom& g,
                                            int H, int W, int tid) {
     constexpr int S = CIN + 4;
     constexpr int C4 = CIN / 4;
-    constexpr int UNR = 4;
     const float* src = in + (size_t)g.rs0 * W * CIN;
     const int HW = H * W;
     const int total = g.nps * C4;
@@ -59,7 +78,7 @@ __device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int idx = base + u * NTHREADS + tid;
-            if (idx < total) v[u] = *reinterpret_cast<const float4*>(src + (size_t)idx * 4);
+            if (idx < total) v[u] = ld_stream(src + (size_t)idx * 4);
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
