@@ -133,6 +133,12 @@ int sbc_plan_create(const sbc_op* ops, int32_t n_ops, sbc_plan** out_plan) {
             po.endc = *(const sbc_endconv*)ops[i].ext;
         }
         po.op.ext = nullptr;
+        // resolve kernel variants / set function attributes now, so a later hipGraph capture sees launches only
+        int rc = SBC_OK;
+        if (po.op.kind == SBC_OP_CONV) rc = launch_conv(po.op, nullptr, true);
+        else if (po.op.kind == SBC_OP_END_CONV) rc = launch_end_conv(po.op, po.endc, nullptr, true);
+        else if (po.op.kind == SBC_OP_LANGEVIN) rc = launch_langevin(po.op, po.lang, nullptr, true);
+        if (rc) { delete plan; return rc; }
     }
     *out_plan = plan;
     return SBC_OK;

@@ -29,12 +29,13 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 // per-kind launchers (each validates its op, then launches asynchronously on `stream`)
-int launch_conv(const sbc_op& op, hipStream_t stream);
+// dry = true: validate, resolve the kernel variant and set its function attributes, but do not launch
+int launch_conv(const sbc_op& op, hipStream_t stream, bool dry = false);
 int launch_begin_conv(const sbc_op& op, hipStream_t stream);
 int launch_inorm_stats(const sbc_op& op, hipStream_t stream);
 int launch_maxpool5(const sbc_op& op, hipStream_t stream);
-int launch_end_conv(const sbc_op& op, const sbc_endconv& ext, hipStream_t stream);
-int launch_langevin(const sbc_op& op, const sbc_langevin& ext, hipStream_t stream);
+int launch_end_conv(const sbc_op& op, const sbc_endconv& ext, hipStream_t stream, bool dry = false);
+int launch_langevin(const sbc_op& op, const sbc_langevin& ext, hipStream_t stream, bool dry = false);
 int launch_measure(const sbc_op& op, const sbc_langevin& ext, hipStream_t stream);
 int launch_step_inc(const sbc_op& op, hipStream_t stream);
 

@@ -8,28 +8,25 @@
 //   epilogue  bias, residual adds (ResidualBlock :456, RCUBlock :133, CRPBlock :82), 2x2 mean pooling
 //             (ConvMeanPool :311-312) and the bilinear(align_corners) resize-add of MSFBlock (:182-183).
 //
-// GEMM view: M = B*H*W pixels, N = COUT, K = taps*CIN.  A workgroup computes TM = 32*MT*WM pixels x COUT; wave
-// (wm, wn) computes MT 32-pixel blocks x NT 32-channel blocks.  The A operand comes from the LDS tile (tile.h);
-// the B operand (weights, pre-packed on the host into fragment order, weights.py:pack_conv_weight) is loaded
-// straight from global/L2 as one 16-byte load per lane per (tap, 8-channel group) and feeds four MFMAs.
-// K is walked in groups of 8 channels: within a group, lanes 0-31 supply channels g*8+0..3 and lanes 32-63
-// channels g*8+4..7 as the two k-rows of four consecutive 32x32x2 MFMAs (any K permutation is legal as long
-// as A and B agree).
+// GEMM view: M = B*H*W pixels, N = COUT, K = taps*CIN.  A tile is TM = 32*MT*WM pixels x COUT; wave (wm, wn)
+// computes MT 32-pixel blocks x NT 32-channel blocks.  The A operand comes from the LDS tile (tile.h); the B
+// operand (weights, pre-packed on the host into fragment order, weights.py:pack_conv_weight) is one 16-byte load
+// per lane per (tap, 8-channel group) that feeds four MFMAs.  K is walked in groups of 8 channels: within a
+// group, lanes 0-31 supply channels g*8+0..3 and lanes 32-63 channels g*8+4..7 as the two k-rows of four
+// consecutive 32x32x2 MFMAs (any K permutation is legal as long as A and B agree).
+//
+// Two builds per shape.  Plain (PF = false): one tile per workgroup, B fragments straight from global/L2.
+// Persistent (PF = true, used when there are several tiles per resident workgroup): the grid is (resident
+// workgroups per CU) x CUs, each workgroup walks a contiguous range of tiles of "its" XCD, requests the raw rows of
+// tile i+1 and the residual operand of tile i into registers before the MFMA loop of tile i, and -- when the
+// packed weights fit (3x3 32->32: 36 KB) -- keeps them in LDS for its lifetime so the MFMA loop issues no
+// vector-memory loads (vmcnt retires in order: a B-fragment wait would otherwise also wait for the prefetch).
 #include <stdlib.h>
 #include "tile.h"
 
 namespace sbc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-// Performance triage only (SBC_DEBUG_FLAGS=0x20000): per-workgroup phase timestamps (s_memtime) + hardware id.
-#define SBC_PROF_MAX 8192
-__device__ long long sbc_prof[SBC_PROF_MAX * 8];
-#define SBC_PROF(slot)                                                                             \
-    do {                                                                                           \
-        if ((p.flags & 0x20000) && threadIdx.x == 0 && blockIdx.x < SBC_PROF_MAX)                  \
-            sbc_prof[blockIdx.x * 8 + (slot)] = (long long)__builtin_readcyclecounter();           \
-    } while (0)
 
 struct ConvParams {
     const float* __restrict__ in;
@@ -41,10 +38,18 @@ struct ConvParams {
     const float* __restrict__ res2;
     const float* __restrict__ up;
     int B, H, W, dil, flags, up_h, up_w, total_px;
+    int n_tiles, tiles_per_xcd, wg_per_xcd;
 };
 
-template <int CIN, int COUT, int KS, int MT, int NT, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvParams p) {
+// performance-triage switches (SBC_DEBUG_FLAGS, results are wrong when set): skip staging loads / MFMA loop /
+// output stores / residual prefetch
+#define SBC_DBG_NOSTAGE 0x1000
+#define SBC_DBG_NOLOOP 0x2000
+#define SBC_DBG_NOSTORE 0x4000
+#define SBC_DBG_NORES 0x8000
+
+template <int CIN, int COUT, int KS, int MT, int NT, int WM, int WN, bool PF>
+__global__ __launch_bounds__(64 * WM * WN, PF ? 2 : 1) void conv_mfma_kernel(ConvParams p) {
     constexpr int TM = 32 * MT * WM;
     constexpr int S = CIN + 4;
     constexpr int KG = CIN / 8;
@@ -52,260 +57,347 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvParams p) {
     constexpr int NTHREADS = 64 * WM * WN;
     constexpr int TAPS = KS * KS;
     constexpr int NIT = TAPS * KG;
+    constexpr int ES = COUT + 4;
+    constexpr int C4 = COUT / 4;
     static_assert(WN * NT == NBLK, "waves x blocks must cover COUT");
-    // 16-byte staging requests in flight per thread: the whole tile + 1-row halo at W <= 16 in one batch when it is
-    // at most 10 requests, else batches of 9
-    constexpr int STAGE_NEED = ((TM + 32) * (CIN / 4) + NTHREADS - 1) / NTHREADS;
-    constexpr int STAGE_UNR = STAGE_NEED <= 10 ? STAGE_NEED : 9;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    static_assert(KG % 2 == 0, "two register sets alternate per 8-channel group");
+    // 16-byte staging chunks per thread covering the tile + a 32-pixel halo allowance, capped at 10 (register
+    // budget); anything beyond is fetched synchronously inside stage_commit
+    constexpr int NPF_FULL = ((TM + 32) * (CIN / 4) + NTHREADS - 1) / NTHREADS;
+    constexpr int NPF = NPF_FULL <= 10 ? NPF_FULL : 10;
+    // residual operand chunks per thread (non-pooled epilogue)
+    constexpr int ITER = TM * C4 / NTHREADS;
+    static_assert(TM * C4 % NTHREADS == 0, "epilogue chunks must divide evenly");
+    constexpr bool RES_PF = PF && ITER <= 8;            // keep the residual of the current tile in registers too
+    constexpr int EC = ITER < 4 ? ITER : 4;             // 16-byte requests in flight per thread and phase
+    static_assert(ITER % EC == 0, "epilogue chunking");
+    constexpr int WFLOATS = TAPS * CIN * COUT;
+    constexpr bool BLDS = PF && WFLOATS * 4 <= 40 * 1024;   // weights resident in LDS
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];
+    float* const lds = lds_all + (BLDS ? WFLOATS : 0);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int H = p.H, W = p.W;
-    const TileGeom g = tile_geom(blockIdx.x, TM, p.B, H, W, KS == 3 ? p.dil : 0);
-
-    SBC_PROF(0);
-    if ((p.flags & 0x20000) && threadIdx.x == 0 && blockIdx.x < SBC_PROF_MAX) {
-        unsigned hwid, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        sbc_prof[blockIdx.x * 8 + 7] = ((long long)xcc << 32) | hwid;
-    }
-    if (!(p.flags & 0x1000)) stage_tile<CIN, NTHREADS, STAGE_UNR>(lds, p.in, p.stats, p.flags, g, H, W, tid);
-    SBC_PROF(1);
-
-    // this lane's A rows: pixel (lane & 31) of each of the wave's MT blocks
-    int row[MT], hh0[MT], ww0[MT];
-    bool live[MT];
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi) {
-        const int px = g.p0 + (wm * MT + mi) * 32 + (lane & 31);
-        live[mi] = px < p.total_px;
-        row[mi] = px / W;
-        ww0[mi] = px - row[mi] * W;
-        hh0[mi] = row[mi] % H;
-    }
+    const int H = p.H, W = p.W, HW = H * W;
+    const int halo = KS == 3 ? p.dil : 0;
     const int khalf = 4 * (lane >> 5);
+    const int col = lane & 31, rhalf = 4 * (lane >> 5);
+    const float4* wp = p.wpk + (size_t)(wn * NT) * 64 + lane;      // + it * NBLK * 64 per K step
+    const float4* wl = reinterpret_cast<const float4*>(lds_all) + (wn * NT) * 64 + lane;
 
-    // LDS float offset of this lane's A fragment for tap `tap` (zero pixel when the tap leaves the image)
-    auto tap_offset = [&](int tap, int mi) {
-        const int dh = KS == 3 ? (tap / 3 - 1) * p.dil : 0;
-        const int dw = KS == 3 ? (tap % 3 - 1) * p.dil : 0;
-        const int hh = hh0[mi] + dh, ww = ww0[mi] + dw;
-        const bool ok = live[mi] && hh >= 0 && hh < H && ww >= 0 && ww < W;
-        return (ok ? (row[mi] + dh - g.rs0) * W + ww : g.nps) * S + khalf;
-    };
+    // tiles of this workgroup: XCD x (= blockIdx % 8, how the dispatcher places workgroups) owns the contiguous tile
+    // range [x * tiles_per_xcd, (x+1) * tiles_per_xcd); its workgroups take them round-robin.  Placement only
+    // affects L2 locality of halo rows, never correctness.
+    const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3;
+    const int t_lo = xcd * p.tiles_per_xcd;
+    const int t_hi = min(t_lo + p.tiles_per_xcd, p.n_tiles);
+    int tile = t_lo + j0;
+    if (tile >= t_hi) return;
 
-    f32x16 acc[MT][NT];
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NT; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-    // K loop, software-pipelined by one (tap, 8-channel group) step with two statically indexed register sets:
-    // the B fragment (global/L2) and the A fragment (LDS) of step it+1 are requested, then the MFMAs of step it
-    // are issued.  sched_barrier pins that order so the waits the compiler inserts in front of the MFMAs are
-    // counted (vmcnt(NT) / lgkmcnt(MT): "everything but the requests just issued"), never a full drain.
-    static_assert(KG % 2 == 0, "two register sets alternate per 8-channel group");
-    const float4* wp = p.wpk + (size_t)(wn * NT) * 64 + lane;      // + it * NBLK * 64 per step
-    int aoff[MT], aoff_n[MT];
-    float4 aS[2][MT], bS[2][NT];
-#pragma unroll
-    for (int ni = 0; ni < NT; ++ni) bS[0][ni] = wp[ni * 64];
-    __syncthreads();                                               // staged tile visible
-    SBC_PROF(2);
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi) {
-        aoff[mi] = tap_offset(0, mi);
-        aS[0][mi] = *reinterpret_cast<const float4*>(__builtin_assume_aligned(lds + aoff[mi], 16));
+    if (BLDS) {
+        for (int i = tid; i < WFLOATS / 4; i += NTHREADS) reinterpret_cast<float4*>(lds_all)[i] = p.wpk[i];
     }
+
+    float4 pf[NPF];
+    TileGeom g = tile_geom(tile, TM, p.B, H, W, halo);
+    if (!(p.flags & SBC_DBG_NOSTAGE)) stage_issue<CIN, NTHREADS, NPF>(pf, p.in, g, W, tid);
+    stage_commit<CIN, NTHREADS, NPF>(lds, pf, p.in, p.stats, p.flags, g, H, W, tid);
+
+    for (;;) {
+        const int tile_n = tile + p.wg_per_xcd;
+        const bool has_next = PF && tile_n < t_hi;
+        TileGeom gn = g;
+        if (has_next) {
+            gn = tile_geom(tile_n, TM, p.B, H, W, halo);
+            if (!(p.flags & SBC_DBG_NOSTAGE))
+                stage_issue<CIN, NTHREADS, NPF>(pf, p.in, gn, W, tid);       // in flight across the MFMA loop
+        }
+        float4 rpf[RES_PF ? ITER : 1];
+        if (RES_PF && p.res1 && !(p.flags & (SBC_EPI_POOL | SBC_DBG_NORES))) {
+#pragma unroll
+            for (int i = 0; i < (RES_PF ? ITER : 0); ++i) {
+                const int idx = tid + i * NTHREADS;
+                const int pl = idx / C4;
+                if (g.p0 + pl < p.total_px)
+                    rpf[i] = ld_stream(p.res1 + (size_t)(g.p0 + pl) * COUT + (idx % C4) * 4);
+            }
+        }
+
+        // this lane's A rows: pixel (lane & 31) of each of the wave's MT blocks
+        int row[MT], hh0[MT], ww0[MT];
+        bool live[MT];
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            const int px = g.p0 + (wm * MT + mi) * 32 + (lane & 31);
+            live[mi] = px < p.total_px;
+            row[mi] = px / W;
+            ww0[mi] = px - row[mi] * W;
+            hh0[mi] = row[mi] % H;
+        }
+        // LDS float offset of this lane's A fragment for tap `tap` (zero pixel when the tap leaves the image)
+        auto tap_offset = [&](int tap, int mi) {
+            const int dh = KS == 3 ? (tap / 3 - 1) * p.dil : 0;
+            const int dw = KS == 3 ? (tap % 3 - 1) * p.dil : 0;
+            const int hh = hh0[mi] + dh, ww = ww0[mi] + dw;
+            const bool ok = live[mi] && hh >= 0 && hh < H && ww >= 0 && ww < W;
+            return (ok ? (row[mi] + dh - g.rs0) * W + ww : g.nps) * S + khalf;
+        };
+
+        f32x16 acc[MT][NT];
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+        // K loop, software-pipelined by one (tap, 8-channel group) step with two statically indexed register
+        // sets: the B fragment and the A fragment of step it+1 are requested, then the MFMAs of step it are
+        // issued.  sched_barrier pins that order so the waits the compiler inserts in front of the MFMAs are
+        // counted ("everything but the requests just issued"), never a full drain.
+        int aoff[MT], aoff_n[MT];
+        float4 aS[2][MT], bS[2][NT];
+        if (!BLDS) {
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) bS[0][ni] = wp[ni * 64];
+        }
+        __syncthreads();                                               // staged tile (and weights) visible
+        if (BLDS) {
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) bS[0][ni] = wl[ni * 64];
+        }
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            aoff[mi] = tap_offset(0, mi);
+            aS[0][mi] = *reinterpret_cast<const float4*>(__builtin_assume_aligned(lds + aoff[mi], 16));
+        }
 #pragma unroll 1
-    for (int tap = 0; tap < ((p.flags & 0x2000) ? 0 : TAPS); ++tap) {
-        const int tap_n = tap + 1 < TAPS ? tap + 1 : tap;
+        for (int tap = 0; tap < ((p.flags & SBC_DBG_NOLOOP) ? 0 : TAPS); ++tap) {
+            const int tap_n = tap + 1 < TAPS ? tap + 1 : tap;
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) aoff_n[mi] = tap_offset(tap_n, mi);
+            for (int mi = 0; mi < MT; ++mi) aoff_n[mi] = tap_offset(tap_n, mi);
 #pragma unroll
-        for (int kg = 0; kg < KG; ++kg) {
-            const int cur = kg & 1, nxt = cur ^ 1;
-            const int it = tap * KG + kg;
-            const int it_n = it + 1 < NIT ? it + 1 : it;
+            for (int kg = 0; kg < KG; ++kg) {
+                const int cur = kg & 1, nxt = cur ^ 1;
+                const int it = tap * KG + kg;
+                const int it_n = it + 1 < NIT ? it + 1 : it;
 #pragma unroll
-            for (int ni = 0; ni < NT; ++ni) bS[nxt][ni] = wp[(size_t)(it_n * NBLK + ni) * 64];
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-                aS[nxt][mi] = *reinterpret_cast<const float4*>(
-                    __builtin_assume_aligned(lds + (kg + 1 < KG ? aoff[mi] + (kg + 1) * 8 : aoff_n[mi]), 16));
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int ni = 0; ni < NT; ++ni)
+                    bS[nxt][ni] = BLDS ? wl[(it_n * NBLK + ni) * 64] : wp[(size_t)(it_n * NBLK + ni) * 64];
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi)
+                    aS[nxt][mi] = *reinterpret_cast<const float4*>(
+                        __builtin_assume_aligned(lds + (kg + 1 < KG ? aoff[mi] + (kg + 1) * 8 : aoff_n[mi]), 16));
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int ni = 0; ni < NT; ++ni) {
-                        const float4 a4 = aS[cur][mi], b4 = bS[cur][ni];
-                        const float av = j == 0 ? a4.x : j == 1 ? a4.y : j == 2 ? a4.z : a4.w;
-                        const float bv = j == 0 ? b4.x : j == 1 ? b4.y : j == 2 ? b4.z : b4.w;
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mi][ni], 0, 0, 0);
-                    }
-            __builtin_amdgcn_sched_barrier(0);
-        }
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) aoff[mi] = aoff_n[mi];
-    }
-
-    // ---------------------------------------------------------------- epilogue
-    // The accumulators (32x32 MFMA map: column = lane & 31 = output channel, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
-    // go through LDS as [pixel][COUT + 4] so that every global access of the epilogue is a 16-byte access of 4
-    // consecutive channels, and all loads of a phase are issued before any is consumed.
-    constexpr int ES = COUT + 4;
-    constexpr int C4 = COUT / 4;
-    const int col = lane & 31, rhalf = 4 * (lane >> 5);
-    SBC_PROF(3);
-    __syncthreads();   // every wave is done reading the staged tile
-    SBC_PROF(4);
+                    for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NT; ++ni) {
-            const int co = (wn * NT + ni) * 32 + col;
-            const float bv = p.bias ? p.bias[co] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int pl = (wm * MT + mi) * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
-                lds[pl * ES + co] = acc[mi][ni][r] + bv;
+                        for (int ni = 0; ni < NT; ++ni) {
+                            const float4 a4 = aS[cur][mi], b4 = bS[cur][ni];
+                            const float av = j == 0 ? a4.x : j == 1 ? a4.y : j == 2 ? a4.z : a4.w;
+                            const float bv = j == 0 ? b4.x : j == 1 ? b4.y : j == 2 ? b4.z : b4.w;
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mi][ni], 0, 0, 0);
+                        }
+                __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) aoff[mi] = aoff_n[mi];
         }
-    __syncthreads();
 
-    if (p.flags & 0x4000) return;
-    if (p.flags & SBC_EPI_POOL) {
-        // ((((0 + a) + b) + c) + d) / 4 with a=[0::2,0::2] b=[1::2,0::2] c=[0::2,1::2] d=[1::2,1::2]  (layers.py:311-312)
-        constexpr int PTOT = (TM / 4) * C4;              // pooled 16-byte outputs of the tile
-        constexpr int PC = 4;
-        const int Wo = W / 2, Ho = H / 2;
-        const int r0 = g.p0 / W;                       // first global row of the tile (even)
+        // ------------------------------------------------------------ epilogue
+        // The accumulators (32x32 MFMA map: column = lane & 31 = output channel, row = (r&3) + 8*(r>>2) +
+        // 4*(lane>>5)) go through LDS as [pixel][COUT + 4] so that every global access of the epilogue is a
+        // 16-byte access of 4 consecutive channels, and all loads of a phase are issued before any is consumed.
+        __syncthreads();   // every wave is done reading the staged tile
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+                const int co = (wn * NT + ni) * 32 + col;
+                const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pl = (wm * MT + mi) * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
+                    lds[pl * ES + co] = acc[mi][ni][r] + bv;
+                }
+            }
+        __syncthreads();
+
+        if (p.flags & SBC_EPI_POOL) {
+            // ((((0 + a) + b) + c) + d) / 4, a=[0::2,0::2] b=[1::2,0::2] c=[0::2,1::2] d=[1::2,1::2] (layers.py:311-312)
+            constexpr int PTOT = (TM / 4) * C4;              // pooled 16-byte outputs of the tile
+            constexpr int PC = 4;
+            const int Wo = W / 2, Ho = H / 2;
+            const int r0 = g.p0 / W;                       // first global row of the tile (even)
 #pragma unroll 1
-        for (int base = 0; base < PTOT; base += PC * NTHREADS) {
-            float4 v[PC], rr[PC];
-            unsigned o[PC];
-            bool ok[PC];
-#pragma unroll
-            for (int i = 0; i < PC; ++i) {
-                const int idx = base + i * NTHREADS + tid;
-                const int c4 = idx % C4, q = idx / C4;
-                const int qr = q / Wo, qc = q - qr * Wo;
-                const int grow = r0 + 2 * qr;
-                ok[i] = idx < PTOT && grow < p.B * H;
-                const float* e = lds + (ok[i] ? ((2 * qr) * W + 2 * qc) * ES + c4 * 4 : 0);
-                const float4 a = *reinterpret_cast<const float4*>(e), b = *reinterpret_cast<const float4*>(e + W * ES);
-                const float4 c = *reinterpret_cast<const float4*>(e + ES), d = *reinterpret_cast<const float4*>(e + (W + 1) * ES);
-                v[i].x = (((a.x + b.x) + c.x) + d.x) * 0.25f;
-                v[i].y = (((a.y + b.y) + c.y) + d.y) * 0.25f;
-                v[i].z = (((a.z + b.z) + c.z) + d.z) * 0.25f;
-                v[i].w = (((a.w + b.w) + c.w) + d.w) * 0.25f;
-                const int n = grow / H, ho = (grow - n * H) >> 1;
-                o[i] = ((unsigned)(n * Ho + ho) * Wo + qc) * COUT + c4 * 4;
-            }
-            if (p.res1) {
-#pragma unroll
-                for (int i = 0; i < PC; ++i)
-                    if (ok[i]) rr[i] = *reinterpret_cast<const float4*>(p.res1 + o[i]);
+            for (int base = 0; base < PTOT; base += PC * NTHREADS) {
+                float4 v[PC], rr[PC];
+                unsigned o[PC];
+                bool ok[PC];
 #pragma unroll
                 for (int i = 0; i < PC; ++i) {
-                    v[i].x = rr[i].x + v[i].x; v[i].y = rr[i].y + v[i].y;
-                    v[i].z = rr[i].z + v[i].z; v[i].w = rr[i].w + v[i].w;
+                    const int idx = base + i * NTHREADS + tid;
+                    const int c4 = idx % C4, q = idx / C4;
+                    const int qr = q / Wo, qc = q - qr * Wo;
+                    const int grow = r0 + 2 * qr;
+                    ok[i] = idx < PTOT && grow < p.B * H;
+                    const float* e = lds + (ok[i] ? ((2 * qr) * W + 2 * qc) * ES + c4 * 4 : 0);
+                    const float4 a = *reinterpret_cast<const float4*>(e), b = *reinterpret_cast<const float4*>(e + W * ES);
+                    const float4 c = *reinterpret_cast<const float4*>(e + ES), d = *reinterpret_cast<const float4*>(e + (W + 1) * ES);
+                    v[i].x = (((a.x + b.x) + c.x) + d.x) * 0.25f;
+                    v[i].y = (((a.y + b.y) + c.y) + d.y) * 0.25f;
+                    v[i].z = (((a.z + b.z) + c.z) + d.z) * 0.25f;
+                    v[i].w = (((a.w + b.w) + c.w) + d.w) * 0.25f;
+                    const int n = grow / H, ho = (grow - n * H) >> 1;
+                    o[i] = ((unsigned)(n * Ho + ho) * Wo + qc) * COUT + c4 * 4;
                 }
+                if (p.res1) {
+#pragma unroll
+                    for (int i = 0; i < PC; ++i)
+                        if (ok[i]) rr[i] = ld_stream(p.res1 + o[i]);
+#pragma unroll
+                    for (int i = 0; i < PC; ++i) {
+                        v[i].x = rr[i].x + v[i].x; v[i].y = rr[i].y + v[i].y;
+                        v[i].z = rr[i].z + v[i].z; v[i].w = rr[i].w + v[i].w;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < PC; ++i)
+                    if (ok[i]) st_stream(p.out + o[i], v[i]);
             }
+        } else {
+            const float sh = (p.flags & SBC_EPI_UP) && H > 1 ? (float)(p.up_h - 1) / (float)(H - 1) : 0.f;
+            const float sw = (p.flags & SBC_EPI_UP) && W > 1 ? (float)(p.up_w - 1) / (float)(W - 1) : 0.f;
 #pragma unroll
-            for (int i = 0; i < PC; ++i)
-                if (ok[i]) *reinterpret_cast<float4*>(p.out + o[i]) = v[i];
-        }
-        return;
-    }
-
-    constexpr int ITER = TM * C4 / NTHREADS;
-    static_assert(TM * C4 % NTHREADS == 0, "epilogue chunks must divide evenly");
-    constexpr int EC = ITER < 8 ? ITER : 8;            // 16-byte requests in flight per thread and phase
-    static_assert(ITER % EC == 0, "epilogue chunking");
-    const int HW = H * W;
-    const float sh = (p.flags & SBC_EPI_UP) && H > 1 ? (float)(p.up_h - 1) / (float)(H - 1) : 0.f;
-    const float sw = (p.flags & SBC_EPI_UP) && W > 1 ? (float)(p.up_w - 1) / (float)(W - 1) : 0.f;
-#pragma unroll 1
-    for (int c0 = 0; c0 < ITER; c0 += EC) {
-        float4 v[EC], rr[EC];
-        unsigned o[EC];
-        bool ok[EC];
-#pragma unroll
-        for (int i = 0; i < EC; ++i) {
-            const int idx = tid + (c0 + i) * NTHREADS;
-            const int c4 = idx % C4, pl = idx / C4;
-            v[i] = *reinterpret_cast<const float4*>(lds + pl * ES + c4 * 4);
-            ok[i] = g.p0 + pl < p.total_px;
-            o[i] = (unsigned)(g.p0 + pl) * COUT + c4 * 4;
-        }
-        if (p.res1) {
-#pragma unroll
-            for (int i = 0; i < EC; ++i)
-                if (ok[i]) rr[i] = ld_stream(p.res1 + o[i]);
-            if (p.flags & SBC_EPI_RES1_ELU) {
-#pragma unroll
-                for (int i = 0; i < EC; ++i) rr[i] = elu4(rr[i]);
-            }
-            if (p.res2) {
-                float4 r2[EC];
-#pragma unroll
-                for (int i = 0; i < EC; ++i)
-                    if (ok[i]) r2[i] = ld_stream(p.res2 + o[i]);
+            for (int c0 = 0; c0 < ITER; c0 += EC) {
+                float4 v[EC], rr[EC];
+                unsigned o[EC];
+                bool ok[EC];
 #pragma unroll
                 for (int i = 0; i < EC; ++i) {
-                    rr[i].x = r2[i].x + rr[i].x; rr[i].y = r2[i].y + rr[i].y;
-                    rr[i].z = r2[i].z + rr[i].z; rr[i].w = r2[i].w + rr[i].w;
+                    const int idx = tid + (c0 + i) * NTHREADS;
+                    const int c4 = idx % C4, pl = idx / C4;
+                    v[i] = *reinterpret_cast<const float4*>(lds + pl * ES + c4 * 4);
+                    ok[i] = g.p0 + pl < p.total_px;
+                    o[i] = (unsigned)(g.p0 + pl) * COUT + c4 * 4;
                 }
-            }
+                if (p.res1) {
 #pragma unroll
-            for (int i = 0; i < EC; ++i) {
-                v[i].x = v[i].x + rr[i].x; v[i].y = v[i].y + rr[i].y;
-                v[i].z = v[i].z + rr[i].z; v[i].w = v[i].w + rr[i].w;
+                    for (int i = 0; i < EC; ++i) {
+                        if (RES_PF) rr[i] = rpf[RES_PF ? c0 + i : 0];     // chunk loop is unrolled: static index
+                        else if (ok[i]) rr[i] = ld_stream(p.res1 + o[i]);
+                    }
+                    if (p.flags & SBC_EPI_RES1_ELU) {
+#pragma unroll
+                        for (int i = 0; i < EC; ++i) rr[i] = elu4(rr[i]);
+                    }
+                    if (p.res2) {
+                        float4 r2[EC];
+#pragma unroll
+                        for (int i = 0; i < EC; ++i)
+                            if (ok[i]) r2[i] = ld_stream(p.res2 + o[i]);
+#pragma unroll
+                        for (int i = 0; i < EC; ++i) {
+                            rr[i].x = r2[i].x + rr[i].x; rr[i].y = r2[i].y + rr[i].y;
+                            rr[i].z = r2[i].z + rr[i].z; rr[i].w = r2[i].w + rr[i].w;
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < EC; ++i) {
+                        v[i].x = v[i].x + rr[i].x; v[i].y = v[i].y + rr[i].y;
+                        v[i].z = v[i].z + rr[i].z; v[i].w = v[i].w + rr[i].w;
+                    }
+                }
+                if (p.flags & SBC_EPI_UP) {
+                    // F.interpolate(bilinear, align_corners=True) of `up` added on top (MSFBlock, layers.py:182-183)
+#pragma unroll
+                    for (int i = 0; i < EC; ++i) {
+                        if (!ok[i]) continue;
+                        const int idx = tid + (c0 + i) * NTHREADS;
+                        const int c4 = idx % C4, px = g.p0 + idx / C4;
+                        const int n = px / HW, rem = px - n * HW;
+                        const int h = rem / W, w = rem - h * W;
+                        const float fh = sh * (float)h, fw = sw * (float)w;
+                        const int h0 = min((int)fh, p.up_h - 1), w0 = min((int)fw, p.up_w - 1);
+                        const int h1 = min(h0 + 1, p.up_h - 1), w1 = min(w0 + 1, p.up_w - 1);
+                        const float lh1 = fh - (float)h0, lw1 = fw - (float)w0;
+                        const float lh0 = 1.f - lh1, lw0 = 1.f - lw1;
+                        const float* u = p.up + (size_t)n * p.up_h * p.up_w * COUT + c4 * 4;
+                        const float4 v00 = *reinterpret_cast<const float4*>(u + (size_t)(h0 * p.up_w + w0) * COUT);
+                        const float4 v01 = *reinterpret_cast<const float4*>(u + (size_t)(h0 * p.up_w + w1) * COUT);
+                        const float4 v10 = *reinterpret_cast<const float4*>(u + (size_t)(h1 * p.up_w + w0) * COUT);
+                        const float4 v11 = *reinterpret_cast<const float4*>(u + (size_t)(h1 * p.up_w + w1) * COUT);
+                        v[i].x = v[i].x + (lh0 * (lw0 * v00.x + lw1 * v01.x) + lh1 * (lw0 * v10.x + lw1 * v11.x));
+                        v[i].y = v[i].y + (lh0 * (lw0 * v00.y + lw1 * v01.y) + lh1 * (lw0 * v10.y + lw1 * v11.y));
+                        v[i].z = v[i].z + (lh0 * (lw0 * v00.z + lw1 * v01.z) + lh1 * (lw0 * v10.z + lw1 * v11.z));
+                        v[i].w = v[i].w + (lh0 * (lw0 * v00.w + lw1 * v01.w) + lh1 * (lw0 * v10.w + lw1 * v11.w));
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < EC; ++i)
+                    if (ok[i] && !(p.flags & SBC_DBG_NOSTORE)) st_stream(p.out + o[i], v[i]);
             }
         }
-        if (p.flags & SBC_EPI_UP) {
-            // F.interpolate(bilinear, align_corners=True) of `up` added on top (MSFBlock, layers.py:182-183)
-#pragma unroll
-            for (int i = 0; i < EC; ++i) {
-                if (!ok[i]) continue;
-                const int idx = tid + (c0 + i) * NTHREADS;
-                const int c4 = idx % C4, px = g.p0 + idx / C4;
-                const int n = px / HW, rem = px - n * HW;
-                const int h = rem / W, w = rem - h * W;
-                const float fh = sh * (float)h, fw = sw * (float)w;
-                const int h0 = min((int)fh, p.up_h - 1), w0 = min((int)fw, p.up_w - 1);
-                const int h1 = min(h0 + 1, p.up_h - 1), w1 = min(w0 + 1, p.up_w - 1);
-                const float lh1 = fh - (float)h0, lw1 = fw - (float)w0;
-                const float lh0 = 1.f - lh1, lw0 = 1.f - lw1;
-                const float* u = p.up + (size_t)n * p.up_h * p.up_w * COUT + c4 * 4;
-                const float4 v00 = *reinterpret_cast<const float4*>(u + (size_t)(h0 * p.up_w + w0) * COUT);
-                const float4 v01 = *reinterpret_cast<const float4*>(u + (size_t)(h0 * p.up_w + w1) * COUT);
-                const float4 v10 = *reinterpret_cast<const float4*>(u + (size_t)(h1 * p.up_w + w0) * COUT);
-                const float4 v11 = *reinterpret_cast<const float4*>(u + (size_t)(h1 * p.up_w + w1) * COUT);
-                v[i].x = v[i].x + (lh0 * (lw0 * v00.x + lw1 * v01.x) + lh1 * (lw0 * v10.x + lw1 * v11.x));
-                v[i].y = v[i].y + (lh0 * (lw0 * v00.y + lw1 * v01.y) + lh1 * (lw0 * v10.y + lw1 * v11.y));
-                v[i].z = v[i].z + (lh0 * (lw0 * v00.z + lw1 * v01.z) + lh1 * (lw0 * v10.z + lw1 * v11.z));
-                v[i].w = v[i].w + (lh0 * (lw0 * v00.w + lw1 * v01.w) + lh1 * (lw0 * v10.w + lw1 * v11.w));
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < EC; ++i)
-            if (ok[i]) st_stream(p.out + o[i], v[i]);
+
+        if (!has_next) break;
+        __syncthreads();                 // epilogue reads of the LDS tile are done
+        g = gn;
+        tile = tile_n;
+        stage_commit<CIN, NTHREADS, NPF>(lds, pf, p.in, p.stats, p.flags, g, H, W, tid);
     }
-    SBC_PROF(5);
 }
 
 // ------------------------------------------------------------------------------------------------ dispatch
+static int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+template <int CIN, int COUT, int KS, int MT, int NT, int WM, int WN, bool PF>
+static int launch_kernel(ConvParams p, size_t lds, hipStream_t stream, bool dry) {
+    constexpr int TM = 32 * MT * WM;
+    auto kern = conv_mfma_kernel<CIN, COUT, KS, MT, NT, WM, WN, PF>;
+    static size_t lds_attr = 0;   // per instantiation
+    static int occ = 0;
+    if (lds > lds_attr) {
+        SBC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_attr = lds;
+        occ = 0;
+    }
+    if (!occ) {
+        SBC_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern),
+                                                                  64 * WM * WN, lds_attr));
+        if (occ < 1) occ = 1;
+        if (getenv("SBC_OCC")) occ = min(occ, atoi(getenv("SBC_OCC")));      // tuning aid
+    }
+    if (dry) return SBC_OK;
+    p.n_tiles = (p.total_px + TM - 1) / TM;
+    p.tiles_per_xcd = (p.n_tiles + 7) / 8;
+    int grid;
+    if (PF) {
+        p.wg_per_xcd = min(p.tiles_per_xcd, max(1, occ * num_cus() / 8));
+        grid = p.wg_per_xcd * 8;
+    } else {
+        p.wg_per_xcd = p.tiles_per_xcd;         // one tile per workgroup
+        grid = p.tiles_per_xcd * 8;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), lds, stream, p);
+    SBC_CHECK_HIP(hipGetLastError());
+    return SBC_OK;
+}
+
 template <int CIN, int COUT, int KS, int MT, int NT, int WM, int WN>
-static int launch_variant(const ConvParams& p, hipStream_t stream) {
+static int launch_variant(const ConvParams& p, hipStream_t stream, bool dry) {
     constexpr int TM = 32 * MT * WM;
     constexpr int S = CIN + 4;
     const int HW = p.H * p.W;
@@ -317,30 +409,27 @@ static int launch_variant(const ConvParams& p, hipStream_t stream) {
     size_t lds = (size_t)(TM + halo_px + 1) * S * sizeof(float);
     lds = max(lds, (size_t)TM * (COUT + 4) * sizeof(float));       // epilogue transposes through LDS
     SBC_REQUIRE(lds <= 160 * 1024, "conv tile needs %zu bytes of LDS (> 160 KiB)", lds);
-    auto kern = conv_mfma_kernel<CIN, COUT, KS, MT, NT, WM, WN>;
-    static size_t lds_attr = 0;   // per instantiation
-    if (lds > lds_attr) {
-        SBC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_attr = lds;
+    // several tiles per resident workgroup -> persistent build that prefetches the next tile
+    const long n_tiles = (p.total_px + TM - 1) / TM;
+    if (n_tiles >= 3L * num_cus()) {
+        constexpr size_t wbytes = (size_t)KS * KS * CIN * COUT * sizeof(float);
+        if (wbytes <= 40 * 1024) lds += wbytes;                     // weights resident in LDS (BLDS in the kernel)
+        return launch_kernel<CIN, COUT, KS, MT, NT, WM, WN, true>(p, lds, stream, dry);
     }
-    const int grid = (p.total_px + TM - 1) / TM;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), lds, stream, p);
-    SBC_CHECK_HIP(hipGetLastError());
-    return SBC_OK;
+    return launch_kernel<CIN, COUT, KS, MT, NT, WM, WN, false>(p, lds, stream, dry);
 }
 
 // Tile choice: as many pixels per workgroup as still leaves >= ~2 workgroups per CU (256 CUs), subject to the
 // tile fitting the image (whole rows of one sample, or whole samples) and, for pooling, holding whole 2x2 blocks.
 template <int CIN, int COUT, int KS>
-static int launch_sized(const ConvParams& p, hipStream_t stream) {
+static int launch_sized(const ConvParams& p, hipStream_t stream, bool dry) {
     constexpr int NB = COUT / 32;
     const int HW = p.H * p.W;
     const long px = p.total_px;
     auto fits = [&](int tm) {
         return tm % p.W == 0 && (HW % tm == 0 || tm % HW == 0) && (!(p.flags & SBC_EPI_POOL) || tm % (2 * p.W) == 0);
     };
-    static const int force = getenv("SBC_TILE") ? atoi(getenv("SBC_TILE")) : 0;
+    static const int force = getenv("SBC_TILE") ? atoi(getenv("SBC_TILE")) : 0;     // tuning aid
     int tm = 0;
     if (force && fits(force)) tm = force;
     else if (fits(256) && px >= 256L * 512) tm = 256;
@@ -349,18 +438,20 @@ static int launch_sized(const ConvParams& p, hipStream_t stream) {
     else if (fits(128)) tm = 128;
     else if (fits(256)) tm = 256;
     SBC_REQUIRE(tm != 0, "conv: no tile of 64/128/256 pixels fits image %dx%d (flags 0x%x)", p.H, p.W, p.flags);
-    if (tm == 256) return launch_variant<CIN, COUT, KS, 2, NB, 4, 1>(p, stream);
+    if (tm == 256) return launch_variant<CIN, COUT, KS, 2, NB, 4, 1>(p, stream, dry);
     if constexpr (NB >= 2) {
-        if (tm == 128) return launch_variant<CIN, COUT, KS, 2, NB / 2, 2, 2>(p, stream);
-        if constexpr (NB >= 4) return launch_variant<CIN, COUT, KS, 2, 1, 1, 4>(p, stream);
-        else return launch_variant<CIN, COUT, KS, 1, 1, 2, 2>(p, stream);
+        if (tm == 128) return launch_variant<CIN, COUT, KS, 2, NB / 2, 2, 2>(p, stream, dry);
+        if constexpr (NB >= 4) return launch_variant<CIN, COUT, KS, 2, 1, 1, 4>(p, stream, dry);
+        else return launch_variant<CIN, COUT, KS, 1, 1, 2, 2>(p, stream, dry);
     } else {
-        if (tm == 128) return launch_variant<CIN, COUT, KS, 2, 1, 2, 1>(p, stream);
-        return launch_variant<CIN, COUT, KS, 1, 1, 2, 1>(p, stream);
+        if (tm == 128) return launch_variant<CIN, COUT, KS, 1, 1, 4, 1>(p, stream, dry);
+        return launch_variant<CIN, COUT, KS, 1, 1, 2, 1>(p, stream, dry);
     }
 }
 
-int launch_conv(const sbc_op& op, hipStream_t stream) {
+// dry = true: resolve the kernel variant and set its function attributes without launching (done at plan creation
+// so that nothing but kernel launches happens inside a hipGraph capture)
+int launch_conv(const sbc_op& op, hipStream_t stream, bool dry) {
     SBC_REQUIRE(op.in && op.out && op.weight, "conv: in/out/weight must be set");
     SBC_REQUIRE(op.B > 0 && op.H > 0 && op.W > 0, "conv: bad shape B=%d H=%d W=%d", op.B, op.H, op.W);
     SBC_REQUIRE(op.ksize == 1 || op.ksize == 3, "conv: ksize %d (only 1 and 3)", op.ksize);
@@ -374,21 +465,22 @@ int launch_conv(const sbc_op& op, hipStream_t stream) {
     p.in = (const float*)op.in; p.out = (float*)op.out; p.wpk = (const float4*)op.weight;
     p.bias = (const float*)op.bias; p.stats = (const float*)op.stats;
     p.res1 = (const float*)op.res1; p.res2 = (const float*)op.res2; p.up = (const float*)op.up;
-    p.B = op.B; p.H = op.H; p.W = op.W; p.dil = op.dil; p.flags = op.flags;
+    p.B = op.B; p.H = op.H; p.W = op.W; p.dil = op.dil; p.flags = op.flags & 0xfff;
     p.up_h = op.up_h; p.up_w = op.up_w; p.total_px = op.B * op.H * op.W;
+    p.n_tiles = p.tiles_per_xcd = p.wg_per_xcd = 0;
     static const int dbg = getenv("SBC_DEBUG_FLAGS") ? (int)strtol(getenv("SBC_DEBUG_FLAGS"), nullptr, 0) : 0;
-    p.flags |= dbg & 0x27000;     // phase-skipping switches for performance triage only (results are wrong)
+    p.flags |= dbg & 0xf000;
     const int key = op.cin * 100000 + op.cout * 100 + op.ksize;
     switch (key) {
-        case 32 * 100000 + 32 * 100 + 3: return launch_sized<32, 32, 3>(p, stream);
-        case 32 * 100000 + 64 * 100 + 3: return launch_sized<32, 64, 3>(p, stream);
-        case 32 * 100000 + 64 * 100 + 1: return launch_sized<32, 64, 1>(p, stream);
-        case 64 * 100000 + 64 * 100 + 3: return launch_sized<64, 64, 3>(p, stream);
-        case 64 * 100000 + 64 * 100 + 1: return launch_sized<64, 64, 1>(p, stream);
-        case 64 * 100000 + 32 * 100 + 3: return launch_sized<64, 32, 3>(p, stream);
-        case 64 * 100000 + 128 * 100 + 3: return launch_sized<64, 128, 3>(p, stream);
-        case 128 * 100000 + 128 * 100 + 3: return launch_sized<128, 128, 3>(p, stream);
-        case 128 * 100000 + 64 * 100 + 3: return launch_sized<128, 64, 3>(p, stream);
+        case 32 * 100000 + 32 * 100 + 3: return launch_sized<32, 32, 3>(p, stream, dry);
+        case 32 * 100000 + 64 * 100 + 3: return launch_sized<32, 64, 3>(p, stream, dry);
+        case 32 * 100000 + 64 * 100 + 1: return launch_sized<32, 64, 1>(p, stream, dry);
+        case 64 * 100000 + 64 * 100 + 3: return launch_sized<64, 64, 3>(p, stream, dry);
+        case 64 * 100000 + 64 * 100 + 1: return launch_sized<64, 64, 1>(p, stream, dry);
+        case 64 * 100000 + 32 * 100 + 3: return launch_sized<64, 32, 3>(p, stream, dry);
+        case 64 * 100000 + 128 * 100 + 3: return launch_sized<64, 128, 3>(p, stream, dry);
+        case 128 * 100000 + 128 * 100 + 3: return launch_sized<128, 128, 3>(p, stream, dry);
+        case 128 * 100000 + 64 * 100 + 3: return launch_sized<128, 64, 3>(p, stream, dry);
         default:
             set_error("conv: no kernel for cin=%d cout=%d ksize=%d (NCSNv2Deepest with ngf=32 needs "
                       "32/64/128 channels)", op.cin, op.cout, op.ksize);
@@ -397,7 +489,3 @@ int launch_conv(const sbc_op& op, hipStream_t stream) {
 }
 
 }  // namespace sbc
-
-extern "C" int sbc_debug_read_prof(long long* out, int n_blocks) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(sbc::sbc_prof), sizeof(long long) * 8 * n_blocks) == hipSuccess ? 0 : -2;
-}

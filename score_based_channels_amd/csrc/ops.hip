@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void end_conv_kernel(const float* __restrict__
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const TileGeom g = tile_geom(blockIdx.x, TM, B, H, W, 1);
-    stage_tile<CIN, 256>(lds, in, stats, SBC_PRO_NORM | SBC_PRO_ELU, g, H, W, tid);
+    stage_tile<CIN, 256, 9>(lds, in, stats, SBC_PRO_NORM | SBC_PRO_ELU, g, H, W, tid);
     float* wl = lds + (size_t)(g.nps + 1) * S;          // [9][CIN][2]
     for (int i = tid; i < 9 * CIN * 2; i += 256) {
         const int o = i & 1, c = (i >> 1) % CIN, tap = i / (2 * CIN);
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void end_conv_kernel(const float* __restrict__
     *reinterpret_cast<float2*>(out + (size_t)px * 2) = o;
 }
 
-int launch_end_conv(const sbc_op& op, const sbc_endconv& e, hipStream_t stream) {
+int launch_end_conv(const sbc_op& op, const sbc_endconv& e, hipStream_t stream, bool dry) {
     SBC_REQUIRE(op.in && op.out && op.weight && op.bias && op.stats, "end_conv: in/out/weight/bias/stats must be set");
     SBC_REQUIRE(op.cout == 2, "end_conv: cout=%d", op.cout);
     SBC_REQUIRE((e.labels && e.sigmas) || (e.sigma_of_step && e.step), "end_conv: no noise-level source");
@@ -258,6 +258,7 @@ int launch_end_conv(const sbc_op& op, const sbc_endconv& e, hipStream_t stream) 
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_attr = lds;
     }
+    if (dry) return SBC_OK;
     hipLaunchKernelGGL(end_conv_kernel<32>, dim3((total + TM - 1) / TM), dim3(256), lds, stream, (const float*)op.in,
                        (const float*)op.stats, (const float*)op.weight, (const float*)op.bias, (float*)op.out, e, op.B,
                        op.H, op.W);
@@ -377,7 +378,7 @@ static int check_langevin(const sbc_op& op, const sbc_langevin& a, bool measure)
     return SBC_OK;
 }
 
-int launch_langevin(const sbc_op& op, const sbc_langevin& a, hipStream_t stream) {
+int launch_langevin(const sbc_op& op, const sbc_langevin& a, hipStream_t stream, bool dry) {
     const int rc = check_langevin(op, a, false);
     if (rc) return rc;
     const size_t lds_all = (size_t)(a.Nt + a.Np) * a.Nr * sizeof(float2);
@@ -389,6 +390,7 @@ int launch_langevin(const sbc_op& op, const sbc_langevin& a, hipStream_t stream)
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_attr = lds;
     }
+    if (dry) return SBC_OK;
     hipLaunchKernelGGL(langevin_kernel, dim3(op.B), dim3(256), lds, stream, a, op.B, x_in_lds);
     SBC_CHECK_HIP(hipGetLastError());
     return SBC_OK;

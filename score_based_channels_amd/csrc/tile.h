@@ -62,46 +62,67 @@ __device__ __forceinline__ TileGeom tile_geom(int tile, int TM, int B, int H, in
     return g;
 }
 
-// Copy the staged rows into LDS with the prologue applied.  stats = [B][3][CIN] (mu, scale, shift).
-// Loads are issued in batches of UNR 16-byte requests per thread before any is consumed.
-template <int CIN, int NTHREADS, int UNR = 4>
-__device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__ in,
-                                           const float* __restrict__ stats, int flags, const TileGeom& g,
-                                           int H, int W, int tid) {
+// Staging is split in two so a persistent workgroup can request tile i+1 before it computes tile i:
+//   stage_issue   requests up to NPF 16-byte chunks per thread of the staged rows (raw values, registers only);
+//   stage_commit  applies the prologue (stats = [B][3][CIN]: mu, scale, shift; ELU) and writes the LDS tile; chunks
+//                 beyond NPF * NTHREADS (unusually wide halos) are fetched synchronously here.
+template <int CIN, int NTHREADS, int NPF>
+__device__ __forceinline__ void stage_issue(float4 (&pf)[NPF], const float* __restrict__ in, const TileGeom& g,
+                                            int W, int tid) {
+    const float* src = in + (size_t)g.rs0 * W * CIN;
+    const int total = g.nps * (CIN / 4);
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) {
+        const int idx = u * NTHREADS + tid;
+        if (idx < total) pf[u] = ld_stream(src + (size_t)idx * 4);
+    }
+}
+
+template <int CIN>
+__device__ __forceinline__ void stage_put(float* lds, float4 x, int idx, const float* __restrict__ stats, int flags,
+                                          const TileGeom& g, int HW) {
     constexpr int S = CIN + 4;
     constexpr int C4 = CIN / 4;
-    const float* src = in + (size_t)g.rs0 * W * CIN;
-    const int HW = H * W;
-    const int total = g.nps * C4;
-    for (int base = 0; base < total; base += UNR * NTHREADS) {
-        float4 v[UNR];
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int idx = base + u * NTHREADS + tid;
-            if (idx < total) v[u] = ld_stream(src + (size_t)idx * 4);
-        }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int idx = base + u * NTHREADS + tid;
-            if (idx >= total) continue;
-            const int pix = idx / C4, c4 = idx % C4;
-            float4 x = v[u];
-            if (flags & SBC_PRO_NORM) {
-                const int n = g.n_first + (g.multi ? pix / HW : 0);
-                const float* st = stats + (size_t)n * 3 * CIN + c4 * 4;
-                const float4 mu = *reinterpret_cast<const float4*>(st);
-                const float4 sc = *reinterpret_cast<const float4*>(st + CIN);
-                const float4 sh = *reinterpret_cast<const float4*>(st + 2 * CIN);
-                x.x = (x.x - mu.x) * sc.x + sh.x;
-                x.y = (x.y - mu.y) * sc.y + sh.y;
-                x.z = (x.z - mu.z) * sc.z + sh.z;
-                x.w = (x.w - mu.w) * sc.w + sh.w;
-            }
-            if (flags & SBC_PRO_ELU) x = elu4(x);
-            *reinterpret_cast<float4*>(lds + pix * S + c4 * 4) = x;
-        }
+    const int pix = idx / C4, c4 = idx % C4;
+    if (flags & SBC_PRO_NORM) {
+        const int n = g.n_first + (g.multi ? pix / HW : 0);
+        const float* st = stats + (size_t)n * 3 * CIN + c4 * 4;
+        const float4 mu = *reinterpret_cast<const float4*>(st);
+        const float4 sc = *reinterpret_cast<const float4*>(st + CIN);
+        const float4 sh = *reinterpret_cast<const float4*>(st + 2 * CIN);
+        x.x = (x.x - mu.x) * sc.x + sh.x;
+        x.y = (x.y - mu.y) * sc.y + sh.y;
+        x.z = (x.z - mu.z) * sc.z + sh.z;
+        x.w = (x.w - mu.w) * sc.w + sh.w;
     }
+    if (flags & SBC_PRO_ELU) x = elu4(x);
+    *reinterpret_cast<float4*>(lds + pix * S + c4 * 4) = x;
+}
+
+template <int CIN, int NTHREADS, int NPF>
+__device__ __forceinline__ void stage_commit(float* lds, const float4 (&pf)[NPF], const float* __restrict__ in,
+                                             const float* __restrict__ stats, int flags, const TileGeom& g, int H,
+                                             int W, int tid) {
+    constexpr int S = CIN + 4;
+    const int HW = H * W;
+    const int total = g.nps * (CIN / 4);
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) {
+        const int idx = u * NTHREADS + tid;
+        if (idx < total) stage_put<CIN>(lds, pf[u], idx, stats, flags, g, HW);
+    }
+    const float* src = in + (size_t)g.rs0 * W * CIN;
+    for (int idx = NPF * NTHREADS + tid; idx < total; idx += NTHREADS)
+        stage_put<CIN>(lds, ld_stream(src + (size_t)idx * 4), idx, stats, flags, g, HW);
     for (int i = tid; i < S; i += NTHREADS) lds[g.nps * S + i] = 0.f;
+}
+
+template <int CIN, int NTHREADS, int NPF>
+__device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__ in, const float* __restrict__ stats,
+                                           int flags, const TileGeom& g, int H, int W, int tid) {
+    float4 pf[NPF];
+    stage_issue<CIN, NTHREADS, NPF>(pf, in, g, W, tid);
+    stage_commit<CIN, NTHREADS, NPF>(lds, pf, in, stats, flags, g, H, W, tid);
 }
 
 }  // namespace sbc
