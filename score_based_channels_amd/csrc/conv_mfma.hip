@@ -124,24 +124,31 @@ __global__ __launch_bounds__(64 * WM * WN, PF ? 2 : 1) void conv_mfma_kernel(Con
             }
         }
 
-        // this lane's A rows: pixel (lane & 31) of each of the wave's MT blocks
-        int row[MT], hh0[MT], ww0[MT];
-        bool live[MT];
+        // This lane's A rows: pixel (lane & 31) of each of the wave's MT blocks.  Per block one LDS base offset and a
+        // 9-bit mask of the taps that stay inside the image, so that the per-tap work inside the MFMA loop is a
+        // bit test and a select (tap deltas are wave-uniform); out-of-image taps read the shared zero pixel.
+        int abase[MT];
+        unsigned amask[MT];
+        const int zoff = g.nps * S + khalf;
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
             const int px = g.p0 + (wm * MT + mi) * 32 + (lane & 31);
-            live[mi] = px < p.total_px;
-            row[mi] = px / W;
-            ww0[mi] = px - row[mi] * W;
-            hh0[mi] = row[mi] % H;
+            const int row = px / W, ww = px - row * W, hh = row % H;
+            abase[mi] = ((row - g.rs0) * W + ww) * S + khalf;
+            unsigned m = 0;
+            if (px < p.total_px) {
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) {
+                    const int dh = KS == 3 ? (t / 3 - 1) * p.dil : 0, dw = KS == 3 ? (t % 3 - 1) * p.dil : 0;
+                    if (hh + dh >= 0 && hh + dh < H && ww + dw >= 0 && ww + dw < W) m |= 1u << t;
+                }
+            }
+            amask[mi] = m;
         }
-        // LDS float offset of this lane's A fragment for tap `tap` (zero pixel when the tap leaves the image)
         auto tap_offset = [&](int tap, int mi) {
             const int dh = KS == 3 ? (tap / 3 - 1) * p.dil : 0;
             const int dw = KS == 3 ? (tap % 3 - 1) * p.dil : 0;
-            const int hh = hh0[mi] + dh, ww = ww0[mi] + dw;
-            const bool ok = live[mi] && hh >= 0 && hh < H && ww >= 0 && ww < W;
-            return (ok ? (row[mi] + dh - g.rs0) * W + ww : g.nps) * S + khalf;
+            return ((amask[mi] >> tap) & 1u) ? abase[mi] + (dh * W + dw) * S : zoff;
         };
 
         f32x16 acc[MT][NT];
