@@ -40,8 +40,11 @@ int launch_measure(const sbc_op& op, const sbc_langevin& ext, hipStream_t stream
 int launch_step_inc(const sbc_op& op, hipStream_t stream);
 
 #if defined(__HIPCC__)
-// nn.ELU(alpha=1): x > 0 ? x : exp(x) - 1   (ncsnv2/models/layers.py:12-13)
-__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+// nn.ELU(alpha=1): x > 0 ? x : exp(x) - 1   (ncsnv2/models/layers.py:12-13).  Written the way PyTorch's own ELU
+// kernels evaluate it, exp(x) - 1, on the hardware exponential (v_exp_f32 of x*log2(e), ~1 ulp) rather than a
+// ~20-instruction expm1: on gfx950 fp32 VALU work and fp32 MFMA share the same ALUs (tools/mfma_valu_coissue.hip:
+// 146 TF + 130 TF alone, 83 + 42 TF together), so every vector instruction of the staging path is MFMA time.
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
 __device__ __forceinline__ float4 elu4(float4 v) {
     return make_float4(elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w));
 }

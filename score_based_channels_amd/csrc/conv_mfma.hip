@@ -39,6 +39,7 @@ struct ConvParams {
     const float* __restrict__ up;
     int B, H, W, dil, flags, up_h, up_w, total_px;
     int n_tiles, tiles_per_xcd, wg_per_xcd;
+    int hsh, wsh;         // log2(H), log2(W) for the power-of-two builds
 };
 
 // performance-triage switches (SBC_DEBUG_FLAGS, results are wrong when set): skip staging loads / MFMA loop /
@@ -48,7 +49,7 @@ struct ConvParams {
 #define SBC_DBG_NOSTORE 0x4000
 #define SBC_DBG_NORES 0x8000
 
-template <int CIN, int COUT, int KS, int MT, int NT, int WM, int WN, bool PF>
+template <int CIN, int COUT, int KS, int MT, int NT, int WM, int WN, bool PF, bool P2>
 __global__ __launch_bounds__(64 * WM * WN, PF ? 2 : 1) void conv_mfma_kernel(ConvParams p) {
     constexpr int TM = 32 * MT * WM;
     constexpr int S = CIN + 4;
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(64 * WM * WN, PF ? 2 : 1) void conv_mfma_kernel(Con
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int H = p.H, W = p.W, HW = H * W;
+    const Dims<P2> dm{H, W, HW, p.hsh, p.wsh};
     const int halo = KS == 3 ? p.dil : 0;
     const int khalf = 4 * (lane >> 5);
     const int col = lane & 31, rhalf = 4 * (lane >> 5);
@@ -100,16 +102,16 @@ __global__ __launch_bounds__(64 * WM * WN, PF ? 2 : 1) void conv_mfma_kernel(Con
     }
 
     float4 pf[NPF];
-    TileGeom g = tile_geom(tile, TM, p.B, H, W, halo);
+    TileGeom g = tile_geom(tile, TM, p.B, dm, halo);
     if (!(p.flags & SBC_DBG_NOSTAGE)) stage_issue<CIN, NTHREADS, NPF>(pf, p.in, g, W, tid);
-    stage_commit<CIN, NTHREADS, NPF>(lds, pf, p.in, p.stats, p.flags, g, H, W, tid);
+    stage_commit<CIN, NTHREADS, NPF, P2>(lds, pf, p.in, p.stats, p.flags, g, dm, tid);
 
     for (;;) {
         const int tile_n = tile + p.wg_per_xcd;
         const bool has_next = PF && tile_n < t_hi;
         TileGeom gn = g;
         if (has_next) {
-            gn = tile_geom(tile_n, TM, p.B, H, W, halo);
+            gn = tile_geom(tile_n, TM, p.B, dm, halo);
             if (!(p.flags & SBC_DBG_NOSTAGE))
                 stage_issue<CIN, NTHREADS, NPF>(pf, p.in, gn, W, tid);       // in flight across the MFMA loop
         }
@@ -133,18 +135,28 @@ __global__ __launch_bounds__(64 * WM * WN, PF ? 2 : 1) void conv_mfma_kernel(Con
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
             const int px = g.p0 + (wm * MT + mi) * 32 + (lane & 31);
-            const int row = px / W, ww = px - row * W, hh = row % H;
+            const int row = dm.div_w(px), ww = dm.mod_w(px), hh = dm.mod_h(row);
             abase[mi] = ((row - g.rs0) * W + ww) * S + khalf;
-            unsigned m = 0;
-            if (px < p.total_px) {
-#pragma unroll
-                for (int t = 0; t < TAPS; ++t) {
-                    const int dh = KS == 3 ? (t / 3 - 1) * p.dil : 0, dw = KS == 3 ? (t % 3 - 1) * p.dil : 0;
-                    if (hh + dh >= 0 && hh + dh < H && ww + dw >= 0 && ww + dw < W) m |= 1u << t;
-                }
+            // 3 row bits x 3 column bits -> 9 tap bits (bit t = kh*3 + kw)
+            unsigned rb = 2u, cb = 2u;                       // centre row / column always inside
+            if (KS == 3) {
+                rb |= (hh - p.dil >= 0 ? 1u : 0u) | (hh + p.dil < H ? 4u : 0u);
+                cb |= (ww - p.dil >= 0 ? 1u : 0u) | (ww + p.dil < W ? 4u : 0u);
             }
-            amask[mi] = m;
+            unsigned m = ((rb & 1u) ? cb : 0u) | ((rb & 2u) ? cb << 3 : 0u) | ((rb & 4u) ? cb << 6 : 0u);
+            if (KS == 1) m = 1u;
+            amask[mi] = px < p.total_px ? m : 0u;
         }
+        // taps that are outside the image for every lane of this wave contribute exact zeros: skip them (at 8x2 with
+        // dilation 2 / 4 that is 6 of the 9 taps)
+        unsigned lane_or = 0;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) lane_or |= amask[mi];
+        unsigned tapmask = 0;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+            if (__ballot((lane_or >> t) & 1u)) tapmask |= 1u << t;
+        if (p.flags & SBC_DBG_NOLOOP) tapmask = 0;
         auto tap_offset = [&](int tap, int mi) {
             const int dh = KS == 3 ? (tap / 3 - 1) * p.dil : 0;
             const int dw = KS == 3 ? (tap % 3 - 1) * p.dil : 0;
@@ -165,30 +177,32 @@ __global__ __launch_bounds__(64 * WM * WN, PF ? 2 : 1) void conv_mfma_kernel(Con
         // counted ("everything but the requests just issued"), never a full drain.
         int aoff[MT], aoff_n[MT];
         float4 aS[2][MT], bS[2][NT];
+        int tap = tapmask ? __builtin_ctz(tapmask) : TAPS;                 // first tap with work
+        const int it0 = (tap < TAPS ? tap : 0) * KG;
         if (!BLDS) {
 #pragma unroll
-            for (int ni = 0; ni < NT; ++ni) bS[0][ni] = wp[ni * 64];
+            for (int ni = 0; ni < NT; ++ni) bS[0][ni] = wp[(size_t)(it0 * NBLK + ni) * 64];
         }
         __syncthreads();                                               // staged tile (and weights) visible
         if (BLDS) {
 #pragma unroll
-            for (int ni = 0; ni < NT; ++ni) bS[0][ni] = wl[ni * 64];
+            for (int ni = 0; ni < NT; ++ni) bS[0][ni] = wl[(it0 * NBLK + ni) * 64];
         }
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
-            aoff[mi] = tap_offset(0, mi);
+            aoff[mi] = tap_offset(tap < TAPS ? tap : 0, mi);
             aS[0][mi] = *reinterpret_cast<const float4*>(__builtin_assume_aligned(lds + aoff[mi], 16));
         }
 #pragma unroll 1
-        for (int tap = 0; tap < ((p.flags & SBC_DBG_NOLOOP) ? 0 : TAPS); ++tap) {
-            const int tap_n = tap + 1 < TAPS ? tap + 1 : tap;
+        while (tap < TAPS) {
+            const unsigned rest = tapmask >> (tap + 1);
+            const int tap_n = rest ? tap + 1 + __builtin_ctz(rest) : tap;   // next tap with work (or stay)
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi) aoff_n[mi] = tap_offset(tap_n, mi);
 #pragma unroll
             for (int kg = 0; kg < KG; ++kg) {
                 const int cur = kg & 1, nxt = cur ^ 1;
-                const int it = tap * KG + kg;
-                const int it_n = it + 1 < NIT ? it + 1 : it;
+                const int it_n = kg + 1 < KG ? tap * KG + kg + 1 : tap_n * KG + (tap_n == tap ? KG - 1 : 0);
 #pragma unroll
                 for (int ni = 0; ni < NT; ++ni)
                     bS[nxt][ni] = BLDS ? wl[(it_n * NBLK + ni) * 64] : wp[(size_t)(it_n * NBLK + ni) * 64];
@@ -210,8 +224,10 @@ __global__ __launch_bounds__(64 * WM * WN, PF ? 2 : 1) void conv_mfma_kernel(Con
                         }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (tap_n == tap) break;
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi) aoff[mi] = aoff_n[mi];
+            tap = tap_n;
         }
 
         // ------------------------------------------------------------ epilogue
@@ -224,11 +240,14 @@ __global__ __launch_bounds__(64 * WM * WN, PF ? 2 : 1) void conv_mfma_kernel(Con
 #pragma unroll
             for (int ni = 0; ni < NT; ++ni) {
                 const int co = (wn * NT + ni) * 32 + col;
-                const float bv = p.bias ? p.bias[co] : 0.f;
+                float* e = lds + ((wm * MT + mi) * 32 + rhalf) * ES + co;
+                if (p.bias) {
+                    const float bv = p.bias[co];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int pl = (wm * MT + mi) * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
-                    lds[pl * ES + co] = acc[mi][ni][r] + bv;
+                    for (int r = 0; r < 16; ++r) e[((r & 3) + 8 * (r >> 2)) * ES] = acc[mi][ni][r] + bv;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) e[((r & 3) + 8 * (r >> 2)) * ES] = acc[mi][ni][r];
                 }
             }
         __syncthreads();
@@ -238,7 +257,7 @@ __global__ __launch_bounds__(64 * WM * WN, PF ? 2 : 1) void conv_mfma_kernel(Con
             constexpr int PTOT = (TM / 4) * C4;              // pooled 16-byte outputs of the tile
             constexpr int PC = 4;
             const int Wo = W / 2, Ho = H / 2;
-            const int r0 = g.p0 / W;                       // first global row of the tile (even)
+            const int r0 = dm.div_w(g.p0);                 // first global row of the tile (even)
 #pragma unroll 1
             for (int base = 0; base < PTOT; base += PC * NTHREADS) {
                 float4 v[PC], rr[PC];
@@ -248,7 +267,7 @@ __global__ __launch_bounds__(64 * WM * WN, PF ? 2 : 1) void conv_mfma_kernel(Con
                 for (int i = 0; i < PC; ++i) {
                     const int idx = base + i * NTHREADS + tid;
                     const int c4 = idx % C4, q = idx / C4;
-                    const int qr = q / Wo, qc = q - qr * Wo;
+                    const int qr = P2 ? q >> (p.wsh - 1) : q / Wo, qc = q - qr * Wo;
                     const int grow = r0 + 2 * qr;
                     ok[i] = idx < PTOT && grow < p.B * H;
                     const float* e = lds + (ok[i] ? ((2 * qr) * W + 2 * qc) * ES + c4 * 4 : 0);
@@ -258,7 +277,7 @@ __global__ __launch_bounds__(64 * WM * WN, PF ? 2 : 1) void conv_mfma_kernel(Con
                     v[i].y = (((a.y + b.y) + c.y) + d.y) * 0.25f;
                     v[i].z = (((a.z + b.z) + c.z) + d.z) * 0.25f;
                     v[i].w = (((a.w + b.w) + c.w) + d.w) * 0.25f;
-                    const int n = grow / H, ho = (grow - n * H) >> 1;
+                    const int n = dm.div_h(grow), ho = (grow - n * H) >> 1;
                     o[i] = ((unsigned)(n * Ho + ho) * Wo + qc) * COUT + c4 * 4;
                 }
                 if (p.res1) {
@@ -325,8 +344,8 @@ __global__ __launch_bounds__(64 * WM * WN, PF ? 2 : 1) void conv_mfma_kernel(Con
                         if (!ok[i]) continue;
                         const int idx = tid + (c0 + i) * NTHREADS;
                         const int c4 = idx % C4, px = g.p0 + idx / C4;
-                        const int n = px / HW, rem = px - n * HW;
-                        const int h = rem / W, w = rem - h * W;
+                        const int n = dm.div_hw(px), rem = px - n * HW;
+                        const int h = dm.div_w(rem), w = rem - h * W;
                         const float fh = sh * (float)h, fw = sw * (float)w;
                         const int h0 = min((int)fh, p.up_h - 1), w0 = min((int)fw, p.up_w - 1);
                         const int h1 = min(h0 + 1, p.up_h - 1), w1 = min(w0 + 1, p.up_w - 1);
@@ -353,7 +372,7 @@ __global__ __launch_bounds__(64 * WM * WN, PF ? 2 : 1) void conv_mfma_kernel(Con
         __syncthreads();                 // epilogue reads of the LDS tile are done
         g = gn;
         tile = tile_n;
-        stage_commit<CIN, NTHREADS, NPF>(lds, pf, p.in, p.stats, p.flags, g, H, W, tid);
+        stage_commit<CIN, NTHREADS, NPF, P2>(lds, pf, p.in, p.stats, p.flags, g, dm, tid);
     }
 }
 
@@ -369,10 +388,10 @@ static int num_cus() {
     return n;
 }
 
-template <int CIN, int COUT, int KS, int MT, int NT, int WM, int WN, bool PF>
+template <int CIN, int COUT, int KS, int MT, int NT, int WM, int WN, bool PF, bool P2>
 static int launch_kernel(ConvParams p, size_t lds, hipStream_t stream, bool dry) {
     constexpr int TM = 32 * MT * WM;
-    auto kern = conv_mfma_kernel<CIN, COUT, KS, MT, NT, WM, WN, PF>;
+    auto kern = conv_mfma_kernel<CIN, COUT, KS, MT, NT, WM, WN, PF, P2>;
     static size_t lds_attr = 0;   // per instantiation
     static int occ = 0;
     if (lds > lds_attr) {
@@ -421,9 +440,11 @@ static int launch_variant(const ConvParams& p, hipStream_t stream, bool dry) {
     if (n_tiles >= 3L * num_cus()) {
         constexpr size_t wbytes = (size_t)KS * KS * CIN * COUT * sizeof(float);
         if (wbytes <= 40 * 1024) lds += wbytes;                     // weights resident in LDS (BLDS in the kernel)
-        return launch_kernel<CIN, COUT, KS, MT, NT, WM, WN, true>(p, lds, stream, dry);
+        if (p.hsh >= 0 && p.wsh >= 1) return launch_kernel<CIN, COUT, KS, MT, NT, WM, WN, true, true>(p, lds, stream, dry);
+        return launch_kernel<CIN, COUT, KS, MT, NT, WM, WN, true, false>(p, lds, stream, dry);
     }
-    return launch_kernel<CIN, COUT, KS, MT, NT, WM, WN, false>(p, lds, stream, dry);
+    if (p.hsh >= 0 && p.wsh >= 1) return launch_kernel<CIN, COUT, KS, MT, NT, WM, WN, false, true>(p, lds, stream, dry);
+    return launch_kernel<CIN, COUT, KS, MT, NT, WM, WN, false, false>(p, lds, stream, dry);
 }
 
 // Tile choice: as many pixels per workgroup as still leaves >= ~2 workgroups per CU (256 CUs), subject to the
@@ -475,6 +496,7 @@ int launch_conv(const sbc_op& op, hipStream_t stream, bool dry) {
     p.B = op.B; p.H = op.H; p.W = op.W; p.dil = op.dil; p.flags = op.flags & 0xfff;
     p.up_h = op.up_h; p.up_w = op.up_w; p.total_px = op.B * op.H * op.W;
     p.n_tiles = p.tiles_per_xcd = p.wg_per_xcd = 0;
+    p.hsh = log2_exact(op.H); p.wsh = log2_exact(op.W);
     static const int dbg = getenv("SBC_DEBUG_FLAGS") ? (int)strtol(getenv("SBC_DEBUG_FLAGS"), nullptr, 0) : 0;
     p.flags |= dbg & 0xf000;
     const int key = op.cin * 100000 + op.cout * 100 + op.ksize;

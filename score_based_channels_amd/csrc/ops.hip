@@ -206,8 +206,9 @@ __global__ __launch_bounds__(256) void end_conv_kernel(const float* __restrict__
     constexpr int TM = 256, S = CIN + 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
-    const TileGeom g = tile_geom(blockIdx.x, TM, B, H, W, 1);
-    stage_tile<CIN, 256, 9>(lds, in, stats, SBC_PRO_NORM | SBC_PRO_ELU, g, H, W, tid);
+    const Dims<false> d{H, W, H * W, 0, 0};
+    const TileGeom g = tile_geom(blockIdx.x, TM, B, d, 1);
+    stage_tile<CIN, 256, 9, false>(lds, in, stats, SBC_PRO_NORM | SBC_PRO_ELU, g, d, tid);
     float* wl = lds + (size_t)(g.nps + 1) * S;          // [9][CIN][2]
     for (int i = tid; i < 9 * CIN * 2; i += 256) {
         const int o = i & 1, c = (i >> 1) % CIN, tap = i / (2 * CIN);

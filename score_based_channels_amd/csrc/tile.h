@@ -32,6 +32,19 @@ __device__ __forceinline__ void st_stream(float* p, float4 v) {
 #endif
 }
 
+// Image dimensions with the divisions the kernels need.  P2 = true: H and W are powers of two (every shape the
+// score network produces for Nt, Nr in {16, 64, 256}), so / and % are shifts and masks -- on gfx950 fp32 MFMA
+// shares the vector ALU with every other vector instruction, and a runtime integer division is ~25 of them.
+template <bool P2>
+struct Dims {
+    int H, W, HW, hsh, wsh;
+    __device__ __forceinline__ int div_w(int x) const { return P2 ? x >> wsh : x / W; }
+    __device__ __forceinline__ int mod_w(int x) const { return P2 ? x & (W - 1) : x % W; }
+    __device__ __forceinline__ int div_h(int x) const { return P2 ? x >> hsh : x / H; }
+    __device__ __forceinline__ int mod_h(int x) const { return P2 ? x & (H - 1) : x % H; }
+    __device__ __forceinline__ int div_hw(int x) const { return P2 ? x >> (hsh + wsh) : x / HW; }
+};
+
 struct TileGeom {
     int p0;        // first output pixel (flattened n*H*W + h*W + w)
     int rs0;       // first staged global row (n*H + h)
@@ -40,25 +53,25 @@ struct TileGeom {
     int multi;     // tile spans whole samples (no halo)
 };
 
-__device__ __forceinline__ TileGeom tile_geom(int tile, int TM, int B, int H, int W, int halo_rows) {
+template <bool P2>
+__device__ __forceinline__ TileGeom tile_geom(int tile, int TM, int B, const Dims<P2>& d, int halo_rows) {
     TileGeom g;
-    const int HW = H * W;
     g.p0 = tile * TM;
-    const int r0 = g.p0 / W;
-    int r1 = r0 + TM / W;
-    if (r1 > B * H) r1 = B * H;
-    g.multi = TM >= HW;
+    const int r0 = d.div_w(g.p0);
+    int r1 = r0 + d.div_w(TM);
+    if (r1 > B * d.H) r1 = B * d.H;
+    g.multi = TM >= d.HW;
     int rs1;
     if (g.multi) {
         g.rs0 = r0;
         rs1 = r1;
     } else {
-        const int n = r0 / H;
-        g.rs0 = max(r0 - halo_rows, n * H);
-        rs1 = min(r1 + halo_rows, (n + 1) * H);
+        const int n = d.div_h(r0);
+        g.rs0 = max(r0 - halo_rows, n * d.H);
+        rs1 = min(r1 + halo_rows, (n + 1) * d.H);
     }
-    g.nps = (rs1 - g.rs0) * W;
-    g.n_first = g.rs0 / H;
+    g.nps = (rs1 - g.rs0) * d.W;
+    g.n_first = d.div_h(g.rs0);
     return g;
 }
 
@@ -78,14 +91,14 @@ __device__ __forceinline__ void stage_issue(float4 (&pf)[NPF], const float* __re
     }
 }
 
-template <int CIN>
+template <int CIN, bool P2>
 __device__ __forceinline__ void stage_put(float* lds, float4 x, int idx, const float* __restrict__ stats, int flags,
-                                          const TileGeom& g, int HW) {
+                                          const TileGeom& g, const Dims<P2>& d) {
     constexpr int S = CIN + 4;
     constexpr int C4 = CIN / 4;
     const int pix = idx / C4, c4 = idx % C4;
     if (flags & SBC_PRO_NORM) {
-        const int n = g.n_first + (g.multi ? pix / HW : 0);
+        const int n = g.n_first + (g.multi ? d.div_hw(pix) : 0);
         const float* st = stats + (size_t)n * 3 * CIN + c4 * 4;
         const float4 mu = *reinterpret_cast<const float4*>(st);
         const float4 sc = *reinterpret_cast<const float4*>(st + CIN);
@@ -99,30 +112,38 @@ __device__ __forceinline__ void stage_put(float* lds, float4 x, int idx, const f
     *reinterpret_cast<float4*>(lds + pix * S + c4 * 4) = x;
 }
 
-template <int CIN, int NTHREADS, int NPF>
+template <int CIN, int NTHREADS, int NPF, bool P2>
 __device__ __forceinline__ void stage_commit(float* lds, const float4 (&pf)[NPF], const float* __restrict__ in,
-                                             const float* __restrict__ stats, int flags, const TileGeom& g, int H,
-                                             int W, int tid) {
+                                             const float* __restrict__ stats, int flags, const TileGeom& g,
+                                             const Dims<P2>& d, int tid) {
     constexpr int S = CIN + 4;
-    const int HW = H * W;
+    const int W = d.W;
     const int total = g.nps * (CIN / 4);
 #pragma unroll
     for (int u = 0; u < NPF; ++u) {
         const int idx = u * NTHREADS + tid;
-        if (idx < total) stage_put<CIN>(lds, pf[u], idx, stats, flags, g, HW);
+        if (idx < total) stage_put<CIN, P2>(lds, pf[u], idx, stats, flags, g, d);
     }
     const float* src = in + (size_t)g.rs0 * W * CIN;
     for (int idx = NPF * NTHREADS + tid; idx < total; idx += NTHREADS)
-        stage_put<CIN>(lds, ld_stream(src + (size_t)idx * 4), idx, stats, flags, g, HW);
+        stage_put<CIN, P2>(lds, ld_stream(src + (size_t)idx * 4), idx, stats, flags, g, d);
     for (int i = tid; i < S; i += NTHREADS) lds[g.nps * S + i] = 0.f;
 }
 
-template <int CIN, int NTHREADS, int NPF>
+template <int CIN, int NTHREADS, int NPF, bool P2>
 __device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__ in, const float* __restrict__ stats,
-                                           int flags, const TileGeom& g, int H, int W, int tid) {
+                                           int flags, const TileGeom& g, const Dims<P2>& d, int tid) {
     float4 pf[NPF];
-    stage_issue<CIN, NTHREADS, NPF>(pf, in, g, W, tid);
-    stage_commit<CIN, NTHREADS, NPF>(lds, pf, in, stats, flags, g, H, W, tid);
+    stage_issue<CIN, NTHREADS, NPF>(pf, in, g, d.W, tid);
+    stage_commit<CIN, NTHREADS, NPF, P2>(lds, pf, in, stats, flags, g, d, tid);
+}
+
+// host side: log2 of a power of two, or -1
+inline int log2_exact(int v) {
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return s;
 }
 
 }  // namespace sbc

@@ -59,6 +59,11 @@ CONV_CASES = [
     (32, 32, 3, 1, 2, 64, 16, 'up_2x'),
     (32, 32, 3, 1, 1, 256, 64, 'norm_elu_res'),    # large-array config: row tiles with halo at W=64
     (64, 64, 3, 1, 1100, 16, 4, 'elu_res'),        # TM=128 variant
+    (32, 32, 3, 1, 3, 24, 16, 'norm_elu_res'),     # H not a power of two: generic index math
+    (32, 64, 3, 1, 2, 48, 8, 'norm_elu_pool_res'),
+    (64, 64, 3, 2, 5, 24, 8, 'up_same'),
+    (32, 32, 3, 1, 900, 32, 8, 'crp2'),            # persistent build (several tiles per workgroup), weights in LDS
+    (64, 64, 3, 1, 2500, 32, 8, 'norm_elu_res'),   # persistent build, weights from L2
 ]
 
 
