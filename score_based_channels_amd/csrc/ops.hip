@@ -163,32 +163,46 @@ int launch_inorm_stats(const sbc_op& op, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------ max pool
 // nn.MaxPool2d(5, stride 1, padding 2) with -inf padding (layers.py:69).  With SBC_PRO_ELU the result is
 // ELU(max) == max(ELU) because ELU is monotone (CRPBlock: x = act(x); path = maxpool(x), layers.py:77-80).
+// One thread per (sample, column w, channel quad) walks down the rows with a sliding window of 5 row maxima, so each
+// output costs 5 (L1-resident) 16-byte loads instead of 25.
+__device__ __forceinline__ float4 max4(float4 a, float4 b) {
+    return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
+}
+
 __global__ __launch_bounds__(256) void maxpool5_kernel(const float* __restrict__ in, float* __restrict__ out, int B,
                                                         int H, int W, int C4, int flags) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const long total = (long)B * H * W * C4;
-    if (idx >= total) return;
-    const int c4 = idx % C4;
-    const long px = idx / C4;
-    const int w = px % W;
-    const long row = px / W;
-    const int h = row % H;
-    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-    for (int dh = -2; dh <= 2; ++dh) {
-        if (h + dh < 0 || h + dh >= H) continue;
-        for (int dw = -2; dw <= 2; ++dw) {
-            if (w + dw < 0 || w + dw >= W) continue;
-            const float4 v = *reinterpret_cast<const float4*>(in + (((row + dh) * W + w + dw) * C4 + c4) * 4);
-            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
-        }
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * W * C4) return;
+    const int c4 = idx % C4, w = (idx / C4) % W, n = idx / (C4 * W);
+    const size_t row_stride = (size_t)W * C4 * 4;
+    const float* base = in + (size_t)n * H * row_stride + ((size_t)w * C4 + c4) * 4;
+    float* obase = out + (size_t)n * H * row_stride + ((size_t)w * C4 + c4) * 4;
+    const float NEG = -INFINITY;
+    const float4 ninf = make_float4(NEG, NEG, NEG, NEG);
+    const bool l2 = w >= 2, l1 = w >= 1, r1 = w + 1 < W, r2 = w + 2 < W;
+    auto rowmax = [&](int r) {
+        if (r >= H) return ninf;
+        const float* q = base + (size_t)r * row_stride;
+        float4 m = *reinterpret_cast<const float4*>(q);
+        if (l1) m = max4(m, *reinterpret_cast<const float4*>(q - C4 * 4));
+        if (l2) m = max4(m, *reinterpret_cast<const float4*>(q - 2 * C4 * 4));
+        if (r1) m = max4(m, *reinterpret_cast<const float4*>(q + C4 * 4));
+        if (r2) m = max4(m, *reinterpret_cast<const float4*>(q + 2 * C4 * 4));
+        return m;
+    };
+    float4 m0 = ninf, m1 = ninf, m2 = rowmax(0), m3 = rowmax(1), m4 = rowmax(2);     // rows h-2 .. h+2
+    for (int h = 0; h < H; ++h) {
+        float4 m = max4(max4(max4(m0, m1), max4(m2, m3)), m4);
+        if (flags & SBC_PRO_ELU) m = elu4(m);
+        *reinterpret_cast<float4*>(obase + (size_t)h * row_stride) = m;
+        m0 = m1; m1 = m2; m2 = m3; m3 = m4;
+        m4 = rowmax(h + 3);
     }
-    if (flags & SBC_PRO_ELU) m = elu4(m);
-    *reinterpret_cast<float4*>(out + idx * 4) = m;
 }
 
 int launch_maxpool5(const sbc_op& op, hipStream_t stream) {
     SBC_REQUIRE(op.in && op.out && op.cin % 4 == 0, "maxpool5: in/out must be set, channels %% 4 == 0");
-    const long total = (long)op.B * op.H * op.W * (op.cin / 4);
+    const long total = (long)op.B * op.W * (op.cin / 4);
     hipLaunchKernelGGL(maxpool5_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, stream, (const float*)op.in,
                        (float*)op.out, op.B, op.H, op.W, op.cin / 4, op.flags);
     SBC_CHECK_HIP(hipGetLastError());
