@@ -66,6 +66,7 @@ def main():
     ap.add_argument('--graph', type=int, default=0, help='replay the step as a hipGraph (no per-kernel timing)')
     ap.add_argument('--full-schedule', action='store_true', help='time all 6933 steps instead of --steps')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--streams', type=int, default=1, help='split the trajectories into this many concurrent HIP streams')
     args = ap.parse_args()
 
     import torch
@@ -99,11 +100,26 @@ def main():
     idx = np.tile(np.arange(nch), len(snr))
     ln = np.repeat(snr_to_noise(snr, nt), nch)
     traj = rank * T + np.arange(T)
-    ald = AldBatch(net, H, Pm, idx, idx, ln, alpha_step=3e-11, beta_noise=0.01, seed=1234, traj_id=traj)
     init = torch.randn(nch, nt, nr, dtype=torch.complex64, device=net.device,
                        generator=torch.Generator(net.device).manual_seed(rank))
-    ald.set_init(init.repeat(len(snr), 1, 1))            # one initial estimate shared by all SNR points (:115)
-    ald.synthesize_measurements()
+    init = init.repeat(len(snr), 1, 1)                   # one initial estimate shared by all SNR points (:115)
+    # the trajectory list may be split over several HIP streams: independent sub-batches whose kernels the GPU
+    # interleaves (fills the tail of one launch with the head of another, overlaps memory-bound with MFMA-bound ones)
+    parts = np.array_split(np.arange(T), args.streams)
+    alds, streams = [], []
+    for part in parts:
+        a = AldBatch(net, H, Pm, idx[part], idx[part], ln[part], alpha_step=3e-11, beta_noise=0.01, seed=1234,
+                     traj_id=traj[part])
+        a.set_init(init[torch.from_numpy(part)])
+        a.synthesize_measurements()
+        alds.append(a)
+        streams.append(torch.cuda.Stream(net.device) if args.streams > 1 else torch.cuda.current_stream(net.device))
+    ald = alds[0]
+
+    def run_all(n, graph):
+        for a, st in zip(alds, streams):
+            with torch.cuda.stream(st):
+                a.run(n, use_graph=graph)
 
     K = STEPS_PER_CHANNEL - args.warmup if args.full_schedule else args.steps
     use_graph = bool(args.graph)
@@ -113,12 +129,12 @@ def main():
         if world > 1:
             dist.barrier()
 
-    ald.run(args.warmup, use_graph=use_graph)
+    run_all(args.warmup, use_graph)
     if not use_graph:
         ald.plan.profile(P.TAG_CONV_TOP)
     sync()
     t0 = time.perf_counter()
-    ald.run(K, use_graph=use_graph)
+    run_all(K, use_graph)
     sync()
     dt = time.perf_counter() - t0
     kern_ms, kern_n = ald.plan.profile_read() if not use_graph else (0.0, 0)
@@ -129,7 +145,7 @@ def main():
     dt = float(tmax.item())
 
     # the one collective of the path: gather the per-step mean NMSE curves of every rank (RCCL over xGMI)
-    curves = ald.nmse_log()[:args.warmup + K].view(-1, len(snr), nch).mean(-1)
+    curves = torch.cat([a.nmse_log()[:args.warmup + K] for a in alds], dim=1).view(-1, len(snr), nch).mean(-1)
     t_g = time.perf_counter()
     if world > 1:
         gathered = [torch.empty_like(curves) for _ in range(world)]
@@ -153,14 +169,14 @@ def main():
                        'trajectories_per_gpu': T, 'steps_per_channel': STEPS_PER_CHANNEL, 'num_pilots': npil,
                        'step_definition': 'one Langevin step (score forward + DC gradient + update + NMSE) of all '
                                           'trajectories; channels/s = trajectories / (6933 * s_per_step)',
-                       'full_schedule_timed': bool(args.full_schedule), 'graph_replay': use_graph,
+                       'full_schedule_timed': bool(args.full_schedule), 'graph_replay': use_graph, 'streams': args.streams,
                        'parallelism': 'independent trajectories sharded over %d GPU(s); one RCCL all_gather of NMSE '
                                       'curves at the end (%.2f ms)' % (world, gather_ms),
                        'nmse_finite': finite},
             'step_conv_tflops': flops_fwd / (ms_per_step * 1e-3) / 1e12,
         }
         if kern_n:
-            per_launch = 2.0 * T * nt * nr * 9 * 32 * 32                    # 3x3 conv 32->32 at 64x16, 2*MACs
+            per_launch = 2.0 * alds[0].T * nt * nr * 9 * 32 * 32            # 3x3 conv 32->32 at 64x16, 2*MACs
             ach = per_launch / (kern_ms / kern_n * 1e-3) / 1e12
             out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,

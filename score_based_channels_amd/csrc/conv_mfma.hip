@@ -8,19 +8,23 @@
 //   epilogue  bias, residual adds (ResidualBlock :456, RCUBlock :133, CRPBlock :82), 2x2 mean pooling
 //             (ConvMeanPool :311-312) and the bilinear(align_corners) resize-add of MSFBlock (:182-183).
 //
-// GEMM view: M = B*H*W pixels, N = COUT, K = taps*CIN.  A tile is TM = 32*MT*WM pixels x COUT; wave (wm, wn)
-// computes MT 32-pixel blocks x NT 32-channel blocks.  The A operand comes from the LDS tile (tile.h); the B
-// operand (weights, pre-packed on the host into fragment order, weights.py:pack_conv_weight) is one 16-byte load
-// per lane per (tap, 8-channel group) that feeds four MFMAs.  K is walked in groups of 8 channels: within a
-// group, lanes 0-31 supply channels g*8+0..3 and lanes 32-63 channels g*8+4..7 as the two k-rows of four
-// consecutive 32x32x2 MFMAs (any K permutation is legal as long as A and B agree).
+// GEMM view: M = B*H*W pixels, N = COUT, K = taps*CIN.  A workgroup computes one tile of TM = 32*MT*WM pixels x
+// COUT; wave (wm, wn) computes MT 32-pixel blocks x NT 32-channel blocks.  The A operand comes from the LDS tile
+// (tile.h); the B operand (weights, pre-packed on the host into fragment order, weights.py:pack_conv_weight) is
+// loaded straight from global/L2 as one 16-byte load per lane per (tap, 8-channel group) and feeds four MFMAs.
+// K is walked in groups of 8 channels: within a group, lanes 0-31 supply channels g*8+0..3 and lanes 32-63
+// channels g*8+4..7 as the two k-rows of four consecutive 32x32x2 MFMAs (any K permutation is legal as long as A
+// and B agree).
 //
-// Two builds per shape.  Plain (PF = false): one tile per workgroup, B fragments straight from global/L2.
-// Persistent (PF = true, used when there are several tiles per resident workgroup): the grid is (resident
-// workgroups per CU) x CUs, each workgroup walks a contiguous range of tiles of "its" XCD, requests the raw rows of
-// tile i+1 and the residual operand of tile i into registers before the MFMA loop of tile i, and -- when the
-// packed weights fit (3x3 32->32: 36 KB) -- keeps them in LDS for its lifetime so the MFMA loop issues no
-// vector-memory loads (vmcnt retires in order: a B-fragment wait would otherwise also wait for the prefetch).
+// On gfx950 the fp32 MFMA executes on the vector ALU (tools/mfma_valu_coissue.hip: MFMA 146 TF alone, v_fma 130 TF
+// alone, 83 + 42 TF interleaved -- integer VALU and v_exp serialise with it in the same way), so every vector
+// instruction outside the MFMAs is paid in MFMA time: index math uses shifts (power-of-two H, W build), per-tap
+// offsets come from a bit mask, ELU uses the hardware exponential, taps that are outside the image for a whole
+// wave are skipped, and all epilogue traffic is 16 bytes per lane.
+//
+// A persistent variant (several tiles per workgroup, next tile + residual prefetched into registers across the
+// MFMA loop, 3x3 32->32 weights resident in LDS) was built and measured in round 1: it needs ~250 VGPRs, i.e. two
+// workgroups per CU instead of three, and was 3 % slower end to end than this build.
 #include <stdlib.h>
 #include "tile.h"
 
@@ -38,385 +42,289 @@ struct ConvParams {
     const float* __restrict__ res2;
     const float* __restrict__ up;
     int B, H, W, dil, flags, up_h, up_w, total_px;
-    int n_tiles, tiles_per_xcd, wg_per_xcd;
     int hsh, wsh;         // log2(H), log2(W) for the power-of-two builds
 };
 
-// performance-triage switches (SBC_DEBUG_FLAGS, results are wrong when set): skip staging loads / MFMA loop /
-// output stores / residual prefetch
-#define SBC_DBG_NOSTAGE 0x1000
-#define SBC_DBG_NOLOOP 0x2000
-#define SBC_DBG_NOSTORE 0x4000
-#define SBC_DBG_NORES 0x8000
-
-template <int CIN, int COUT, int KS, int MT, int NT, int WM, int WN, bool PF, bool P2>
-__global__ __launch_bounds__(64 * WM * WN, PF ? 2 : 1) void conv_mfma_kernel(ConvParams p) {
+template <int CIN, int COUT, int KS, int MT, int NT, int WM, int WN, bool P2>
+__global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvParams p) {
     constexpr int TM = 32 * MT * WM;
     constexpr int S = CIN + 4;
     constexpr int KG = CIN / 8;
     constexpr int NBLK = COUT / 32;
     constexpr int NTHREADS = 64 * WM * WN;
     constexpr int TAPS = KS * KS;
-    constexpr int NIT = TAPS * KG;
     constexpr int ES = COUT + 4;
     constexpr int C4 = COUT / 4;
     static_assert(WN * NT == NBLK, "waves x blocks must cover COUT");
     static_assert(KG % 2 == 0, "two register sets alternate per 8-channel group");
-    // 16-byte staging chunks per thread covering the tile + a 32-pixel halo allowance, capped at 10 (register
-    // budget); anything beyond is fetched synchronously inside stage_commit
+    // 16-byte staging requests in flight per thread: the tile + a 32-pixel halo allowance, at most 10 at a time
     constexpr int NPF_FULL = ((TM + 32) * (CIN / 4) + NTHREADS - 1) / NTHREADS;
     constexpr int NPF = NPF_FULL <= 10 ? NPF_FULL : 10;
-    // residual operand chunks per thread (non-pooled epilogue)
-    constexpr int ITER = TM * C4 / NTHREADS;
+    constexpr int ITER = TM * C4 / NTHREADS;            // 16-byte output chunks per thread
     static_assert(TM * C4 % NTHREADS == 0, "epilogue chunks must divide evenly");
-    constexpr bool RES_PF = PF && ITER <= 8;            // keep the residual of the current tile in registers too
     constexpr int EC = ITER < 4 ? ITER : 4;             // 16-byte requests in flight per thread and phase
     static_assert(ITER % EC == 0, "epilogue chunking");
-    constexpr int WFLOATS = TAPS * CIN * COUT;
-    constexpr bool BLDS = PF && WFLOATS * 4 <= 40 * 1024;   // weights resident in LDS
-    extern __shared__ __attribute__((aligned(16))) float lds_all[];
-    float* const lds = lds_all + (BLDS ? WFLOATS : 0);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int H = p.H, W = p.W, HW = H * W;
     const Dims<P2> dm{H, W, HW, p.hsh, p.wsh};
-    const int halo = KS == 3 ? p.dil : 0;
     const int khalf = 4 * (lane >> 5);
     const int col = lane & 31, rhalf = 4 * (lane >> 5);
     const float4* wp = p.wpk + (size_t)(wn * NT) * 64 + lane;      // + it * NBLK * 64 per K step
-    const float4* wl = reinterpret_cast<const float4*>(lds_all) + (wn * NT) * 64 + lane;
 
-    // tiles of this workgroup: XCD x (= blockIdx % 8, how the dispatcher places workgroups) owns the contiguous tile
-    // range [x * tiles_per_xcd, (x+1) * tiles_per_xcd); its workgroups take them round-robin.  Placement only
-    // affects L2 locality of halo rows, never correctness.
-    const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3;
-    const int t_lo = xcd * p.tiles_per_xcd;
-    const int t_hi = min(t_lo + p.tiles_per_xcd, p.n_tiles);
-    int tile = t_lo + j0;
-    if (tile >= t_hi) return;
+    const TileGeom g = tile_geom(blockIdx.x, TM, p.B, dm, KS == 3 ? p.dil : 0);
+    stage_tile<CIN, NTHREADS, NPF, P2>(lds, p.in, p.stats, p.flags, g, dm, tid);
 
-    if (BLDS) {
-        for (int i = tid; i < WFLOATS / 4; i += NTHREADS) reinterpret_cast<float4*>(lds_all)[i] = p.wpk[i];
+    // This lane's A rows: pixel (lane & 31) of each of the wave's MT blocks.  Per block one LDS base offset and a
+    // 9-bit mask of the taps that stay inside the image, so that the per-tap work inside the MFMA loop is a bit
+    // test and a select (tap deltas are wave-uniform); out-of-image taps read the shared zero pixel.
+    int abase[MT];
+    unsigned amask[MT];
+    const int zoff = g.nps * S + khalf;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+        const int px = g.p0 + (wm * MT + mi) * 32 + (lane & 31);
+        const int row = dm.div_w(px), ww = dm.mod_w(px), hh = dm.mod_h(row);
+        abase[mi] = ((row - g.rs0) * W + ww) * S + khalf;
+        // 3 row bits x 3 column bits -> 9 tap bits (bit t = kh*3 + kw)
+        unsigned rb = 2u, cb = 2u;                       // centre row / column always inside
+        if (KS == 3) {
+            rb |= (hh - p.dil >= 0 ? 1u : 0u) | (hh + p.dil < H ? 4u : 0u);
+            cb |= (ww - p.dil >= 0 ? 1u : 0u) | (ww + p.dil < W ? 4u : 0u);
+        }
+        unsigned m = ((rb & 1u) ? cb : 0u) | ((rb & 2u) ? cb << 3 : 0u) | ((rb & 4u) ? cb << 6 : 0u);
+        if (KS == 1) m = 1u;
+        amask[mi] = px < p.total_px ? m : 0u;
     }
+    // taps that are outside the image for every lane of this wave contribute exact zeros: skip them (at 8x2 with
+    // dilation 2 / 4 that is 6 of the 9 taps)
+    unsigned lane_or = 0;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) lane_or |= amask[mi];
+    unsigned tapmask = 0;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+        if (__ballot((lane_or >> t) & 1u)) tapmask |= 1u << t;
+    auto tap_offset = [&](int tap, int mi) {
+        const int dh = KS == 3 ? (tap / 3 - 1) * p.dil : 0;
+        const int dw = KS == 3 ? (tap % 3 - 1) * p.dil : 0;
+        return ((amask[mi] >> tap) & 1u) ? abase[mi] + (dh * W + dw) * S : zoff;
+    };
 
-    float4 pf[NPF];
-    TileGeom g = tile_geom(tile, TM, p.B, dm, halo);
-    if (!(p.flags & SBC_DBG_NOSTAGE)) stage_issue<CIN, NTHREADS, NPF>(pf, p.in, g, W, tid);
-    stage_commit<CIN, NTHREADS, NPF, P2>(lds, pf, p.in, p.stats, p.flags, g, dm, tid);
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    for (;;) {
-        const int tile_n = tile + p.wg_per_xcd;
-        const bool has_next = PF && tile_n < t_hi;
-        TileGeom gn = g;
-        if (has_next) {
-            gn = tile_geom(tile_n, TM, p.B, dm, halo);
-            if (!(p.flags & SBC_DBG_NOSTAGE))
-                stage_issue<CIN, NTHREADS, NPF>(pf, p.in, gn, W, tid);       // in flight across the MFMA loop
-        }
-        float4 rpf[RES_PF ? ITER : 1];
-        if (RES_PF && p.res1 && !(p.flags & (SBC_EPI_POOL | SBC_DBG_NORES))) {
+    // K loop over the taps that have work, software-pipelined by one (tap, 8-channel group) step with two statically
+    // indexed register sets: the B fragment (global/L2) and the A fragment (LDS) of step it+1 are requested, then the
+    // MFMAs of step it are issued.  sched_barrier pins that order so the waits the compiler inserts in front of the
+    // MFMAs are counted ("everything but the requests just issued"), never a full drain.
+    int aoff[MT], aoff_n[MT];
+    float4 aS[2][MT], bS[2][NT];
+    int tap = tapmask ? __builtin_ctz(tapmask) : TAPS;                 // first tap with work
+    const int it0 = (tap < TAPS ? tap : 0) * KG;
 #pragma unroll
-            for (int i = 0; i < (RES_PF ? ITER : 0); ++i) {
-                const int idx = tid + i * NTHREADS;
-                const int pl = idx / C4;
-                if (g.p0 + pl < p.total_px)
-                    rpf[i] = ld_stream(p.res1 + (size_t)(g.p0 + pl) * COUT + (idx % C4) * 4);
-            }
-        }
-
-        // This lane's A rows: pixel (lane & 31) of each of the wave's MT blocks.  Per block one LDS base offset and a
-        // 9-bit mask of the taps that stay inside the image, so that the per-tap work inside the MFMA loop is a
-        // bit test and a select (tap deltas are wave-uniform); out-of-image taps read the shared zero pixel.
-        int abase[MT];
-        unsigned amask[MT];
-        const int zoff = g.nps * S + khalf;
+    for (int ni = 0; ni < NT; ++ni) bS[0][ni] = wp[(size_t)(it0 * NBLK + ni) * 64];
+    __syncthreads();                                                   // staged tile visible
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-            const int px = g.p0 + (wm * MT + mi) * 32 + (lane & 31);
-            const int row = dm.div_w(px), ww = dm.mod_w(px), hh = dm.mod_h(row);
-            abase[mi] = ((row - g.rs0) * W + ww) * S + khalf;
-            // 3 row bits x 3 column bits -> 9 tap bits (bit t = kh*3 + kw)
-            unsigned rb = 2u, cb = 2u;                       // centre row / column always inside
-            if (KS == 3) {
-                rb |= (hh - p.dil >= 0 ? 1u : 0u) | (hh + p.dil < H ? 4u : 0u);
-                cb |= (ww - p.dil >= 0 ? 1u : 0u) | (ww + p.dil < W ? 4u : 0u);
-            }
-            unsigned m = ((rb & 1u) ? cb : 0u) | ((rb & 2u) ? cb << 3 : 0u) | ((rb & 4u) ? cb << 6 : 0u);
-            if (KS == 1) m = 1u;
-            amask[mi] = px < p.total_px ? m : 0u;
-        }
-        // taps that are outside the image for every lane of this wave contribute exact zeros: skip them (at 8x2 with
-        // dilation 2 / 4 that is 6 of the 9 taps)
-        unsigned lane_or = 0;
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi) lane_or |= amask[mi];
-        unsigned tapmask = 0;
-#pragma unroll
-        for (int t = 0; t < TAPS; ++t)
-            if (__ballot((lane_or >> t) & 1u)) tapmask |= 1u << t;
-        if (p.flags & SBC_DBG_NOLOOP) tapmask = 0;
-        auto tap_offset = [&](int tap, int mi) {
-            const int dh = KS == 3 ? (tap / 3 - 1) * p.dil : 0;
-            const int dw = KS == 3 ? (tap % 3 - 1) * p.dil : 0;
-            return ((amask[mi] >> tap) & 1u) ? abase[mi] + (dh * W + dw) * S : zoff;
-        };
-
-        f32x16 acc[MT][NT];
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-        // K loop, software-pipelined by one (tap, 8-channel group) step with two statically indexed register
-        // sets: the B fragment and the A fragment of step it+1 are requested, then the MFMAs of step it are
-        // issued.  sched_barrier pins that order so the waits the compiler inserts in front of the MFMAs are
-        // counted ("everything but the requests just issued"), never a full drain.
-        int aoff[MT], aoff_n[MT];
-        float4 aS[2][MT], bS[2][NT];
-        int tap = tapmask ? __builtin_ctz(tapmask) : TAPS;                 // first tap with work
-        const int it0 = (tap < TAPS ? tap : 0) * KG;
-        if (!BLDS) {
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni) bS[0][ni] = wp[(size_t)(it0 * NBLK + ni) * 64];
-        }
-        __syncthreads();                                               // staged tile (and weights) visible
-        if (BLDS) {
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni) bS[0][ni] = wl[(it0 * NBLK + ni) * 64];
-        }
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-            aoff[mi] = tap_offset(tap < TAPS ? tap : 0, mi);
-            aS[0][mi] = *reinterpret_cast<const float4*>(__builtin_assume_aligned(lds + aoff[mi], 16));
-        }
+    for (int mi = 0; mi < MT; ++mi) {
+        aoff[mi] = tap_offset(tap < TAPS ? tap : 0, mi);
+        aS[0][mi] = *reinterpret_cast<const float4*>(__builtin_assume_aligned(lds + aoff[mi], 16));
+    }
 #pragma unroll 1
-        while (tap < TAPS) {
-            const unsigned rest = tapmask >> (tap + 1);
-            const int tap_n = rest ? tap + 1 + __builtin_ctz(rest) : tap;   // next tap with work (or stay)
+    while (tap < TAPS) {
+        const unsigned rest = tapmask >> (tap + 1);
+        const int tap_n = rest ? tap + 1 + __builtin_ctz(rest) : tap;   // next tap with work (or stay)
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi) aoff_n[mi] = tap_offset(tap_n, mi);
+        for (int mi = 0; mi < MT; ++mi) aoff_n[mi] = tap_offset(tap_n, mi);
 #pragma unroll
-            for (int kg = 0; kg < KG; ++kg) {
-                const int cur = kg & 1, nxt = cur ^ 1;
-                const int it_n = kg + 1 < KG ? tap * KG + kg + 1 : tap_n * KG + (tap_n == tap ? KG - 1 : 0);
+        for (int kg = 0; kg < KG; ++kg) {
+            const int cur = kg & 1, nxt = cur ^ 1;
+            const int it_n = kg + 1 < KG ? tap * KG + kg + 1 : tap_n * KG + (tap_n == tap ? KG - 1 : 0);
 #pragma unroll
-                for (int ni = 0; ni < NT; ++ni)
-                    bS[nxt][ni] = BLDS ? wl[(it_n * NBLK + ni) * 64] : wp[(size_t)(it_n * NBLK + ni) * 64];
+            for (int ni = 0; ni < NT; ++ni) bS[nxt][ni] = wp[(size_t)(it_n * NBLK + ni) * 64];
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+                aS[nxt][mi] = *reinterpret_cast<const float4*>(
+                    __builtin_assume_aligned(lds + (kg + 1 < KG ? aoff[mi] + (kg + 1) * 8 : aoff_n[mi]), 16));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi)
-                    aS[nxt][mi] = *reinterpret_cast<const float4*>(
-                        __builtin_assume_aligned(lds + (kg + 1 < KG ? aoff[mi] + (kg + 1) * 8 : aoff_n[mi]), 16));
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < NT; ++ni) {
-                            const float4 a4 = aS[cur][mi], b4 = bS[cur][ni];
-                            const float av = j == 0 ? a4.x : j == 1 ? a4.y : j == 2 ? a4.z : a4.w;
-                            const float bv = j == 0 ? b4.x : j == 1 ? b4.y : j == 2 ? b4.z : b4.w;
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mi][ni], 0, 0, 0);
-                        }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (tap_n == tap) break;
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi) aoff[mi] = aoff_n[mi];
-            tap = tap_n;
-        }
-
-        // ------------------------------------------------------------ epilogue
-        // The accumulators (32x32 MFMA map: column = lane & 31 = output channel, row = (r&3) + 8*(r>>2) +
-        // 4*(lane>>5)) go through LDS as [pixel][COUT + 4] so that every global access of the epilogue is a
-        // 16-byte access of 4 consecutive channels, and all loads of a phase are issued before any is consumed.
-        __syncthreads();   // every wave is done reading the staged tile
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni) {
-                const int co = (wn * NT + ni) * 32 + col;
-                float* e = lds + ((wm * MT + mi) * 32 + rhalf) * ES + co;
-                if (p.bias) {
-                    const float bv = p.bias[co];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) e[((r & 3) + 8 * (r >> 2)) * ES] = acc[mi][ni][r] + bv;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) e[((r & 3) + 8 * (r >> 2)) * ES] = acc[mi][ni][r];
-                }
-            }
-        __syncthreads();
-
-        if (p.flags & SBC_EPI_POOL) {
-            // ((((0 + a) + b) + c) + d) / 4, a=[0::2,0::2] b=[1::2,0::2] c=[0::2,1::2] d=[1::2,1::2] (layers.py:311-312)
-            constexpr int PTOT = (TM / 4) * C4;              // pooled 16-byte outputs of the tile
-            constexpr int PC = 4;
-            const int Wo = W / 2, Ho = H / 2;
-            const int r0 = dm.div_w(g.p0);                 // first global row of the tile (even)
-#pragma unroll 1
-            for (int base = 0; base < PTOT; base += PC * NTHREADS) {
-                float4 v[PC], rr[PC];
-                unsigned o[PC];
-                bool ok[PC];
-#pragma unroll
-                for (int i = 0; i < PC; ++i) {
-                    const int idx = base + i * NTHREADS + tid;
-                    const int c4 = idx % C4, q = idx / C4;
-                    const int qr = P2 ? q >> (p.wsh - 1) : q / Wo, qc = q - qr * Wo;
-                    const int grow = r0 + 2 * qr;
-                    ok[i] = idx < PTOT && grow < p.B * H;
-                    const float* e = lds + (ok[i] ? ((2 * qr) * W + 2 * qc) * ES + c4 * 4 : 0);
-                    const float4 a = *reinterpret_cast<const float4*>(e), b = *reinterpret_cast<const float4*>(e + W * ES);
-                    const float4 c = *reinterpret_cast<const float4*>(e + ES), d = *reinterpret_cast<const float4*>(e + (W + 1) * ES);
-                    v[i].x = (((a.x + b.x) + c.x) + d.x) * 0.25f;
-                    v[i].y = (((a.y + b.y) + c.y) + d.y) * 0.25f;
-                    v[i].z = (((a.z + b.z) + c.z) + d.z) * 0.25f;
-                    v[i].w = (((a.w + b.w) + c.w) + d.w) * 0.25f;
-                    const int n = dm.div_h(grow), ho = (grow - n * H) >> 1;
-                    o[i] = ((unsigned)(n * Ho + ho) * Wo + qc) * COUT + c4 * 4;
-                }
-                if (p.res1) {
-#pragma unroll
-                    for (int i = 0; i < PC; ++i)
-                        if (ok[i]) rr[i] = ld_stream(p.res1 + o[i]);
-#pragma unroll
-                    for (int i = 0; i < PC; ++i) {
-                        v[i].x = rr[i].x + v[i].x; v[i].y = rr[i].y + v[i].y;
-                        v[i].z = rr[i].z + v[i].z; v[i].w = rr[i].w + v[i].w;
+                    for (int ni = 0; ni < NT; ++ni) {
+                        const float4 a4 = aS[cur][mi], b4 = bS[cur][ni];
+                        const float av = j == 0 ? a4.x : j == 1 ? a4.y : j == 2 ? a4.z : a4.w;
+                        const float bv = j == 0 ? b4.x : j == 1 ? b4.y : j == 2 ? b4.z : b4.w;
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mi][ni], 0, 0, 0);
                     }
-                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (tap_n == tap) break;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) aoff[mi] = aoff_n[mi];
+        tap = tap_n;
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    // The accumulators (32x32 MFMA map: column = lane & 31 = output channel, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+    // go through LDS as [pixel][COUT + 4] so that every global access of the epilogue is a 16-byte access of 4
+    // consecutive channels, and all loads of a phase are issued before any is consumed.
+    __syncthreads();   // every wave is done reading the staged tile
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+            const int co = (wn * NT + ni) * 32 + col;
+            float* e = lds + ((wm * MT + mi) * 32 + rhalf) * ES + co;
+            if (p.bias) {
+                const float bv = p.bias[co];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) e[((r & 3) + 8 * (r >> 2)) * ES] = acc[mi][ni][r] + bv;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) e[((r & 3) + 8 * (r >> 2)) * ES] = acc[mi][ni][r];
+            }
+        }
+    __syncthreads();
+
+    if (p.flags & SBC_EPI_POOL) {
+        // ((((0 + a) + b) + c) + d) / 4, a=[0::2,0::2] b=[1::2,0::2] c=[0::2,1::2] d=[1::2,1::2] (layers.py:311-312)
+        constexpr int PTOT = (TM / 4) * C4;              // pooled 16-byte outputs of the tile
+        constexpr int PC = 4;
+        const int Wo = W / 2, Ho = H / 2;
+        const int r0 = dm.div_w(g.p0);                 // first global row of the tile (even)
+#pragma unroll 1
+        for (int base = 0; base < PTOT; base += PC * NTHREADS) {
+            float4 v[PC], rr[PC];
+            unsigned o[PC];
+            bool ok[PC];
+#pragma unroll
+            for (int i = 0; i < PC; ++i) {
+                const int idx = base + i * NTHREADS + tid;
+                const int c4 = idx % C4, q = idx / C4;
+                const int qr = P2 ? q >> (p.wsh - 1) : q / Wo, qc = q - qr * Wo;
+                const int grow = r0 + 2 * qr;
+                ok[i] = idx < PTOT && grow < p.B * H;
+                const float* e = lds + (ok[i] ? ((2 * qr) * W + 2 * qc) * ES + c4 * 4 : 0);
+                const float4 a = *reinterpret_cast<const float4*>(e), b = *reinterpret_cast<const float4*>(e + W * ES);
+                const float4 c = *reinterpret_cast<const float4*>(e + ES), d = *reinterpret_cast<const float4*>(e + (W + 1) * ES);
+                v[i].x = (((a.x + b.x) + c.x) + d.x) * 0.25f;
+                v[i].y = (((a.y + b.y) + c.y) + d.y) * 0.25f;
+                v[i].z = (((a.z + b.z) + c.z) + d.z) * 0.25f;
+                v[i].w = (((a.w + b.w) + c.w) + d.w) * 0.25f;
+                const int n = dm.div_h(grow), ho = (grow - n * H) >> 1;
+                o[i] = ((unsigned)(n * Ho + ho) * Wo + qc) * COUT + c4 * 4;
+            }
+            if (p.res1) {
 #pragma unroll
                 for (int i = 0; i < PC; ++i)
-                    if (ok[i]) st_stream(p.out + o[i], v[i]);
+                    if (ok[i]) rr[i] = ld_stream(p.res1 + o[i]);
+#pragma unroll
+                for (int i = 0; i < PC; ++i) {
+                    v[i].x = rr[i].x + v[i].x; v[i].y = rr[i].y + v[i].y;
+                    v[i].z = rr[i].z + v[i].z; v[i].w = rr[i].w + v[i].w;
+                }
             }
-        } else {
-            const float sh = (p.flags & SBC_EPI_UP) && H > 1 ? (float)(p.up_h - 1) / (float)(H - 1) : 0.f;
-            const float sw = (p.flags & SBC_EPI_UP) && W > 1 ? (float)(p.up_w - 1) / (float)(W - 1) : 0.f;
 #pragma unroll
-            for (int c0 = 0; c0 < ITER; c0 += EC) {
-                float4 v[EC], rr[EC];
-                unsigned o[EC];
-                bool ok[EC];
+            for (int i = 0; i < PC; ++i)
+                if (ok[i]) st_stream(p.out + o[i], v[i]);
+        }
+        return;
+    }
+
+    const float sh = (p.flags & SBC_EPI_UP) && H > 1 ? (float)(p.up_h - 1) / (float)(H - 1) : 0.f;
+    const float sw = (p.flags & SBC_EPI_UP) && W > 1 ? (float)(p.up_w - 1) / (float)(W - 1) : 0.f;
+#pragma unroll 1
+    for (int c0 = 0; c0 < ITER; c0 += EC) {
+        float4 v[EC], rr[EC];
+        unsigned o[EC];
+        bool ok[EC];
 #pragma unroll
-                for (int i = 0; i < EC; ++i) {
-                    const int idx = tid + (c0 + i) * NTHREADS;
-                    const int c4 = idx % C4, pl = idx / C4;
-                    v[i] = *reinterpret_cast<const float4*>(lds + pl * ES + c4 * 4);
-                    ok[i] = g.p0 + pl < p.total_px;
-                    o[i] = (unsigned)(g.p0 + pl) * COUT + c4 * 4;
-                }
-                if (p.res1) {
+        for (int i = 0; i < EC; ++i) {
+            const int idx = tid + (c0 + i) * NTHREADS;
+            const int c4 = idx % C4, pl = idx / C4;
+            v[i] = *reinterpret_cast<const float4*>(lds + pl * ES + c4 * 4);
+            ok[i] = g.p0 + pl < p.total_px;
+            o[i] = (unsigned)(g.p0 + pl) * COUT + c4 * 4;
+        }
+        if (p.res1) {
 #pragma unroll
-                    for (int i = 0; i < EC; ++i) {
-                        if (RES_PF) rr[i] = rpf[RES_PF ? c0 + i : 0];     // chunk loop is unrolled: static index
-                        else if (ok[i]) rr[i] = ld_stream(p.res1 + o[i]);
-                    }
-                    if (p.flags & SBC_EPI_RES1_ELU) {
+            for (int i = 0; i < EC; ++i)
+                if (ok[i]) rr[i] = ld_stream(p.res1 + o[i]);
+            if (p.flags & SBC_EPI_RES1_ELU) {
 #pragma unroll
-                        for (int i = 0; i < EC; ++i) rr[i] = elu4(rr[i]);
-                    }
-                    if (p.res2) {
-                        float4 r2[EC];
-#pragma unroll
-                        for (int i = 0; i < EC; ++i)
-                            if (ok[i]) r2[i] = ld_stream(p.res2 + o[i]);
-#pragma unroll
-                        for (int i = 0; i < EC; ++i) {
-                            rr[i].x = r2[i].x + rr[i].x; rr[i].y = r2[i].y + rr[i].y;
-                            rr[i].z = r2[i].z + rr[i].z; rr[i].w = r2[i].w + rr[i].w;
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < EC; ++i) {
-                        v[i].x = v[i].x + rr[i].x; v[i].y = v[i].y + rr[i].y;
-                        v[i].z = v[i].z + rr[i].z; v[i].w = v[i].w + rr[i].w;
-                    }
-                }
-                if (p.flags & SBC_EPI_UP) {
-                    // F.interpolate(bilinear, align_corners=True) of `up` added on top (MSFBlock, layers.py:182-183)
-#pragma unroll
-                    for (int i = 0; i < EC; ++i) {
-                        if (!ok[i]) continue;
-                        const int idx = tid + (c0 + i) * NTHREADS;
-                        const int c4 = idx % C4, px = g.p0 + idx / C4;
-                        const int n = dm.div_hw(px), rem = px - n * HW;
-                        const int h = dm.div_w(rem), w = rem - h * W;
-                        const float fh = sh * (float)h, fw = sw * (float)w;
-                        const int h0 = min((int)fh, p.up_h - 1), w0 = min((int)fw, p.up_w - 1);
-                        const int h1 = min(h0 + 1, p.up_h - 1), w1 = min(w0 + 1, p.up_w - 1);
-                        const float lh1 = fh - (float)h0, lw1 = fw - (float)w0;
-                        const float lh0 = 1.f - lh1, lw0 = 1.f - lw1;
-                        const float* u = p.up + (size_t)n * p.up_h * p.up_w * COUT + c4 * 4;
-                        const float4 v00 = *reinterpret_cast<const float4*>(u + (size_t)(h0 * p.up_w + w0) * COUT);
-                        const float4 v01 = *reinterpret_cast<const float4*>(u + (size_t)(h0 * p.up_w + w1) * COUT);
-                        const float4 v10 = *reinterpret_cast<const float4*>(u + (size_t)(h1 * p.up_w + w0) * COUT);
-                        const float4 v11 = *reinterpret_cast<const float4*>(u + (size_t)(h1 * p.up_w + w1) * COUT);
-                        v[i].x = v[i].x + (lh0 * (lw0 * v00.x + lw1 * v01.x) + lh1 * (lw0 * v10.x + lw1 * v11.x));
-                        v[i].y = v[i].y + (lh0 * (lw0 * v00.y + lw1 * v01.y) + lh1 * (lw0 * v10.y + lw1 * v11.y));
-                        v[i].z = v[i].z + (lh0 * (lw0 * v00.z + lw1 * v01.z) + lh1 * (lw0 * v10.z + lw1 * v11.z));
-                        v[i].w = v[i].w + (lh0 * (lw0 * v00.w + lw1 * v01.w) + lh1 * (lw0 * v10.w + lw1 * v11.w));
-                    }
-                }
+                for (int i = 0; i < EC; ++i) rr[i] = elu4(rr[i]);
+            }
+            if (p.res2) {
+                float4 r2[EC];
 #pragma unroll
                 for (int i = 0; i < EC; ++i)
-                    if (ok[i] && !(p.flags & SBC_DBG_NOSTORE)) st_stream(p.out + o[i], v[i]);
+                    if (ok[i]) r2[i] = ld_stream(p.res2 + o[i]);
+#pragma unroll
+                for (int i = 0; i < EC; ++i) {
+                    rr[i].x = r2[i].x + rr[i].x; rr[i].y = r2[i].y + rr[i].y;
+                    rr[i].z = r2[i].z + rr[i].z; rr[i].w = r2[i].w + rr[i].w;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < EC; ++i) {
+                v[i].x = v[i].x + rr[i].x; v[i].y = v[i].y + rr[i].y;
+                v[i].z = v[i].z + rr[i].z; v[i].w = v[i].w + rr[i].w;
             }
         }
-
-        if (!has_next) break;
-        __syncthreads();                 // epilogue reads of the LDS tile are done
-        g = gn;
-        tile = tile_n;
-        stage_commit<CIN, NTHREADS, NPF, P2>(lds, pf, p.in, p.stats, p.flags, g, dm, tid);
+        if (p.flags & SBC_EPI_UP) {
+            // F.interpolate(bilinear, align_corners=True) of `up` added on top (MSFBlock, layers.py:182-183)
+#pragma unroll
+            for (int i = 0; i < EC; ++i) {
+                if (!ok[i]) continue;
+                const int idx = tid + (c0 + i) * NTHREADS;
+                const int c4 = idx % C4, px = g.p0 + idx / C4;
+                const int n = dm.div_hw(px), rem = px - n * HW;
+                const int h = dm.div_w(rem), w = rem - h * W;
+                const float fh = sh * (float)h, fw = sw * (float)w;
+                const int h0 = min((int)fh, p.up_h - 1), w0 = min((int)fw, p.up_w - 1);
+                const int h1 = min(h0 + 1, p.up_h - 1), w1 = min(w0 + 1, p.up_w - 1);
+                const float lh1 = fh - (float)h0, lw1 = fw - (float)w0;
+                const float lh0 = 1.f - lh1, lw0 = 1.f - lw1;
+                const float* u = p.up + (size_t)n * p.up_h * p.up_w * COUT + c4 * 4;
+                const float4 v00 = *reinterpret_cast<const float4*>(u + (size_t)(h0 * p.up_w + w0) * COUT);
+                const float4 v01 = *reinterpret_cast<const float4*>(u + (size_t)(h0 * p.up_w + w1) * COUT);
+                const float4 v10 = *reinterpret_cast<const float4*>(u + (size_t)(h1 * p.up_w + w0) * COUT);
+                const float4 v11 = *reinterpret_cast<const float4*>(u + (size_t)(h1 * p.up_w + w1) * COUT);
+                v[i].x = v[i].x + (lh0 * (lw0 * v00.x + lw1 * v01.x) + lh1 * (lw0 * v10.x + lw1 * v11.x));
+                v[i].y = v[i].y + (lh0 * (lw0 * v00.y + lw1 * v01.y) + lh1 * (lw0 * v10.y + lw1 * v11.y));
+                v[i].z = v[i].z + (lh0 * (lw0 * v00.z + lw1 * v01.z) + lh1 * (lw0 * v10.z + lw1 * v11.z));
+                v[i].w = v[i].w + (lh0 * (lw0 * v00.w + lw1 * v01.w) + lh1 * (lw0 * v10.w + lw1 * v11.w));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < EC; ++i)
+            if (ok[i]) st_stream(p.out + o[i], v[i]);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ dispatch
-static int num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
-
-template <int CIN, int COUT, int KS, int MT, int NT, int WM, int WN, bool PF, bool P2>
-static int launch_kernel(ConvParams p, size_t lds, hipStream_t stream, bool dry) {
+template <int CIN, int COUT, int KS, int MT, int NT, int WM, int WN, bool P2>
+static int launch_kernel(const ConvParams& p, size_t lds, hipStream_t stream, bool dry) {
     constexpr int TM = 32 * MT * WM;
-    auto kern = conv_mfma_kernel<CIN, COUT, KS, MT, NT, WM, WN, PF, P2>;
+    auto kern = conv_mfma_kernel<CIN, COUT, KS, MT, NT, WM, WN, P2>;
     static size_t lds_attr = 0;   // per instantiation
-    static int occ = 0;
     if (lds > lds_attr) {
         SBC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_attr = lds;
-        occ = 0;
-    }
-    if (!occ) {
-        SBC_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern),
-                                                                  64 * WM * WN, lds_attr));
-        if (occ < 1) occ = 1;
-        if (getenv("SBC_OCC")) occ = min(occ, atoi(getenv("SBC_OCC")));      // tuning aid
     }
     if (dry) return SBC_OK;
-    p.n_tiles = (p.total_px + TM - 1) / TM;
-    p.tiles_per_xcd = (p.n_tiles + 7) / 8;
-    int grid;
-    if (PF) {
-        p.wg_per_xcd = min(p.tiles_per_xcd, max(1, occ * num_cus() / 8));
-        grid = p.wg_per_xcd * 8;
-    } else {
-        p.wg_per_xcd = p.tiles_per_xcd;         // one tile per workgroup
-        grid = p.tiles_per_xcd * 8;
-    }
+    const int grid = (p.total_px + TM - 1) / TM;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), lds, stream, p);
     SBC_CHECK_HIP(hipGetLastError());
     return SBC_OK;
@@ -435,16 +343,8 @@ static int launch_variant(const ConvParams& p, hipStream_t stream, bool dry) {
     size_t lds = (size_t)(TM + halo_px + 1) * S * sizeof(float);
     lds = max(lds, (size_t)TM * (COUT + 4) * sizeof(float));       // epilogue transposes through LDS
     SBC_REQUIRE(lds <= 160 * 1024, "conv tile needs %zu bytes of LDS (> 160 KiB)", lds);
-    // several tiles per resident workgroup -> persistent build that prefetches the next tile
-    const long n_tiles = (p.total_px + TM - 1) / TM;
-    if (n_tiles >= 3L * num_cus()) {
-        constexpr size_t wbytes = (size_t)KS * KS * CIN * COUT * sizeof(float);
-        if (wbytes <= 40 * 1024) lds += wbytes;                     // weights resident in LDS (BLDS in the kernel)
-        if (p.hsh >= 0 && p.wsh >= 1) return launch_kernel<CIN, COUT, KS, MT, NT, WM, WN, true, true>(p, lds, stream, dry);
-        return launch_kernel<CIN, COUT, KS, MT, NT, WM, WN, true, false>(p, lds, stream, dry);
-    }
-    if (p.hsh >= 0 && p.wsh >= 1) return launch_kernel<CIN, COUT, KS, MT, NT, WM, WN, false, true>(p, lds, stream, dry);
-    return launch_kernel<CIN, COUT, KS, MT, NT, WM, WN, false, false>(p, lds, stream, dry);
+    if (p.hsh >= 0 && p.wsh >= 1) return launch_kernel<CIN, COUT, KS, MT, NT, WM, WN, true>(p, lds, stream, dry);
+    return launch_kernel<CIN, COUT, KS, MT, NT, WM, WN, false>(p, lds, stream, dry);
 }
 
 // Tile choice: as many pixels per workgroup as still leaves >= ~2 workgroups per CU (256 CUs), subject to the
@@ -493,12 +393,9 @@ int launch_conv(const sbc_op& op, hipStream_t stream, bool dry) {
     p.in = (const float*)op.in; p.out = (float*)op.out; p.wpk = (const float4*)op.weight;
     p.bias = (const float*)op.bias; p.stats = (const float*)op.stats;
     p.res1 = (const float*)op.res1; p.res2 = (const float*)op.res2; p.up = (const float*)op.up;
-    p.B = op.B; p.H = op.H; p.W = op.W; p.dil = op.dil; p.flags = op.flags & 0xfff;
+    p.B = op.B; p.H = op.H; p.W = op.W; p.dil = op.dil; p.flags = op.flags;
     p.up_h = op.up_h; p.up_w = op.up_w; p.total_px = op.B * op.H * op.W;
-    p.n_tiles = p.tiles_per_xcd = p.wg_per_xcd = 0;
     p.hsh = log2_exact(op.H); p.wsh = log2_exact(op.W);
-    static const int dbg = getenv("SBC_DEBUG_FLAGS") ? (int)strtol(getenv("SBC_DEBUG_FLAGS"), nullptr, 0) : 0;
-    p.flags |= dbg & 0xf000;
     const int key = op.cin * 100000 + op.cout * 100 + op.ksize;
     switch (key) {
         case 32 * 100000 + 32 * 100 + 3: return launch_sized<32, 32, 3>(p, stream, dry);
