@@ -63,66 +63,77 @@ int launch_begin_conv(const sbc_op& op, hipStream_t stream) {
 
 // ------------------------------------------------------------------------------------------------ IN++ stats
 // InstanceNorm2dPlus (normalization.py:163-176), one workgroup per sample:
-//   mu_c = mean_HW(x), var_c = biased variance (two-pass), m = mean_C(mu), v = unbiased var_C(mu),
+//   mu_c = mean_HW(x), var_c = biased variance, m = mean_C(mu), v = unbiased var_C(mu),
 //   out = gamma * ((x - mu_c)/sqrt(var_c + 1e-5) + (mu_c - m)/sqrt(v + 1e-5) * alpha) + beta
 // is stored as (mu, scale = gamma * rstd, shift = gamma * mhat * alpha + beta) so consumers apply
 // (x - mu) * scale + shift while staging.
+// The tensor is read ONCE: every thread accumulates sum and sum of squares of (x - pivot) with its own first value as
+// pivot (so the squares stay at variance scale), turns them into (count, mean, M2), and the partials are merged with
+// the exact pairwise update of Chan et al. (delta = mean_b - mean_a; M2 = M2_a + M2_b + delta^2 n_a n_b / n).
+struct Moments4 { float4 mean, m2; };
+
+__device__ __forceinline__ void chan_merge(float4& mean_a, float4& m2_a, float na, float4 mean_b, float4 m2_b, float nb) {
+    const float n = na + nb, wb = nb / n, wab = na * nb / n;
+    float d;
+    d = mean_b.x - mean_a.x; mean_a.x += d * wb; m2_a.x += m2_b.x + d * d * wab;
+    d = mean_b.y - mean_a.y; mean_a.y += d * wb; m2_a.y += m2_b.y + d * d * wab;
+    d = mean_b.z - mean_a.z; mean_a.z += d * wb; m2_a.z += m2_b.z + d * d * wab;
+    d = mean_b.w - mean_a.w; mean_a.w += d * wb; m2_a.w += m2_b.w + d * d * wab;
+}
+
 template <int C>
 __global__ __launch_bounds__(256) void inorm_stats_kernel(const float* __restrict__ x, const float* __restrict__ agb,
                                                            float* __restrict__ stats, int HW) {
     constexpr int C4 = C / 4;
     constexpr int J = 256 / C4;              // pixel lanes per channel quad
-    __shared__ float4 red[256];
+    __shared__ float4 red_mean[256], red_m2[256];
+    __shared__ float red_n[256];
     __shared__ float mean_s[C], var_s[C];
     const int n = blockIdx.x, tid = threadIdx.x;
     const int c4 = tid % C4, j = tid / C4;
     const float* base = x + (size_t)n * HW * C + c4 * 4;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int px = j; px < HW; px += J) {
-        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)px * C);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s, pivot = s;
+    int cnt = 0;
+    if (j < HW) pivot = *reinterpret_cast<const float4*>(base + (size_t)j * C);
+    constexpr int UNR = 8;                   // independent 16-byte loads in flight per thread
+    for (int px0 = j; px0 < HW; px0 += J * UNR) {
+        float4 v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+            if (px0 + u * J < HW) v[u] = *reinterpret_cast<const float4*>(base + (size_t)(px0 + u * J) * C);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+            if (px0 + u * J < HW) {
+                const float dx = v[u].x - pivot.x, dy = v[u].y - pivot.y, dz = v[u].z - pivot.z, dw = v[u].w - pivot.w;
+                s.x += dx; s.y += dy; s.z += dz; s.w += dw;
+                q.x = fmaf(dx, dx, q.x); q.y = fmaf(dy, dy, q.y); q.z = fmaf(dz, dz, q.z); q.w = fmaf(dw, dw, q.w);
+                ++cnt;
+            }
     }
-    red[tid] = s;
+    const float fn = (float)cnt, inv_n = cnt ? 1.f / fn : 0.f;
+    float4 mean = make_float4(pivot.x + s.x * inv_n, pivot.y + s.y * inv_n, pivot.z + s.z * inv_n, pivot.w + s.w * inv_n);
+    float4 m2 = make_float4(q.x - s.x * s.x * inv_n, q.y - s.y * s.y * inv_n, q.z - s.z * s.z * inv_n, q.w - s.w * s.w * inv_n);
+    red_mean[tid] = mean; red_m2[tid] = m2; red_n[tid] = fn;
     __syncthreads();
     for (int st = J / 2; st > 0; st >>= 1) {
         if (j < st) {
-            const float4 o = red[tid + st * C4];
-            float4 m = red[tid];
-            m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
-            red[tid] = m;
-        }
-        __syncthreads();
-    }
-    const float inv = 1.f / (float)HW;
-    if (j == 0) {
-        const float4 m = red[tid];
-        mean_s[c4 * 4 + 0] = m.x * inv; mean_s[c4 * 4 + 1] = m.y * inv;
-        mean_s[c4 * 4 + 2] = m.z * inv; mean_s[c4 * 4 + 3] = m.w * inv;
-    }
-    __syncthreads();
-    const float4 mu = make_float4(mean_s[c4 * 4], mean_s[c4 * 4 + 1], mean_s[c4 * 4 + 2], mean_s[c4 * 4 + 3]);
-    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int px = j; px < HW; px += J) {
-        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)px * C);
-        const float dx = v.x - mu.x, dy = v.y - mu.y, dz = v.z - mu.z, dw = v.w - mu.w;
-        q.x = fmaf(dx, dx, q.x); q.y = fmaf(dy, dy, q.y); q.z = fmaf(dz, dz, q.z); q.w = fmaf(dw, dw, q.w);
-    }
-    __syncthreads();
-    red[tid] = q;
-    __syncthreads();
-    for (int st = J / 2; st > 0; st >>= 1) {
-        if (j < st) {
-            const float4 o = red[tid + st * C4];
-            float4 m = red[tid];
-            m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
-            red[tid] = m;
+            const float nb = red_n[tid + st * C4];
+            if (nb > 0.f) {
+                float4 ma = red_mean[tid], qa = red_m2[tid];
+                const float na = red_n[tid];
+                if (na > 0.f) chan_merge(ma, qa, na, red_mean[tid + st * C4], red_m2[tid + st * C4], nb);
+                else { ma = red_mean[tid + st * C4]; qa = red_m2[tid + st * C4]; }
+                red_mean[tid] = ma; red_m2[tid] = qa; red_n[tid] = na + nb;
+            }
         }
         __syncthreads();
     }
     if (j == 0) {
-        const float4 m = red[tid];
-        var_s[c4 * 4 + 0] = m.x * inv; var_s[c4 * 4 + 1] = m.y * inv;
-        var_s[c4 * 4 + 2] = m.z * inv; var_s[c4 * 4 + 3] = m.w * inv;
+        const float4 m = red_mean[tid], qq = red_m2[tid];
+        const float inv = 1.f / (float)HW;
+        mean_s[c4 * 4 + 0] = m.x; mean_s[c4 * 4 + 1] = m.y; mean_s[c4 * 4 + 2] = m.z; mean_s[c4 * 4 + 3] = m.w;
+        var_s[c4 * 4 + 0] = qq.x * inv; var_s[c4 * 4 + 1] = qq.y * inv;
+        var_s[c4 * 4 + 2] = qq.z * inv; var_s[c4 * 4 + 3] = qq.w * inv;
     }
     __syncthreads();
     if (tid < C) {
@@ -135,7 +146,7 @@ __global__ __launch_bounds__(256) void inorm_stats_kernel(const float* __restric
         for (int c = 0; c < C; ++c) { const float d = mean_s[c] - m; v = fmaf(d, d, v); }
         v *= 1.f / (float)(C - 1);
         const float mhat = (mean_s[tid] - m) / sqrtf(v + 1e-5f);
-        const float rstd = 1.f / sqrtf(var_s[tid] + 1e-5f);
+        const float rstd = 1.f / sqrtf(fmaxf(var_s[tid], 0.f) + 1e-5f);
         const float alpha = agb[tid], gamma = agb[C + tid], beta = agb[2 * C + tid];
         float* o = stats + (size_t)n * 3 * C;
         o[tid] = mean_s[tid];
