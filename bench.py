@@ -30,7 +30,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md: v_m
 STEPS_PER_CHANNEL = 2311 * 3
 
 
-def cpu_baseline(cfg, sd, n_samples=16, n_steps=2):
+def cpu_baseline(cfg, sd, n_samples=64, n_steps=3):
     """The numpy oracle (oracle/, a port of the reference loop) timed on this host: `n_steps` Langevin steps of
     `n_samples` channels.  Reported, never used by the GPU path."""
     from oracle import ald_oracle as A, ncsnv2_oracle as O
@@ -76,9 +76,12 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
+    local %= max(1, torch.cuda.device_count())           # identity on a full node; lets 2 ranks share 1 GPU in a smoke test
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        backend = os.environ.get('SBC_DIST_BACKEND', 'nccl')   # 'nccl' is RCCL on ROCm
+        kw = {'device_id': torch.device('cuda', local)} if backend == 'nccl' else {}
+        dist.init_process_group(backend, **kw)
 
     from score_based_channels_amd import plan as P, synth
     from score_based_channels_amd.ald import AldBatch, snr_to_noise
@@ -178,8 +181,13 @@ def main():
         if kern_n:
             per_launch = 2.0 * alds[0].T * nt * nr * 9 * 32 * 32            # 3x3 conv 32->32 at 64x16, 2*MACs
             ach = per_launch / (kern_ms / kern_n * 1e-3) / 1e12
+            traffic = None                  # HBM bytes per launch from the PMC passes (profiles/), same workload only
+            tfile = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+            if os.path.exists(tfile) and alds[0].T == 1700:
+                with open(tfile) as f:
+                    traffic = json.load(f).get('hbm_bytes_per_launch')
             out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                               'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
                                'kernel': 'conv_mfma_kernel<32,32,3,...> (3x3 ngf->ngf convs at 64x16; %d launches, '
                                          'avg %.1f us)' % (kern_n, kern_ms / kern_n * 1e3)}
         if world == 1 and not args.no_cpu_baseline:
