@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SBC_ABI_VERSION 1
+#define SBC_ABI_VERSION 2
 
 typedef enum sbc_status {
     SBC_OK = 0,
@@ -91,6 +91,10 @@ typedef struct sbc_op {
     const void* up;
     const void* ext;             /* kind-specific extension struct (sbc_langevin / sbc_endconv), host memory,
                                     copied at sbc_plan_create / read during sbc_op_launch */
+    const void* weight_wino;     /* CONV, optional: the same 3x3 weight in Winograd F(2x2,3x3) form,
+                                    sbc_pack_conv_weight_winograd layout [16][cin/8][cout/32][64][4]; used for
+                                    undilated 3x3 convolutions on power-of-two images (2.25x fewer multiplies),
+                                    `weight` stays the fallback for every other shape */
 } sbc_op;
 
 /* Extension of SBC_OP_END_CONV: where the noise level comes from (ncsnv2.py:295-298). */
@@ -168,6 +172,9 @@ int sbc_plan_profile_read(sbc_plan* plan, double* total_ms, int64_t* n_launches)
  * fragment order consumed by SBC_OP_CONV: [k*k][cin/8][cout/32][64 lanes][4].  dst and src are HOST
  * pointers; cin % 8 == 0, cout % 32 == 0. */
 int sbc_pack_conv_weight(const float* src, int32_t cout, int32_t cin, int32_t ksize, float* dst);
+/* Same for the Winograd form of a 3x3 weight: U = G g G^T per (cout, cin) (computed in double), packed with the 16
+ * transform positions in place of the taps: [16][cin/8][cout/32][64][4]. */
+int sbc_pack_conv_weight_winograd(const float* src, int32_t cout, int32_t cin, float* dst);
 
 #ifdef __cplusplus
 }

@@ -215,4 +215,33 @@ int sbc_pack_conv_weight(const float* src, int32_t cout, int32_t cin, int32_t ks
     return SBC_OK;
 }
 
+int sbc_pack_conv_weight_winograd(const float* src, int32_t cout, int32_t cin, float* dst) {
+    SBC_REQUIRE(src && dst, "sbc_pack_conv_weight_winograd: NULL pointer");
+    SBC_REQUIRE(cin % 8 == 0 && cout % 32 == 0, "sbc_pack_conv_weight_winograd: cin %% 8, cout %% 32 required (got %d, %d)",
+                cin, cout);
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    std::vector<float> u((size_t)cout * cin * 16);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+            const float* g = src + ((size_t)co * cin + ci) * 9;
+            for (int i = 0; i < 4; ++i)
+                for (int l = 0; l < 4; ++l) {
+                    double s = 0;
+                    for (int j = 0; j < 3; ++j)
+                        for (int k = 0; k < 3; ++k) s += G[i][j] * (double)g[j * 3 + k] * G[l][k];
+                    u[((size_t)co * cin + ci) * 16 + i * 4 + l] = (float)s;
+                }
+        }
+    const int KG = cin / 8, NB = cout / 32;
+    for (int tap = 0; tap < 16; ++tap)
+        for (int g = 0; g < KG; ++g)
+            for (int nb = 0; nb < NB; ++nb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j) {
+                        const int co = nb * 32 + (lane & 31), ci = g * 8 + 4 * (lane >> 5) + j;
+                        dst[((((size_t)tap * KG + g) * NB + nb) * 64 + lane) * 4 + j] = u[((size_t)co * cin + ci) * 16 + tap];
+                    }
+    return SBC_OK;
+}
+
 }  // extern "C"

@@ -26,24 +26,9 @@
 // MFMA loop, 3x3 32->32 weights resident in LDS) was built and measured in round 1: it needs ~250 VGPRs, i.e. two
 // workgroups per CU instead of three, and was 3 % slower end to end than this build.
 #include <stdlib.h>
-#include "tile.h"
+#include "conv_common.h"
 
 namespace sbc {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct ConvParams {
-    const float* __restrict__ in;
-    float* __restrict__ out;
-    const float4* __restrict__ wpk;
-    const float* __restrict__ bias;
-    const float* __restrict__ stats;
-    const float* __restrict__ res1;
-    const float* __restrict__ res2;
-    const float* __restrict__ up;
-    int B, H, W, dil, flags, up_h, up_w, total_px;
-    int hsh, wsh;         // log2(H), log2(W) for the power-of-two builds
-};
 
 template <int CIN, int COUT, int KS, int MT, int NT, int WM, int WN, bool P2>
 __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvParams p) {
@@ -396,6 +381,13 @@ int launch_conv(const sbc_op& op, hipStream_t stream, bool dry) {
     p.B = op.B; p.H = op.H; p.W = op.W; p.dil = op.dil; p.flags = op.flags;
     p.up_h = op.up_h; p.up_w = op.up_w; p.total_px = op.B * op.H * op.W;
     p.hsh = log2_exact(op.H); p.wsh = log2_exact(op.W);
+    static const bool no_wino = getenv("SBC_NO_WINO") != nullptr;                  // A/B aid
+    if (op.weight_wino && op.ksize == 3 && op.dil == 1 && !no_wino) {
+        ConvParams pw = p;
+        pw.wpk = (const float4*)op.weight_wino;
+        const int rc = launch_conv_wino(pw, op.cin, op.cout, stream, dry);
+        if (rc <= 0) return rc;                                                    // launched (0) or failed (< 0)
+    }
     const int key = op.cin * 100000 + op.cout * 100 + op.ksize;
     switch (key) {
         case 32 * 100000 + 32 * 100 + 3: return launch_sized<32, 32, 3>(p, stream, dry);

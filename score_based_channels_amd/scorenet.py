@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from . import plan as P
-from .weights import check_state_dict, get_sigmas, pack_conv_weight
+from .weights import check_state_dict, get_sigmas, pack_conv_weight, pack_conv_weight_winograd
 
 
 def _ptr(t, offset_elems=0):
@@ -101,6 +101,8 @@ class ScoreNet:
                 continue
             if name.endswith('.weight') and w.ndim == 4 and name not in ('begin_conv.weight', 'end_conv.weight'):
                 add(name, pack_conv_weight(w))
+                if w.shape[2:] == (3, 3):
+                    add(name + '#winograd', pack_conv_weight_winograd(w))
             elif name.endswith('.alpha'):
                 pre = name[:-len('.alpha')]
                 add(pre, np.concatenate([sd[pre + '.alpha'], sd[pre + '.gamma'], sd[pre + '.beta']]))
@@ -144,6 +146,8 @@ class ScoreNet:
             o.out = _ptr(slots[op.dst.slot])
             if op.weight is not None:
                 o.weight = _ptr(self._wdev, self._woff[op.weight])
+                if op.kind == P.CONV and op.ksize == 3 and op.dil == 1:
+                    o.weight_wino = _ptr(self._wdev, self._woff[op.weight + '#winograd'])
             if op.bias is not None:
                 o.bias = _ptr(self._wdev, self._woff[op.bias])
             if op.stats is not None:

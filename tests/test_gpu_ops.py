@@ -67,11 +67,16 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize('algo', ['direct', 'winograd'])
 @pytest.mark.parametrize('cin,cout,k,dil,B,H,W,mode', CONV_CASES)
-def test_conv_matches_oracle(gpu, cin, cout, k, dil, B, H, W, mode):
+def test_conv_matches_oracle(gpu, cin, cout, k, dil, B, H, W, mode, algo):
+    """Both convolution algorithms behind SBC_OP_CONV: the direct implicit GEMM (weight) and, when the op also
+    carries weight_wino, Winograd F(2x2,3x3) for undilated 3x3 convs (shapes it does not cover fall back to direct)."""
     torch, _lib = gpu
     from score_based_channels_amd import plan as P
-    from score_based_channels_amd.weights import pack_conv_weight
+    from score_based_channels_amd.weights import pack_conv_weight, pack_conv_weight_winograd
+    if algo == 'winograd' and (k != 3 or dil != 1):
+        pytest.skip('Winograd F(2x2,3x3) applies to undilated 3x3 convolutions')
     rng = np.random.default_rng(hash((cin, cout, k, dil, B, H, W)) % (2 ** 31))
     x = rng.standard_normal((B, H, W, cin)).astype(F32) * 1.5 + 0.3
     w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(F32)
@@ -119,6 +124,9 @@ def test_conv_matches_oracle(gpu, cin, cout, k, dil, B, H, W, mode):
             setattr(op, name, _p(d[name]))
     if up is not None:
         op.up_h, op.up_w = up.shape[1], up.shape[2]
+    if algo == 'winograd':
+        ww = _dev(torch, pack_conv_weight_winograd(w))
+        op.weight_wino = _p(ww)
     _launch(gpu, op)
     got = out.cpu().numpy()
     assert np.isfinite(got).all()
