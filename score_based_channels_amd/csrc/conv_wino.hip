@@ -17,6 +17,7 @@
 // (T_b = sum_nu M[xi][nu] A[nu][b], in registers), the T planes go through LDS, and every thread finishes
 // Y[a][b] = sum_xi A^T[a][xi] T[xi][b] for one (tile, 4 channels): the four pixels of a 2x2 block -- which is also
 // the window of the 2x2 mean pool.  Bias / residual / ELU / bilinear-add / pool / store follow as in the direct kernel.
+#include <stdlib.h>
 #include "conv_common.h"
 
 namespace sbc {
@@ -28,7 +29,7 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(ConvParams p) {
     constexpr int S = CIN + 4;
     constexpr int KG = CIN / 8;
     constexpr int NBLK = COUT / 32;
-    constexpr int NBP = MB == 2 ? 1 : (NBLK < 2 ? NBLK : 2);   // output-channel blocks per phase
+    constexpr int NBP = 1;                       // output-channel blocks per phase (keeps T at 32 regs per tile block)
     constexpr int PH = NBLK / NBP;               // phases (each: K loops of MB*NBP passes, then one output round)
     constexpr int TS = 36;                       // floats per (tile) row of a T plane: 32 channels + 4 pad
     constexpr int NTHREADS = 256;
@@ -94,34 +95,48 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(ConvParams p) {
                     for (int r = 0; r < 16; ++r) acc[nu][r] = 0.f;
                 // packed U: [xi*4 + nu][kg][nb][lane]
                 const float4* wp = p.wpk + ((size_t)(xi * 4) * KG * NBLK + nb) * 64 + lane;
-#pragma unroll 2
-                for (int kg = 0; kg < KG; ++kg) {
-                    float4 b[4], da[4], db[4];
+                // software pipeline over the 8-channel groups: operands of group kg+1 (4 B fragments from L2, 2 x 4
+                // patch pixels from LDS) are requested before the transform + MFMAs of group kg; two statically
+                // indexed register sets, order pinned so the compiler's waits are counted
+                float4 bS[2][4], dA[2][4], dB[2][4];
 #pragma unroll
-                    for (int nu = 0; nu < 4; ++nu) b[nu] = wp[(size_t)((nu * KG + kg) * NBLK) * 64];
+                for (int nu = 0; nu < 4; ++nu) bS[0][nu] = wp[(size_t)((nu * KG) * NBLK) * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    dA[0][j] = *reinterpret_cast<const float4*>(__builtin_assume_aligned(lds + off[mb][0][j], 16));
+                    dB[0][j] = *reinterpret_cast<const float4*>(__builtin_assume_aligned(lds + off[mb][1][j], 16));
+                }
+#pragma unroll
+                for (int kg = 0; kg < KG; ++kg) {
+                    const int cur = kg & 1, nxt = cur ^ 1;
+                    const int kn = kg + 1 < KG ? kg + 1 : kg;
+#pragma unroll
+                    for (int nu = 0; nu < 4; ++nu) bS[nxt][nu] = wp[(size_t)((nu * KG + kn) * NBLK) * 64];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        da[j] = *reinterpret_cast<const float4*>(__builtin_assume_aligned(lds + off[mb][0][j] + kg * 8, 16));
-                        db[j] = *reinterpret_cast<const float4*>(__builtin_assume_aligned(lds + off[mb][1][j] + kg * 8, 16));
+                        dA[nxt][j] = *reinterpret_cast<const float4*>(__builtin_assume_aligned(lds + off[mb][0][j] + kn * 8, 16));
+                        dB[nxt][j] = *reinterpret_cast<const float4*>(__builtin_assume_aligned(lds + off[mb][1][j] + kn * 8, 16));
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                     float4 R[4], V[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        R[j].x = fmaf(sgn, db[j].x, da[j].x); R[j].y = fmaf(sgn, db[j].y, da[j].y);
-                        R[j].z = fmaf(sgn, db[j].z, da[j].z); R[j].w = fmaf(sgn, db[j].w, da[j].w);
+                        const float4 a4 = dA[cur][j], b4 = dB[cur][j];
+                        R[j].x = fmaf(sgn, b4.x, a4.x); R[j].y = fmaf(sgn, b4.y, a4.y);
+                        R[j].z = fmaf(sgn, b4.z, a4.z); R[j].w = fmaf(sgn, b4.w, a4.w);
                     }
                     // columns of B: nu=0: R0 - R2, nu=1: R1 + R2, nu=2: R2 - R1, nu=3: R1 - R3
                     V[0] = make_float4(R[0].x - R[2].x, R[0].y - R[2].y, R[0].z - R[2].z, R[0].w - R[2].w);
                     V[1] = make_float4(R[1].x + R[2].x, R[1].y + R[2].y, R[1].z + R[2].z, R[1].w + R[2].w);
                     V[2] = make_float4(R[2].x - R[1].x, R[2].y - R[1].y, R[2].z - R[1].z, R[2].w - R[1].w);
                     V[3] = make_float4(R[1].x - R[3].x, R[1].y - R[3].y, R[1].z - R[3].z, R[1].w - R[3].w);
-                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
                         for (int nu = 0; nu < 4; ++nu) {
+                            const float4 b4 = bS[cur][nu];
                             const float av = j == 0 ? V[nu].x : j == 1 ? V[nu].y : j == 2 ? V[nu].z : V[nu].w;
-                            const float bv = j == 0 ? b[nu].x : j == 1 ? b[nu].y : j == 2 ? b[nu].z : b[nu].w;
+                            const float bv = j == 0 ? b4.x : j == 1 ? b4.y : j == 2 ? b4.z : b4.w;
                             acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[nu], 0, 0, 0);
                         }
                     __builtin_amdgcn_sched_barrier(0);
@@ -270,7 +285,7 @@ static int launch_wino(const ConvParams& p, hipStream_t stream, bool dry) {
     constexpr int TM = 128 * MB;
     constexpr int S = CIN + 4;
     constexpr int NBLK = COUT / 32;
-    constexpr int NBP = MB == 2 ? 1 : (NBLK < 2 ? NBLK : 2);
+    constexpr int NBP = 1;
     constexpr int PH = NBLK / NBP;
     const int HW = p.H * p.W;
     const bool multi = TM >= HW;
@@ -296,7 +311,8 @@ static int launch_wino_sized(const ConvParams& p, hipStream_t stream, bool dry) 
     const int HW = p.H * p.W;
     auto fits = [&](int tm) { return tm % (2 * p.W) == 0 && (HW % tm == 0 || tm % HW == 0); };
     constexpr bool mb2_ok = (COUT == 32);          // 256-pixel tiles only where one output block keeps registers low
-    if (mb2_ok && fits(256) && p.total_px >= 256L * 512) return launch_wino<CIN, COUT, 2>(p, stream, dry);
+    static const bool force1 = getenv("SBC_WINO_MB1") != nullptr;                   // tuning aid
+    if (mb2_ok && !force1 && fits(256) && p.total_px >= 256L * 512) return launch_wino<CIN, COUT, 2>(p, stream, dry);
     if (fits(128)) return launch_wino<CIN, COUT, 1>(p, stream, dry);
     if (mb2_ok && fits(256)) return launch_wino<CIN, COUT, 2>(p, stream, dry);
     return 1;
