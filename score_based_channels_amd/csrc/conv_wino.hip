@@ -29,13 +29,11 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(ConvParams p) {
     constexpr int S = CIN + 4;
     constexpr int KG = CIN / 8;
     constexpr int NBLK = COUT / 32;
-    constexpr int NBP = 1;                       // output-channel blocks per phase (keeps T at 32 regs per tile block)
-    constexpr int PH = NBLK / NBP;               // phases (each: K loops of MB*NBP passes, then one output round)
+    constexpr int PH = NBLK;                     // phases: one 32-channel output block each (K loops, then output)
     constexpr int TS = 36;                       // floats per (tile) row of a T plane: 32 channels + 4 pad
     constexpr int NTHREADS = 256;
     constexpr int NPF_FULL = ((TM + 32) * (CIN / 4) + NTHREADS - 1) / NTHREADS;
     constexpr int NPF = NPF_FULL <= 10 ? NPF_FULL : 10;
-    static_assert(NBLK % NBP == 0, "phases must divide the output blocks");
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -82,84 +80,84 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(ConvParams p) {
     __syncthreads();                                                  // staged tile visible
 
     for (int ph = 0; ph < PH; ++ph) {
-        f32x16 T[MB * NBP][2];
+        const int nb = ph;                        // output-channel block of this phase
+        f32x16 T[MB][2];
+        f32x16 acc[4];
+        // packed U: [xi*4 + nu][kg][nb][lane]
+        const float4* wp = p.wpk + ((size_t)(xi * 4) * KG * NBLK + nb) * 64 + lane;
+        // One software pipeline over all (tile block, 8-channel group) steps of the phase: the operands of step s+1
+        // (4 B fragments from L2, 2 x 4 patch pixels from LDS) are requested before the transform + MFMAs of step
+        // s, also across tile blocks; two statically indexed register sets, order pinned so the compiler's waits
+        // are counted.
+        float4 bS[2][4], dA[2][4], dB[2][4];
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
+        for (int nu = 0; nu < 4; ++nu) bS[0][nu] = wp[(size_t)((nu * KG) * NBLK) * 64];
 #pragma unroll
-            for (int nq = 0; nq < NBP; ++nq) {
-                const int nb = ph * NBP + nq;
-                f32x16 acc[4];
+        for (int j = 0; j < 4; ++j) {
+            dA[0][j] = *reinterpret_cast<const float4*>(__builtin_assume_aligned(lds + off[0][0][j], 16));
+            dB[0][j] = *reinterpret_cast<const float4*>(__builtin_assume_aligned(lds + off[0][1][j], 16));
+        }
+#pragma unroll
+        for (int s = 0; s < MB * KG; ++s) {
+            const int mb = s / KG, kg = s % KG;
+            const int cur = s & 1, nxt = cur ^ 1;
+            const int sn = s + 1 < MB * KG ? s + 1 : s;
+            const int mbn = sn / KG, kn = sn % KG;
+            if (kg == 0) {
 #pragma unroll
                 for (int nu = 0; nu < 4; ++nu)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[nu][r] = 0.f;
-                // packed U: [xi*4 + nu][kg][nb][lane]
-                const float4* wp = p.wpk + ((size_t)(xi * 4) * KG * NBLK + nb) * 64 + lane;
-                // software pipeline over the 8-channel groups: operands of group kg+1 (4 B fragments from L2, 2 x 4
-                // patch pixels from LDS) are requested before the transform + MFMAs of group kg; two statically
-                // indexed register sets, order pinned so the compiler's waits are counted
-                float4 bS[2][4], dA[2][4], dB[2][4];
+            }
 #pragma unroll
-                for (int nu = 0; nu < 4; ++nu) bS[0][nu] = wp[(size_t)((nu * KG) * NBLK) * 64];
+            for (int nu = 0; nu < 4; ++nu) bS[nxt][nu] = wp[(size_t)((nu * KG + kn) * NBLK) * 64];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    dA[0][j] = *reinterpret_cast<const float4*>(__builtin_assume_aligned(lds + off[mb][0][j], 16));
-                    dB[0][j] = *reinterpret_cast<const float4*>(__builtin_assume_aligned(lds + off[mb][1][j], 16));
+            for (int j = 0; j < 4; ++j) {
+                dA[nxt][j] = *reinterpret_cast<const float4*>(__builtin_assume_aligned(lds + off[mbn][0][j] + kn * 8, 16));
+                dB[nxt][j] = *reinterpret_cast<const float4*>(__builtin_assume_aligned(lds + off[mbn][1][j] + kn * 8, 16));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float4 R[4], V[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 a4 = dA[cur][j], b4 = dB[cur][j];
+                R[j].x = fmaf(sgn, b4.x, a4.x); R[j].y = fmaf(sgn, b4.y, a4.y);
+                R[j].z = fmaf(sgn, b4.z, a4.z); R[j].w = fmaf(sgn, b4.w, a4.w);
+            }
+            // columns of B: nu=0: R0 - R2, nu=1: R1 + R2, nu=2: R2 - R1, nu=3: R1 - R3
+            V[0] = make_float4(R[0].x - R[2].x, R[0].y - R[2].y, R[0].z - R[2].z, R[0].w - R[2].w);
+            V[1] = make_float4(R[1].x + R[2].x, R[1].y + R[2].y, R[1].z + R[2].z, R[1].w + R[2].w);
+            V[2] = make_float4(R[2].x - R[1].x, R[2].y - R[1].y, R[2].z - R[1].z, R[2].w - R[1].w);
+            V[3] = make_float4(R[1].x - R[3].x, R[1].y - R[3].y, R[1].z - R[3].z, R[1].w - R[3].w);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int nu = 0; nu < 4; ++nu) {
+                    const float4 b4 = bS[cur][nu];
+                    const float av = j == 0 ? V[nu].x : j == 1 ? V[nu].y : j == 2 ? V[nu].z : V[nu].w;
+                    const float bv = j == 0 ? b4.x : j == 1 ? b4.y : j == 2 ? b4.z : b4.w;
+                    acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[nu], 0, 0, 0);
                 }
-#pragma unroll
-                for (int kg = 0; kg < KG; ++kg) {
-                    const int cur = kg & 1, nxt = cur ^ 1;
-                    const int kn = kg + 1 < KG ? kg + 1 : kg;
-#pragma unroll
-                    for (int nu = 0; nu < 4; ++nu) bS[nxt][nu] = wp[(size_t)((nu * KG + kn) * NBLK) * 64];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        dA[nxt][j] = *reinterpret_cast<const float4*>(__builtin_assume_aligned(lds + off[mb][0][j] + kn * 8, 16));
-                        dB[nxt][j] = *reinterpret_cast<const float4*>(__builtin_assume_aligned(lds + off[mb][1][j] + kn * 8, 16));
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    float4 R[4], V[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float4 a4 = dA[cur][j], b4 = dB[cur][j];
-                        R[j].x = fmaf(sgn, b4.x, a4.x); R[j].y = fmaf(sgn, b4.y, a4.y);
-                        R[j].z = fmaf(sgn, b4.z, a4.z); R[j].w = fmaf(sgn, b4.w, a4.w);
-                    }
-                    // columns of B: nu=0: R0 - R2, nu=1: R1 + R2, nu=2: R2 - R1, nu=3: R1 - R3
-                    V[0] = make_float4(R[0].x - R[2].x, R[0].y - R[2].y, R[0].z - R[2].z, R[0].w - R[2].w);
-                    V[1] = make_float4(R[1].x + R[2].x, R[1].y + R[2].y, R[1].z + R[2].z, R[1].w + R[2].w);
-                    V[2] = make_float4(R[2].x - R[1].x, R[2].y - R[1].y, R[2].z - R[1].z, R[2].w - R[1].w);
-                    V[3] = make_float4(R[1].x - R[3].x, R[1].y - R[3].y, R[1].z - R[3].z, R[1].w - R[3].w);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int nu = 0; nu < 4; ++nu) {
-                            const float4 b4 = bS[cur][nu];
-                            const float av = j == 0 ? V[nu].x : j == 1 ? V[nu].y : j == 2 ? V[nu].z : V[nu].w;
-                            const float bv = j == 0 ? b4.x : j == 1 ? b4.y : j == 2 ? b4.z : b4.w;
-                            acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[nu], 0, 0, 0);
-                        }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+            __builtin_amdgcn_sched_barrier(0);
+            if (kg == KG - 1) {
                 // A^T = [[1, 1, 1, 0], [0, 1, -1, -1]] applied over nu
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    T[mb * NBP + nq][0][r] = (acc[0][r] + acc[1][r]) + acc[2][r];
-                    T[mb * NBP + nq][1][r] = (acc[1][r] - acc[2][r]) - acc[3][r];
+                    T[mb][0][r] = (acc[0][r] + acc[1][r]) + acc[2][r];
+                    T[mb][1][r] = (acc[1][r] - acc[2][r]) - acc[3][r];
                 }
             }
+        }
 
         if (PH == 1) __syncthreads();             // all waves are done with the staged tile (T planes overlay it)
-#pragma unroll 1
-        for (int nq = 0; nq < NBP; ++nq) {
-            const int nb = ph * NBP + nq;
+        {
             // T planes of this output block -> LDS [xi][b][tile][TS]
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     float* e = tl + ((size_t)((xi * 2 + b) * NTW + mb * 32 + rhalf)) * TS + col;
-                    const f32x16 tv = nq == 0 ? T[mb * NBP][b] : T[mb * NBP + (NBP > 1 ? 1 : 0)][b];
+                    const f32x16 tv = T[mb][b];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) e[((r & 3) + 8 * (r >> 2)) * TS] = tv[r];
                 }
@@ -274,7 +272,7 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(ConvParams p) {
 #pragma unroll
                     for (int b = 0; b < 2; ++b) st_stream(p.out + o[a][b], y[a][b]);
             }
-            if (nq + 1 < NBP || ph + 1 < PH) __syncthreads();          // T planes are rewritten next round
+            if (ph + 1 < PH) __syncthreads();                          // T planes are rewritten next phase
         }
     }
 }
@@ -285,8 +283,7 @@ static int launch_wino(const ConvParams& p, hipStream_t stream, bool dry) {
     constexpr int TM = 128 * MB;
     constexpr int S = CIN + 4;
     constexpr int NBLK = COUT / 32;
-    constexpr int NBP = 1;
-    constexpr int PH = NBLK / NBP;
+    constexpr int PH = NBLK;
     const int HW = p.H * p.W;
     const bool multi = TM >= HW;
     const size_t staged = (size_t)(multi ? TM + 1 : TM + 2 * p.W + 1) * S * sizeof(float);
