@@ -66,6 +66,8 @@ def main():
     ap.add_argument('--graph', type=int, default=0, help='replay the step as a hipGraph (no per-kernel timing)')
     ap.add_argument('--full-schedule', action='store_true', help='time all 6933 steps instead of --steps')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--conv-mode', default='f32', choices=['bf16x3', 'f32'],
+                    help='convolution multiplier (scorenet.CONV_MODES)')
     ap.add_argument('--streams', type=int, default=1, help='split the trajectories into this many concurrent HIP streams')
     args = ap.parse_args()
 
@@ -91,7 +93,7 @@ def main():
 
     cfg = default_config('CDL-C')
     sd = seeded_state_dict(cfg, 2024)                     # random-init weights of the reference architecture
-    net = ScoreNet(cfg, 'cuda:%d' % local).load_state_dict(sd)
+    net = ScoreNet(cfg, 'cuda:%d' % local, conv_mode=args.conv_mode).load_state_dict(sd)
     nt, nr, npil = 64, 16, int(np.floor(64 * 0.6))
     nch, nsnr = args.channels, args.snr_points
     raw = synth.generate_channels('CDL-C', nch, nt, nr, 0.5, seed=4321 + rank)       # per-rank channel batch

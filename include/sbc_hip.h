@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SBC_ABI_VERSION 2
+#define SBC_ABI_VERSION 3
 
 typedef enum sbc_status {
     SBC_OK = 0,
@@ -95,6 +95,12 @@ typedef struct sbc_op {
                                     sbc_pack_conv_weight_winograd layout [16][cin/8][cout/32][64][4]; used for
                                     undilated 3x3 convolutions on power-of-two images (2.25x fewer multiplies),
                                     `weight` stays the fallback for every other shape */
+    const void* weight_split;    /* CONV, optional: the same weight with every fp32 value split exactly into three
+                                    bf16 terms, sbc_pack_conv_weight_split layout [k*k][cin/16][cout/32][3][64][8]
+                                    (uint16).  When set, the convolution runs on the bf16 matrix cores as six bf16
+                                    MFMAs per fp32 product block with fp32 accumulation (fp32-level accuracy, see
+                                    csrc/conv_x3.hip); takes precedence over `weight_wino` and `weight`, which then
+                                    may be NULL.  SBC_CONV_MODE=f32 in the environment ignores it. */
 } sbc_op;
 
 /* Extension of SBC_OP_END_CONV: where the noise level comes from (ncsnv2.py:295-298). */
@@ -116,8 +122,8 @@ typedef struct sbc_endconv {
  *   noise  [n_steps][B][Nt][Nr] CN(0,1) draws or NULL -> in-kernel Philox4x32-10 keyed by
  *          (seed, traj_id[b], step, element)                            (:160-161)
  *   nmse   [n_steps][B] float32 log, row *step is written               (:168-170)
- * MEASURE uses X as H input?  no: it reads Htrue/P and writes Y; `noise` is then [B][Np][Nr] and
- * `meas_scale[b]` = float32(sqrt(local_noise)).
+ * SBC_OP_MEASURE reads Htrue and P and writes Y; its `noise` is [B][Np][Nr] and `meas_scale[b]` =
+ * float32(sqrt(local_noise)).
  */
 typedef struct sbc_langevin {
     float* X;
@@ -175,6 +181,10 @@ int sbc_pack_conv_weight(const float* src, int32_t cout, int32_t cin, int32_t ks
 /* Same for the Winograd form of a 3x3 weight: U = G g G^T per (cout, cin) (computed in double), packed with the 16
  * transform positions in place of the taps: [16][cin/8][cout/32][64][4]. */
 int sbc_pack_conv_weight_winograd(const float* src, int32_t cout, int32_t cin, float* dst);
+/* Split-bf16 form: w = wh + wm + wl with wh = bf16(w), wm = bf16(w - wh), wl = bf16(w - wh - wm) (round to nearest
+ * even; the sum is exact), as bf16 bit patterns in B-operand fragment order [k*k][cin/16][cout/32][3][64 lanes][8]:
+ * lane l of block (tap, g, n) holds w[n*32 + (l & 31)][g*16 + 8*(l >> 5) + j][tap], j = 0..7.  cin % 16 == 0. */
+int sbc_pack_conv_weight_split(const float* src, int32_t cout, int32_t cin, int32_t ksize, uint16_t* dst);
 
 #ifdef __cplusplus
 }

@@ -244,4 +244,43 @@ int sbc_pack_conv_weight_winograd(const float* src, int32_t cout, int32_t cin, f
     return SBC_OK;
 }
 
+// round-to-nearest-even fp32 -> bf16 (bit pattern), as v_cvt_pk_bf16_f32 does for finite values
+static inline uint16_t bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_f32(uint16_t b) {
+    const uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+int sbc_pack_conv_weight_split(const float* src, int32_t cout, int32_t cin, int32_t ksize, uint16_t* dst) {
+    SBC_REQUIRE(src && dst, "sbc_pack_conv_weight_split: NULL pointer");
+    SBC_REQUIRE(cin % 16 == 0 && cout % 32 == 0 && (ksize == 1 || ksize == 3),
+                "sbc_pack_conv_weight_split: cin %% 16, cout %% 32, ksize in {1,3} required (got %d, %d, %d)", cin, cout,
+                ksize);
+    const int taps = ksize * ksize, KG = cin / 16, NB = cout / 32;
+    for (int tap = 0; tap < taps; ++tap)
+        for (int g = 0; g < KG; ++g)
+            for (int nb = 0; nb < NB; ++nb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = nb * 32 + (lane & 31), ci = g * 16 + 8 * (lane >> 5) + j;
+                        const float w = src[((size_t)co * cin + ci) * taps + tap];
+                        const uint16_t h = bf16_rne(w);
+                        const float r1 = w - bf16_to_f32(h);
+                        const uint16_t m = bf16_rne(r1);
+                        const uint16_t l = bf16_rne(r1 - bf16_to_f32(m));
+                        const size_t base = (((size_t)tap * KG + g) * NB + nb) * 3;
+                        dst[((base + 0) * 64 + lane) * 8 + j] = h;
+                        dst[((base + 1) * 64 + lane) * 8 + j] = m;
+                        dst[((base + 2) * 64 + lane) * 8 + j] = l;
+                    }
+    return SBC_OK;
+}
+
 }  // extern "C"

@@ -17,11 +17,16 @@ struct ConvParams {
     const float* __restrict__ up;
     int B, H, W, dil, flags, up_h, up_w, total_px;
     int hsh, wsh;         // log2(H), log2(W) for the power-of-two builds
+    int plane;            // conv_x3: 16-bit elements per LDS plane
 };
 
 
 // Winograd F(2x2,3x3) path (conv_wino.hip): returns SBC_OK after launching, or 1 when the shape is not eligible
 // (the caller then uses the direct kernel).  `p.wpk` must point at the Winograd-packed weights.
 int launch_conv_wino(const ConvParams& p, int cin, int cout, hipStream_t stream, bool dry);
+
+// Split-bf16 path (conv_x3.hip): fp32 operands as three bf16 terms each, six bf16 MFMAs per fp32 product block.
+// `p.wpk` must point at sbc_pack_conv_weight_split weights.
+int launch_conv_x3(const ConvParams& p, int cin, int cout, int ksize, hipStream_t stream, bool dry);
 
 }  // namespace sbc

@@ -138,6 +138,71 @@ __device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__
     stage_commit<CIN, NTHREADS, NPF, P2>(lds, pf, in, stats, flags, g, d, tid);
 }
 
+
+// ---- split-bf16 staging (conv_x3.hip) ---------------------------------------------------------------------------
+// Every fp32 activation x is written as three bf16 terms h + m + l = x (h = bf16(x), m = bf16(x - h), l = x - h - m:
+// 8 + 8 + 8 significand bits, the sum is exact), one LDS plane per term, each [pixel][CIN + 8] bf16.  The 16-byte pad
+// makes the pixel stride an odd number of 16-byte slots (conflict-free ds_read_b128 over 16 consecutive pixels).
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3(float4 x, bf16x4& h, bf16x4& m, bf16x4& l) {
+    h[0] = (__bf16)x.x; h[1] = (__bf16)x.y; h[2] = (__bf16)x.z; h[3] = (__bf16)x.w;
+    x.x -= (float)h[0]; x.y -= (float)h[1]; x.z -= (float)h[2]; x.w -= (float)h[3];
+    m[0] = (__bf16)x.x; m[1] = (__bf16)x.y; m[2] = (__bf16)x.z; m[3] = (__bf16)x.w;
+    x.x -= (float)m[0]; x.y -= (float)m[1]; x.z -= (float)m[2]; x.w -= (float)m[3];
+    l[0] = (__bf16)x.x; l[1] = (__bf16)x.y; l[2] = (__bf16)x.z; l[3] = (__bf16)x.w;
+}
+
+// lds16: LDS viewed as 16-bit elements; `plane` = elements per plane
+template <int CIN, bool P2>
+__device__ __forceinline__ void stage_put_split(unsigned short* lds16, int plane, float4 x, int idx,
+                                                const float* __restrict__ stats, int flags, const TileGeom& g,
+                                                const Dims<P2>& d) {
+    constexpr int SH = CIN + 8;
+    constexpr int C4 = CIN / 4;
+    const int pix = idx / C4, c4 = idx % C4;
+    if (flags & SBC_PRO_NORM) {
+        const int n = g.n_first + (g.multi ? d.div_hw(pix) : 0);
+        const float* st = stats + (size_t)n * 3 * CIN + c4 * 4;
+        const float4 mu = *reinterpret_cast<const float4*>(st);
+        const float4 sc = *reinterpret_cast<const float4*>(st + CIN);
+        const float4 sh = *reinterpret_cast<const float4*>(st + 2 * CIN);
+        x.x = (x.x - mu.x) * sc.x + sh.x;
+        x.y = (x.y - mu.y) * sc.y + sh.y;
+        x.z = (x.z - mu.z) * sc.z + sh.z;
+        x.w = (x.w - mu.w) * sc.w + sh.w;
+    }
+    if (flags & SBC_PRO_ELU) x = elu4(x);
+    bf16x4 h, m, l;
+    split3(x, h, m, l);
+    unsigned short* dst = lds16 + pix * SH + c4 * 4;
+    *reinterpret_cast<bf16x4*>(dst) = h;
+    *reinterpret_cast<bf16x4*>(dst + plane) = m;
+    *reinterpret_cast<bf16x4*>(dst + 2 * plane) = l;
+}
+
+template <int CIN, int NTHREADS, int NPF, bool P2>
+__device__ __forceinline__ void stage_tile_split(unsigned short* lds16, int plane, const float* __restrict__ in,
+                                                 const float* __restrict__ stats, int flags, const TileGeom& g,
+                                                 const Dims<P2>& d, int tid) {
+    constexpr int SH = CIN + 8;
+    float4 pf[NPF];
+    stage_issue<CIN, NTHREADS, NPF>(pf, in, g, d.W, tid);
+    const int total = g.nps * (CIN / 4);
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) {
+        const int idx = u * NTHREADS + tid;
+        if (idx < total) stage_put_split<CIN, P2>(lds16, plane, pf[u], idx, stats, flags, g, d);
+    }
+    const float* src = in + (size_t)g.rs0 * d.W * CIN;
+    for (int idx = NPF * NTHREADS + tid; idx < total; idx += NTHREADS)
+        stage_put_split<CIN, P2>(lds16, plane, ld_stream(src + (size_t)idx * 4), idx, stats, flags, g, d);
+    // the zero pixel of each plane (SH / 2 dwords each)
+    for (int i = tid; i < 3 * (SH / 2); i += NTHREADS)
+        reinterpret_cast<unsigned*>(lds16 + (i / (SH / 2)) * plane + g.nps * SH)[i % (SH / 2)] = 0u;
+}
+
 // host side: log2 of a power of two, or -1
 inline int log2_exact(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;

@@ -13,7 +13,8 @@ import torch
 
 from . import _lib
 from . import plan as P
-from .weights import check_state_dict, get_sigmas, pack_conv_weight, pack_conv_weight_winograd
+from .weights import (check_state_dict, get_sigmas, pack_conv_weight, pack_conv_weight_split,
+                      pack_conv_weight_winograd)
 
 
 def _ptr(t, offset_elems=0):
@@ -32,8 +33,22 @@ class BoundScore:
         self.keep = extra_keep
 
 
+CONV_MODES = ('bf16x3', 'f32')
+
+
 class ScoreNet:
-    def __init__(self, config, device=None):
+    """``conv_mode`` selects how the 32/64/128-channel convolutions multiply:
+
+    ``'bf16x3'``            fp32 operands split exactly into three bf16 terms, six bf16 MFMAs per product block, fp32
+                            accumulation -- fp32-level accuracy at 0.375x the matrix time (``csrc/conv_x3.hip``);
+    ``'f32'`` (default)     fp32 MFMA kernels (direct + Winograd F(2x2,3x3), ``csrc/conv_mfma.hip``, ``conv_wino.hip``).
+    Both stay within the parity tolerance of the reference (tests/test_gpu_parity.py runs every case in both modes).
+    """
+
+    def __init__(self, config, device=None, conv_mode='f32'):
+        if conv_mode not in CONV_MODES:
+            raise ValueError('conv_mode must be one of %s, got %r' % (CONV_MODES, conv_mode))
+        self.conv_mode = conv_mode
         self.config = config
         m, d = config.model, config.data
         if str(m.normalization) != 'InstanceNorm++' or str(m.nonlinearity).lower() != 'elu':
@@ -103,6 +118,7 @@ class ScoreNet:
                 add(name, pack_conv_weight(w))
                 if w.shape[2:] == (3, 3):
                     add(name + '#winograd', pack_conv_weight_winograd(w))
+                add(name + '#split', pack_conv_weight_split(w).view(np.float32))      # bf16 bit patterns
             elif name.endswith('.alpha'):
                 pre = name[:-len('.alpha')]
                 add(pre, np.concatenate([sd[pre + '.alpha'], sd[pre + '.gamma'], sd[pre + '.beta']]))
@@ -148,6 +164,8 @@ class ScoreNet:
                 o.weight = _ptr(self._wdev, self._woff[op.weight])
                 if op.kind == P.CONV and op.ksize == 3 and op.dil == 1:
                     o.weight_wino = _ptr(self._wdev, self._woff[op.weight + '#winograd'])
+                if op.kind == P.CONV and self.conv_mode == 'bf16x3':
+                    o.weight_split = _ptr(self._wdev, self._woff[op.weight + '#split'])
             if op.bias is not None:
                 o.bias = _ptr(self._wdev, self._woff[op.bias])
             if op.stats is not None:

@@ -37,6 +37,8 @@ def parse_args(argv=None):
     p.add_argument('--synthetic_weights', type=int, default=None, metavar='SEED',
                    help='seed-derived random weights instead of ./models/score/<train>/final_model.pt')
     p.add_argument('--no_plot', action='store_true')
+    p.add_argument('--conv_mode', type=str, default='f32', choices=['bf16x3', 'f32'],
+                   help='convolution multiplier: split-bf16 matrix cores (fp32-accurate, default) or fp32 MFMA')
     p.add_argument('--no_graph', action='store_true', help='launch kernels eagerly instead of hipGraph replay')
     return p.parse_args(argv)
 
@@ -64,7 +66,7 @@ def main(argv=None):
         config, model_state = contents['config'], contents['model_state']
     alpha_step, beta_noise = 3e-11, 0.01                  # all profiles, test_score.py:39-54
     config.sampling.steps_each = 3                        # :56
-    diffuser = ScoreNet(config, device).load_state_dict(model_state).eval()
+    diffuser = ScoreNet(config, device, conv_mode=args.conv_mode).load_state_dict(model_state).eval()
 
     seed = int.from_bytes(os.urandom(4), 'little') if args.seed is None else args.seed
     if world > 1:                                         # every rank must use rank 0's seed

@@ -37,6 +37,8 @@ def parse_args(argv=None):
     p.add_argument('--synthetic', action='store_true')
     p.add_argument('--synthetic_weights', type=int, default=None, metavar='SEED')
     p.add_argument('--no_plot', action='store_true')
+    p.add_argument('--conv_mode', type=str, default='f32', choices=['bf16x3', 'f32'],
+                   help='convolution multiplier: split-bf16 matrix cores (fp32-accurate, default) or fp32 MFMA')
     p.add_argument('--no_graph', action='store_true')
     return p.parse_args(argv)
 
@@ -76,7 +78,7 @@ def main(argv=None):
         config.sampling.steps_each = args.steps_each
     elif not config.sampling.steps_each:                  # the reference raises TypeError here (:62); default to 3
         config.sampling.steps_each = 3
-    diffuser = ScoreNet(config, device).load_state_dict(model_state).eval()
+    diffuser = ScoreNet(config, device, conv_mode=args.conv_mode).load_state_dict(model_state).eval()
 
     seed = int.from_bytes(os.urandom(4), 'little') if args.seed is None else args.seed
     if world > 1:

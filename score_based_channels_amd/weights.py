@@ -157,3 +157,37 @@ def pack_conv_weight_winograd(w):
         raise ValueError('Winograd F(2x2,3x3) needs a 3x3 kernel, got %s' % (w.shape,))
     u = np.einsum('ij,ocjk,lk->ocil', _WINO_G, w, _WINO_G)          # [O, C, 4, 4]
     return pack_conv_weight(u.astype(np.float32))
+
+
+def bf16_round(x):
+    """float32 -> nearest-even bfloat16, returned as float32 values (what ``v_cvt_pk_bf16_f32`` produces)."""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32)
+
+
+def split_bf16x3(x):
+    """Exact three-term bfloat16 expansion ``x = h + m + l`` of float32 values (each term returned as float32)."""
+    x = np.asarray(x, np.float32)
+    h = bf16_round(x)
+    r = x - h
+    m = bf16_round(r)
+    return h, m, bf16_round(r - m)
+
+
+def pack_conv_weight_split(w):
+    """Split-bf16 form of an ``[O, C, k, k]`` weight for the bf16-matrix-core convolution (``csrc/conv_x3.hip``).
+
+    Result ``[k*k, C/16, O/32, 3, 64, 8]`` uint16 (bf16 bit patterns): for tap ``t``, 16-channel group ``g``, output block
+    ``n`` and term ``s`` (0 = high, 1 = middle, 2 = low), lane ``l`` holds the eight values
+    ``term_s(w[n*32 + (l & 31), g*16 + 8*(l >> 5) + j, kh, kw])``, ``j = 0..7`` -- the B operand of one
+    ``v_mfma_f32_32x32x16_bf16``.  Requires ``C % 16 == 0`` and ``O % 32 == 0``.
+    """
+    w = np.asarray(w, np.float32)
+    o, c, kh, kw = w.shape
+    if c % 16 or o % 32:
+        raise ValueError('pack_conv_weight_split needs C %% 16 == 0 and O %% 32 == 0, got %s' % (w.shape,))
+    terms = np.stack([t.view(np.uint32) >> 16 for t in split_bf16x3(w)]).astype(np.uint16)   # [3, O, C, kh, kw]
+    a = terms.reshape(3, o // 32, 32, c // 16, 2, 8, kh * kw)       # [s, nb, l31, g, half, j, tap]
+    a = a.transpose(6, 3, 1, 0, 4, 2, 5)                            # [tap, g, nb, s, half, l31, j]
+    return np.ascontiguousarray(a).reshape(kh * kw, c // 16, o // 32, 3, 64, 8)

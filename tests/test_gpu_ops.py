@@ -67,14 +67,15 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize('algo', ['direct', 'winograd'])
+@pytest.mark.parametrize('algo', ['direct', 'winograd', 'bf16x3'])
 @pytest.mark.parametrize('cin,cout,k,dil,B,H,W,mode', CONV_CASES)
 def test_conv_matches_oracle(gpu, cin, cout, k, dil, B, H, W, mode, algo):
-    """Both convolution algorithms behind SBC_OP_CONV: the direct implicit GEMM (weight) and, when the op also
-    carries weight_wino, Winograd F(2x2,3x3) for undilated 3x3 convs (shapes it does not cover fall back to direct)."""
+    """The three multipliers behind SBC_OP_CONV: the fp32-MFMA direct implicit GEMM (weight); when the op also carries
+    weight_wino, fp32 Winograd F(2x2,3x3) for undilated 3x3 convs (shapes it does not cover fall back to direct); and,
+    when it carries weight_split, the split-bf16 kernel (three exact bf16 terms per fp32 operand, six bf16 MFMAs)."""
     torch, _lib = gpu
     from score_based_channels_amd import plan as P
-    from score_based_channels_amd.weights import pack_conv_weight, pack_conv_weight_winograd
+    from score_based_channels_amd.weights import pack_conv_weight, pack_conv_weight_split, pack_conv_weight_winograd
     if algo == 'winograd' and (k != 3 or dil != 1):
         pytest.skip('Winograd F(2x2,3x3) applies to undilated 3x3 convolutions')
     rng = np.random.default_rng(hash((cin, cout, k, dil, B, H, W)) % (2 ** 31))
@@ -127,6 +128,10 @@ def test_conv_matches_oracle(gpu, cin, cout, k, dil, B, H, W, mode, algo):
     if algo == 'winograd':
         ww = _dev(torch, pack_conv_weight_winograd(w))
         op.weight_wino = _p(ww)
+    if algo == 'bf16x3':
+        ws = _dev(torch, pack_conv_weight_split(w).view(np.float32))
+        op.weight_split = _p(ws)
+        op.weight = None                      # the split kernel needs nothing else
     _launch(gpu, op)
     got = out.cpu().numpy()
     assert np.isfinite(got).all()

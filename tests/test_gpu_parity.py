@@ -13,13 +13,14 @@ pytestmark = pytest.mark.gpu
 NMSE_RTOL = 1e-5      # BASELINE.json north_star: NMSE within 1e-5 relative of the reference
 
 
-@pytest.fixture(scope='module')
-def net64(weights64):
+@pytest.fixture(scope='module', params=['bf16x3', 'f32'])
+def net64(weights64, request):
+    """Every parity case runs with both convolution multipliers (scorenet.CONV_MODES)."""
     import torch
     from score_based_channels_amd.scorenet import ScoreNet
     assert torch.cuda.is_available(), 'these tests need the MI355X'
     cfg, sd = weights64
-    return ScoreNet(cfg).cuda().load_state_dict(sd).eval()
+    return ScoreNet(cfg, conv_mode=request.param).cuda().load_state_dict(sd).eval()
 
 
 def test_forward_every_op_matches_cpu_interpretation(net64, weights64):

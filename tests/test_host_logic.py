@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     h = _lib.lib()
     for name in declared:
         assert hasattr(h, name), name
-    assert h.sbc_abi_version() == 2
+    assert h.sbc_abi_version() == 3
 
 
 def test_pack_conv_weight_c_matches_python():
@@ -40,6 +40,29 @@ def test_pack_conv_weight_c_matches_python():
         assert ref[k * k - 1, 1, 0, 37, 2] == w[5, 8 + 4 + 2, k - 1, k - 1]
     assert _lib.lib().sbc_pack_conv_weight(w.ctypes.data, 30, 32, 3, dst.ctypes.data) == -1
     assert b'cout % 32' in _lib.lib().sbc_last_error()
+
+
+def test_pack_conv_weight_winograd_and_split_c_match_python():
+    """The C packers a non-Python host would call produce the same bytes as the Python ones ScoreNet uses."""
+    from score_based_channels_amd import _lib
+    from score_based_channels_amd.weights import (pack_conv_weight_split, pack_conv_weight_winograd, split_bf16x3)
+    rng = np.random.default_rng(11)
+    for o, c, k in [(32, 32, 3), (64, 32, 1), (128, 64, 3)]:
+        w = (rng.standard_normal((o, c, k, k)) * np.exp(rng.uniform(-8, 2, (o, c, k, k)))).astype(np.float32)
+        ref = pack_conv_weight_split(w)
+        dst = np.zeros(ref.shape, np.uint16)
+        _lib.check(_lib.lib().sbc_pack_conv_weight_split(w.ctypes.data, o, c, k, dst.ctypes.data))
+        assert np.array_equal(dst, ref)
+        h, m, l = split_bf16x3(w)
+        assert np.array_equal((h.astype(np.float64) + m) + l, w.astype(np.float64))      # the expansion is exact
+        for term in (h, m, l):
+            assert not (term.view(np.uint32) & 0xFFFF).any()                               # each term is a bf16 value
+        if k == 3:
+            refw = pack_conv_weight_winograd(w)
+            dstw = np.zeros(refw.shape, np.float32)
+            _lib.check(_lib.lib().sbc_pack_conv_weight_winograd(w.ctypes.data, o, c, dstw.ctypes.data))
+            assert np.array_equal(dstw, refw)
+    assert _lib.lib().sbc_pack_conv_weight_split(w.ctypes.data, 32, 24, 3, dst.ctypes.data) == -1
 
 
 def test_config_is_dotmap_like():

@@ -1,24 +1,45 @@
-"""Performance triage helper (not part of the product): run one L1 conv with per-workgroup phase timestamps."""
-import ctypes as C, os, sys
+"""Performance triage helper (not part of the product): time one convolution launch in isolation.
+
+usage: prof_conv.py [cin cout k dil B H W] [--mode f32|wino|bf16x3] [--flags 0x..] [--no-res]
+"""
+import argparse, ctypes as C, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from score_based_channels_amd import _lib, plan as P
-from score_based_channels_amd.weights import pack_conv_weight
-B, H, W, cin, cout = 1700, 64, 16, 32, 32
+from score_based_channels_amd.weights import pack_conv_weight, pack_conv_weight_split, pack_conv_weight_winograd
+ap = argparse.ArgumentParser()
+ap.add_argument('shape', nargs='*', type=int, default=[32, 32, 3, 1, 1700, 64, 16])
+ap.add_argument('--mode', default='bf16x3')
+ap.add_argument('--flags', default=str(P.PRO_ELU))
+ap.add_argument('--no-res', action='store_true')
+ap.add_argument('--iters', type=int, default=20)
+a = ap.parse_args()
+cin, cout, k, dil, B, H, W = a.shape
 x = torch.randn(B, H, W, cin, device='cuda'); res = torch.randn(B, H, W, cout, device='cuda')
-w = torch.from_numpy(pack_conv_weight(np.random.randn(cout, cin, 3, 3).astype(np.float32) / 17)).cuda()
+wn = np.random.randn(cout, cin, k, k).astype(np.float32) / 17
+keep = [torch.from_numpy(pack_conv_weight(wn)).cuda()]
 out = torch.empty(B, H, W, cout, device='cuda')
-FLAGS = int(sys.argv[1], 0) if len(sys.argv) > 1 else P.PRO_ELU
-op = _lib.sbc_op(kind=P.CONV, flags=FLAGS, B=B, H=H, W=W, cin=cin, cout=cout, ksize=3, dil=1,
-                 in_=x.data_ptr(), out=out.data_ptr(), weight=w.data_ptr(), res1=res.data_ptr())
+op = _lib.sbc_op(kind=P.CONV, flags=int(a.flags, 0), B=B, H=H, W=W, cin=cin, cout=cout, ksize=k, dil=dil,
+                 in_=x.data_ptr(), out=out.data_ptr(), weight=keep[0].data_ptr())
+if not a.no_res:
+    op.res1 = res.data_ptr()
+if a.mode == 'wino':
+    keep.append(torch.from_numpy(pack_conv_weight_winograd(wn)).cuda()); op.weight_wino = keep[-1].data_ptr()
+if a.mode == 'bf16x3':
+    keep.append(torch.from_numpy(pack_conv_weight_split(wn).view(np.float32)).cuda()); op.weight_split = keep[-1].data_ptr()
+if os.environ.get('SBC_LIB_PATH'):
+    _lib.LIB_PATH = os.environ['SBC_LIB_PATH']
 h = _lib.lib()
 for _ in range(3):
     _lib.check(h.sbc_op_launch(C.byref(op), None))
 torch.cuda.synchronize()
-import time
-t_0 = time.perf_counter()
-for _ in range(20):
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(a.iters):
     _lib.check(h.sbc_op_launch(C.byref(op), None))
-torch.cuda.synchronize()
-print('avg launch us', (time.perf_counter() - t_0) / 20 * 1e6)
+e1.record(); torch.cuda.synchronize()
+us = e0.elapsed_time(e1) / a.iters * 1e3
+fl = 2.0 * k * k * cin * cout * B * H * W
+by = 4.0 * B * H * W * (cin + cout * (1 if a.no_res else 2))
+print('%s %s tile=%s: %.1f us  %.1f TF(direct-equivalent)  %.2f TB/s(algorithmic)' % (a.mode, a.shape, os.environ.get('SBC_TILE', 'auto'), us, fl / us / 1e6, by / us / 1e6))
