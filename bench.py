@@ -66,7 +66,7 @@ def main():
     ap.add_argument('--graph', type=int, default=0, help='replay the step as a hipGraph (no per-kernel timing)')
     ap.add_argument('--full-schedule', action='store_true', help='time all 6933 steps instead of --steps')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--conv-mode', default='f32', choices=['bf16x3', 'f32'],
+    ap.add_argument('--conv-mode', default='f32', choices=['f32', 'mixed', 'bf16x3'],
                     help='convolution multiplier (scorenet.CONV_MODES)')
     ap.add_argument('--streams', type=int, default=1, help='split the trajectories into this many concurrent HIP streams')
     args = ap.parse_args()

@@ -93,62 +93,104 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_x3_kernel(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    // K loop over the taps that have work, software-pipelined by one (tap, 16-channel group) step: the three weight
-    // fragments (global/L2) and three activation fragments (LDS) of step it+1 are requested, then the MFMAs of step it
-    // are issued; two statically indexed register sets alternate.
-    int aoff[MT], aoff_n[MT];
+    // K loop, software-pipelined by one (tap, 16-channel group) step: the three weight fragments (global/L2) and three
+    // activation fragments (LDS) of step it+1 are requested, then the MFMAs of step it are issued; two statically
+    // indexed register sets alternate.
     bf16x8 aS[2][MT][3], bS[2][NT][3];
-    int tap = tapmask ? __builtin_ctz(tapmask) : TAPS;
-    const int it0 = (tap < TAPS ? tap : 0) * KG;
+    auto mfma_step = [&](int cur) {
+        // partial products, smallest first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
 #pragma unroll
-    for (int ni = 0; ni < NT; ++ni)
-#pragma unroll
-        for (int t = 0; t < 3; ++t) bS[0][ni][t] = w_frag(it0, ni, t);
-    __syncthreads();                                                   // staged tile visible
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi) {
-        aoff[mi] = tap_offset(tap < TAPS ? tap : 0, mi);
-#pragma unroll
-        for (int t = 0; t < 3; ++t) aS[0][mi][t] = lds_frag(aoff[mi], t);
-    }
-#pragma unroll 1
-    while (tap < TAPS) {
-        const unsigned rest = tapmask >> (tap + 1);
-        const int tap_n = rest ? tap + 1 + __builtin_ctz(rest) : tap;
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi) aoff_n[mi] = tap_offset(tap_n, mi);
-#pragma unroll
-        for (int kg = 0; kg < KG; ++kg) {
-            const int cur = kg & 1, nxt = cur ^ 1;
-            const int it_n = kg + 1 < KG ? tap * KG + kg + 1 : tap_n * KG + (tap_n == tap ? KG - 1 : 0);
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni)
-#pragma unroll
-                for (int t = 0; t < 3; ++t) bS[nxt][ni][t] = w_frag(it_n, ni, t);
+        for (int q = 0; q < 6; ++q) {
+            const int ta = q == 0 ? 2 : (q == 2 || q == 3) ? 1 : 0;
+            const int tb = q == 1 ? 2 : (q == 2 || q == 4) ? 1 : 0;
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-                for (int t = 0; t < 3; ++t)
-                    aS[nxt][mi][t] = lds_frag(kg + 1 < KG ? aoff[mi] + (kg + 1) * 16 : aoff_n[mi], t);
-            __builtin_amdgcn_sched_barrier(0);
-            // partial products, smallest first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+                for (int ni = 0; ni < NT; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aS[cur][mi][ta], bS[cur][ni][tb], acc[mi][ni],
+                                                                          0, 0, 0);
+        }
+    };
+    if (tapmask == (1u << TAPS) - 1u) {
+        // Every tap has work for this wave (always, except on images a few pixels high): the whole walk is unrolled, so
+        // tap deltas, fragment indices and register sets are compile-time and the loop is loads + MFMAs only -- with
+        // the dynamic tap walk below, ~35 scalar instructions per step sat between the MFMA blocks (-30 % K time).
 #pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                const int ta = q == 0 ? 2 : (q == 2 || q == 3) ? 1 : 0;
-                const int tb = q == 1 ? 2 : (q == 2 || q == 4) ? 1 : 0;
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) bS[0][ni][t] = w_frag(0, ni, t);
+        __syncthreads();                                               // staged tile visible
+        int aoff[MT];
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            aoff[mi] = tap_offset(0, mi);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) aS[0][mi][t] = lds_frag(aoff[mi], t);
+        }
+#pragma unroll
+        for (int it = 0; it < TAPS * KG; ++it) {
+            const int cur = it & 1, nxt = cur ^ 1;
+            if (it + 1 < TAPS * KG) {
+                const int tap_n = (it + 1) / KG, kg_n = (it + 1) % KG;
+                if (kg_n == 0) {
+#pragma unroll
+                    for (int mi = 0; mi < MT; ++mi) aoff[mi] = tap_offset(tap_n, mi);
+                }
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) bS[nxt][ni][t] = w_frag(it + 1, ni, t);
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < NT; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aS[cur][mi][ta], bS[cur][ni][tb],
-                                                                              acc[mi][ni], 0, 0, 0);
+                    for (int t = 0; t < 3; ++t) aS[nxt][mi][t] = lds_frag(aoff[mi] + kg_n * 16, t);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(cur);
         }
-        if (tap_n == tap) break;
+    } else {
+        // general walk over the taps that have work (taps outside the image for the whole wave are skipped)
+        int aoff[MT], aoff_n[MT];
+        int tap = tapmask ? __builtin_ctz(tapmask) : TAPS;
+        const int it0 = (tap < TAPS ? tap : 0) * KG;
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) aoff[mi] = aoff_n[mi];
-        tap = tap_n;
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) bS[0][ni][t] = w_frag(it0, ni, t);
+        __syncthreads();                                               // staged tile visible
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            aoff[mi] = tap_offset(tap < TAPS ? tap : 0, mi);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) aS[0][mi][t] = lds_frag(aoff[mi], t);
+        }
+#pragma unroll 1
+        while (tap < TAPS) {
+            const unsigned rest = tapmask >> (tap + 1);
+            const int tap_n = rest ? tap + 1 + __builtin_ctz(rest) : tap;
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) aoff_n[mi] = tap_offset(tap_n, mi);
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg) {
+                const int cur = kg & 1, nxt = cur ^ 1;
+                const int it_n = kg + 1 < KG ? tap * KG + kg + 1 : tap_n * KG + (tap_n == tap ? KG - 1 : 0);
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) bS[nxt][ni][t] = w_frag(it_n, ni, t);
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+                        aS[nxt][mi][t] = lds_frag(kg + 1 < KG ? aoff[mi] + (kg + 1) * 16 : aoff_n[mi], t);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_step(cur);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (tap_n == tap) break;
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) aoff[mi] = aoff_n[mi];
+            tap = tap_n;
+        }
     }
 
     // ---------------------------------------------------------------- epilogue (conv_epilogue.h)

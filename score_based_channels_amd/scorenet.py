@@ -33,7 +33,7 @@ class BoundScore:
         self.keep = extra_keep
 
 
-CONV_MODES = ('bf16x3', 'f32')
+CONV_MODES = ('mixed', 'bf16x3', 'f32')
 
 
 class ScoreNet:
@@ -41,8 +41,10 @@ class ScoreNet:
 
     ``'bf16x3'``            fp32 operands split exactly into three bf16 terms, six bf16 MFMAs per product block, fp32
                             accumulation -- fp32-level accuracy at 0.375x the matrix time (``csrc/conv_x3.hip``);
-    ``'f32'`` (default)     fp32 MFMA kernels (direct + Winograd F(2x2,3x3), ``csrc/conv_mfma.hip``, ``conv_wino.hip``).
-    Both stay within the parity tolerance of the reference (tests/test_gpu_parity.py runs every case in both modes).
+    ``'f32'`` (default)     fp32 MFMA kernels (direct + Winograd F(2x2,3x3), ``csrc/conv_mfma.hip``, ``conv_wino.hip``);
+    ``'mixed'``             every weight form is bound and the library picks per layer: split-bf16 everywhere except
+                            the HBM-bound full-resolution 32 -> 32 layers, which stay on fp32 Winograd.
+    All three stay within the parity tolerance of the reference (tests/test_gpu_parity.py runs every case in each).
     """
 
     def __init__(self, config, device=None, conv_mode='f32'):
@@ -162,9 +164,9 @@ class ScoreNet:
             o.out = _ptr(slots[op.dst.slot])
             if op.weight is not None:
                 o.weight = _ptr(self._wdev, self._woff[op.weight])
-                if op.kind == P.CONV and op.ksize == 3 and op.dil == 1:
+                if op.kind == P.CONV and op.ksize == 3 and op.dil == 1 and self.conv_mode != 'bf16x3':
                     o.weight_wino = _ptr(self._wdev, self._woff[op.weight + '#winograd'])
-                if op.kind == P.CONV and self.conv_mode == 'bf16x3':
+                if op.kind == P.CONV and self.conv_mode != 'f32':
                     o.weight_split = _ptr(self._wdev, self._woff[op.weight + '#split'])
             if op.bias is not None:
                 o.bias = _ptr(self._wdev, self._woff[op.bias])
