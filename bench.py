@@ -174,7 +174,7 @@ def main():
                        'trajectories_per_gpu': T, 'steps_per_channel': STEPS_PER_CHANNEL, 'num_pilots': npil,
                        'step_definition': 'one Langevin step (score forward + DC gradient + update + NMSE) of all '
                                           'trajectories; channels/s = trajectories / (6933 * s_per_step)',
-                       'full_schedule_timed': bool(args.full_schedule), 'graph_replay': use_graph, 'streams': args.streams,
+                       'full_schedule_timed': bool(args.full_schedule), 'conv_mode': args.conv_mode, 'graph_replay': use_graph, 'streams': args.streams,
                        'parallelism': 'independent trajectories sharded over %d GPU(s); one RCCL all_gather of NMSE '
                                       'curves at the end (%.2f ms)' % (world, gather_ms),
                        'nmse_finite': finite},
@@ -185,13 +185,20 @@ def main():
             ach = per_launch / (kern_ms / kern_n * 1e-3) / 1e12
             traffic = None                  # HBM bytes per launch from the PMC passes (profiles/), same workload only
             tfile = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-            if os.path.exists(tfile) and alds[0].T == 1700:
+            if os.path.exists(tfile) and alds[0].T == 1700 and args.conv_mode != 'bf16x3':
                 with open(tfile) as f:
                     traffic = json.load(f).get('hbm_bytes_per_launch')
+            if args.conv_mode == 'bf16x3':
+                kname = ('conv_x3_kernel<32, 32, 3, 2, 1, 4, 1, true>: the 18 3x3 32->32 convolutions at 64x16 of every step '
+                         '(%d launches, avg %.1f us); fp32 results from 6 bf16 MFMAs per product block, priced against the '
+                         'fp32 MFMA peak like the default path' % (kern_n, kern_ms / kern_n * 1e3))
+            else:
+                kname = ('conv_wino_kernel<32, 32, 2, true>: the 18 3x3 32->32 convolutions at 64x16 of every step (%d '
+                         'launches, avg %.1f us).  achieved = direct-convolution FLOPs (2*9*32*32 per pixel) / time; the '
+                         'kernel executes 16/36 of them (fp32 Winograd F(2x2,3x3)), i.e. %.1f TFLOP/s on the MFMA pipe'
+                         % (kern_n, kern_ms / kern_n * 1e3, ach * 16 / 36))
             out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
-                               'kernel': 'conv_mfma_kernel<32,32,3,...> (3x3 ngf->ngf convs at 64x16; %d launches, '
-                                         'avg %.1f us)' % (kern_n, kern_ms / kern_n * 1e3)}
+                               'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic, 'kernel': kname}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, sd)
         print(json.dumps(out))

@@ -309,7 +309,9 @@ static int launch_wino_sized(const ConvParams& p, hipStream_t stream, bool dry) 
     auto fits = [&](int tm) { return tm % (2 * p.W) == 0 && (HW % tm == 0 || tm % HW == 0); };
     constexpr bool mb2_ok = (COUT == 32);          // 256-pixel tiles only where one output block keeps registers low
     static const bool force1 = getenv("SBC_WINO_MB1") != nullptr;                   // tuning aid
-    if (mb2_ok && !force1 && fits(256) && p.total_px >= 256L * 512) return launch_wino<CIN, COUT, 2>(p, stream, dry);
+    // 256-pixel tiles for the full-resolution level only (>= 4096 tiles); 128-pixel tiles measure within 2 % below that
+    // and keep one kernel symbol per level, so per-kernel profiler averages are per level too
+    if (mb2_ok && !force1 && fits(256) && p.total_px >= 256L * 4096) return launch_wino<CIN, COUT, 2>(p, stream, dry);
     if (fits(128)) return launch_wino<CIN, COUT, 1>(p, stream, dry);
     if (mb2_ok && fits(256)) return launch_wino<CIN, COUT, 2>(p, stream, dry);
     return 1;

@@ -7,56 +7,64 @@ namespace sbc {
 
 // ------------------------------------------------------------------------------------------------ begin conv
 // h = 2x - 1 (ncsnv2.py:270-273), then begin_conv: Conv2d(2 -> COUT, 3x3, pad 1) + bias (ncsnv2.py:209,275).
-// Zero padding applies to h, not x.  One thread per (pixel, output channel); the 18*COUT weights sit in LDS.
+// Zero padding applies to h, not x.  The kernel is bound by its 128-byte-per-pixel output stream, so the arithmetic
+// has to stay out of the way: a thread owns one channel quad (its 72 weights live in registers) and walks PPT pixels
+// 32 apart, so that every store instruction of a workgroup covers 32 consecutive pixels x 128 bytes; the 3x3x2 input
+// patch comes through the vector cache (8 threads share each address).
+template <bool P2>
 __global__ __launch_bounds__(256) void begin_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ out,
-                                                          int B, int H, int W, int cout) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];   // [18][cout]: k = ci*9 + kh*3 + kw
-    for (int i = threadIdx.x; i < cout * 18; i += 256) {
-        const int co = i / 18, k = i - co * 18;                  // torch order [co][ci][kh][kw]
-        wl[k * cout + co] = w[i];
-    }
-    __syncthreads();
-    const int C4 = cout >> 2;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;       // (pixel, channel quad)
-    if (idx >= (long)B * H * W * C4) return;
-    const int c4 = idx % C4;
-    const long px = idx / C4;
-    const int wq = px % W;
-    const long row = px / W;
-    const int h = row % H;
-    float4 acc = *reinterpret_cast<const float4*>(bias + c4 * 4);
+                                                          int total_px, int H, int W, int hsh, int wsh) {
+    constexpr int COUT = 32, PPT = 8;
+    const int c4 = threadIdx.x & 7, slot = threadIdx.x >> 3;
+    float4 wr[18];                                               // [ci*9 + kh*3 + kw] for channels c4*4 .. c4*4+3
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
+    for (int k = 0; k < 18; ++k)                                 // torch order [co][ci][kh][kw]
+        wr[k] = make_float4(w[(c4 * 4 + 0) * 18 + k], w[(c4 * 4 + 1) * 18 + k], w[(c4 * 4 + 2) * 18 + k],
+                            w[(c4 * 4 + 3) * 18 + k]);
+    const float4 b4 = *reinterpret_cast<const float4*>(bias + c4 * 4);
+    const Dims<P2> d{H, W, H * W, hsh, wsh};
+#pragma unroll 2
+    for (int it = 0; it < PPT; ++it) {
+        const int px = (blockIdx.x * PPT + it) * 32 + slot;
+        if (px >= total_px) return;
+        const int row = d.div_w(px), wq = d.mod_w(px), h = d.mod_h(row);
+        float4 acc = b4;
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const int hh = h + kh - 1, ww = wq + kw - 1;
-            float2 v = make_float2(0.f, 0.f);                    // zero padding applies to h = 2x - 1
-            if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
-                v = *reinterpret_cast<const float2*>(x + ((row + kh - 1) * W + ww) * 2);
-                v.x = 2.f * v.x - 1.f;
-                v.y = 2.f * v.y - 1.f;
+        for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int hh = h + kh - 1, ww = wq + kw - 1;
+                float2 v = make_float2(0.f, 0.f);                // zero padding applies to h = 2x - 1
+                if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
+                    v = *reinterpret_cast<const float2*>(x + ((size_t)(row + kh - 1) * W + ww) * 2);
+                    v.x = 2.f * v.x - 1.f;
+                    v.y = 2.f * v.y - 1.f;
+                }
+                const float4 w0 = wr[kh * 3 + kw], w1 = wr[9 + kh * 3 + kw];
+                acc.x = fmaf(w0.x, v.x, fmaf(w1.x, v.y, acc.x));
+                acc.y = fmaf(w0.y, v.x, fmaf(w1.y, v.y, acc.y));
+                acc.z = fmaf(w0.z, v.x, fmaf(w1.z, v.y, acc.z));
+                acc.w = fmaf(w0.w, v.x, fmaf(w1.w, v.y, acc.w));
             }
-            const float4 w0 = *reinterpret_cast<const float4*>(wl + (kh * 3 + kw) * cout + c4 * 4);
-            const float4 w1 = *reinterpret_cast<const float4*>(wl + (9 + kh * 3 + kw) * cout + c4 * 4);
-            acc.x = fmaf(w0.x, v.x, fmaf(w1.x, v.y, acc.x));
-            acc.y = fmaf(w0.y, v.x, fmaf(w1.y, v.y, acc.y));
-            acc.z = fmaf(w0.z, v.x, fmaf(w1.z, v.y, acc.z));
-            acc.w = fmaf(w0.w, v.x, fmaf(w1.w, v.y, acc.w));
         }
+        st_stream(out + (size_t)px * COUT + c4 * 4, acc);
     }
-    *reinterpret_cast<float4*>(out + idx * 4) = acc;
 }
 
 int launch_begin_conv(const sbc_op& op, hipStream_t stream) {
     SBC_REQUIRE(op.in && op.out && op.weight && op.bias, "begin_conv: in/out/weight/bias must be set");
-    SBC_REQUIRE(op.cin == 2 && op.cout > 0 && op.cout <= 256 && op.cout % 4 == 0, "begin_conv: cin=%d cout=%d", op.cin,
-                op.cout);
-    const long total = (long)op.B * op.H * op.W * (op.cout / 4);
-    const int grid = (int)((total + 255) / 256);
-    hipLaunchKernelGGL(begin_conv_kernel, dim3(grid), dim3(256), op.cout * 18 * sizeof(float), stream,
-                       (const float*)op.in, (const float*)op.weight, (const float*)op.bias, (float*)op.out, op.B,
-                       op.H, op.W, op.cout);
+    SBC_REQUIRE(op.cin == 2 && op.cout == 32, "begin_conv: cin=%d cout=%d (kernel is built for 2 -> 32)", op.cin, op.cout);
+    SBC_REQUIRE((long)op.B * op.H * op.W < (1L << 31) / 64, "begin_conv: tensor too large for 32-bit pixel index");
+    const int total_px = op.B * op.H * op.W;
+    const int grid = (total_px + 255) / 256;
+    const int hsh = log2_exact(op.H), wsh = log2_exact(op.W);
+    if (hsh >= 0 && wsh >= 0)
+        hipLaunchKernelGGL(begin_conv_kernel<true>, dim3(grid), dim3(256), 0, stream, (const float*)op.in,
+                           (const float*)op.weight, (const float*)op.bias, (float*)op.out, total_px, op.H, op.W, hsh, wsh);
+    else
+        hipLaunchKernelGGL(begin_conv_kernel<false>, dim3(grid), dim3(256), 0, stream, (const float*)op.in,
+                           (const float*)op.weight, (const float*)op.bias, (float*)op.out, total_px, op.H, op.W, hsh, wsh);
     SBC_CHECK_HIP(hipGetLastError());
     return SBC_OK;
 }
@@ -174,17 +182,17 @@ int launch_inorm_stats(const sbc_op& op, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------ max pool
 // nn.MaxPool2d(5, stride 1, padding 2) with -inf padding (layers.py:69).  With SBC_PRO_ELU the result is
 // ELU(max) == max(ELU) because ELU is monotone (CRPBlock: x = act(x); path = maxpool(x), layers.py:77-80).
-// One thread per (sample, column w, channel quad) walks down the rows with a sliding window of 5 row maxima, so each
-// output costs 5 (L1-resident) 16-byte loads instead of 25.
+// One thread per (sample, row segment, column w, channel quad) walks down its rows with a sliding window of 5 row
+// maxima, so each output costs ~7 (L1-resident) 16-byte loads instead of 25.
 __device__ __forceinline__ float4 max4(float4 a, float4 b) {
     return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
 }
 
 __global__ __launch_bounds__(256) void maxpool5_kernel(const float* __restrict__ in, float* __restrict__ out, int B,
-                                                        int H, int W, int C4, int flags) {
+                                                        int H, int W, int C4, int flags, int seg, int nseg) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= B * W * C4) return;
-    const int c4 = idx % C4, w = (idx / C4) % W, n = idx / (C4 * W);
+    if (idx >= B * nseg * W * C4) return;
+    const int c4 = idx % C4, w = (idx / C4) % W, sg = (idx / (C4 * W)) % nseg, n = idx / (C4 * W * nseg);
     const size_t row_stride = (size_t)W * C4 * 4;
     const float* base = in + (size_t)n * H * row_stride + ((size_t)w * C4 + c4) * 4;
     float* obase = out + (size_t)n * H * row_stride + ((size_t)w * C4 + c4) * 4;
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(256) void maxpool5_kernel(const float* __restrict__
     const float4 ninf = make_float4(NEG, NEG, NEG, NEG);
     const bool l2 = w >= 2, l1 = w >= 1, r1 = w + 1 < W, r2 = w + 2 < W;
     auto rowmax = [&](int r) {
-        if (r >= H) return ninf;
+        if (r < 0 || r >= H) return ninf;
         const float* q = base + (size_t)r * row_stride;
         float4 m = *reinterpret_cast<const float4*>(q);
         if (l1) m = max4(m, *reinterpret_cast<const float4*>(q - C4 * 4));
@@ -201,21 +209,26 @@ __global__ __launch_bounds__(256) void maxpool5_kernel(const float* __restrict__
         if (r2) m = max4(m, *reinterpret_cast<const float4*>(q + 2 * C4 * 4));
         return m;
     };
-    float4 m0 = ninf, m1 = ninf, m2 = rowmax(0), m3 = rowmax(1), m4 = rowmax(2);     // rows h-2 .. h+2
-    for (int h = 0; h < H; ++h) {
+    // this thread's rows [h0, h1): a sliding window of the row maxima h-2 .. h+2
+    const int h0 = sg * seg, h1 = min(h0 + seg, H);
+    float4 m0 = rowmax(h0 - 2), m1 = rowmax(h0 - 1), m2 = rowmax(h0), m3 = rowmax(h0 + 1), m4 = rowmax(h0 + 2);
+    for (int h = h0; h < h1; ++h) {
         float4 m = max4(max4(max4(m0, m1), max4(m2, m3)), m4);
         if (flags & SBC_PRO_ELU) m = elu4(m);
-        *reinterpret_cast<float4*>(obase + (size_t)h * row_stride) = m;
+        st_stream(obase + (size_t)h * row_stride, m);
         m0 = m1; m1 = m2; m2 = m3; m3 = m4;
-        m4 = rowmax(h + 3);
+        if (h + 1 < h1) m4 = rowmax(h + 3);
     }
 }
 
 int launch_maxpool5(const sbc_op& op, hipStream_t stream) {
     SBC_REQUIRE(op.in && op.out && op.cin % 4 == 0, "maxpool5: in/out must be set, channels %% 4 == 0");
-    const long total = (long)op.B * op.W * (op.cin / 4);
+    // rows are walked in segments of 8 (4 extra row maxima per segment) so that tall images still give every CU
+    // tens of waves; images of <= 8 rows are one segment
+    const int seg = 8, nseg = (op.H + seg - 1) / seg;
+    const long total = (long)op.B * nseg * op.W * (op.cin / 4);
     hipLaunchKernelGGL(maxpool5_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, stream, (const float*)op.in,
-                       (float*)op.out, op.B, op.H, op.W, op.cin / 4, op.flags);
+                       (float*)op.out, op.B, op.H, op.W, op.cin / 4, op.flags, seg, nseg);
     SBC_CHECK_HIP(hipGetLastError());
     return SBC_OK;
 }
