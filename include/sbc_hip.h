@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SBC_ABI_VERSION 3
+#define SBC_ABI_VERSION 4
 
 typedef enum sbc_status {
     SBC_OK = 0,
@@ -101,6 +101,11 @@ typedef struct sbc_op {
                                     MFMAs per fp32 product block with fp32 accumulation (fp32-level accuracy, see
                                     csrc/conv_x3.hip); takes precedence over `weight_wino` and `weight`, which then
                                     may be NULL.  SBC_CONV_MODE=f32 in the environment ignores it. */
+    const void* weight_wino_split; /* CONV, optional: the Winograd form of a 3x3 weight with every value split into three
+                                    bf16 terms, sbc_pack_conv_weight_winograd_split layout [16][cin/16][cout/32][3][64][8]
+                                    (uint16): Winograd F(2x2,3x3) with its 16 products on the bf16 matrix cores
+                                    (csrc/conv_wx3.hip).  Used for undilated 3x3 convolutions on power-of-two images,
+                                    ahead of `weight_split`. */
 } sbc_op;
 
 /* Extension of SBC_OP_END_CONV: where the noise level comes from (ncsnv2.py:295-298). */
@@ -185,6 +190,9 @@ int sbc_pack_conv_weight_winograd(const float* src, int32_t cout, int32_t cin, f
  * even; the sum is exact), as bf16 bit patterns in B-operand fragment order [k*k][cin/16][cout/32][3][64 lanes][8]:
  * lane l of block (tap, g, n) holds w[n*32 + (l & 31)][g*16 + 8*(l >> 5) + j][tap], j = 0..7.  cin % 16 == 0. */
 int sbc_pack_conv_weight_split(const float* src, int32_t cout, int32_t cin, int32_t ksize, uint16_t* dst);
+/* Winograd form U = G g G^T (double, rounded once to float) of a 3x3 weight, split like sbc_pack_conv_weight_split with
+ * the 16 transform positions in place of the taps: [16][cin/16][cout/32][3][64][8] uint16. */
+int sbc_pack_conv_weight_winograd_split(const float* src, int32_t cout, int32_t cin, uint16_t* dst);
 
 #ifdef __cplusplus
 }

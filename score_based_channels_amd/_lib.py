@@ -8,12 +8,12 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsbc_hip.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 EXPORTS = ('sbc_abi_version', 'sbc_last_error', 'sbc_device_count', 'sbc_op_launch', 'sbc_plan_create',
            'sbc_plan_run', 'sbc_plan_destroy', 'sbc_plan_profile', 'sbc_plan_profile_read',
            'sbc_pack_conv_weight', 'sbc_pack_conv_weight_winograd',
-           'sbc_pack_conv_weight_split')
+           'sbc_pack_conv_weight_split', 'sbc_pack_conv_weight_winograd_split')
 
 
 class SbcError(RuntimeError):
@@ -27,7 +27,8 @@ class sbc_op(C.Structure):
                 ('up_h', C.c_int32), ('up_w', C.c_int32), ('tag', C.c_int32),
                 ('in_', C.c_void_p), ('out', C.c_void_p), ('weight', C.c_void_p), ('bias', C.c_void_p),
                 ('stats', C.c_void_p), ('res1', C.c_void_p), ('res2', C.c_void_p), ('up', C.c_void_p),
-                ('ext', C.c_void_p), ('weight_wino', C.c_void_p), ('weight_split', C.c_void_p)]
+                ('ext', C.c_void_p), ('weight_wino', C.c_void_p), ('weight_split', C.c_void_p),
+                ('weight_wino_split', C.c_void_p)]
 
 
 class sbc_endconv(C.Structure):
@@ -68,6 +69,7 @@ def lib():
     h.sbc_pack_conv_weight.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     h.sbc_pack_conv_weight_winograd.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     h.sbc_pack_conv_weight_split.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    h.sbc_pack_conv_weight_winograd_split.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     if h.sbc_abi_version() != ABI_VERSION:
         raise SbcError('libsbc_hip.so ABI %d != expected %d' % (h.sbc_abi_version(), ABI_VERSION))
     _lib = h

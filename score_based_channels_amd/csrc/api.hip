@@ -283,4 +283,41 @@ int sbc_pack_conv_weight_split(const float* src, int32_t cout, int32_t cin, int3
     return SBC_OK;
 }
 
+int sbc_pack_conv_weight_winograd_split(const float* src, int32_t cout, int32_t cin, uint16_t* dst) {
+    SBC_REQUIRE(src && dst, "sbc_pack_conv_weight_winograd_split: NULL pointer");
+    SBC_REQUIRE(cin % 16 == 0 && cout % 32 == 0, "sbc_pack_conv_weight_winograd_split: cin %% 16, cout %% 32 required (got %d, %d)",
+                cin, cout);
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    std::vector<float> u((size_t)cout * cin * 16);             // torch-like [cout][cin][4][4]
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+            const float* g = src + ((size_t)co * cin + ci) * 9;
+            for (int i = 0; i < 4; ++i)
+                for (int l = 0; l < 4; ++l) {
+                    double s = 0;
+                    for (int j = 0; j < 3; ++j)
+                        for (int k = 0; k < 3; ++k) s += G[i][j] * (double)g[j * 3 + k] * G[l][k];
+                    u[((size_t)co * cin + ci) * 16 + i * 4 + l] = (float)s;
+                }
+        }
+    const int KG = cin / 16, NB = cout / 32;
+    for (int tap = 0; tap < 16; ++tap)
+        for (int g = 0; g < KG; ++g)
+            for (int nb = 0; nb < NB; ++nb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = nb * 32 + (lane & 31), ci = g * 16 + 8 * (lane >> 5) + j;
+                        const float w = u[((size_t)co * cin + ci) * 16 + tap];
+                        const uint16_t h = bf16_rne(w);
+                        const float r1 = w - bf16_to_f32(h);
+                        const uint16_t m = bf16_rne(r1);
+                        const uint16_t l = bf16_rne(r1 - bf16_to_f32(m));
+                        const size_t base = (((size_t)tap * KG + g) * NB + nb) * 3;
+                        dst[((base + 0) * 64 + lane) * 8 + j] = h;
+                        dst[((base + 1) * 64 + lane) * 8 + j] = m;
+                        dst[((base + 2) * 64 + lane) * 8 + j] = l;
+                    }
+    return SBC_OK;
+}
+
 }  // extern "C"

@@ -29,4 +29,8 @@ int launch_conv_wino(const ConvParams& p, int cin, int cout, hipStream_t stream,
 // `p.wpk` must point at sbc_pack_conv_weight_split weights.
 int launch_conv_x3(const ConvParams& p, int cin, int cout, int ksize, hipStream_t stream, bool dry);
 
+// Winograd F(2x2,3x3) with split-bf16 products (conv_wx3.hip): SBC_OK after launching, 1 when the shape is not eligible.
+// `p.wpk` must point at sbc_pack_conv_weight_winograd_split weights.
+int launch_conv_wx3(const ConvParams& p, int cin, int cout, hipStream_t stream, bool dry);
+
 }  // namespace sbc

@@ -251,6 +251,12 @@ int launch_conv(const sbc_op& op, hipStream_t stream, bool dry) {
     p.B = op.B; p.H = op.H; p.W = op.W; p.dil = op.dil; p.flags = op.flags;
     p.up_h = op.up_h; p.up_w = op.up_w; p.total_px = op.B * op.H * op.W;
     p.hsh = log2_exact(op.H); p.wsh = log2_exact(op.W);
+    if (op.weight_wino_split && !f32_only && !hbm_bound_layer && op.ksize == 3 && op.dil == 1) {
+        ConvParams pw = p;
+        pw.wpk = (const float4*)op.weight_wino_split;
+        const int rc = launch_conv_wx3(pw, op.cin, op.cout, stream, dry);
+        if (rc <= 0) return rc;                                                    // launched (0) or failed (< 0)
+    }
     if (x3) {
         p.wpk = (const float4*)op.weight_split;
         return launch_conv_x3(p, op.cin, op.cout, op.ksize, stream, dry);

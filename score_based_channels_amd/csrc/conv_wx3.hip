@@ -1,0 +1,343 @@
+// 3x3 stride-1 convolution (padding 1, no dilation) by Winograd F(2x2, 3x3) with the 16 element-wise products on the
+// bf16 matrix cores of gfx950, fp32 in / fp32 out / fp32 accumulate.
+//
+// Same decomposition, work split, T-plane exchange and epilogue as conv_wino.hip (read that header first); only the 16
+// GEMMs M[xi][nu] = V[xi][nu] U[xi][nu] differ.  The fp32 MFMA of conv_wino.hip runs on the vector ALU, so its 16 MFMAs
+// per step serialise with the transform adds, the staging and the epilogue of every wave on the SIMD.  Here each fp32
+// operand is split exactly into three bf16 terms (conv_x3.hip): the transformed input V = B^T d B is formed in fp32
+// from the staged fp32 tile exactly as before and split in registers, the transformed filter U = G g G^T is split on
+// the host (sbc_pack_conv_weight_winograd_split), and a step of 16 input channels issues 4 nu x 6 =
+// 24 v_mfma_f32_32x32x16_bf16 (768 matrix-core cycles) where conv_wino.hip needs 32 fp32 MFMAs (2048 vector-ALU
+// cycles) -- and the vector ALU is free meanwhile for the ~240 transform + split instructions of the next step.
+// Because the split happens AFTER the input transform, the LDS tile stays fp32 ([pixel][CIN + 4], 144 B per pixel at
+// 32 channels) instead of the three bf16 planes of conv_x3.hip.
+#include <stdlib.h>
+#include "conv_common.h"
+
+namespace sbc {
+
+// WPE: waves per SIMD the register allocation must allow (2 = 256 registers, 3 = 168).  A third resident workgroup per CU
+// is worth ~20 % where the kernel fits without spilling (32 -> 32 with 128-pixel tiles); the wider variants would spill.
+template <int CIN, int COUT, int MB, bool P2, int WPE>
+__global__ __launch_bounds__(256, WPE) void conv_wx3_kernel(ConvParams p) {
+    constexpr int TM = 128 * MB;                 // output pixels per workgroup
+    constexpr int NTW = 32 * MB;                 // Winograd tiles (2x2 output blocks) per workgroup
+    constexpr int S = CIN + 4;
+    constexpr int KG = CIN / 16;                 // K steps: 16 input channels each
+    constexpr int NBLK = COUT / 32;
+    constexpr int PH = NBLK;                     // phases: one 32-channel output block each (K loops, then output)
+    constexpr int TS = 36;                       // floats per (tile) row of a T plane: 32 channels + 4 pad
+    constexpr int NTHREADS = 256;
+    constexpr int NPF_FULL = ((TM + 32) * (CIN / 4) + NTHREADS - 1) / NTHREADS;
+    constexpr int NPF = NPF_FULL <= 10 ? NPF_FULL : 10;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int xi = __builtin_amdgcn_readfirstlane(tid >> 6);         // transform row of this wave
+    const int H = p.H, W = p.W, HW = H * W;
+    const Dims<P2> dm{H, W, HW, p.hsh, p.wsh};
+    const int khalf = 8 * (lane >> 5);
+    const int col = lane & 31, rhalf = 4 * (lane >> 5);
+
+    const TileGeom g = tile_geom(blockIdx.x, TM, p.B, dm, 1);
+    stage_tile<CIN, NTHREADS, NPF, P2>(lds, p.in, p.stats, p.flags, g, dm, tid);
+    // T planes [xi][b][tile][TS]: overlay the staged tile when there is a single phase, else live behind it
+    float* const tl = PH == 1 ? lds : lds + (size_t)(g.multi ? TM + 1 : TM + 2 * W + 1) * S;
+
+    // B^T rows: xi=0: d0 - d2, xi=1: d1 + d2, xi=2: d2 - d1, xi=3: d1 - d3   ->  R = d[ia] + sgn * d[ib]
+    const int ia = xi == 0 ? 0 : xi == 2 ? 2 : 1;
+    const int ib = xi == 0 ? 2 : xi == 1 ? 2 : xi == 2 ? 1 : 3;
+    const float sgn = xi == 1 ? 1.f : -1.f;
+
+    // per lane: LDS offsets of the 2 x 4 patch pixels of its tile (lane & 31) in each tile block
+    const int Wt = W >> 1;                                            // tiles per image row
+    const int r0 = dm.div_w(g.p0);                                    // first output row of the workgroup (even)
+    const int zoff = g.nps * S + khalf;
+    int off[MB][2][4];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int t = mb * 32 + (lane & 31);
+        const int tr = P2 ? t >> (p.wsh - 1) : t / Wt, tc = t - tr * Wt;
+        const int grow = r0 + 2 * tr;                                 // even output row of the tile
+        const int h = dm.mod_h(grow);
+        const bool tile_ok = grow < p.B * H;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int ii = k == 0 ? ia : ib;
+            const int hh = h - 1 + ii;
+            const bool rok = tile_ok && hh >= 0 && hh < H;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ww = 2 * tc - 1 + j;
+                off[mb][k][j] = (rok && ww >= 0 && ww < W) ? ((grow - 1 + ii - g.rs0) * W + ww) * S + khalf : zoff;
+            }
+        }
+    }
+    __syncthreads();                                                  // staged tile visible
+
+    for (int ph = 0; ph < PH; ++ph) {
+        const int nb = ph;                        // output-channel block of this phase
+        f32x16 T[MB][2];
+        f32x16 acc[4];
+        // split U: [(xi*4 + nu)][kg][nb][term][lane] 16-byte fragments
+        const uint4* wp = reinterpret_cast<const uint4*>(p.wpk) + ((size_t)(xi * 4) * KG * NBLK + nb) * 3 * 64 + lane;
+        auto u_frag = [&](int nu, int kg, int t) {
+            return __builtin_bit_cast(bf16x8, wp[((size_t)((nu * KG + kg) * NBLK) * 3 + t) * 64]);
+        };
+        // The filter fragments of a (tile block, 16-channel) step are requested one step ahead -- fragment nu right
+        // after the MFMAs that consumed its predecessor -- so their L2 latency never sits in front of an MFMA; the
+        // order of these groups is pinned (sched_barrier), inside a group the compiler interleaves freely.
+        bf16x8 uB[4][3];
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) uB[nu][t] = u_frag(nu, 0, t);
+#pragma unroll
+        for (int s = 0; s < MB * KG; ++s) {
+            const int mb = s / KG, kg = s % KG;
+            const int kgn = (s + 1) % KG;                      // the step after the last re-reads step 0 (harmless)
+            if (kg == 0) {
+#pragma unroll
+                for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[nu][r] = 0.f;
+            }
+            // rows of B^T d for this lane's tile: R_j = d[ia][j] + sgn * d[ib][j], 8 channels each
+            float R[4][8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float* qa = lds + off[mb][0][j] + kg * 16;
+                const float* qb = lds + off[mb][1][j] + kg * 16;
+                const float4 a0 = *reinterpret_cast<const float4*>(__builtin_assume_aligned(qa, 16));
+                const float4 a1 = *reinterpret_cast<const float4*>(__builtin_assume_aligned(qa + 4, 16));
+                const float4 b0 = *reinterpret_cast<const float4*>(__builtin_assume_aligned(qb, 16));
+                const float4 b1 = *reinterpret_cast<const float4*>(__builtin_assume_aligned(qb + 4, 16));
+                R[j][0] = fmaf(sgn, b0.x, a0.x); R[j][1] = fmaf(sgn, b0.y, a0.y);
+                R[j][2] = fmaf(sgn, b0.z, a0.z); R[j][3] = fmaf(sgn, b0.w, a0.w);
+                R[j][4] = fmaf(sgn, b1.x, a1.x); R[j][5] = fmaf(sgn, b1.y, a1.y);
+                R[j][6] = fmaf(sgn, b1.z, a1.z); R[j][7] = fmaf(sgn, b1.w, a1.w);
+            }
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) {
+                // columns of B: nu=0: R0 - R2, nu=1: R1 + R2, nu=2: R2 - R1, nu=3: R1 - R3; then the exact split
+                bf16x8 vh, vm, vl;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float v = nu == 0 ? R[0][c] - R[2][c] : nu == 1 ? R[1][c] + R[2][c]
+                                  : nu == 2 ? R[2][c] - R[1][c] : R[1][c] - R[3][c];
+                    const __bf16 h = (__bf16)v;
+                    const float r1 = v - (float)h;
+                    const __bf16 m = (__bf16)r1;
+                    vh[c] = h; vm[c] = m; vl[c] = (__bf16)(r1 - (float)m);
+                }
+                const bf16x8 uh = uB[nu][0], um = uB[nu][1], ul = uB[nu][2];
+                // partial products, smallest first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+                acc[nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, uh, acc[nu], 0, 0, 0);
+                acc[nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ul, acc[nu], 0, 0, 0);
+                acc[nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vm, um, acc[nu], 0, 0, 0);
+                acc[nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vm, uh, acc[nu], 0, 0, 0);
+                acc[nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, um, acc[nu], 0, 0, 0);
+                acc[nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, uh, acc[nu], 0, 0, 0);
+                if (s + 1 < MB * KG) {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) uB[nu][t] = u_frag(nu, kgn, t);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (kg == KG - 1) {
+                // A^T = [[1, 1, 1, 0], [0, 1, -1, -1]] applied over nu
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    T[mb][0][r] = (acc[0][r] + acc[1][r]) + acc[2][r];
+                    T[mb][1][r] = (acc[1][r] - acc[2][r]) - acc[3][r];
+                }
+            }
+        }
+
+        if (PH == 1) __syncthreads();             // all waves are done with the staged tile (T planes overlay it)
+        {
+            // T planes of this output block -> LDS [xi][b][tile][TS]
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    float* e = tl + ((size_t)((xi * 2 + b) * NTW + mb * 32 + rhalf)) * TS + col;
+                    const f32x16 tv = T[mb][b];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) e[((r & 3) + 8 * (r >> 2)) * TS] = tv[r];
+                }
+            __syncthreads();
+            // finish: one (tile, channel quad) per thread and round
+#pragma unroll 1
+            for (int task = tid; task < NTW * 8; task += NTHREADS) {
+                const int t = task >> 3, c4 = task & 7;
+                const int co = nb * 32 + c4 * 4;
+                float4 y[2][2];                                       // [a][b]
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    float4 tx[4];
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+                        tx[x] = *reinterpret_cast<const float4*>(tl + ((size_t)((x * 2 + b) * NTW + t)) * TS + c4 * 4);
+                    y[0][b] = make_float4((tx[0].x + tx[1].x) + tx[2].x, (tx[0].y + tx[1].y) + tx[2].y,
+                                          (tx[0].z + tx[1].z) + tx[2].z, (tx[0].w + tx[1].w) + tx[2].w);
+                    y[1][b] = make_float4((tx[1].x - tx[2].x) - tx[3].x, (tx[1].y - tx[2].y) - tx[3].y,
+                                          (tx[1].z - tx[2].z) - tx[3].z, (tx[1].w - tx[2].w) - tx[3].w);
+                }
+                const int tr = P2 ? t >> (p.wsh - 1) : t / Wt, tc = t - tr * Wt;
+                const int grow = r0 + 2 * tr;
+                if (grow >= p.B * H) continue;
+                if (p.bias) {
+                    const float4 bv = *reinterpret_cast<const float4*>(p.bias + co);
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            y[a][b].x += bv.x; y[a][b].y += bv.y; y[a][b].z += bv.z; y[a][b].w += bv.w;
+                        }
+                }
+                if (p.flags & SBC_EPI_POOL) {
+                    // ((((0 + a) + b) + c) + d) / 4 with a=[0::2,0::2] b=[1::2,0::2] c=[0::2,1::2] d=[1::2,1::2]
+                    float4 v;
+                    v.x = (((y[0][0].x + y[1][0].x) + y[0][1].x) + y[1][1].x) * 0.25f;
+                    v.y = (((y[0][0].y + y[1][0].y) + y[0][1].y) + y[1][1].y) * 0.25f;
+                    v.z = (((y[0][0].z + y[1][0].z) + y[0][1].z) + y[1][1].z) * 0.25f;
+                    v.w = (((y[0][0].w + y[1][0].w) + y[0][1].w) + y[1][1].w) * 0.25f;
+                    const int n = dm.div_h(grow), ho = (grow - n * H) >> 1;
+                    const size_t o = ((size_t)(n * (H >> 1) + ho) * Wt + tc) * COUT + co;
+                    if (p.res1) {
+                        const float4 rr = ld_stream(p.res1 + o);
+                        v.x = rr.x + v.x; v.y = rr.y + v.y; v.z = rr.z + v.z; v.w = rr.w + v.w;
+                    }
+                    st_stream(p.out + o, v);
+                    continue;
+                }
+                size_t o[2][2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) o[a][b] = ((size_t)(grow + a) * W + 2 * tc + b) * COUT + co;
+                if (p.res1) {
+                    float4 rr[2][2];
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) rr[a][b] = ld_stream(p.res1 + o[a][b]);
+                    if (p.flags & SBC_EPI_RES1_ELU) {
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int b = 0; b < 2; ++b) rr[a][b] = elu4(rr[a][b]);
+                    }
+                    if (p.res2) {
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int b = 0; b < 2; ++b) {
+                                const float4 r2 = ld_stream(p.res2 + o[a][b]);
+                                rr[a][b].x = r2.x + rr[a][b].x; rr[a][b].y = r2.y + rr[a][b].y;
+                                rr[a][b].z = r2.z + rr[a][b].z; rr[a][b].w = r2.w + rr[a][b].w;
+                            }
+                    }
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            y[a][b].x += rr[a][b].x; y[a][b].y += rr[a][b].y;
+                            y[a][b].z += rr[a][b].z; y[a][b].w += rr[a][b].w;
+                        }
+                }
+                if (p.flags & SBC_EPI_UP) {
+                    // F.interpolate(bilinear, align_corners=True) of `up` added on top (MSFBlock, layers.py:182-183)
+                    const float sh = H > 1 ? (float)(p.up_h - 1) / (float)(H - 1) : 0.f;
+                    const float sw = W > 1 ? (float)(p.up_w - 1) / (float)(W - 1) : 0.f;
+                    const int n = dm.div_h(grow), hrow = grow - n * H;
+                    const float* u = p.up + (size_t)n * p.up_h * p.up_w * COUT + co;
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            const float fh = sh * (float)(hrow + a), fw = sw * (float)(2 * tc + b);
+                            const int h0 = min((int)fh, p.up_h - 1), w0 = min((int)fw, p.up_w - 1);
+                            const int h1 = min(h0 + 1, p.up_h - 1), w1 = min(w0 + 1, p.up_w - 1);
+                            const float lh1 = fh - (float)h0, lw1 = fw - (float)w0;
+                            const float lh0 = 1.f - lh1, lw0 = 1.f - lw1;
+                            const float4 v00 = *reinterpret_cast<const float4*>(u + (size_t)(h0 * p.up_w + w0) * COUT);
+                            const float4 v01 = *reinterpret_cast<const float4*>(u + (size_t)(h0 * p.up_w + w1) * COUT);
+                            const float4 v10 = *reinterpret_cast<const float4*>(u + (size_t)(h1 * p.up_w + w0) * COUT);
+                            const float4 v11 = *reinterpret_cast<const float4*>(u + (size_t)(h1 * p.up_w + w1) * COUT);
+                            y[a][b].x += lh0 * (lw0 * v00.x + lw1 * v01.x) + lh1 * (lw0 * v10.x + lw1 * v11.x);
+                            y[a][b].y += lh0 * (lw0 * v00.y + lw1 * v01.y) + lh1 * (lw0 * v10.y + lw1 * v11.y);
+                            y[a][b].z += lh0 * (lw0 * v00.z + lw1 * v01.z) + lh1 * (lw0 * v10.z + lw1 * v11.z);
+                            y[a][b].w += lh0 * (lw0 * v00.w + lw1 * v01.w) + lh1 * (lw0 * v10.w + lw1 * v11.w);
+                        }
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) st_stream(p.out + o[a][b], y[a][b]);
+            }
+            if (ph + 1 < PH) __syncthreads();                          // T planes are rewritten next phase
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dispatch
+template <int CIN, int COUT, int MB>
+static int launch_wx3(const ConvParams& p, hipStream_t stream, bool dry) {
+    constexpr int TM = 128 * MB;
+    constexpr int S = CIN + 4;
+    constexpr int NBLK = COUT / 32;
+    constexpr int PH = NBLK;
+    const int HW = p.H * p.W;
+    const bool multi = TM >= HW;
+    const size_t staged = (size_t)(multi ? TM + 1 : TM + 2 * p.W + 1) * S * sizeof(float);
+    const size_t tplanes = (size_t)8 * 32 * MB * 36 * sizeof(float);
+    const size_t lds = PH == 1 ? max(staged, tplanes) : staged + tplanes;
+    if (lds > 160 * 1024) return 1;
+    constexpr int WPE = (CIN == 32 && COUT == 32 && MB == 1) ? 3 : 2;
+    auto kern = conv_wx3_kernel<CIN, COUT, MB, true, WPE>;
+    static size_t lds_attr = 0;
+    if (lds > lds_attr) {
+        SBC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_attr = lds;
+    }
+    if (dry) return SBC_OK;
+    hipLaunchKernelGGL(kern, dim3((p.total_px + TM - 1) / TM), dim3(256), lds, stream, p);
+    SBC_CHECK_HIP(hipGetLastError());
+    return SBC_OK;
+}
+
+template <int CIN, int COUT>
+static int launch_wx3_sized(const ConvParams& p, hipStream_t stream, bool dry) {
+    const int HW = p.H * p.W;
+    auto fits = [&](int tm) { return tm % (2 * p.W) == 0 && (HW % tm == 0 || tm % HW == 0); };
+    // 128-pixel tiles: more resident workgroups beat the smaller halo overhead of 256-pixel tiles (32 -> 32 at 64x16:
+    // 205 us with three 128-pixel workgroups per CU against 227 us with two 256-pixel ones); 256 only when 128 does
+    // not tile the image
+    constexpr bool mb2_ok = (COUT == 32);
+    static const bool force2 = getenv("SBC_WX3_MB2") != nullptr;                   // tuning aid
+    if (mb2_ok && force2 && fits(256)) return launch_wx3<CIN, COUT, 2>(p, stream, dry);
+    if (fits(128)) return launch_wx3<CIN, COUT, 1>(p, stream, dry);
+    if (mb2_ok && fits(256)) return launch_wx3<CIN, COUT, 2>(p, stream, dry);
+    return 1;
+}
+
+int launch_conv_wx3(const ConvParams& p, int cin, int cout, hipStream_t stream, bool dry) {
+    // power-of-two images with even sides only (every level the score network produces for Nt, Nr in {16, 64, 256})
+    if (p.dil != 1 || p.hsh < 1 || p.wsh < 1) return 1;
+    const int key = cin * 1000 + cout;
+    switch (key) {
+        case 32 * 1000 + 32: return launch_wx3_sized<32, 32>(p, stream, dry);
+        case 32 * 1000 + 64: return launch_wx3_sized<32, 64>(p, stream, dry);
+        case 64 * 1000 + 64: return launch_wx3_sized<64, 64>(p, stream, dry);
+        case 64 * 1000 + 32: return launch_wx3_sized<64, 32>(p, stream, dry);
+        case 64 * 1000 + 128: return launch_wx3_sized<64, 128>(p, stream, dry);
+        case 128 * 1000 + 128: return launch_wx3_sized<128, 128>(p, stream, dry);
+        case 128 * 1000 + 64: return launch_wx3_sized<128, 64>(p, stream, dry);
+        default: return 1;
+    }
+}
+
+}  // namespace sbc

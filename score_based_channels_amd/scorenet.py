@@ -14,7 +14,7 @@ import torch
 from . import _lib
 from . import plan as P
 from .weights import (check_state_dict, get_sigmas, pack_conv_weight, pack_conv_weight_split,
-                      pack_conv_weight_winograd)
+                      pack_conv_weight_winograd, pack_conv_weight_winograd_split)
 
 
 def _ptr(t, offset_elems=0):
@@ -120,6 +120,7 @@ class ScoreNet:
                 add(name, pack_conv_weight(w))
                 if w.shape[2:] == (3, 3):
                     add(name + '#winograd', pack_conv_weight_winograd(w))
+                    add(name + '#winograd_split', pack_conv_weight_winograd_split(w).view(np.float32))
                 add(name + '#split', pack_conv_weight_split(w).view(np.float32))      # bf16 bit patterns
             elif name.endswith('.alpha'):
                 pre = name[:-len('.alpha')]
@@ -168,6 +169,8 @@ class ScoreNet:
                     o.weight_wino = _ptr(self._wdev, self._woff[op.weight + '#winograd'])
                 if op.kind == P.CONV and self.conv_mode != 'f32':
                     o.weight_split = _ptr(self._wdev, self._woff[op.weight + '#split'])
+                    if op.ksize == 3 and op.dil == 1:
+                        o.weight_wino_split = _ptr(self._wdev, self._woff[op.weight + '#winograd_split'])
             if op.bias is not None:
                 o.bias = _ptr(self._wdev, self._woff[op.bias])
             if op.stats is not None:

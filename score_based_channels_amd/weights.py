@@ -191,3 +191,13 @@ def pack_conv_weight_split(w):
     a = terms.reshape(3, o // 32, 32, c // 16, 2, 8, kh * kw)       # [s, nb, l31, g, half, j, tap]
     a = a.transpose(6, 3, 1, 0, 4, 2, 5)                            # [tap, g, nb, s, half, l31, j]
     return np.ascontiguousarray(a).reshape(kh * kw, c // 16, o // 32, 3, 64, 8)
+
+
+def pack_conv_weight_winograd_split(w):
+    """Winograd F(2x2, 3x3) weights ``U = G g G^T`` (float64, rounded once to float32) split into three bf16 terms in
+    MFMA B-operand fragment order ``[16, C/16, O/32, 3, 64, 8]`` uint16 (``csrc/conv_wx3.hip``)."""
+    w = np.asarray(w, np.float64)
+    if w.shape[2:] != (3, 3):
+        raise ValueError('Winograd F(2x2,3x3) needs a 3x3 kernel, got %s' % (w.shape,))
+    u = np.einsum('ij,ocjk,lk->ocil', _WINO_G, w, _WINO_G)          # [O, C, 4, 4]
+    return pack_conv_weight_split(u.astype(np.float32))

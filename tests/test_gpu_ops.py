@@ -67,7 +67,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize('algo', ['direct', 'winograd', 'bf16x3'])
+@pytest.mark.parametrize('algo', ['direct', 'winograd', 'bf16x3', 'winograd_bf16x3'])
 @pytest.mark.parametrize('cin,cout,k,dil,B,H,W,mode', CONV_CASES)
 def test_conv_matches_oracle(gpu, cin, cout, k, dil, B, H, W, mode, algo):
     """The three multipliers behind SBC_OP_CONV: the fp32-MFMA direct implicit GEMM (weight); when the op also carries
@@ -75,8 +75,9 @@ def test_conv_matches_oracle(gpu, cin, cout, k, dil, B, H, W, mode, algo):
     when it carries weight_split, the split-bf16 kernel (three exact bf16 terms per fp32 operand, six bf16 MFMAs)."""
     torch, _lib = gpu
     from score_based_channels_amd import plan as P
-    from score_based_channels_amd.weights import pack_conv_weight, pack_conv_weight_split, pack_conv_weight_winograd
-    if algo == 'winograd' and (k != 3 or dil != 1):
+    from score_based_channels_amd.weights import (pack_conv_weight, pack_conv_weight_split, pack_conv_weight_winograd,
+                                                  pack_conv_weight_winograd_split)
+    if algo.startswith('winograd') and (k != 3 or dil != 1):
         pytest.skip('Winograd F(2x2,3x3) applies to undilated 3x3 convolutions')
     rng = np.random.default_rng(hash((cin, cout, k, dil, B, H, W)) % (2 ** 31))
     x = rng.standard_normal((B, H, W, cin)).astype(F32) * 1.5 + 0.3
@@ -128,6 +129,9 @@ def test_conv_matches_oracle(gpu, cin, cout, k, dil, B, H, W, mode, algo):
     if algo == 'winograd':
         ww = _dev(torch, pack_conv_weight_winograd(w))
         op.weight_wino = _p(ww)
+    if algo == 'winograd_bf16x3':
+        wws = _dev(torch, pack_conv_weight_winograd_split(w).view(np.float32))
+        op.weight_wino_split = _p(wws)
     if algo == 'bf16x3':
         ws = _dev(torch, pack_conv_weight_split(w).view(np.float32))
         op.weight_split = _p(ws)

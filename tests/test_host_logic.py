@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     h = _lib.lib()
     for name in declared:
         assert hasattr(h, name), name
-    assert h.sbc_abi_version() == 3
+    assert h.sbc_abi_version() == 4
 
 
 def test_pack_conv_weight_c_matches_python():
@@ -45,7 +45,8 @@ def test_pack_conv_weight_c_matches_python():
 def test_pack_conv_weight_winograd_and_split_c_match_python():
     """The C packers a non-Python host would call produce the same bytes as the Python ones ScoreNet uses."""
     from score_based_channels_amd import _lib
-    from score_based_channels_amd.weights import (pack_conv_weight_split, pack_conv_weight_winograd, split_bf16x3)
+    from score_based_channels_amd.weights import (pack_conv_weight_split, pack_conv_weight_winograd,
+                                                  pack_conv_weight_winograd_split, split_bf16x3)
     rng = np.random.default_rng(11)
     for o, c, k in [(32, 32, 3), (64, 32, 1), (128, 64, 3)]:
         w = (rng.standard_normal((o, c, k, k)) * np.exp(rng.uniform(-8, 2, (o, c, k, k)))).astype(np.float32)
@@ -62,6 +63,10 @@ def test_pack_conv_weight_winograd_and_split_c_match_python():
             dstw = np.zeros(refw.shape, np.float32)
             _lib.check(_lib.lib().sbc_pack_conv_weight_winograd(w.ctypes.data, o, c, dstw.ctypes.data))
             assert np.array_equal(dstw, refw)
+            refs = pack_conv_weight_winograd_split(w)
+            dsts = np.zeros(refs.shape, np.uint16)
+            _lib.check(_lib.lib().sbc_pack_conv_weight_winograd_split(w.ctypes.data, o, c, dsts.ctypes.data))
+            assert np.array_equal(dsts, refs)
     assert _lib.lib().sbc_pack_conv_weight_split(w.ctypes.data, 32, 24, 3, dst.ctypes.data) == -1
 
 

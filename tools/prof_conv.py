@@ -7,7 +7,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from score_based_channels_amd import _lib, plan as P
-from score_based_channels_amd.weights import pack_conv_weight, pack_conv_weight_split, pack_conv_weight_winograd
+from score_based_channels_amd.weights import (pack_conv_weight, pack_conv_weight_split, pack_conv_weight_winograd,
+                                              pack_conv_weight_winograd_split)
 ap = argparse.ArgumentParser()
 ap.add_argument('shape', nargs='*', type=int, default=[32, 32, 3, 1, 1700, 64, 16])
 ap.add_argument('--mode', default='bf16x3')
@@ -30,6 +31,8 @@ if a.mode == 'bf16x3':
     keep.append(torch.from_numpy(pack_conv_weight_split(wn).view(np.float32)).cuda()); op.weight_split = keep[-1].data_ptr()
 if os.environ.get('SBC_LIB_PATH'):
     _lib.LIB_PATH = os.environ['SBC_LIB_PATH']
+if a.mode == 'wx3':
+    keep.append(torch.from_numpy(pack_conv_weight_winograd_split(wn).view(np.float32)).cuda()); op.weight_wino_split = keep[-1].data_ptr()
 h = _lib.lib()
 for _ in range(3):
     _lib.check(h.sbc_op_launch(C.byref(op), None))
@@ -42,4 +45,10 @@ e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / a.iters * 1e3
 fl = 2.0 * k * k * cin * cout * B * H * W
 by = 4.0 * B * H * W * (cin + cout * (1 if a.no_res else 2))
+if os.environ.get('WINO_TIMING'):
+    dbg = torch.zeros(4096 * 4 * 6, device='cuda'); op.up = dbg.data_ptr()
+    _lib.check(h.sbc_op_launch(C.byref(op), None)); torch.cuda.synchronize()
+    d = dbg.view(4096, 4, 6).cpu().numpy()
+    names = ['stage', 'barrier', 'K loop', 'T write', 'barrier2', 'finish']
+    print('wave 0 cycles/WG (mean):', {n: int(d[:, 0, i].mean()) for i, n in enumerate(names)}, 'sum', int(d[:, 0].sum(1).mean()))
 print('%s %s tile=%s: %.1f us  %.1f TF(direct-equivalent)  %.2f TB/s(algorithmic)' % (a.mode, a.shape, os.environ.get('SBC_TILE', 'auto'), us, fl / us / 1e6, by / us / 1e6))
