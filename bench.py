@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2516.6     # same guide: v_mfma_f32_32x32x16_bf16 dense, 16x the fp32 MFMA rate ("~2.5 PF")
 STEPS_PER_CHANNEL = 2311 * 3
 
 
@@ -66,7 +67,7 @@ def main():
     ap.add_argument('--graph', type=int, default=0, help='replay the step as a hipGraph (no per-kernel timing)')
     ap.add_argument('--full-schedule', action='store_true', help='time all 6933 steps instead of --steps')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--conv-mode', default='f32', choices=['f32', 'mixed', 'bf16x3'],
+    ap.add_argument('--conv-mode', default='bf16x3', choices=['bf16x3', 'f32'],
                     help='convolution multiplier (scorenet.CONV_MODES)')
     ap.add_argument('--streams', type=int, default=1, help='split the trajectories into this many concurrent HIP streams')
     args = ap.parse_args()
@@ -167,7 +168,8 @@ def main():
         out = {
             'metric': 'channels/s full ALD inference, CDL-C Nt64xNr16', 'value': value, 'unit': 'channels/s',
             'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if args.conv_mode == 'f32' else 'f32 (products as exact 3-term bf16 splits on the bf16 matrix cores, fp32 accumulate)',
             'data': 'synthetic (CDL-C-like cluster channels, QPSK pilots, seed-derived random-init weights)',
             'config': {'workload': 'CDL-C Nt64xNr16, batch=100 channels x 17 SNR points (-10..30 dB) = 1700 '
                                    'lock-step trajectories per GPU, full 2311x3 schedule',
@@ -185,20 +187,27 @@ def main():
             ach = per_launch / (kern_ms / kern_n * 1e-3) / 1e12
             traffic = None                  # HBM bytes per launch from the PMC passes (profiles/), same workload only
             tfile = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-            if os.path.exists(tfile) and alds[0].T == 1700 and args.conv_mode != 'bf16x3':
+            if os.path.exists(tfile) and alds[0].T == 1700 and args.conv_mode == 'bf16x3':
                 with open(tfile) as f:
                     traffic = json.load(f).get('hbm_bytes_per_launch')
             if args.conv_mode == 'bf16x3':
-                kname = ('conv_x3_kernel<32, 32, 3, 2, 1, 4, 1, true>: the 18 3x3 32->32 convolutions at 64x16 of every step '
-                         '(%d launches, avg %.1f us); fp32 results from 6 bf16 MFMAs per product block, priced against the '
-                         'fp32 MFMA peak like the default path' % (kern_n, kern_ms / kern_n * 1e3))
+                # fp32-exact products on the bf16 matrix cores: 6 bf16 MFMAs per fp32 product block, so the roofline of
+                # the instruction the kernel issues is the dense bf16 MFMA peak / 6
+                peak = PEAK_BF16_MFMA_TFLOPS / 6.0
+                kname = ('conv_wx3_kernel<32, 32, 1, true, 3, true>: the 18 3x3 32->32 convolutions at 64x16 of every step (%d '
+                         'tagged launches, avg %.1f us).  achieved = direct-convolution FLOPs (2*9*32*32 per pixel) / '
+                         'time; peak = dense bf16 MFMA peak %.1f / 6 (fp32 operands as three exact bf16 terms, six bf16 '
+                         'MFMAs per product block); the kernel executes 16/36 of the products (Winograd F(2x2,3x3)), '
+                         'i.e. %.0f TFLOP/s of bf16 MFMA' % (kern_n, kern_ms / kern_n * 1e3, PEAK_BF16_MFMA_TFLOPS,
+                                                            ach * 6 * 16 / 36))
             else:
+                peak = PEAK_F32_MFMA_TFLOPS
                 kname = ('conv_wino_kernel<32, 32, 2, true>: the 18 3x3 32->32 convolutions at 64x16 of every step (%d '
                          'launches, avg %.1f us).  achieved = direct-convolution FLOPs (2*9*32*32 per pixel) / time; the '
                          'kernel executes 16/36 of them (fp32 Winograd F(2x2,3x3)), i.e. %.1f TFLOP/s on the MFMA pipe'
                          % (kern_n, kern_ms / kern_n * 1e3, ach * 16 / 36))
-            out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic, 'kernel': kname}
+            out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
+                               'frac': ach / peak, 'traffic': traffic, 'kernel': kname}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, sd)
         print(json.dumps(out))

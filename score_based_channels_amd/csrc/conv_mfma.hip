@@ -229,12 +229,7 @@ static int launch_sized(const ConvParams& p, hipStream_t stream, bool dry) {
 // so that nothing but kernel launches happens inside a hipGraph capture)
 int launch_conv(const sbc_op& op, hipStream_t stream, bool dry) {
     static const bool f32_only = getenv("SBC_CONV_MODE") && !strcmp(getenv("SBC_CONV_MODE"), "f32");   // A/B aid
-    // Multiplier choice when the op carries several weight forms: split-bf16 (conv_x3.hip) everywhere except the
-    // full-resolution 32 -> 32 3x3 layers, which are bound by HBM and staging work rather than by the multiply and
-    // run faster on the fp32 Winograd kernel (tools/prof_plan_convs.py).
-    const bool hbm_bound_layer = op.weight_wino && op.cin == 32 && op.cout == 32 && op.ksize == 3 && op.dil == 1 &&
-                                 op.H * op.W >= 1024 && !(op.flags & SBC_EPI_POOL);
-    const bool x3 = op.weight_split && !f32_only && !hbm_bound_layer;
+    const bool x3 = op.weight_split && !f32_only;
     SBC_REQUIRE(op.in && op.out && (op.weight || x3), "conv: in/out/weight must be set");
     SBC_REQUIRE(op.B > 0 && op.H > 0 && op.W > 0, "conv: bad shape B=%d H=%d W=%d", op.B, op.H, op.W);
     SBC_REQUIRE(op.ksize == 1 || op.ksize == 3, "conv: ksize %d (only 1 and 3)", op.ksize);
@@ -251,7 +246,7 @@ int launch_conv(const sbc_op& op, hipStream_t stream, bool dry) {
     p.B = op.B; p.H = op.H; p.W = op.W; p.dil = op.dil; p.flags = op.flags;
     p.up_h = op.up_h; p.up_w = op.up_w; p.total_px = op.B * op.H * op.W;
     p.hsh = log2_exact(op.H); p.wsh = log2_exact(op.W);
-    if (op.weight_wino_split && !f32_only && !hbm_bound_layer && op.ksize == 3 && op.dil == 1) {
+    if (op.weight_wino_split && !f32_only && op.ksize == 3 && op.dil == 1) {
         ConvParams pw = p;
         pw.wpk = (const float4*)op.weight_wino_split;
         const int rc = launch_conv_wx3(pw, op.cin, op.cout, stream, dry);

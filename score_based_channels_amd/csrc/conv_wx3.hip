@@ -18,7 +18,10 @@ namespace sbc {
 
 // WPE: waves per SIMD the register allocation must allow (2 = 256 registers, 3 = 168).  A third resident workgroup per CU
 // is worth ~20 % where the kernel fits without spilling (32 -> 32 with 128-pixel tiles); the wider variants would spill.
-template <int CIN, int COUT, int MB, bool P2, int WPE>
+// TOP: instantiation tag without effect on the code -- launches with >= 2^20 pixels (the full-resolution level of the
+// score network) get their own kernel symbol, so per-symbol profiler statistics (rocprofv3 --stats) separate them from
+// the same channel configuration at 32x8, and bench.py's hipEvent average of that level can be checked against them.
+template <int CIN, int COUT, int MB, bool P2, int WPE, bool TOP>
 __global__ __launch_bounds__(256, WPE) void conv_wx3_kernel(ConvParams p) {
     constexpr int TM = 128 * MB;                 // output pixels per workgroup
     constexpr int NTW = 32 * MB;                 // Winograd tiles (2x2 output blocks) per workgroup
@@ -296,8 +299,11 @@ static int launch_wx3(const ConvParams& p, hipStream_t stream, bool dry) {
     const size_t lds = PH == 1 ? max(staged, tplanes) : staged + tplanes;
     if (lds > 160 * 1024) return 1;
     constexpr int WPE = (CIN == 32 && COUT == 32 && MB == 1) ? 3 : 2;
-    auto kern = conv_wx3_kernel<CIN, COUT, MB, true, WPE>;
-    static size_t lds_attr = 0;
+    const bool top = (CIN == 32 && COUT == 32) && p.total_px >= (1 << 20);
+    auto kern = top ? conv_wx3_kernel<CIN, COUT, MB, true, WPE, (CIN == 32 && COUT == 32)>
+                    : conv_wx3_kernel<CIN, COUT, MB, true, WPE, false>;
+    static size_t lds_attr2[2] = {0, 0};   // per kernel symbol
+    size_t& lds_attr = lds_attr2[top ? 1 : 0];
     if (lds > lds_attr) {
         SBC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -33,21 +33,21 @@ class BoundScore:
         self.keep = extra_keep
 
 
-CONV_MODES = ('mixed', 'bf16x3', 'f32')
+CONV_MODES = ('bf16x3', 'f32')
 
 
 class ScoreNet:
     """``conv_mode`` selects how the 32/64/128-channel convolutions multiply:
 
-    ``'bf16x3'``            fp32 operands split exactly into three bf16 terms, six bf16 MFMAs per product block, fp32
-                            accumulation -- fp32-level accuracy at 0.375x the matrix time (``csrc/conv_x3.hip``);
-    ``'f32'`` (default)     fp32 MFMA kernels (direct + Winograd F(2x2,3x3), ``csrc/conv_mfma.hip``, ``conv_wino.hip``);
-    ``'mixed'``             every weight form is bound and the library picks per layer: split-bf16 everywhere except
-                            the HBM-bound full-resolution 32 -> 32 layers, which stay on fp32 Winograd.
-    All three stay within the parity tolerance of the reference (tests/test_gpu_parity.py runs every case in each).
+    ``'bf16x3'`` (default)  fp32 operands split exactly into three bf16 terms (8 + 8 + 8 significand bits), six bf16 MFMAs
+                            per product block, fp32 accumulation: fp32-level accuracy (forward error vs the reference
+                            0.8e-6, the fp32 kernels 1.0e-6) on the bf16 matrix cores -- Winograd F(2x2,3x3) for the
+                            undilated 3x3 layers (``csrc/conv_wx3.hip``), direct for the rest (``csrc/conv_x3.hip``);
+    ``'f32'``               fp32 MFMA kernels (Winograd ``csrc/conv_wino.hip`` + direct ``csrc/conv_mfma.hip``).
+    Both stay within the parity tolerance of the reference (tests/test_gpu_parity.py runs every case in each).
     """
 
-    def __init__(self, config, device=None, conv_mode='f32'):
+    def __init__(self, config, device=None, conv_mode='bf16x3'):
         if conv_mode not in CONV_MODES:
             raise ValueError('conv_mode must be one of %s, got %r' % (CONV_MODES, conv_mode))
         self.conv_mode = conv_mode
@@ -165,9 +165,9 @@ class ScoreNet:
             o.out = _ptr(slots[op.dst.slot])
             if op.weight is not None:
                 o.weight = _ptr(self._wdev, self._woff[op.weight])
-                if op.kind == P.CONV and op.ksize == 3 and op.dil == 1 and self.conv_mode != 'bf16x3':
+                if op.kind == P.CONV and op.ksize == 3 and op.dil == 1 and self.conv_mode == 'f32':
                     o.weight_wino = _ptr(self._wdev, self._woff[op.weight + '#winograd'])
-                if op.kind == P.CONV and self.conv_mode != 'f32':
+                if op.kind == P.CONV and self.conv_mode == 'bf16x3':
                     o.weight_split = _ptr(self._wdev, self._woff[op.weight + '#split'])
                     if op.ksize == 3 and op.dil == 1:
                         o.weight_wino_split = _ptr(self._wdev, self._woff[op.weight + '#winograd_split'])

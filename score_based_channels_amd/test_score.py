@@ -37,7 +37,7 @@ def parse_args(argv=None):
     p.add_argument('--synthetic_weights', type=int, default=None, metavar='SEED',
                    help='seed-derived random weights instead of ./models/score/<train>/final_model.pt')
     p.add_argument('--no_plot', action='store_true')
-    p.add_argument('--conv_mode', type=str, default='f32', choices=['f32', 'mixed', 'bf16x3'],
+    p.add_argument('--conv_mode', type=str, default='bf16x3', choices=['bf16x3', 'f32'],
                    help='convolution multiplier: split-bf16 matrix cores (fp32-accurate, default) or fp32 MFMA')
     p.add_argument('--no_graph', action='store_true', help='launch kernels eagerly instead of hipGraph replay')
     return p.parse_args(argv)

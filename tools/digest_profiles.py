@@ -3,12 +3,12 @@ import collections, csv, json, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 R = os.path.join(ROOT, 'gpurun_out', 'profile_passes') + '/'
 P = os.path.join(ROOT, 'profiles') + '/'
-DOMINANT = 'conv_wino_kernel<32, 32, 2, true>'
+DOMINANT = 'conv_wx3_kernel<32, 32, 1, true, 3, true>'
 
 rows = list(csv.reader(open(R + 'stats/s_kernel_stats.csv')))
 with open(P + 'r01_kernel_stats_bench_steps10.csv', 'w', newline='') as f:
     f.write('# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 10 --no-cpu-baseline '
-            '(13 steps incl. 3 warm-up), 1x MI355X, conv_mode f32, T=1700\n')
+            '(13 steps incl. 3 warm-up), 1x MI355X, conv_mode bf16x3 (default), T=1700\n')
     w = csv.writer(f, quoting=csv.QUOTE_ALL)
     for r in rows:
         w.writerow(r)
