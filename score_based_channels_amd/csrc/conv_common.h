@@ -18,6 +18,7 @@ struct ConvParams {
     int B, H, W, dil, flags, up_h, up_w, total_px;
     int hsh, wsh;         // log2(H), log2(W) for the power-of-two builds
     int plane;            // conv_x3: 16-bit elements per LDS plane
+    int stats_off;        // conv_wx3: float offset of the statistics copy in LDS
 };
 
 

@@ -21,14 +21,20 @@ namespace sbc {
 // TOP: instantiation tag without effect on the code -- launches with >= 2^20 pixels (the full-resolution level of the
 // score network) get their own kernel symbol, so per-symbol profiler statistics (rocprofv3 --stats) separate them from
 // the same channel configuration at 32x8, and bench.py's hipEvent average of that level can be checked against them.
-template <int CIN, int COUT, int MB, bool P2, int WPE, bool TOP>
+// NBP: output blocks (32 channels) per phase.  (One workgroup per (tile, phase) was tried for the low-resolution
+// levels, where a launch has fewer tiles than the chip has CUs: slower, because staging the 128-channel tile dominates
+// there and would be repeated per phase.)
+template <int CIN, int COUT, int MB, bool P2, int WPE, bool TOP, int NBP>
 __global__ __launch_bounds__(256, WPE) void conv_wx3_kernel(ConvParams p) {
     constexpr int TM = 128 * MB;                 // output pixels per workgroup
     constexpr int NTW = 32 * MB;                 // Winograd tiles (2x2 output blocks) per workgroup
     constexpr int S = CIN + 4;
     constexpr int KG = CIN / 16;                 // K steps: 16 input channels each
     constexpr int NBLK = COUT / 32;
-    constexpr int PH = NBLK;                     // phases: one 32-channel output block each (K loops, then output)
+    // Output blocks of a phase share the transformed + split input (two for 64 output channels; with 128 the longer
+    // unrolled walk spills at two blocks and measures slower).
+    constexpr int PH = NBLK / NBP;               // phases (K loops, then the outputs of NBP blocks)
+    static_assert(MB == 1 || NBP == 1, "two tile blocks only with one output block per phase (registers)");
     constexpr int TS = 36;                       // floats per (tile) row of a T plane: 32 channels + 4 pad
     constexpr int NTHREADS = 256;
     constexpr int NPF_FULL = ((TM + 32) * (CIN / 4) + NTHREADS - 1) / NTHREADS;
@@ -43,9 +49,19 @@ __global__ __launch_bounds__(256, WPE) void conv_wx3_kernel(ConvParams p) {
     const int col = lane & 31, rhalf = 4 * (lane >> 5);
 
     const TileGeom g = tile_geom(blockIdx.x, TM, p.B, dm, 1);
-    stage_tile<CIN, NTHREADS, NPF, P2>(lds, p.in, p.stats, p.flags, g, dm, tid);
-    // T planes [xi][b][tile][TS]: overlay the staged tile when there is a single phase, else live behind it
-    float* const tl = PH == 1 ? lds : lds + (size_t)(g.multi ? TM + 1 : TM + 2 * W + 1) * S;
+    {
+        float4 pf[NPF];
+        stage_issue<CIN, NTHREADS, NPF>(pf, p.in, g, W, tid);
+        // InstanceNorm++ statistics of the tile's samples through LDS (behind the staged tile and the T planes)
+        float* st_lds = lds + p.stats_off;
+        if (p.flags & SBC_PRO_NORM) {
+            stage_stats_to_lds<CIN, NTHREADS, P2>(st_lds, p.stats, g, dm, tid);
+            __syncthreads();
+        }
+        stage_commit<CIN, NTHREADS, NPF, P2>(lds, pf, p.in, st_lds, p.flags, g, dm, tid, 0);
+    }
+    // T planes [xi][b][tile][TS]: overlay the staged tile when there is a single output block, else live behind it
+    float* const tl = NBLK == 1 ? lds : lds + (size_t)(g.multi ? TM + 1 : TM + 2 * W + 1) * S;
 
     // B^T rows: xi=0: d0 - d2, xi=1: d1 + d2, xi=2: d2 - d1, xi=3: d1 - d3   ->  R = d[ia] + sgn * d[ib]
     const int ia = xi == 0 ? 0 : xi == 2 ? 2 : 1;
@@ -79,31 +95,38 @@ __global__ __launch_bounds__(256, WPE) void conv_wx3_kernel(ConvParams p) {
     __syncthreads();                                                  // staged tile visible
 
     for (int ph = 0; ph < PH; ++ph) {
-        const int nb = ph;                        // output-channel block of this phase
-        f32x16 T[MB][2];
-        f32x16 acc[4];
+        f32x16 T[MB][NBP][2];
+        f32x16 acc[NBP][4];
         // split U: [(xi*4 + nu)][kg][nb][term][lane] 16-byte fragments
-        const uint4* wp = reinterpret_cast<const uint4*>(p.wpk) + ((size_t)(xi * 4) * KG * NBLK + nb) * 3 * 64 + lane;
-        auto u_frag = [&](int nu, int kg, int t) {
-            return __builtin_bit_cast(bf16x8, wp[((size_t)((nu * KG + kg) * NBLK) * 3 + t) * 64]);
+        const uint4* wp = reinterpret_cast<const uint4*>(p.wpk) + ((size_t)(xi * 4) * KG * NBLK + ph * NBP) * 3 * 64 + lane;
+        auto u_frag = [&](int nu, int kg, int q, int t) {
+            return __builtin_bit_cast(bf16x8, wp[((size_t)((nu * KG + kg) * NBLK + q) * 3 + t) * 64]);
         };
-        // The filter fragments of a (tile block, 16-channel) step are requested one step ahead -- fragment nu right
-        // after the MFMAs that consumed its predecessor -- so their L2 latency never sits in front of an MFMA; the
-        // order of these groups is pinned (sched_barrier), inside a group the compiler interleaves freely.
-        bf16x8 uB[4][3];
+        // The filter fragments are requested D = SETS - 1 transform columns ahead of the MFMAs that consume them (a
+        // ring of SETS statically indexed register sets over the sequence g = step * 4 + nu), so their L2 latency hides
+        // behind the MFMAs and splits in between: three columns ahead with one output block per phase, one column
+        // ahead with two (twice the MFMAs per column; 48 registers either way).
+        constexpr int SETS = NBP == 1 ? 4 : 2, D = SETS - 1, NG = MB * KG * 4;
+        bf16x8 uB[SETS][NBP][3];
+        auto u_load = [&](int gq) {                                   // gq is a compile-time constant at every call
+            const int gg = gq % NG, nu_g = gg & 3, kg_g = (gg >> 2) % KG;
 #pragma unroll
-        for (int nu = 0; nu < 4; ++nu)
+            for (int q = 0; q < NBP; ++q)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) uB[nu][t] = u_frag(nu, 0, t);
+                for (int t = 0; t < 3; ++t) uB[gq % SETS][q][t] = u_frag(nu_g, kg_g, q, t);
+        };
+#pragma unroll
+        for (int gq = 0; gq < D; ++gq) u_load(gq);
 #pragma unroll
         for (int s = 0; s < MB * KG; ++s) {
             const int mb = s / KG, kg = s % KG;
-            const int kgn = (s + 1) % KG;                      // the step after the last re-reads step 0 (harmless)
             if (kg == 0) {
 #pragma unroll
-                for (int nu = 0; nu < 4; ++nu)
+                for (int q = 0; q < NBP; ++q)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[nu][r] = 0.f;
+                    for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[q][nu][r] = 0.f;
             }
             // rows of B^T d for this lane's tile: R_j = d[ia][j] + sgn * d[ib][j], 8 channels each
             float R[4][8];
@@ -122,6 +145,8 @@ __global__ __launch_bounds__(256, WPE) void conv_wx3_kernel(ConvParams p) {
             }
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu) {
+                const int gq = s * 4 + nu, cur = gq % SETS;
+                u_load(gq + D);                                       // wraps to a harmless re-read at the very end
                 // columns of B: nu=0: R0 - R2, nu=1: R1 + R2, nu=2: R2 - R1, nu=3: R1 - R3; then the exact split
                 bf16x8 vh, vm, vl;
 #pragma unroll
@@ -133,39 +158,43 @@ __global__ __launch_bounds__(256, WPE) void conv_wx3_kernel(ConvParams p) {
                     const __bf16 m = (__bf16)r1;
                     vh[c] = h; vm[c] = m; vl[c] = (__bf16)(r1 - (float)m);
                 }
-                const bf16x8 uh = uB[nu][0], um = uB[nu][1], ul = uB[nu][2];
-                // partial products, smallest first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
-                acc[nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, uh, acc[nu], 0, 0, 0);
-                acc[nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ul, acc[nu], 0, 0, 0);
-                acc[nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vm, um, acc[nu], 0, 0, 0);
-                acc[nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vm, uh, acc[nu], 0, 0, 0);
-                acc[nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, um, acc[nu], 0, 0, 0);
-                acc[nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, uh, acc[nu], 0, 0, 0);
-                if (s + 1 < MB * KG) {
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) uB[nu][t] = u_frag(nu, kgn, t);
+                for (int q = 0; q < NBP; ++q) {
+                    const bf16x8 uh = uB[cur][q][0], um = uB[cur][q][1], ul = uB[cur][q][2];
+                    // partial products, smallest first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+                    acc[q][nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, uh, acc[q][nu], 0, 0, 0);
+                    acc[q][nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ul, acc[q][nu], 0, 0, 0);
+                    acc[q][nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vm, um, acc[q][nu], 0, 0, 0);
+                    acc[q][nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vm, uh, acc[q][nu], 0, 0, 0);
+                    acc[q][nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, um, acc[q][nu], 0, 0, 0);
+                    acc[q][nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, uh, acc[q][nu], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (kg == KG - 1) {
                 // A^T = [[1, 1, 1, 0], [0, 1, -1, -1]] applied over nu
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    T[mb][0][r] = (acc[0][r] + acc[1][r]) + acc[2][r];
-                    T[mb][1][r] = (acc[1][r] - acc[2][r]) - acc[3][r];
-                }
+                for (int q = 0; q < NBP; ++q)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        T[mb][q][0][r] = (acc[q][0][r] + acc[q][1][r]) + acc[q][2][r];
+                        T[mb][q][1][r] = (acc[q][1][r] - acc[q][2][r]) - acc[q][3][r];
+                    }
             }
         }
 
-        if (PH == 1) __syncthreads();             // all waves are done with the staged tile (T planes overlay it)
-        {
+        if (NBLK == 1) __syncthreads();           // all waves are done with the staged tile (T planes overlay it)
+#pragma unroll
+        for (int q = 0; q < NBP; ++q) {
+            const int nb = ph * NBP + q;          // output-channel block
             // T planes of this output block -> LDS [xi][b][tile][TS]
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     float* e = tl + ((size_t)((xi * 2 + b) * NTW + mb * 32 + rhalf)) * TS + col;
-                    const f32x16 tv = T[mb][b];
+                    const f32x16 tv = T[mb][q][b];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) e[((r & 3) + 8 * (r >> 2)) * TS] = tv[r];
                 }
@@ -280,7 +309,7 @@ __global__ __launch_bounds__(256, WPE) void conv_wx3_kernel(ConvParams p) {
 #pragma unroll
                     for (int b = 0; b < 2; ++b) st_stream(p.out + o[a][b], y[a][b]);
             }
-            if (ph + 1 < PH) __syncthreads();                          // T planes are rewritten next phase
+            if (nb + 1 < NBLK) __syncthreads();                        // the T planes are rewritten for the next block
         }
     }
 }
@@ -291,26 +320,33 @@ static int launch_wx3(const ConvParams& p, hipStream_t stream, bool dry) {
     constexpr int TM = 128 * MB;
     constexpr int S = CIN + 4;
     constexpr int NBLK = COUT / 32;
-    constexpr int PH = NBLK;
     const int HW = p.H * p.W;
     const bool multi = TM >= HW;
     const size_t staged = (size_t)(multi ? TM + 1 : TM + 2 * p.W + 1) * S * sizeof(float);
     const size_t tplanes = (size_t)8 * 32 * MB * 36 * sizeof(float);
-    const size_t lds = PH == 1 ? max(staged, tplanes) : staged + tplanes;
-    if (lds > 160 * 1024) return 1;
+    const size_t lds = NBLK == 1 ? max(staged, tplanes) : staged + tplanes;
+    // + the statistics of the samples of a tile: [samples][3][CIN] floats
+    const size_t nsamp = multi ? TM / HW : 1;
+    const size_t stats_off = lds / sizeof(float);
+    const size_t lds_all = lds + ((p.flags & SBC_PRO_NORM) ? nsamp * 3 * CIN * sizeof(float) : 0);
+    if (lds_all > 160 * 1024) return 1;
     constexpr int WPE = (CIN == 32 && COUT == 32 && MB == 1) ? 3 : 2;
+    constexpr int NBP_BIG = NBLK == 2 ? 2 : 1;
     const bool top = (CIN == 32 && COUT == 32) && p.total_px >= (1 << 20);
-    auto kern = top ? conv_wx3_kernel<CIN, COUT, MB, true, WPE, (CIN == 32 && COUT == 32)>
-                    : conv_wx3_kernel<CIN, COUT, MB, true, WPE, false>;
+    const int ntiles = (p.total_px + TM - 1) / TM;
+    auto kern = top ? conv_wx3_kernel<CIN, COUT, MB, true, WPE, (CIN == 32 && COUT == 32), NBP_BIG>
+                    : conv_wx3_kernel<CIN, COUT, MB, true, WPE, false, NBP_BIG>;
     static size_t lds_attr2[2] = {0, 0};   // per kernel symbol
     size_t& lds_attr = lds_attr2[top ? 1 : 0];
-    if (lds > lds_attr) {
+    if (lds_all > lds_attr) {
         SBC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_attr = lds;
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all));
+        lds_attr = lds_all;
     }
     if (dry) return SBC_OK;
-    hipLaunchKernelGGL(kern, dim3((p.total_px + TM - 1) / TM), dim3(256), lds, stream, p);
+    ConvParams q = p;
+    q.stats_off = (int)stats_off;
+    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), lds_all, stream, q);
     SBC_CHECK_HIP(hipGetLastError());
     return SBC_OK;
 }
@@ -324,9 +360,13 @@ static int launch_wx3_sized(const ConvParams& p, hipStream_t stream, bool dry) {
     // not tile the image
     constexpr bool mb2_ok = (COUT == 32);
     static const bool force2 = getenv("SBC_WX3_MB2") != nullptr;                   // tuning aid
-    if (mb2_ok && force2 && fits(256)) return launch_wx3<CIN, COUT, 2>(p, stream, dry);
+    if constexpr (mb2_ok) {
+        if (force2 && fits(256)) return launch_wx3<CIN, COUT, 2>(p, stream, dry);
+    }
     if (fits(128)) return launch_wx3<CIN, COUT, 1>(p, stream, dry);
-    if (mb2_ok && fits(256)) return launch_wx3<CIN, COUT, 2>(p, stream, dry);
+    if constexpr (mb2_ok) {
+        if (fits(256)) return launch_wx3<CIN, COUT, 2>(p, stream, dry);
+    }
     return 1;
 }
 

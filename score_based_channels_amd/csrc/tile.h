@@ -91,14 +91,17 @@ __device__ __forceinline__ void stage_issue(float4 (&pf)[NPF], const float* __re
     }
 }
 
+// `stats` is indexed by sample: global [B][3][CIN] with n0 = first sample of the staged rows, or a copy of the tile's
+// samples in LDS with n0 = 0 (stage_stats_to_lds) -- the latter keeps three dependent L2 round trips per 16-byte chunk
+// out of the staging loop.
 template <int CIN, bool P2>
 __device__ __forceinline__ void stage_put(float* lds, float4 x, int idx, const float* __restrict__ stats, int flags,
-                                          const TileGeom& g, const Dims<P2>& d) {
+                                          const TileGeom& g, const Dims<P2>& d, int n0 = -1) {
     constexpr int S = CIN + 4;
     constexpr int C4 = CIN / 4;
     const int pix = idx / C4, c4 = idx % C4;
     if (flags & SBC_PRO_NORM) {
-        const int n = g.n_first + (g.multi ? d.div_hw(pix) : 0);
+        const int n = (n0 < 0 ? g.n_first : n0) + (g.multi ? d.div_hw(pix) : 0);
         const float* st = stats + (size_t)n * 3 * CIN + c4 * 4;
         const float4 mu = *reinterpret_cast<const float4*>(st);
         const float4 sc = *reinterpret_cast<const float4*>(st + CIN);
@@ -112,21 +115,31 @@ __device__ __forceinline__ void stage_put(float* lds, float4 x, int idx, const f
     *reinterpret_cast<float4*>(lds + pix * S + c4 * 4) = x;
 }
 
+// copy the InstanceNorm++ statistics of the samples a tile touches to LDS ([sample][3][CIN]); the caller puts a
+// barrier between this and stage_commit(..., n0 = 0)
+template <int CIN, int NTHREADS, bool P2>
+__device__ __forceinline__ void stage_stats_to_lds(float* st_lds, const float* __restrict__ stats, const TileGeom& g,
+                                                   const Dims<P2>& d, int tid) {
+    const int nsamp = g.multi ? d.div_hw(g.nps) : 1;
+    const float4* src = reinterpret_cast<const float4*>(stats + (size_t)g.n_first * 3 * CIN);
+    for (int i = tid; i < nsamp * 3 * CIN / 4; i += NTHREADS) reinterpret_cast<float4*>(st_lds)[i] = src[i];
+}
+
 template <int CIN, int NTHREADS, int NPF, bool P2>
 __device__ __forceinline__ void stage_commit(float* lds, const float4 (&pf)[NPF], const float* __restrict__ in,
                                              const float* __restrict__ stats, int flags, const TileGeom& g,
-                                             const Dims<P2>& d, int tid) {
+                                             const Dims<P2>& d, int tid, int n0 = -1) {
     constexpr int S = CIN + 4;
     const int W = d.W;
     const int total = g.nps * (CIN / 4);
 #pragma unroll
     for (int u = 0; u < NPF; ++u) {
         const int idx = u * NTHREADS + tid;
-        if (idx < total) stage_put<CIN, P2>(lds, pf[u], idx, stats, flags, g, d);
+        if (idx < total) stage_put<CIN, P2>(lds, pf[u], idx, stats, flags, g, d, n0);
     }
     const float* src = in + (size_t)g.rs0 * W * CIN;
     for (int idx = NPF * NTHREADS + tid; idx < total; idx += NTHREADS)
-        stage_put<CIN, P2>(lds, ld_stream(src + (size_t)idx * 4), idx, stats, flags, g, d);
+        stage_put<CIN, P2>(lds, ld_stream(src + (size_t)idx * 4), idx, stats, flags, g, d, n0);
     for (int i = tid; i < S; i += NTHREADS) lds[g.nps * S + i] = 0.f;
 }
 
