@@ -69,7 +69,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--conv-mode', default='bf16x3', choices=['bf16x3', 'f32'],
                     help='convolution multiplier (scorenet.CONV_MODES)')
-    ap.add_argument('--streams', type=int, default=1, help='split the trajectories into this many concurrent HIP streams')
+    ap.add_argument('--streams', type=int, default=1,
+                    help='split the trajectories into this many concurrent sub-batch streams (the CLIs use 2: +5-7 %%, '
+                         'but overlapping kernels make per-kernel durations, and hence the roofline entry, ill-defined)')
     args = ap.parse_args()
 
     import torch
@@ -187,9 +189,11 @@ def main():
             ach = per_launch / (kern_ms / kern_n * 1e-3) / 1e12
             traffic = None                  # HBM bytes per launch from the PMC passes (profiles/), same workload only
             tfile = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-            if os.path.exists(tfile) and alds[0].T == 1700 and args.conv_mode == 'bf16x3':
+            if os.path.exists(tfile) and args.conv_mode == 'bf16x3':
                 with open(tfile) as f:
-                    traffic = json.load(f).get('hbm_bytes_per_launch')
+                    tj = json.load(f)
+                if tj.get('trajectories_per_launch') == alds[0].T:
+                    traffic = tj.get('hbm_bytes_per_launch')
             if args.conv_mode == 'bf16x3':
                 # fp32-exact products on the bf16 matrix cores: 6 bf16 MFMAs per fp32 product block, so the roofline of
                 # the instruction the kernel issues is the dense bf16 MFMA peak / 6

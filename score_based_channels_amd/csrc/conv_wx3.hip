@@ -18,8 +18,8 @@ namespace sbc {
 
 // WPE: waves per SIMD the register allocation must allow (2 = 256 registers, 3 = 168).  A third resident workgroup per CU
 // is worth ~20 % where the kernel fits without spilling (32 -> 32 with 128-pixel tiles); the wider variants would spill.
-// TOP: instantiation tag without effect on the code -- launches with >= 2^20 pixels (the full-resolution level of the
-// score network) get their own kernel symbol, so per-symbol profiler statistics (rocprofv3 --stats) separate them from
+// TOP: instantiation tag without effect on the code -- launches on images of >= 1024 pixels (the full-resolution level
+// of the score network) get their own kernel symbol, so per-symbol profiler statistics (rocprofv3 --stats) separate them from
 // the same channel configuration at 32x8, and bench.py's hipEvent average of that level can be checked against them.
 // NBP: output blocks (32 channels) per phase.  (One workgroup per (tile, phase) was tried for the low-resolution
 // levels, where a launch has fewer tiles than the chip has CUs: slower, because staging the 128-channel tile dominates
@@ -332,7 +332,7 @@ static int launch_wx3(const ConvParams& p, hipStream_t stream, bool dry) {
     if (lds_all > 160 * 1024) return 1;
     constexpr int WPE = (CIN == 32 && COUT == 32 && MB == 1) ? 3 : 2;
     constexpr int NBP_BIG = NBLK == 2 ? 2 : 1;
-    const bool top = (CIN == 32 && COUT == 32) && p.total_px >= (1 << 20);
+    const bool top = (CIN == 32 && COUT == 32) && p.H * p.W >= 1024;
     const int ntiles = (p.total_px + TM - 1) / TM;
     auto kern = top ? conv_wx3_kernel<CIN, COUT, MB, true, WPE, (CIN == 32 && COUT == 32), NBP_BIG>
                     : conv_wx3_kernel<CIN, COUT, MB, true, WPE, false, NBP_BIG>;

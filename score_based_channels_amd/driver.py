@@ -30,10 +30,15 @@ def shared_init(n_channels, nt, nr, seed, combo):
 
 
 def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, beta_noise, levels, steps_each,
-                     seed, init, traj_base=0, max_batch=4096, use_graph=True, rank=0, world=1):
+                     seed, init, traj_base=0, max_batch=4096, use_graph=True, rank=0, world=1, n_streams=2):
     """Run ``T = len(h_index)`` trajectories, sharded over ``world`` ranks; returns the full NMSE log
     ``[n_steps, T]`` (float32 numpy, identical on every rank).  ``init``: ``[nH, Nt, Nr]`` complex64 initial
-    estimates indexed by ``h_index``.  Trajectory ``t`` draws its noise from Philox stream ``traj_base + t``."""
+    estimates indexed by ``h_index``.  Trajectory ``t`` draws its noise from Philox stream ``traj_base + t``.
+
+    A chunk is run as ``n_streams`` independent sub-batches on concurrent HIP streams: a quarter of the step is
+    spent in launches of the low-resolution levels that have fewer workgroups than the chip has CUs, and those of one
+    sub-batch overlap with the full-resolution launches of the other (+7 % at two streams on MI355X, none beyond).
+    Results do not depend on the split (per-trajectory noise keys, per-sample normalisation)."""
     h_index = np.asarray(h_index, np.int64)
     T = len(h_index)
     bc = lambda a: np.broadcast_to(np.asarray(a), (T,))            # noqa: E731
@@ -41,16 +46,27 @@ def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, b
     lo, hi = shard.my_block(T, rank, world)
     n_steps = len(levels) * steps_each
     local = torch.zeros(n_steps, hi - lo, dtype=torch.float32, device=net.device)
+    cur = torch.cuda.current_stream(net.device)
+    streams = [torch.cuda.Stream(net.device) for _ in range(max(1, int(n_streams)))]
     for c0 in range(lo, hi, max_batch):
         c1 = min(hi, c0 + max_batch)
-        sl = slice(c0, c1)
-        ald = AldBatch(net, Htrue, P, h_index[sl], p_index[sl], local_noise[sl], alpha_step[sl], beta_noise[sl],
-                       levels=levels, steps_each=steps_each, seed=seed, traj_id=traj_base + np.arange(c0, c1))
-        ald.set_init(init[torch.from_numpy(h_index[sl])])
-        ald.synthesize_measurements()
-        ald.run(use_graph=use_graph)
-        local[:, c0 - lo:c1 - lo] = ald.nmse_log()
-        del ald
+        running = []
+        for part, st in zip(np.array_split(np.arange(c0, c1), len(streams)), streams):
+            if len(part) == 0:
+                continue
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                ald = AldBatch(net, Htrue, P, h_index[part], p_index[part], local_noise[part], alpha_step[part],
+                               beta_noise[part], levels=levels, steps_each=steps_each, seed=seed,
+                               traj_id=traj_base + part)
+                ald.set_init(init[torch.from_numpy(h_index[part])])
+                ald.synthesize_measurements()
+                ald.run(use_graph=use_graph)
+            running.append((part, ald, st))
+        for part, ald, st in running:
+            cur.wait_stream(st)
+            local[:, part[0] - lo:part[-1] + 1 - lo] = ald.nmse_log()
+        del running
     torch.cuda.synchronize(net.device)
     full = shard.gather_trajectory_logs(local, T, rank, world)
     return full.cpu().numpy()
