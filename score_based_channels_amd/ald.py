@@ -25,7 +25,7 @@ def snr_to_noise(snr_db, nt):
     return 10 ** (-np.asarray(snr_db, np.float64) / 10.) * nt
 
 
-def schedule_tables(sigmas_f32, sigma_end, levels, steps_each, alpha_step, beta_noise, local_noise):
+def schedule_tables(sigmas_f32, sigma_end, levels, steps_each, alpha_step, beta_noise, local_noise, dc_boost=1.0):
     """Per-step scalars of the loop, computed in float64 exactly like the python code of
     test_score.py:137-165 and rounded to float32 where they meet a complex64 tensor.
 
@@ -37,6 +37,8 @@ def schedule_tables(sigmas_f32, sigma_end, levels, steps_each, alpha_step, beta_
     alpha = np.asarray(alpha_step, np.float64)[:, None] * (sig[None, :] / float(sigma_end)) ** 2     # :143-144
     nscale = np.sqrt(2 * alpha * np.asarray(beta_noise, np.float64)[:, None])                        # :160
     dc_div = np.asarray(local_noise, np.float64)[:, None] / 2. + sig[None, :] ** 2                   # :165
+    if dc_boost != 1.0:                      # test_mmse.py:231-233 multiplies the gradient by dc_boost instead
+        dc_div = dc_div / float(dc_boost)
     per_level = np.stack((alpha, dc_div, nscale, np.zeros_like(alpha)), axis=-1).astype(np.float32)
     sched = np.repeat(per_level, steps_each, axis=1)
     sigma_of_step = np.repeat(np.asarray(sigmas_f32, np.float32)[levels], steps_each)
@@ -63,7 +65,7 @@ class AldBatch:
     """
 
     def __init__(self, net, Htrue, P_pilots, h_index, p_index, local_noise, alpha_step=3e-11, beta_noise=0.01,
-                 levels=None, steps_each=3, seed=0, traj_id=None, step_noise=None):
+                 levels=None, steps_each=3, seed=0, traj_id=None, step_noise=None, dc_boost=1.0):
         dev = net.device
         self.net = net
         self.H = _as_c64(Htrue, dev)
@@ -86,7 +88,7 @@ class AldBatch:
         self.n_steps = len(self.levels) * self.steps_each
         rows, group = np.unique(np.stack((a0, be, ln), axis=1), axis=0, return_inverse=True)
         sched, sig_step = schedule_tables(net._sigmas_np, net.config.model.sigma_end, self.levels, self.steps_each,
-                                          rows[:, 0], rows[:, 1], rows[:, 2])
+                                          rows[:, 0], rows[:, 1], rows[:, 2], dc_boost)
         i32 = dict(dtype=torch.int32, device=dev)
         self.d_sched = torch.from_numpy(sched).to(dev)
         self.d_sigma_of_step = torch.from_numpy(sig_step).to(dev)

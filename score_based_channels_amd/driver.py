@@ -30,7 +30,8 @@ def shared_init(n_channels, nt, nr, seed, combo):
 
 
 def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, beta_noise, levels, steps_each,
-                     seed, init, traj_base=0, max_batch=4096, use_graph=True, rank=0, world=1, n_streams=2):
+                     seed, init, traj_base=0, max_batch=4096, use_graph=True, rank=0, world=1, n_streams=2,
+                     return_final=False, n_steps=None, dc_boost=1.0, init_index=None, Y=None, y_index=None):
     """Run ``T = len(h_index)`` trajectories, sharded over ``world`` ranks; returns the full NMSE log
     ``[n_steps, T]`` (float32 numpy, identical on every rank).  ``init``: ``[nH, Nt, Nr]`` complex64 initial
     estimates indexed by ``h_index``.  Trajectory ``t`` draws its noise from Philox stream ``traj_base + t``.
@@ -38,14 +39,23 @@ def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, b
     A chunk is run as ``n_streams`` independent sub-batches on concurrent HIP streams: a quarter of the step is
     spent in launches of the low-resolution levels that have fewer workgroups than the chip has CUs, and those of one
     sub-batch overlap with the full-resolution launches of the other (+7 % at two streams on MI355X, none beyond).
-    Results do not depend on the split (per-trajectory noise keys, per-sample normalisation)."""
+    Results do not depend on the split (per-trajectory noise keys, per-sample normalisation).
+
+    ``init_index`` (default ``h_index``) selects the initial estimate of each trajectory; ``Y`` ``[nY, Np, Nr]`` with
+    ``y_index`` supplies measurements shared by several trajectories instead of synthesising one per trajectory
+    (the 50 chains per sample of ``test_mmse.py:185-193``).  ``return_final``: also return the final estimates ``[T, Nt, Nr]`` complex64 (``--save_channels``); ``n_steps``: stop
+    after that many Langevin steps (early stop of ``test_mmse.py:246-250``)"""
     h_index = np.asarray(h_index, np.int64)
     T = len(h_index)
     bc = lambda a: np.broadcast_to(np.asarray(a), (T,))            # noqa: E731
     p_index, local_noise, alpha_step, beta_noise = bc(p_index), bc(local_noise), bc(alpha_step), bc(beta_noise)
+    init_index = h_index if init_index is None else np.asarray(init_index, np.int64)
     lo, hi = shard.my_block(T, rank, world)
-    n_steps = len(levels) * steps_each
+    n_all = len(levels) * steps_each
+    n_steps = n_all if n_steps is None else min(int(n_steps), n_all)
     local = torch.zeros(n_steps, hi - lo, dtype=torch.float32, device=net.device)
+    nt, nr = init.shape[-2], init.shape[-1]
+    final = torch.zeros(hi - lo, nt, nr, dtype=torch.complex64, device=net.device) if return_final else None
     cur = torch.cuda.current_stream(net.device)
     streams = [torch.cuda.Stream(net.device) for _ in range(max(1, int(n_streams)))]
     for c0 in range(lo, hi, max_batch):
@@ -58,15 +68,24 @@ def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, b
             with torch.cuda.stream(st):
                 ald = AldBatch(net, Htrue, P, h_index[part], p_index[part], local_noise[part], alpha_step[part],
                                beta_noise[part], levels=levels, steps_each=steps_each, seed=seed,
-                               traj_id=traj_base + part)
-                ald.set_init(init[torch.from_numpy(h_index[part])])
-                ald.synthesize_measurements()
-                ald.run(use_graph=use_graph)
+                               traj_id=traj_base + part, dc_boost=dc_boost)
+                ald.set_init(init[torch.from_numpy(init_index[part])])
+                if Y is None:
+                    ald.synthesize_measurements()
+                else:
+                    ald.set_measurements(Y[torch.from_numpy(np.asarray(y_index)[part])])
+                ald.run(n_steps, use_graph=use_graph)
             running.append((part, ald, st))
         for part, ald, st in running:
             cur.wait_stream(st)
-            local[:, part[0] - lo:part[-1] + 1 - lo] = ald.nmse_log()
+            local[:, part[0] - lo:part[-1] + 1 - lo] = ald.nmse_log()[:n_steps]
+            if return_final:
+                final[part[0] - lo:part[-1] + 1 - lo] = ald.X
         del running
     torch.cuda.synchronize(net.device)
     full = shard.gather_trajectory_logs(local, T, rank, world)
-    return full.cpu().numpy()
+    if not return_final:
+        return full.cpu().numpy()
+    flat = torch.view_as_real(final).reshape(hi - lo, -1).t().contiguous()          # [2 Nt Nr, T_local]
+    est = shard.gather_trajectory_logs(flat, T, rank, world).t().contiguous().view(T, nt, nr, 2)
+    return full.cpu().numpy(), torch.view_as_complex(est).cpu().numpy()

@@ -88,6 +88,7 @@ def main(argv=None):
     levels = level_subset(config.model.num_classes, args.levels_stride, args.num_levels)
     n_steps = len(levels) * config.sampling.steps_each
     nmse_log = np.zeros((len(spacing_range), len(pilot_alpha_range), len(snr_range), n_steps, num_channels))
+    saved_H = None                                        # --save_channels: final estimates per (spacing, alpha, SNR, channel)
     result_dir = './results/score/train-%s_test-%s' % (args.train, args.test)
     if rank == 0:
         os.makedirs(result_dir, exist_ok=True)
@@ -109,10 +110,17 @@ def main(argv=None):
         init = shared_init(num_channels, nt, nr, seed, meta_idx)        # one init for all SNR points (:115,126)
         S = len(snr_range)
         idx = np.tile(np.arange(num_channels), S)                       # trajectory t = snr * B + channel
-        log = run_trajectories(diffuser, val_H, val_P, idx, idx, np.repeat(noise_range, num_channels), alpha_step,
+        out = run_trajectories(diffuser, val_H, val_P, idx, idx, np.repeat(noise_range, num_channels), alpha_step,
                                beta_noise, levels, config.sampling.steps_each, seed, init,
                                traj_base=meta_idx * S * num_channels, use_graph=not args.no_graph,
-                               rank=rank, world=world)
+                               rank=rank, world=world, return_final=bool(args.save_channels))
+        if args.save_channels:
+            log, est = out
+            if saved_H is None:
+                saved_H = np.zeros((len(spacing_range), len(pilot_alpha_range), S, num_channels, nt, nr), np.complex64)
+            saved_H[spacing_idx, pilot_alpha_idx] = est.reshape(S, num_channels, nt, nr)
+        else:
+            log = out
         nmse_log[spacing_idx, pilot_alpha_idx] = log.reshape(n_steps, S, num_channels).transpose(1, 0, 2)
 
     avg_nmse = np.mean(nmse_log, axis=-1)                 # :174
@@ -136,10 +144,14 @@ def main(argv=None):
                 plt.close()
             except ImportError:
                 print('matplotlib not available: skipping results.png')
-        torch.save({'nmse_log': nmse_log, 'avg_nmse': avg_nmse, 'best_nmse': best_nmse,
-                    'spacing_range': spacing_range, 'pilot_alpha_range': pilot_alpha_range, 'snr_range': snr_range,
-                    'val_config': val_config, 'seed': seed, 'levels': np.asarray(levels)},
-                   os.path.join(result_dir, 'results.pt'))
+        results = {'nmse_log': nmse_log, 'avg_nmse': avg_nmse, 'best_nmse': best_nmse,
+                   'spacing_range': spacing_range, 'pilot_alpha_range': pilot_alpha_range, 'snr_range': snr_range,
+                   'val_config': val_config, 'seed': seed, 'levels': np.asarray(levels)}
+        if saved_H is not None:
+            # the reference parses --save_channels but never uses it (test_score.py:19); here it stores the estimates
+            # after the last Langevin step, normalised Hermitian layout [.., Nt, Nr] like val_H (:112-113)
+            results['saved_H'] = saved_H
+        torch.save(results, os.path.join(result_dir, 'results.pt'))
         print('best NMSE [dB] per SNR:', np.round(10 * np.log10(best_nmse[0, 0]), 2))
     if world > 1:
         torch.distributed.destroy_process_group()

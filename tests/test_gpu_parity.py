@@ -213,8 +213,11 @@ def test_cli_test_score_drop_in_outputs(net64, tmp_path, monkeypatch):
     assert {'nmse_log', 'avg_nmse', 'best_nmse', 'spacing_range', 'pilot_alpha_range', 'snr_range',
             'val_config'} <= set(res)
     assert np.array_equal(res['best_nmse'], np.min(np.mean(nmse_log, -1), -1)) and res['val_config'].data.num_pilots == 38
-    again, _, _ = test_score.main(argv + ['--no_graph'])            # same seed => same result, graph or eager
+    again, _, _ = test_score.main(argv + ['--no_graph', '--save_channels', '1'])   # same seed => same result, graph or eager
     assert np.array_equal(again, nmse_log)
+    res = torch.load(tmp_path / 'results/score/train-CDL-C_test-CDL-C/results.pt', weights_only=False)
+    assert res['saved_H'].shape == (1, 1, 17, 4, 64, 16) and res['saved_H'].dtype == np.complex64
+    assert np.isfinite(res['saved_H'].view(np.float32)).all()
     # low SNR must not beat high SNR after the same number of steps on the same channels (sanity of per-SNR scalars)
     assert not np.array_equal(nmse_log[0, 0, 0], nmse_log[0, 0, -1])
 
@@ -231,3 +234,28 @@ def test_cli_tune_hparams_drop_in_outputs(net64, tmp_path, monkeypatch):
     assert {'nmse_log', 'avg_nmse', 'best_nmse', 'best_alpha_snr', 'best_beta_snr', 'snr_range', 'alpha_step_range',
             'beta_noise_range', 'config', 'args'} <= set(res)
     assert set(ba) <= {3e-11, 3e-10} and set(bb) <= {0.1, 0.01}
+
+
+def test_cli_test_mmse_posterior_mean(net64, tmp_path, monkeypatch):
+    """``python -m score_based_channels_amd.test_mmse``: chains of a sample share its measurement, the
+    stored NMSE log is the NMSE of the stored chains, early stopping follows the hyper-parameter file."""
+    import torch
+    from score_based_channels_amd import test_mmse
+    monkeypatch.chdir(tmp_path)
+    S = 19
+    torch.save({'best_step_idx': np.full((1, S), 3e-11), 'best_noise_idx': np.full((1, S), 0.01),
+                'best_stop_idx': np.full((1, S), 3, dtype=np.int64)}, tmp_path / 'our_hyperparams_CDL-C.pt')
+    argv = ['--synthetic', '--synthetic_weights', '2024', '--num_levels', '2', '--kept_samples', '3', '--mmse_avg', '4',
+            '--seed', '5']
+    log, saved, mmse_nmse = test_mmse.main(argv)
+    assert log.shape == (1, 1, S, 6, 3, 4) and saved.shape == (1, 1, S, 3, 4, 64, 16) and mmse_nmse.shape == (1, 1, S, 3)
+    assert np.all(log[0, 0, :, 4:] == 0) and np.all(log[0, 0, :, :4] > 0)          # stopped after step index 3
+    res = torch.load(tmp_path / 'TWC_rebuttal_MMSE_aug6_seed4321/model_CDL-C_channel_CDL-C.pt', weights_only=False)
+    assert {'oracle_log', 'oracle_H', 'saved_H', 'snr_range', 'spacing_range', 'pilot_alpha_range', 'config',
+            'val_config', 'args'} <= set(res)
+    H = res['oracle_H']
+    nm = np.sum(np.abs(saved[0, 0] - H[None, :, None]) ** 2, axis=(-1, -2)) / np.sum(np.abs(H) ** 2, axis=(-1, -2))[None, :, None]
+    assert np.allclose(nm, log[0, 0, :, 3], rtol=1e-4)                                # log row at the stop == stored chains
+    assert not np.allclose(saved[0, 0, 0, 0, 0], saved[0, 0, 0, 0, 1])                # chains differ (own start + noise)
+    adj, _, _ = test_mmse.main(argv + ['--start_point', 'Adjoint', '--no_graph'])
+    assert np.isfinite(adj).all() and not np.array_equal(adj, log)
