@@ -173,7 +173,8 @@ def test_inorm_stats_matches_oracle(gpu, C_, B, H, W):
     assert rel_err(y_ref, O.instance_norm_plus(x.transpose(0, 3, 1, 2), agb[0], agb[1], agb[2]).transpose(0, 2, 3, 1)) < 1e-5
 
 
-@pytest.mark.parametrize('C_,B,H,W,elu', [(32, 3, 64, 16, True), (64, 5, 16, 4, False), (128, 9, 8, 2, True)])
+@pytest.mark.parametrize('C_,B,H,W,elu', [(32, 3, 64, 16, True), (64, 5, 16, 4, False), (128, 9, 8, 2, True),
+                                          (64, 4, 32, 8, True), (32, 2, 32, 8, False), (32, 1, 256, 64, True)])
 def test_maxpool5_matches_oracle(gpu, C_, B, H, W, elu):
     torch, _lib = gpu
     from score_based_channels_amd import plan as P
