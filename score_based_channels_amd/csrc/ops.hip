@@ -8,39 +8,48 @@ namespace sbc {
 // ------------------------------------------------------------------------------------------------ begin conv
 // h = 2x - 1 (ncsnv2.py:270-273), then begin_conv: Conv2d(2 -> COUT, 3x3, pad 1) + bias (ncsnv2.py:209,275).
 // Zero padding applies to h, not x.  The kernel is bound by its 128-byte-per-pixel output stream, so the arithmetic
-// has to stay out of the way: a thread owns one channel quad (its 72 weights live in registers) and walks PPT pixels
-// 32 apart, so that every store instruction of a workgroup covers 32 consecutive pixels x 128 bytes; the 3x3x2 input
-// patch comes through the vector cache (8 threads share each address).
-template <bool P2>
+// has to stay out of the way: a workgroup owns a block of rows of one sample (256 pixels), stages h for those rows +
+// 1 halo row/column (zeros outside the image) in LDS, and a thread owns one channel quad (its 72 weights live in
+// registers) and walks 8 pixels 32 apart: every store instruction of a workgroup covers 32 consecutive pixels x
+// 128 bytes, and the nine taps of a pixel are 8-byte LDS reads shared by the 8 threads of the pixel.
 __global__ __launch_bounds__(256) void begin_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ out,
-                                                          int total_px, int H, int W, int hsh, int wsh) {
-    constexpr int COUT = 32, PPT = 8;
-    const int c4 = threadIdx.x & 7, slot = threadIdx.x >> 3;
+                                                          int H, int W, int rows_per_wg) {
+    constexpr int COUT = 32;
+    extern __shared__ __attribute__((aligned(16))) float2 hs[];       // [(rows_per_wg + 2)][W + 2]
+    const int tid = threadIdx.x, c4 = tid & 7, slot = tid >> 3;
+    const int wgs_per_sample = H / rows_per_wg;
+    const int n = blockIdx.x / wgs_per_sample, r0 = (blockIdx.x % wgs_per_sample) * rows_per_wg;
+    const int WP = W + 2;
+    for (int i = tid; i < (rows_per_wg + 2) * WP; i += 256) {
+        const int rr = i / WP, cc = i - rr * WP;
+        const int r = r0 - 1 + rr, c = cc - 1;
+        float2 v = make_float2(0.f, 0.f);                            // zero padding applies to h = 2x - 1
+        if (r >= 0 && r < H && c >= 0 && c < W) {
+            v = *reinterpret_cast<const float2*>(x + (((size_t)n * H + r) * W + c) * 2);
+            v.x = 2.f * v.x - 1.f;
+            v.y = 2.f * v.y - 1.f;
+        }
+        hs[i] = v;
+    }
     float4 wr[18];                                               // [ci*9 + kh*3 + kw] for channels c4*4 .. c4*4+3
 #pragma unroll
     for (int k = 0; k < 18; ++k)                                 // torch order [co][ci][kh][kw]
         wr[k] = make_float4(w[(c4 * 4 + 0) * 18 + k], w[(c4 * 4 + 1) * 18 + k], w[(c4 * 4 + 2) * 18 + k],
                             w[(c4 * 4 + 3) * 18 + k]);
     const float4 b4 = *reinterpret_cast<const float4*>(bias + c4 * 4);
-    const Dims<P2> d{H, W, H * W, hsh, wsh};
+    __syncthreads();
+    const int npx = rows_per_wg * W;
+    float* obase = out + ((size_t)n * H + r0) * W * COUT + c4 * 4;
 #pragma unroll 2
-    for (int it = 0; it < PPT; ++it) {
-        const int px = (blockIdx.x * PPT + it) * 32 + slot;
-        if (px >= total_px) return;
-        const int row = d.div_w(px), wq = d.mod_w(px), h = d.mod_h(row);
+    for (int lp = slot; lp < npx; lp += 32) {
+        const int rr = lp / W, cc = lp - rr * W;                     // local row / column
         float4 acc = b4;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-                const int hh = h + kh - 1, ww = wq + kw - 1;
-                float2 v = make_float2(0.f, 0.f);                // zero padding applies to h = 2x - 1
-                if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
-                    v = *reinterpret_cast<const float2*>(x + ((size_t)(row + kh - 1) * W + ww) * 2);
-                    v.x = 2.f * v.x - 1.f;
-                    v.y = 2.f * v.y - 1.f;
-                }
+                const float2 v = hs[(rr + kh) * WP + cc + kw];
                 const float4 w0 = wr[kh * 3 + kw], w1 = wr[9 + kh * 3 + kw];
                 acc.x = fmaf(w0.x, v.x, fmaf(w1.x, v.y, acc.x));
                 acc.y = fmaf(w0.y, v.x, fmaf(w1.y, v.y, acc.y));
@@ -48,23 +57,21 @@ __global__ __launch_bounds__(256) void begin_conv_kernel(const float* __restrict
                 acc.w = fmaf(w0.w, v.x, fmaf(w1.w, v.y, acc.w));
             }
         }
-        st_stream(out + (size_t)px * COUT + c4 * 4, acc);
+        st_stream(obase + (size_t)lp * COUT, acc);
     }
 }
 
 int launch_begin_conv(const sbc_op& op, hipStream_t stream) {
     SBC_REQUIRE(op.in && op.out && op.weight && op.bias, "begin_conv: in/out/weight/bias must be set");
     SBC_REQUIRE(op.cin == 2 && op.cout == 32, "begin_conv: cin=%d cout=%d (kernel is built for 2 -> 32)", op.cin, op.cout);
-    SBC_REQUIRE((long)op.B * op.H * op.W < (1L << 31) / 64, "begin_conv: tensor too large for 32-bit pixel index");
-    const int total_px = op.B * op.H * op.W;
-    const int grid = (total_px + 255) / 256;
-    const int hsh = log2_exact(op.H), wsh = log2_exact(op.W);
-    if (hsh >= 0 && wsh >= 0)
-        hipLaunchKernelGGL(begin_conv_kernel<true>, dim3(grid), dim3(256), 0, stream, (const float*)op.in,
-                           (const float*)op.weight, (const float*)op.bias, (float*)op.out, total_px, op.H, op.W, hsh, wsh);
-    else
-        hipLaunchKernelGGL(begin_conv_kernel<false>, dim3(grid), dim3(256), 0, stream, (const float*)op.in,
-                           (const float*)op.weight, (const float*)op.bias, (float*)op.out, total_px, op.H, op.W, hsh, wsh);
+    // rows per workgroup: ~256 pixels, a divisor of H
+    int rows = 256 / op.W > 0 ? 256 / op.W : 1;
+    if (rows > op.H) rows = op.H;
+    while (op.H % rows) --rows;
+    const size_t lds = (size_t)(rows + 2) * (op.W + 2) * sizeof(float2);
+    SBC_REQUIRE(lds <= 64 * 1024, "begin_conv: image row of %d pixels too wide", op.W);
+    hipLaunchKernelGGL(begin_conv_kernel, dim3(op.B * (op.H / rows)), dim3(256), lds, stream, (const float*)op.in,
+                       (const float*)op.weight, (const float*)op.bias, (float*)op.out, op.H, op.W, rows);
     SBC_CHECK_HIP(hipGetLastError());
     return SBC_OK;
 }
