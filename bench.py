@@ -70,8 +70,7 @@ def main():
     ap.add_argument('--conv-mode', default='bf16x3', choices=['bf16x3', 'f32'],
                     help='convolution multiplier (scorenet.CONV_MODES)')
     ap.add_argument('--streams', type=int, default=1,
-                    help='split the trajectories into this many concurrent sub-batch streams (the CLIs use 2: +5-7 %%, '
-                         'but overlapping kernels make per-kernel durations, and hence the roofline entry, ill-defined)')
+                    help='split the trajectories into this many concurrent sub-batch streams (DESIGN.md section 7)')
     args = ap.parse_args()
 
     import torch

@@ -30,16 +30,16 @@ def shared_init(n_channels, nt, nr, seed, combo):
 
 
 def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, beta_noise, levels, steps_each,
-                     seed, init, traj_base=0, max_batch=4096, use_graph=True, rank=0, world=1, n_streams=2,
+                     seed, init, traj_base=0, max_batch=4096, use_graph=True, rank=0, world=1, n_streams=1,
                      return_final=False, n_steps=None, dc_boost=1.0, init_index=None, Y=None, y_index=None):
     """Run ``T = len(h_index)`` trajectories, sharded over ``world`` ranks; returns the full NMSE log
     ``[n_steps, T]`` (float32 numpy, identical on every rank).  ``init``: ``[nH, Nt, Nr]`` complex64 initial
     estimates indexed by ``h_index``.  Trajectory ``t`` draws its noise from Philox stream ``traj_base + t``.
 
-    A chunk is run as ``n_streams`` independent sub-batches on concurrent HIP streams: a quarter of the step is
-    spent in launches of the low-resolution levels that have fewer workgroups than the chip has CUs, and those of one
-    sub-batch overlap with the full-resolution launches of the other (+7 % at two streams on MI355X, none beyond).
-    Results do not depend on the split (per-trajectory noise keys, per-sample normalisation).
+    ``n_streams`` > 1 runs a chunk as independent sub-batches on concurrent HIP streams (results do not depend on the
+    split: per-trajectory noise keys, per-sample normalisation).  Measured on MI355X: +5 % at two streams over 30
+    steps, but nothing with hipGraph replay and a loss with eager launches over hundreds of steps (the host queues one
+    stream's launches long before the other's), so the default is one stream.
 
     ``init_index`` (default ``h_index``) selects the initial estimate of each trajectory; ``Y`` ``[nY, Np, Nr]`` with
     ``y_index`` supplies measurements shared by several trajectories instead of synthesising one per trajectory
