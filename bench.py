@@ -197,7 +197,7 @@ def main():
                 # fp32-exact products on the bf16 matrix cores: 6 bf16 MFMAs per fp32 product block, so the roofline of
                 # the instruction the kernel issues is the dense bf16 MFMA peak / 6
                 peak = PEAK_BF16_MFMA_TFLOPS / 6.0
-                kname = ('conv_wx3_kernel<32, 32, 1, true, 3, true, 1>: the 18 3x3 32->32 convolutions at 64x16 of every step (%d '
+                kname = ('conv_wx3_kernel<32, 32, 1, true, 3, true, 1, 1>: the 18 3x3 32->32 convolutions at 64x16 of every step (%d '
                          'tagged launches, avg %.1f us).  achieved = direct-convolution FLOPs (2*9*32*32 per pixel) / '
                          'time; peak = dense bf16 MFMA peak %.1f / 6 (fp32 operands as three exact bf16 terms, six bf16 '
                          'MFMAs per product block); the kernel executes 16/36 of the products (Winograd F(2x2,3x3)), '

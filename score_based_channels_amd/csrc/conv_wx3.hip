@@ -24,8 +24,11 @@ namespace sbc {
 // NBP: output blocks (32 channels) per phase.  (One workgroup per (tile, phase) was tried for the low-resolution
 // levels, where a launch has fewer tiles than the chip has CUs: slower, because staging the 128-channel tile dominates
 // there and would be repeated per phase.)
-template <int CIN, int COUT, int MB, bool P2, int WPE, bool TOP, int NBP>
-__global__ __launch_bounds__(256, WPE) void conv_wx3_kernel(ConvParams p) {
+// NG: wave groups of four waves (one per transform row).  With two groups the phases (output blocks) are dealt between
+// them, so a 128-output-channel layer on the 8x2 level -- a launch with fewer workgroups than CUs, i.e. pure
+// single-workgroup latency -- walks two phases per group instead of four, and twice the threads stage the tile.
+template <int CIN, int COUT, int MB, bool P2, int WPE, bool TOP, int NBP, int NG>
+__global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
     constexpr int TM = 128 * MB;                 // output pixels per workgroup
     constexpr int NTW = 32 * MB;                 // Winograd tiles (2x2 output blocks) per workgroup
     constexpr int S = CIN + 4;
@@ -36,13 +39,15 @@ __global__ __launch_bounds__(256, WPE) void conv_wx3_kernel(ConvParams p) {
     constexpr int PH = NBLK / NBP;               // phases (K loops, then the outputs of NBP blocks)
     static_assert(MB == 1 || NBP == 1, "two tile blocks only with one output block per phase (registers)");
     constexpr int TS = 36;                       // floats per (tile) row of a T plane: 32 channels + 4 pad
-    constexpr int NTHREADS = 256;
+    constexpr int NTHREADS = 256 * NG;           // staging; everything after it works per group of 256
+    static_assert(NG == 1 || (COUT / 32 / NBP) % NG == 0, "phases must divide evenly between the wave groups");
     constexpr int NPF_FULL = ((TM + 32) * (CIN / 4) + NTHREADS - 1) / NTHREADS;
     constexpr int NPF = NPF_FULL <= 10 ? NPF_FULL : 10;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int xi = __builtin_amdgcn_readfirstlane(tid >> 6);         // transform row of this wave
+    const int tid = threadIdx.x, lane = tid & 63, gtid = tid & 255;
+    const int xi = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);   // transform row of this wave
+    const int grp = __builtin_amdgcn_readfirstlane(tid >> 8);        // wave group
     const int H = p.H, W = p.W, HW = H * W;
     const Dims<P2> dm{H, W, HW, p.hsh, p.wsh};
     const int khalf = 8 * (lane >> 5);
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(256, WPE) void conv_wx3_kernel(ConvParams p) {
         stage_commit<CIN, NTHREADS, NPF, P2>(lds, pf, p.in, st_lds, p.flags, g, dm, tid, 0);
     }
     // T planes [xi][b][tile][TS]: overlay the staged tile when there is a single output block, else live behind it
-    float* const tl = NBLK == 1 ? lds : lds + (size_t)(g.multi ? TM + 1 : TM + 2 * W + 1) * S;
+    float* const tl = (NBLK == 1 ? lds : lds + (size_t)(g.multi ? TM + 1 : TM + 2 * W + 1) * S) + (size_t)grp * 8 * NTW * 36;
 
     // B^T rows: xi=0: d0 - d2, xi=1: d1 + d2, xi=2: d2 - d1, xi=3: d1 - d3   ->  R = d[ia] + sgn * d[ib]
     const int ia = xi == 0 ? 0 : xi == 2 ? 2 : 1;
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(256, WPE) void conv_wx3_kernel(ConvParams p) {
     }
     __syncthreads();                                                  // staged tile visible
 
-    for (int ph = 0; ph < PH; ++ph) {
+    for (int ph = grp; ph < PH; ph += NG) {
         f32x16 T[MB][NBP][2];
         f32x16 acc[NBP][4];
         // split U: [(xi*4 + nu)][kg][nb][term][lane] 16-byte fragments
@@ -106,10 +111,10 @@ __global__ __launch_bounds__(256, WPE) void conv_wx3_kernel(ConvParams p) {
         // ring of SETS statically indexed register sets over the sequence g = step * 4 + nu), so their L2 latency hides
         // behind the MFMAs and splits in between: three columns ahead with one output block per phase, one column
         // ahead with two (twice the MFMAs per column; 48 registers either way).
-        constexpr int SETS = NBP == 1 ? 4 : 2, D = SETS - 1, NG = MB * KG * 4;
+        constexpr int SETS = NBP == 1 ? 4 : 2, D = SETS - 1, NSEQ = MB * KG * 4;
         bf16x8 uB[SETS][NBP][3];
         auto u_load = [&](int gq) {                                   // gq is a compile-time constant at every call
-            const int gg = gq % NG, nu_g = gg & 3, kg_g = (gg >> 2) % KG;
+            const int gg = gq % NSEQ, nu_g = gg & 3, kg_g = (gg >> 2) % KG;
 #pragma unroll
             for (int q = 0; q < NBP; ++q)
 #pragma unroll
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(256, WPE) void conv_wx3_kernel(ConvParams p) {
             __syncthreads();
             // finish: one (tile, channel quad) per thread and round
 #pragma unroll 1
-            for (int task = tid; task < NTW * 8; task += NTHREADS) {
+            for (int task = gtid; task < NTW * 8; task += 256) {
                 const int t = task >> 3, c4 = task & 7;
                 const int co = nb * 32 + c4 * 4;
                 float4 y[2][2];                                       // [a][b]
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(256, WPE) void conv_wx3_kernel(ConvParams p) {
 #pragma unroll
                     for (int b = 0; b < 2; ++b) st_stream(p.out + o[a][b], y[a][b]);
             }
-            if (nb + 1 < NBLK) __syncthreads();                        // the T planes are rewritten for the next block
+            if (nb + NG < NBLK) __syncthreads();                       // the T planes are rewritten for the next block
         }
     }
 }
@@ -323,7 +328,11 @@ static int launch_wx3(const ConvParams& p, hipStream_t stream, bool dry) {
     const int HW = p.H * p.W;
     const bool multi = TM >= HW;
     const size_t staged = (size_t)(multi ? TM + 1 : TM + 2 * p.W + 1) * S * sizeof(float);
-    const size_t tplanes = (size_t)8 * 32 * MB * 36 * sizeof(float);
+    // two wave groups where a layer has four output blocks and the launch cannot fill the chip anyway
+    constexpr int NGMAX = (NBLK == 4 && MB == 1) ? 2 : 1;
+    const int ntiles = (p.total_px + TM - 1) / TM;
+    const int ng = (NGMAX == 2 && ntiles <= 512) ? 2 : 1;
+    const size_t tplanes = (size_t)8 * 32 * MB * 36 * sizeof(float) * ng;
     const size_t lds = NBLK == 1 ? max(staged, tplanes) : staged + tplanes;
     // + the statistics of the samples of a tile: [samples][3][CIN] floats
     const size_t nsamp = multi ? TM / HW : 1;
@@ -333,11 +342,11 @@ static int launch_wx3(const ConvParams& p, hipStream_t stream, bool dry) {
     constexpr int WPE = (CIN == 32 && COUT == 32 && MB == 1) ? 3 : 2;
     constexpr int NBP_BIG = NBLK == 2 ? 2 : 1;
     const bool top = (CIN == 32 && COUT == 32) && p.H * p.W >= 1024;
-    const int ntiles = (p.total_px + TM - 1) / TM;
-    auto kern = top ? conv_wx3_kernel<CIN, COUT, MB, true, WPE, (CIN == 32 && COUT == 32), NBP_BIG>
-                    : conv_wx3_kernel<CIN, COUT, MB, true, WPE, false, NBP_BIG>;
-    static size_t lds_attr2[2] = {0, 0};   // per kernel symbol
-    size_t& lds_attr = lds_attr2[top ? 1 : 0];
+    auto kern = ng == 2 ? conv_wx3_kernel<CIN, COUT, MB, true, 2, false, (NGMAX == 2 ? 2 : NBP_BIG), NGMAX>
+              : top     ? conv_wx3_kernel<CIN, COUT, MB, true, WPE, (CIN == 32 && COUT == 32), NBP_BIG, 1>
+                        : conv_wx3_kernel<CIN, COUT, MB, true, WPE, false, NBP_BIG, 1>;
+    static size_t lds_attr3[3] = {0, 0, 0};   // per kernel symbol
+    size_t& lds_attr = lds_attr3[ng == 2 ? 2 : top ? 1 : 0];
     if (lds_all > lds_attr) {
         SBC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all));
@@ -346,7 +355,7 @@ static int launch_wx3(const ConvParams& p, hipStream_t stream, bool dry) {
     if (dry) return SBC_OK;
     ConvParams q = p;
     q.stats_off = (int)stats_off;
-    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), lds_all, stream, q);
+    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256 * ng), lds_all, stream, q);
     SBC_CHECK_HIP(hipGetLastError());
     return SBC_OK;
 }

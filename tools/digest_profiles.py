@@ -3,7 +3,7 @@ import collections, csv, json, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 R = os.path.join(ROOT, 'gpurun_out', 'profile_passes') + '/'
 P = os.path.join(ROOT, 'profiles') + '/'
-DOMINANT = 'conv_wx3_kernel<32, 32, 1, true, 3, true, 1>'
+DOMINANT = 'conv_wx3_kernel<32, 32, 1, true, 3, true, 1, 1>'
 
 rows = list(csv.reader(open(R + 'stats/s_kernel_stats.csv')))
 with open(P + 'r01_kernel_stats_bench_steps10.csv', 'w', newline='') as f:
