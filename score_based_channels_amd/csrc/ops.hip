@@ -417,11 +417,13 @@ __device__ __forceinline__ float2 complex_normal(uint64_t seed, int64_t traj, in
 // X <- X + alpha (S - G / dc_div) + noise_scale * n  (:160-165),  nmse[step][b] = |X - H|^2 / |H|^2  (:168-170).
 // X and R live in LDS; P (per-sample pilots, L2 resident) is read through the vector cache: in both products the
 // 16 lanes that share a pilot entry read the same address.
-__global__ __launch_bounds__(256) void langevin_kernel(sbc_langevin a, int B, int x_in_lds) {
+__global__ __launch_bounds__(256) void langevin_kernel(sbc_langevin a, int B, int x_in_lds, int p_in_lds) {
     extern __shared__ __attribute__((aligned(16))) float2 sm[];
     const int Nt = a.Nt, Nr = a.Nr, Np = a.Np;
     float2* Rs = sm;                   // [Np*Nr]
     float2* Xl = sm + Np * Nr;         // [Nt*Nr] when it fits (64x16: 8 KB); large arrays read X through L1/L2
+    float2* Pl = Xl + Nt * Nr;         // [Np*Nt] when it fits (38x64: 19 KB): both products walk P (2 x 311 KB of 8-byte
+                                       // vector-cache reads per trajectory otherwise, which made the kernel TA-bound)
     __shared__ float red[2][4];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int step = *a.step;
@@ -430,11 +432,16 @@ __global__ __launch_bounds__(256) void langevin_kernel(sbc_langevin a, int B, in
     const float2* Y = reinterpret_cast<const float2*>(a.Y) + (size_t)b * Np * Nr;
     const float2* Ht = reinterpret_cast<const float2*>(a.Htrue) + (size_t)(a.h_index ? a.h_index[b] : b) * Nt * Nr;
     const float2* Sc = reinterpret_cast<const float2*>(a.score) + (size_t)b * Nt * Nr;
+    if (p_in_lds) {
+        const float4* src = reinterpret_cast<const float4*>(P);          // Np*Nt is even: 16-byte copies
+        for (int e = tid; e < Np * Nt / 2; e += 256) reinterpret_cast<float4*>(Pl)[e] = src[e];
+    }
     if (x_in_lds) {
         for (int e = tid; e < Nt * Nr; e += 256) Xl[e] = X[e];
-        __syncthreads();
     }
+    if (x_in_lds || p_in_lds) __syncthreads();
     const float2* Xs = x_in_lds ? Xl : X;
+    if (p_in_lds) P = Pl;
     for (int o = tid; o < Np * Nr; o += 256) {
         const int m = o / Nr, r = o - m * Nr;
         float2 acc = make_float2(0.f, 0.f);
@@ -495,7 +502,9 @@ int launch_langevin(const sbc_op& op, const sbc_langevin& a, hipStream_t stream,
     if (rc) return rc;
     const size_t lds_all = (size_t)(a.Nt + a.Np) * a.Nr * sizeof(float2);
     const int x_in_lds = lds_all <= 64 * 1024;
-    const size_t lds = x_in_lds ? lds_all : (size_t)a.Np * a.Nr * sizeof(float2);
+    const size_t lds_p = (size_t)a.Np * a.Nt * sizeof(float2);
+    const int p_in_lds = x_in_lds && (a.Np * a.Nt) % 2 == 0 && lds_all + lds_p <= 40 * 1024;   // keeps 4 workgroups per CU
+    const size_t lds = (x_in_lds ? lds_all : (size_t)a.Np * a.Nr * sizeof(float2)) + (p_in_lds ? lds_p : 0);
     static size_t lds_attr = 0;
     if (lds > lds_attr) {
         SBC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(langevin_kernel),
@@ -503,7 +512,7 @@ int launch_langevin(const sbc_op& op, const sbc_langevin& a, hipStream_t stream,
         lds_attr = lds;
     }
     if (dry) return SBC_OK;
-    hipLaunchKernelGGL(langevin_kernel, dim3(op.B), dim3(256), lds, stream, a, op.B, x_in_lds);
+    hipLaunchKernelGGL(langevin_kernel, dim3(op.B), dim3(256), lds, stream, a, op.B, x_in_lds, p_in_lds);
     SBC_CHECK_HIP(hipGetLastError());
     return SBC_OK;
 }
