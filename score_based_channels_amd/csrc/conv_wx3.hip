@@ -53,14 +53,7 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
     const int khalf = 8 * (lane >> 5);
     const int col = lane & 31, rhalf = 4 * (lane >> 5);
 
-    // Workgroup ids are dealt round-robin over the 8 XCDs; give every XCD a contiguous run of tiles so that the halo rows
-    // two neighbouring tiles share are read through the same L2.
-    int tile_id = blockIdx.x;
-    {
-        const int per = ((int)gridDim.x + 7) >> 3, cand = (tile_id & 7) * per + (tile_id >> 3);
-        if ((int)gridDim.x >= 64 && (gridDim.x & 7) == 0) tile_id = cand;
-    }
-    const TileGeom g = tile_geom(tile_id, TM, p.B, dm, 1);
+    const TileGeom g = tile_geom(xcd_tile(blockIdx.x, gridDim.x), TM, p.B, dm, 1);
     {
         float4 pf[NPF];
         stage_issue<CIN, NTHREADS, NPF>(pf, p.in, g, W, tid);

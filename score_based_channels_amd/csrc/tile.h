@@ -45,6 +45,13 @@ struct Dims {
     __device__ __forceinline__ int div_hw(int x) const { return P2 ? x >> (hsh + wsh) : x / HW; }
 };
 
+// Workgroup ids are dealt round-robin over the 8 XCDs of the chip (each with its own L2).  Mapping id -> tile so that
+// every XCD walks a contiguous run of tiles lets the halo rows two neighbouring tiles share come through the same L2.
+__device__ __forceinline__ int xcd_tile(int id, int n) {
+    if (n < 64 || (n & 7)) return id;
+    return (id & 7) * (n >> 3) + (id >> 3);
+}
+
 struct TileGeom {
     int p0;        // first output pixel (flattened n*H*W + h*W + w)
     int rs0;       // first staged global row (n*H + h)
