@@ -22,9 +22,8 @@
 // offsets come from a bit mask, ELU uses the hardware exponential, taps that are outside the image for a whole
 // wave are skipped, and all epilogue traffic is 16 bytes per lane.
 //
-// A persistent variant (several tiles per workgroup, next tile + residual prefetched into registers across the
-// MFMA loop, 3x3 32->32 weights resident in LDS) was built and measured in round 1: it needs ~250 VGPRs, i.e. two
-// workgroups per CU instead of three, and was 3 % slower end to end than this build.
+// Experiments around this kernel that did not pay off (persistent workgroups, weights in LDS, staggering, ...) are
+// recorded in DESIGN.md section 5.
 #include <stdlib.h>
 #include <string.h>
 #include "conv_epilogue.h"

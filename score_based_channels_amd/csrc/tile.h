@@ -82,7 +82,7 @@ __device__ __forceinline__ TileGeom tile_geom(int tile, int TM, int B, const Dim
     return g;
 }
 
-// Staging is split in two so a persistent workgroup can request tile i+1 before it computes tile i:
+// Staging is split in two so that other requests (statistics, prefetches) can be issued between the loads and their use:
 //   stage_issue   requests up to NPF 16-byte chunks per thread of the staged rows (raw values, registers only);
 //   stage_commit  applies the prologue (stats = [B][3][CIN]: mu, scale, shift; ELU) and writes the LDS tile; chunks
 //                 beyond NPF * NTHREADS (unusually wide halos) are fetched synchronously here.

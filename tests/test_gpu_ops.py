@@ -62,8 +62,8 @@ CONV_CASES = [
     (32, 32, 3, 1, 3, 24, 16, 'norm_elu_res'),     # H not a power of two: generic index math
     (32, 64, 3, 1, 2, 48, 8, 'norm_elu_pool_res'),
     (64, 64, 3, 2, 5, 24, 8, 'up_same'),
-    (32, 32, 3, 1, 900, 32, 8, 'crp2'),            # persistent build (several tiles per workgroup), weights in LDS
-    (64, 64, 3, 1, 2500, 32, 8, 'norm_elu_res'),   # persistent build, weights from L2
+    (32, 32, 3, 1, 900, 32, 8, 'crp2'),            # many tiles at 32x8: several residency rounds per CU
+    (64, 64, 3, 1, 2500, 32, 8, 'norm_elu_res'),   # > 2^16 pixels x 64 channels: XCD-contiguous tile order active
 ]
 
 
