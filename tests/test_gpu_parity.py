@@ -259,3 +259,22 @@ def test_cli_test_mmse_posterior_mean(net64, tmp_path, monkeypatch):
     assert not np.allclose(saved[0, 0, 0, 0, 0], saved[0, 0, 0, 0, 1])                # chains differ (own start + noise)
     adj, _, _ = test_mmse.main(argv + ['--start_point', 'Adjoint', '--no_graph'])
     assert np.isfinite(adj).all() and not np.array_equal(adj, log)
+
+
+@pytest.mark.parametrize('nt,nr', [(16, 64), (32, 32), (128, 8)])
+def test_forward_other_geometries_match_oracle(nt, nr, weights64):
+    """Array shapes the reference goldens do not cover (wide images, square images, 8-column images): every level still
+    tiles, and the forward agrees with the (reference-pinned) oracle in both multiplier modes."""
+    import torch
+    from oracle import ncsnv2_oracle
+    from score_based_channels_amd.config import default_config
+    from score_based_channels_amd.scorenet import ScoreNet
+    _, sd = weights64                                     # weights do not depend on the array shape
+    cfg = default_config(image_size=(nr, nt))
+    x = np.random.default_rng(nt * 1000 + nr).standard_normal((3, 2, nt, nr)).astype(np.float32)
+    labels = np.array([0, 1155, 2310])
+    ref = ncsnv2_oracle.score_forward(sd, x, labels)
+    for mode in ('bf16x3', 'f32'):
+        net = ScoreNet(cfg, conv_mode=mode).cuda().load_state_dict(sd).eval()
+        out = net(torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda())
+        assert rel_err(out.cpu().numpy(), ref) < 2e-5, (mode, nt, nr)
