@@ -328,10 +328,11 @@ static int launch_wx3(const ConvParams& p, hipStream_t stream, bool dry) {
     const int HW = p.H * p.W;
     const bool multi = TM >= HW;
     const size_t staged = (size_t)(multi ? TM + 1 : TM + 2 * p.W + 1) * S * sizeof(float);
-    // two wave groups where a layer has four output blocks and the launch cannot fill the chip anyway
-    constexpr int NGMAX = (NBLK == 4 && MB == 1) ? 2 : 1;
+    // two wave groups where a layer has two or four output blocks and the launch cannot fill the chip anyway (each group
+    // then walks half of the blocks: one phase of two blocks for 128 output channels, one block for 64)
+    constexpr int NGMAX = ((NBLK == 4 || NBLK == 2) && MB == 1) ? 2 : 1;
     const int ntiles = (p.total_px + TM - 1) / TM;
-    const int ng = (NGMAX == 2 && ntiles <= 512) ? 2 : 1;
+    const int ng = (NGMAX == 2 && ntiles <= (NBLK == 4 ? 512 : 256)) ? 2 : 1;
     const size_t tplanes = (size_t)8 * 32 * MB * 36 * sizeof(float) * ng;
     const size_t lds = NBLK == 1 ? max(staged, tplanes) : staged + tplanes;
     // + the statistics of the samples of a tile: [samples][3][CIN] floats
@@ -342,7 +343,7 @@ static int launch_wx3(const ConvParams& p, hipStream_t stream, bool dry) {
     constexpr int WPE = (CIN == 32 && COUT == 32 && MB == 1) ? 3 : 2;
     constexpr int NBP_BIG = NBLK == 2 ? 2 : 1;
     const bool top = (CIN == 32 && COUT == 32) && p.H * p.W >= 1024;
-    auto kern = ng == 2 ? conv_wx3_kernel<CIN, COUT, MB, true, 2, false, (NGMAX == 2 ? 2 : NBP_BIG), NGMAX>
+    auto kern = ng == 2 ? conv_wx3_kernel<CIN, COUT, MB, true, 2, false, (NBLK == 4 ? 2 : 1), NGMAX>
               : top     ? conv_wx3_kernel<CIN, COUT, MB, true, WPE, (CIN == 32 && COUT == 32), NBP_BIG, 1>
                         : conv_wx3_kernel<CIN, COUT, MB, true, WPE, false, NBP_BIG, 1>;
     static size_t lds_attr3[3] = {0, 0, 0};   // per kernel symbol
