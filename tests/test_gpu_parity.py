@@ -278,3 +278,34 @@ def test_forward_other_geometries_match_oracle(nt, nr, weights64):
         net = ScoreNet(cfg, conv_mode=mode).cuda().load_state_dict(sd).eval()
         out = net(torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda())
         assert rel_err(out.cpu().numpy(), ref) < 2e-5, (mode, nt, nr)
+
+
+def test_full_batch_is_the_sum_of_its_trajectories(net64):
+    """BASELINE config 2 size (100 channels x 17 SNR points = 1700 lock-step trajectories): a trajectory's estimate and
+    NMSE log do not depend on what else is in the batch -- bit for bit, although tiles of the low-resolution levels
+    hold 2 or 8 samples.  Together with the small-batch goldens this pins the full-size run."""
+    import torch
+    from score_based_channels_amd import synth
+    from score_based_channels_amd.ald import AldBatch, snr_to_noise
+    nch, nt, nr, npil = 100, 64, 16, 38
+    raw = synth.generate_channels('CDL-C', nch, nt, nr, 0.5, seed=11)
+    H = np.conj(np.transpose(raw / np.std(raw), (0, 2, 1))).astype(np.complex64)
+    Pm = np.conj(np.transpose(synth.qpsk_pilots(np.random.default_rng(12), nch, nt, npil), (0, 2, 1)))
+    snr = np.arange(-10, 32.5, 2.5)
+    idx = np.tile(np.arange(nch), len(snr))
+    ln = np.repeat(snr_to_noise(snr, nt), nch)
+    init = torch.randn(nch, nt, nr, dtype=torch.complex64, generator=torch.Generator().manual_seed(5))
+
+    def run(sel):
+        ald = AldBatch(net64, H, Pm, idx[sel], idx[sel], ln[sel], levels=[0, 1155], steps_each=3, seed=9, traj_id=sel)
+        ald.set_init(init[torch.from_numpy(idx[sel])])
+        ald.synthesize_measurements()
+        ald.run()
+        torch.cuda.synchronize()
+        return ald.X.cpu().numpy(), ald.nmse_log().cpu().numpy()
+    allsel = np.arange(len(idx))
+    Xa, La = run(allsel)
+    assert np.isfinite(La).all() and La.shape == (6, 1700)
+    pick = np.array([0, 777, 1203, 1699])
+    Xb, Lb = run(pick)
+    assert np.array_equal(Xa[pick], Xb) and np.array_equal(La[:, pick], Lb)
