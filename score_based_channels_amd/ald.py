@@ -129,6 +129,14 @@ class AldBatch:
     def _stream(self):
         return torch.cuda.current_stream(self.net.device).cuda_stream
 
+    def close(self):
+        """Destroy the two plans and drop their back-references: ``AldBatch`` <-> ``Plan(keepalive=self)`` is a reference
+        cycle, so without this the slot buffers of a finished chunk (GBs) live until the cyclic collector runs.  The
+        tensors already handed out (``X``, ``nmse_log()``) stay valid; the batch cannot run again."""
+        for pl in (self.plan, self.score_plan):
+            pl.close()
+            pl._keep = None
+
     # --- inputs -------------------------------------------------------------------------------------
     def set_init(self, X0):
         """``current = init_val_H.clone()`` (test_score.py:115,126); ``X0`` ``[T, Nt, Nr]`` complex64."""

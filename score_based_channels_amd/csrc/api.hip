@@ -2,6 +2,9 @@
 // replay), per-tag kernel timing, host-side weight packing.
 #include <stdarg.h>
 #include <string.h>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 #include "common.h"
 
@@ -14,6 +17,20 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+int ensure_dyn_lds(const void* kernel, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> high;      // (device, kernel) -> limit already set
+    int dev = 0;
+    SBC_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& cur = high[std::make_pair(dev, kernel)];
+    if (bytes > cur) {
+        SBC_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        cur = bytes;
+    }
+    return SBC_OK;
 }
 
 struct PlanOp {

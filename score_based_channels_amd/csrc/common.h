@@ -28,6 +28,11 @@ void set_error(const char* fmt, ...);
         }                                 \
     } while (0)
 
+// Raise a kernel's dynamic-LDS limit to at least `bytes` on the CURRENT device.  hipFuncSetAttribute is per device, so the
+// high-water mark is cached per (device, kernel) behind a mutex: safe for a process that drives several devices or launches
+// from several host threads (include/sbc_hip.h: threading).  Returns SBC_OK or SBC_ERR_HIP.
+int ensure_dyn_lds(const void* kernel, size_t bytes);
+
 // per-kind launchers (each validates its op, then launches asynchronously on `stream`)
 // dry = true: validate, resolve the kernel variant and set its function attributes, but do not launch
 int launch_conv(const sbc_op& op, hipStream_t stream, bool dry = false);

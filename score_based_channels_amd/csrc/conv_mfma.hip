@@ -164,12 +164,7 @@ template <int CIN, int COUT, int KS, int MT, int NT, int WM, int WN, bool P2>
 static int launch_kernel(const ConvParams& p, size_t lds, hipStream_t stream, bool dry) {
     constexpr int TM = 32 * MT * WM;
     auto kern = conv_mfma_kernel<CIN, COUT, KS, MT, NT, WM, WN, P2>;
-    static size_t lds_attr = 0;   // per instantiation
-    if (lds > lds_attr) {
-        SBC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_attr = lds;
-    }
+    { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds); if (rc) return rc; }
     if (dry) return SBC_OK;
     const int grid = (p.total_px + TM - 1) / TM;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), lds, stream, p);
@@ -237,7 +232,10 @@ int launch_conv(const sbc_op& op, hipStream_t stream, bool dry) {
     SBC_REQUIRE(!(op.flags & SBC_EPI_UP) || (op.up && op.up_h > 0 && op.up_w > 0), "conv: EPI_UP without up tensor");
     SBC_REQUIRE(!((op.flags & SBC_EPI_POOL) && (op.res2 || (op.flags & (SBC_EPI_UP | SBC_EPI_RES1_ELU)))),
                 "conv: EPI_POOL combines only with res1");
-    SBC_REQUIRE((long)op.B * op.H * op.W < (1L << 31) / 128, "conv: tensor too large for 32-bit pixel index");
+    // pixel indices are int32, element offsets of the epilogues uint32: bound the larger of the two tensors
+    SBC_REQUIRE((long)op.B * op.H * op.W * (op.cin > op.cout ? op.cin : op.cout) <= 0x7fffffffL,
+                "conv: %d x %d x %d x %d elements exceed the 32-bit element index", op.B, op.H, op.W,
+                op.cin > op.cout ? op.cin : op.cout);
     ConvParams p;
     p.in = (const float*)op.in; p.out = (float*)op.out; p.wpk = (const float4*)op.weight;
     p.bias = (const float*)op.bias; p.stats = (const float*)op.stats;

@@ -291,12 +291,7 @@ static int launch_wino(const ConvParams& p, hipStream_t stream, bool dry) {
     const size_t lds = PH == 1 ? max(staged, tplanes) : staged + tplanes;
     if (lds > 160 * 1024) return 1;
     auto kern = conv_wino_kernel<CIN, COUT, MB, true>;
-    static size_t lds_attr = 0;
-    if (lds > lds_attr) {
-        SBC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_attr = lds;
-    }
+    { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds); if (rc) return rc; }
     if (dry) return SBC_OK;
     hipLaunchKernelGGL(kern, dim3((p.total_px + TM - 1) / TM), dim3(256), lds, stream, p);
     SBC_CHECK_HIP(hipGetLastError());

@@ -314,7 +314,10 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
 #pragma unroll
                     for (int b = 0; b < 2; ++b) st_stream(p.out + o[a][b], y[a][b]);
             }
-            if (nb + NG < NBLK) __syncthreads();                       // the T planes are rewritten for the next block
+            // The T planes of this GROUP are rewritten for its next block: every wave of the group must be done reading
+            // them.  The condition depends only on (q, ph - grp), so both wave groups execute the same barrier sequence
+            // (a workgroup barrier counts all 256 * NG threads).
+            if (q + 1 < NBP || ph + NG < PH) __syncthreads();
         }
     }
 }
@@ -346,13 +349,7 @@ static int launch_wx3(const ConvParams& p, hipStream_t stream, bool dry) {
     auto kern = ng == 2 ? conv_wx3_kernel<CIN, COUT, MB, true, 2, false, (NBLK == 4 ? 2 : 1), NGMAX>
               : top     ? conv_wx3_kernel<CIN, COUT, MB, true, WPE, (CIN == 32 && COUT == 32), NBP_BIG, 1>
                         : conv_wx3_kernel<CIN, COUT, MB, true, WPE, false, NBP_BIG, 1>;
-    static size_t lds_attr3[3] = {0, 0, 0};   // per kernel symbol
-    size_t& lds_attr = lds_attr3[ng == 2 ? 2 : top ? 1 : 0];
-    if (lds_all > lds_attr) {
-        SBC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all));
-        lds_attr = lds_all;
-    }
+    { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds_all); if (rc) return rc; }
     if (dry) return SBC_OK;
     ConvParams q = p;
     q.stats_off = (int)stats_off;

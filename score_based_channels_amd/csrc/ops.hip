@@ -364,12 +364,7 @@ int launch_end_conv(const sbc_op& op, const sbc_endconv& e, hipStream_t stream, 
     const size_t lds = ((size_t)(TM + halo_px + 1) * (op.cin + 4) + 9 * op.cin * 2) * sizeof(float);
     SBC_REQUIRE(lds <= 160 * 1024, "end_conv: tile needs %zu bytes of LDS", lds);
     SBC_REQUIRE(op.cin == 32, "end_conv: %d input channels (only ngf = 32)", op.cin);
-    static size_t lds_attr = 0;
-    if (lds > lds_attr) {
-        SBC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(end_conv_kernel<32>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_attr = lds;
-    }
+    { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(end_conv_kernel<32>), lds); if (rc) return rc; }
     if (dry) return SBC_OK;
     hipLaunchKernelGGL(end_conv_kernel<32>, dim3((total + TM - 1) / TM), dim3(256), lds, stream, (const float*)op.in,
                        (const float*)op.stats, (const float*)op.weight, (const float*)op.bias, (float*)op.out, e, op.B,
@@ -505,12 +500,7 @@ int launch_langevin(const sbc_op& op, const sbc_langevin& a, hipStream_t stream,
     const size_t lds_p = (size_t)a.Np * a.Nt * sizeof(float2);
     const int p_in_lds = x_in_lds && (a.Np * a.Nt) % 2 == 0 && lds_all + lds_p <= 40 * 1024;   // keeps 4 workgroups per CU
     const size_t lds = (x_in_lds ? lds_all : (size_t)a.Np * a.Nr * sizeof(float2)) + (p_in_lds ? lds_p : 0);
-    static size_t lds_attr = 0;
-    if (lds > lds_attr) {
-        SBC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(langevin_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_attr = lds;
-    }
+    { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(langevin_kernel), lds); if (rc) return rc; }
     if (dry) return SBC_OK;
     hipLaunchKernelGGL(langevin_kernel, dim3(op.B), dim3(256), lds, stream, a, op.B, x_in_lds, p_in_lds);
     SBC_CHECK_HIP(hipGetLastError());

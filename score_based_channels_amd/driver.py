@@ -29,6 +29,18 @@ def shared_init(n_channels, nt, nr, seed, combo):
     return torch.randn(n_channels, nt, nr, dtype=torch.complex64, generator=g)
 
 
+def batch_limit(net, nt, nr, requested, reserve=0.25):
+    """Largest lock-step batch for an ``nt x nr`` array: bounded by the caller's ``requested`` size, by the 32-bit element
+    index of the convolution kernels (``B * Nt * Nr * ngf`` elements in the largest tensor) and by the free device memory
+    (the activation slots of ``plan.assign_slots`` dominate: ~1 MB per trajectory at 64x16, 16 MB at 256x64), keeping
+    ``reserve`` of it for the rest of the process."""
+    per_traj = 4 * sum(net.score_plan(nt, nr).slot_elems) + 64 * nt * nr
+    free, _ = torch.cuda.mem_get_info(net.device)
+    by_mem = int(free * (1.0 - reserve)) // per_traj
+    by_index = 0x7fffffff // (nt * nr * net.ngf)                       # wider tensors exist only at lower resolution
+    return max(1, min(int(requested), by_mem, by_index))
+
+
 def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, beta_noise, levels, steps_each,
                      seed, init, traj_base=0, max_batch=4096, use_graph=True, rank=0, world=1, n_streams=1,
                      return_final=False, n_steps=None, dc_boost=1.0, init_index=None, Y=None, y_index=None):
@@ -58,6 +70,7 @@ def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, b
     final = torch.zeros(hi - lo, nt, nr, dtype=torch.complex64, device=net.device) if return_final else None
     cur = torch.cuda.current_stream(net.device)
     streams = [torch.cuda.Stream(net.device) for _ in range(max(1, int(n_streams)))]
+    max_batch = batch_limit(net, nt, nr, max_batch)
     for c0 in range(lo, hi, max_batch):
         c1 = min(hi, c0 + max_batch)
         running = []
@@ -81,6 +94,9 @@ def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, b
             local[:, part[0] - lo:part[-1] + 1 - lo] = ald.nmse_log()[:n_steps]
             if return_final:
                 final[part[0] - lo:part[-1] + 1 - lo] = ald.X
+        torch.cuda.synchronize(net.device)              # the copies above read the chunk's buffers
+        for _, ald, _ in running:
+            ald.close()
         del running
     torch.cuda.synchronize(net.device)
     full = shard.gather_trajectory_logs(local, T, rank, world)
