@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SBC_ABI_VERSION 4
+#define SBC_ABI_VERSION 5
 
 typedef enum sbc_status {
     SBC_OK = 0,
@@ -61,6 +61,10 @@ typedef enum sbc_op_kind {
 #define SBC_EPI_RES1_ELU 0x010  /* ELU the res1 operand before adding (CRP: x = act(x))                    */
 #define SBC_EPI_POOL     0x020  /* 2x2 mean pool of (conv + bias), then + res1 (ConvMeanPool)               */
 #define SBC_EPI_UP       0x040  /* + bilinear(align_corners) resize of `up` [B][up_h][up_w][cout] (MSF)     */
+#define SBC_CONV_F16W    0x100  /* fp16 weights (BASELINE config 5): `weight_split` / `weight_wino_split` hold ONE
+                                   fp16 term per weight (sbc_pack_conv_weight_f16 / _winograd_f16) instead of
+                                   three bf16 terms; activations are rounded to fp16 as they enter the matrix
+                                   cores (v_mfma_f32_32x32x16_f16), accumulation stays fp32                    */
 
 /* One fused launch.  Unused fields are 0 / NULL.  Tensor shapes per kind:
  *   BEGIN_CONV  in [B][H][W][2], weight [cout][2][3][3] (torch layout), bias [cout], out [B][H][W][cout]
@@ -193,6 +197,12 @@ int sbc_pack_conv_weight_split(const float* src, int32_t cout, int32_t cin, int3
 /* Winograd form U = G g G^T (double, rounded once to float) of a 3x3 weight, split like sbc_pack_conv_weight_split with
  * the 16 transform positions in place of the taps: [16][cin/16][cout/32][3][64][8] uint16. */
 int sbc_pack_conv_weight_winograd_split(const float* src, int32_t cout, int32_t cin, uint16_t* dst);
+
+/* fp16 weight forms for SBC_CONV_F16W (round to nearest even): the layouts of sbc_pack_conv_weight_split /
+ * sbc_pack_conv_weight_winograd_split with a single fp16 term, [k*k | 16][cin/16][cout/32][64 lanes][8] uint16.  The
+ * Winograd form rounds U = G g G^T (double) once to fp16. */
+int sbc_pack_conv_weight_f16(const float* src, int32_t cout, int32_t cin, int32_t ksize, uint16_t* dst);
+int sbc_pack_conv_weight_winograd_f16(const float* src, int32_t cout, int32_t cin, uint16_t* dst);
 
 #ifdef __cplusplus
 }

@@ -8,12 +8,13 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsbc_hip.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 EXPORTS = ('sbc_abi_version', 'sbc_last_error', 'sbc_device_count', 'sbc_op_launch', 'sbc_plan_create',
            'sbc_plan_run', 'sbc_plan_destroy', 'sbc_plan_profile', 'sbc_plan_profile_read',
            'sbc_pack_conv_weight', 'sbc_pack_conv_weight_winograd',
-           'sbc_pack_conv_weight_split', 'sbc_pack_conv_weight_winograd_split')
+           'sbc_pack_conv_weight_split', 'sbc_pack_conv_weight_winograd_split',
+           'sbc_pack_conv_weight_f16', 'sbc_pack_conv_weight_winograd_f16')
 
 
 class SbcError(RuntimeError):
@@ -70,6 +71,8 @@ def lib():
     h.sbc_pack_conv_weight_winograd.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     h.sbc_pack_conv_weight_split.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     h.sbc_pack_conv_weight_winograd_split.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    h.sbc_pack_conv_weight_f16.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    h.sbc_pack_conv_weight_winograd_f16.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     if h.sbc_abi_version() != ABI_VERSION:
         raise SbcError('libsbc_hip.so ABI %d != expected %d' % (h.sbc_abi_version(), ABI_VERSION))
     _lib = h

@@ -337,4 +337,50 @@ int sbc_pack_conv_weight_winograd_split(const float* src, int32_t cout, int32_t 
     return SBC_OK;
 }
 
+// round-to-nearest-even fp32 -> fp16 bit pattern (the host compiler's _Float16 conversion is IEEE RNE, like v_cvt_f16_f32)
+static inline uint16_t f16_rne(float f) {
+    const _Float16 h = (_Float16)f;
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+
+int sbc_pack_conv_weight_f16(const float* src, int32_t cout, int32_t cin, int32_t ksize, uint16_t* dst) {
+    SBC_REQUIRE(src && dst, "sbc_pack_conv_weight_f16: NULL pointer");
+    SBC_REQUIRE(cin % 16 == 0 && cout % 32 == 0 && (ksize == 1 || ksize == 3),
+                "sbc_pack_conv_weight_f16: cin %% 16, cout %% 32, ksize in {1,3} required (got %d, %d, %d)", cin, cout, ksize);
+    const int taps = ksize * ksize, KG = cin / 16, NB = cout / 32;
+    for (int tap = 0; tap < taps; ++tap)
+        for (int g = 0; g < KG; ++g)
+            for (int nb = 0; nb < NB; ++nb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = nb * 32 + (lane & 31), ci = g * 16 + 8 * (lane >> 5) + j;
+                        dst[((((size_t)tap * KG + g) * NB + nb) * 64 + lane) * 8 + j] =
+                            f16_rne(src[((size_t)co * cin + ci) * taps + tap]);
+                    }
+    return SBC_OK;
+}
+
+int sbc_pack_conv_weight_winograd_f16(const float* src, int32_t cout, int32_t cin, uint16_t* dst) {
+    SBC_REQUIRE(src && dst, "sbc_pack_conv_weight_winograd_f16: NULL pointer");
+    SBC_REQUIRE(cin % 16 == 0 && cout % 32 == 0, "sbc_pack_conv_weight_winograd_f16: cin %% 16, cout %% 32 required (got %d, %d)",
+                cin, cout);
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const int KG = cin / 16, NB = cout / 32;
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+            const float* g = src + ((size_t)co * cin + ci) * 9;
+            const int nb = co / 32, kg = ci / 16, lane = (co & 31) + 32 * ((ci & 15) >> 3), j = ci & 7;
+            for (int i = 0; i < 4; ++i)
+                for (int l = 0; l < 4; ++l) {
+                    double u = 0;
+                    for (int a = 0; a < 3; ++a)
+                        for (int b = 0; b < 3; ++b) u += G[i][a] * (double)g[a * 3 + b] * G[l][b];
+                    dst[((((size_t)(i * 4 + l) * KG + kg) * NB + nb) * 64 + lane) * 8 + j] = f16_rne((float)u);
+                }
+        }
+    return SBC_OK;
+}
+
 }  // extern "C"

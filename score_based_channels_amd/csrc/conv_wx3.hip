@@ -27,8 +27,12 @@ namespace sbc {
 // NG: wave groups of four waves (one per transform row).  With two groups the phases (output blocks) are dealt between
 // them, so a 128-output-channel layer on the 8x2 level -- a launch with fewer workgroups than CUs, i.e. pure
 // single-workgroup latency -- walks two phases per group instead of four, and twice the threads stage the tile.
-template <int CIN, int COUT, int MB, bool P2, int WPE, bool TOP, int NBP, int NG>
+// F16 (conv_mode f16w, BASELINE config 5 "fp16 score-net weights"): the transformed filter is ONE fp16 term
+// (sbc_pack_conv_weight_winograd_f16), the transformed input V is rounded to fp16 instead of split, and a transform column
+// is one v_mfma_f32_32x32x16_f16 per output block instead of six bf16 MFMAs; everything else is shared.
+template <int CIN, int COUT, int MB, bool P2, int WPE, bool TOP, int NBP, int NG, bool F16>
 __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
+    constexpr int NTERM = F16 ? 1 : 3;           // 16-bit terms per operand
     constexpr int TM = 128 * MB;                 // output pixels per workgroup
     constexpr int NTW = 32 * MB;                 // Winograd tiles (2x2 output blocks) per workgroup
     constexpr int S = CIN + 4;
@@ -103,22 +107,20 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
         f32x16 T[MB][NBP][2];
         f32x16 acc[NBP][4];
         // split U: [(xi*4 + nu)][kg][nb][term][lane] 16-byte fragments
-        const uint4* wp = reinterpret_cast<const uint4*>(p.wpk) + ((size_t)(xi * 4) * KG * NBLK + ph * NBP) * 3 * 64 + lane;
-        auto u_frag = [&](int nu, int kg, int q, int t) {
-            return __builtin_bit_cast(bf16x8, wp[((size_t)((nu * KG + kg) * NBLK + q) * 3 + t) * 64]);
-        };
+        const uint4* wp = reinterpret_cast<const uint4*>(p.wpk) + ((size_t)(xi * 4) * KG * NBLK + ph * NBP) * NTERM * 64 + lane;
+        auto u_frag = [&](int nu, int kg, int q, int t) { return wp[((size_t)((nu * KG + kg) * NBLK + q) * NTERM + t) * 64]; };
         // The filter fragments are requested D = SETS - 1 transform columns ahead of the MFMAs that consume them (a
         // ring of SETS statically indexed register sets over the sequence g = step * 4 + nu), so their L2 latency hides
         // behind the MFMAs and splits in between: three columns ahead with one output block per phase, one column
         // ahead with two (twice the MFMAs per column; 48 registers either way).
         constexpr int SETS = NBP == 1 ? 4 : 2, D = SETS - 1, NSEQ = MB * KG * 4;
-        bf16x8 uB[SETS][NBP][3];
+        uint4 uB[SETS][NBP][NTERM];                                   // 8 x 16-bit fragments (bf16 terms or fp16)
         auto u_load = [&](int gq) {                                   // gq is a compile-time constant at every call
             const int gg = gq % NSEQ, nu_g = gg & 3, kg_g = (gg >> 2) % KG;
 #pragma unroll
             for (int q = 0; q < NBP; ++q)
 #pragma unroll
-                for (int t = 0; t < 3; ++t) uB[gq % SETS][q][t] = u_frag(nu_g, kg_g, q, t);
+                for (int t = 0; t < NTERM; ++t) uB[gq % SETS][q][t] = u_frag(nu_g, kg_g, q, t);
         };
 #pragma unroll
         for (int gq = 0; gq < D; ++gq) u_load(gq);
@@ -153,27 +155,43 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
                 const int gq = s * 4 + nu, cur = gq % SETS;
                 u_load(gq + D);                                       // wraps to a harmless re-read at the very end
                 // columns of B: nu=0: R0 - R2, nu=1: R1 + R2, nu=2: R2 - R1, nu=3: R1 - R3; then the exact split
-                bf16x8 vh, vm, vl;
+                float v[8];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const float v = nu == 0 ? R[0][c] - R[2][c] : nu == 1 ? R[1][c] + R[2][c]
-                                  : nu == 2 ? R[2][c] - R[1][c] : R[1][c] - R[3][c];
-                    const __bf16 h = (__bf16)v;
-                    const float r1 = v - (float)h;
-                    const __bf16 m = (__bf16)r1;
-                    vh[c] = h; vm[c] = m; vl[c] = (__bf16)(r1 - (float)m);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                for (int c = 0; c < 8; ++c)
+                    v[c] = nu == 0 ? R[0][c] - R[2][c] : nu == 1 ? R[1][c] + R[2][c]
+                         : nu == 2 ? R[2][c] - R[1][c] : R[1][c] - R[3][c];
+                if constexpr (F16) {
+                    f16x8 vf;
 #pragma unroll
-                for (int q = 0; q < NBP; ++q) {
-                    const bf16x8 uh = uB[cur][q][0], um = uB[cur][q][1], ul = uB[cur][q][2];
-                    // partial products, smallest first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
-                    acc[q][nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, uh, acc[q][nu], 0, 0, 0);
-                    acc[q][nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ul, acc[q][nu], 0, 0, 0);
-                    acc[q][nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vm, um, acc[q][nu], 0, 0, 0);
-                    acc[q][nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vm, uh, acc[q][nu], 0, 0, 0);
-                    acc[q][nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, um, acc[q][nu], 0, 0, 0);
-                    acc[q][nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, uh, acc[q][nu], 0, 0, 0);
+                    for (int c = 0; c < 8; ++c) vf[c] = (_Float16)v[c];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < NBP; ++q)
+                        acc[q][nu] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, __builtin_bit_cast(f16x8, uB[cur][q][0]),
+                                                                            acc[q][nu], 0, 0, 0);
+                } else {
+                    bf16x8 vh, vm, vl;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const __bf16 h = (__bf16)v[c];
+                        const float r1 = v[c] - (float)h;
+                        const __bf16 m = (__bf16)r1;
+                        vh[c] = h; vm[c] = m; vl[c] = (__bf16)(r1 - (float)m);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < NBP; ++q) {
+                        const bf16x8 uh = __builtin_bit_cast(bf16x8, uB[cur][q][0]),
+                                     um = __builtin_bit_cast(bf16x8, uB[cur][q][NTERM > 1 ? 1 : 0]),
+                                     ul = __builtin_bit_cast(bf16x8, uB[cur][q][NTERM > 2 ? 2 : 0]);
+                        // partial products, smallest first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+                        acc[q][nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, uh, acc[q][nu], 0, 0, 0);
+                        acc[q][nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ul, acc[q][nu], 0, 0, 0);
+                        acc[q][nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vm, um, acc[q][nu], 0, 0, 0);
+                        acc[q][nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vm, uh, acc[q][nu], 0, 0, 0);
+                        acc[q][nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, um, acc[q][nu], 0, 0, 0);
+                        acc[q][nu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, uh, acc[q][nu], 0, 0, 0);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -323,7 +341,7 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------ dispatch
-template <int CIN, int COUT, int MB>
+template <int CIN, int COUT, int MB, bool F16>
 static int launch_wx3(const ConvParams& p, hipStream_t stream, bool dry) {
     constexpr int TM = 128 * MB;
     constexpr int S = CIN + 4;
@@ -346,9 +364,9 @@ static int launch_wx3(const ConvParams& p, hipStream_t stream, bool dry) {
     constexpr int WPE = (CIN == 32 && COUT == 32 && MB == 1) ? 3 : 2;
     constexpr int NBP_BIG = NBLK == 2 ? 2 : 1;
     const bool top = (CIN == 32 && COUT == 32) && p.H * p.W >= 1024;
-    auto kern = ng == 2 ? conv_wx3_kernel<CIN, COUT, MB, true, 2, false, (NBLK == 4 ? 2 : 1), NGMAX>
-              : top     ? conv_wx3_kernel<CIN, COUT, MB, true, WPE, (CIN == 32 && COUT == 32), NBP_BIG, 1>
-                        : conv_wx3_kernel<CIN, COUT, MB, true, WPE, false, NBP_BIG, 1>;
+    auto kern = ng == 2 ? conv_wx3_kernel<CIN, COUT, MB, true, 2, false, (NBLK == 4 ? 2 : 1), NGMAX, F16>
+              : top     ? conv_wx3_kernel<CIN, COUT, MB, true, WPE, (CIN == 32 && COUT == 32), NBP_BIG, 1, F16>
+                        : conv_wx3_kernel<CIN, COUT, MB, true, WPE, false, NBP_BIG, 1, F16>;
     { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds_all); if (rc) return rc; }
     if (dry) return SBC_OK;
     ConvParams q = p;
@@ -356,6 +374,12 @@ static int launch_wx3(const ConvParams& p, hipStream_t stream, bool dry) {
     hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256 * ng), lds_all, stream, q);
     SBC_CHECK_HIP(hipGetLastError());
     return SBC_OK;
+}
+
+template <int CIN, int COUT, int MB>
+static int launch_wx3_mode(const ConvParams& p, hipStream_t stream, bool dry) {
+    return (p.flags & SBC_CONV_F16W) ? launch_wx3<CIN, COUT, MB, true>(p, stream, dry)
+                                     : launch_wx3<CIN, COUT, MB, false>(p, stream, dry);
 }
 
 template <int CIN, int COUT>
@@ -368,11 +392,11 @@ static int launch_wx3_sized(const ConvParams& p, hipStream_t stream, bool dry) {
     constexpr bool mb2_ok = (COUT == 32);
     static const bool force2 = getenv("SBC_WX3_MB2") != nullptr;                   // tuning aid
     if constexpr (mb2_ok) {
-        if (force2 && fits(256)) return launch_wx3<CIN, COUT, 2>(p, stream, dry);
+        if (force2 && fits(256)) return launch_wx3_mode<CIN, COUT, 2>(p, stream, dry);
     }
-    if (fits(128)) return launch_wx3<CIN, COUT, 1>(p, stream, dry);
+    if (fits(128)) return launch_wx3_mode<CIN, COUT, 1>(p, stream, dry);
     if constexpr (mb2_ok) {
-        if (fits(256)) return launch_wx3<CIN, COUT, 2>(p, stream, dry);
+        if (fits(256)) return launch_wx3_mode<CIN, COUT, 2>(p, stream, dry);
     }
     return 1;
 }

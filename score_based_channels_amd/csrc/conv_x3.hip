@@ -21,7 +21,10 @@
 
 namespace sbc {
 
-template <int CIN, int COUT, int KS, int MT, int NT, int WM, int WN, bool P2>
+// TERMS = 3: the exact three-term bf16 split described above.  TERMS = 1 (conv_mode f16w, BASELINE config 5 "fp16
+// score-net weights"): weights are fp16 (sbc_pack_conv_weight_f16), the fp32 activations are rounded to fp16 while they are
+// staged, and a step is ONE v_mfma_f32_32x32x16_f16 with fp32 accumulation -- a sixth of the matrix work, a third of the LDS.
+template <int CIN, int COUT, int KS, int MT, int NT, int WM, int WN, bool P2, int TERMS>
 __global__ __launch_bounds__(64 * WM * WN) void conv_x3_kernel(ConvParams p) {
     constexpr int TM = 32 * MT * WM;
     constexpr int SH = CIN + 8;                         // bf16 elements per staged pixel
@@ -43,10 +46,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_x3_kernel(ConvParams p) {
     const Dims<P2> dm{H, W, HW, p.hsh, p.wsh};
     const int plane = p.plane;
     const int khalf = 8 * (lane >> 5);
-    const uint4* wp = reinterpret_cast<const uint4*>(p.wpk) + (size_t)(wn * NT) * 3 * 64 + lane;
+    const uint4* wp = reinterpret_cast<const uint4*>(p.wpk) + (size_t)(wn * NT) * TERMS * 64 + lane;
 
     const TileGeom g = tile_geom(blockIdx.x, TM, p.B, dm, KS == 3 ? p.dil : 0);
-    stage_tile_split<CIN, NTHREADS, NPF, P2>(lds16, plane, p.in, p.stats, p.flags, g, dm, tid);
+    stage_tile_split<CIN, NTHREADS, NPF, P2, TERMS>(lds16, plane, p.in, p.stats, p.flags, g, dm, tid);
 
     // per 32-pixel block: this lane's LDS base offset and the 9-bit mask of taps inside the image (conv_mfma.hip)
     int abase[MT];
@@ -79,11 +82,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_x3_kernel(ConvParams p) {
         return ((amask[mi] >> tap) & 1u) ? abase[mi] + (dh * W + dw) * SH : zoff;
     };
     auto lds_frag = [&](int off, int term) {
-        return *reinterpret_cast<const bf16x8*>(__builtin_assume_aligned(lds16 + off + term * plane, 16));
+        return *reinterpret_cast<const uint4*>(__builtin_assume_aligned(lds16 + off + term * plane, 16));
     };
-    auto w_frag = [&](int it, int ni, int term) {
-        return __builtin_bit_cast(bf16x8, wp[((size_t)(it * NBLK + ni) * 3 + term) * 64]);
-    };
+    auto w_frag = [&](int it, int ni, int term) { return wp[((size_t)(it * NBLK + ni) * TERMS + term) * 64]; };
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -96,19 +97,30 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_x3_kernel(ConvParams p) {
     // K loop, software-pipelined by one (tap, 16-channel group) step: the three weight fragments (global/L2) and three
     // activation fragments (LDS) of step it+1 are requested, then the MFMAs of step it are issued; two statically
     // indexed register sets alternate.
-    bf16x8 aS[2][MT][3], bS[2][NT][3];
+    uint4 aS[2][MT][TERMS], bS[2][NT][TERMS];          // 8 x 16-bit fragments (bf16 terms or fp16)
     auto mfma_step = [&](int cur) {
-        // partial products, smallest first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            const int ta = q == 0 ? 2 : (q == 2 || q == 3) ? 1 : 0;
-            const int tb = q == 1 ? 2 : (q == 2 || q == 4) ? 1 : 0;
+        if constexpr (TERMS == 1) {
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NT; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aS[cur][mi][ta], bS[cur][ni][tb], acc[mi][ni],
-                                                                          0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aS[cur][mi][0]),
+                                                                         __builtin_bit_cast(f16x8, bS[cur][ni][0]),
+                                                                         acc[mi][ni], 0, 0, 0);
+        } else {
+            // partial products, smallest first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const int ta = q == 0 ? 2 : (q == 2 || q == 3) ? 1 : 0;
+                const int tb = q == 1 ? 2 : (q == 2 || q == 4) ? 1 : 0;
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NT; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, aS[cur][mi][ta]), __builtin_bit_cast(bf16x8, bS[cur][ni][tb]),
+                            acc[mi][ni], 0, 0, 0);
+            }
         }
     };
     if (tapmask == (1u << TAPS) - 1u) {
@@ -118,17 +130,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_x3_kernel(ConvParams p) {
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) bS[0][ni][t] = w_frag(0, ni, t);
+            for (int t = 0; t < TERMS; ++t) bS[0][ni][t] = w_frag(0, ni, t);
         __syncthreads();                                               // staged tile visible
         int aoff[MT];
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
             aoff[mi] = tap_offset(0, mi);
 #pragma unroll
-            for (int t = 0; t < 3; ++t) aS[0][mi][t] = lds_frag(aoff[mi], t);
+            for (int t = 0; t < TERMS; ++t) aS[0][mi][t] = lds_frag(aoff[mi], t);
         }
+        // (two nested fully unrolled loops: as ONE loop of 72 steps the 128-channel fp16 instantiations are peeled first and
+        // then refused by the unroller as too large)
 #pragma unroll
-        for (int it = 0; it < TAPS * KG; ++it) {
+        for (int tap_c = 0; tap_c < TAPS; ++tap_c)
+#pragma unroll
+        for (int kg_c = 0; kg_c < KG; ++kg_c) {
+            const int it = tap_c * KG + kg_c;
             const int cur = it & 1, nxt = cur ^ 1;
             if (it + 1 < TAPS * KG) {
                 const int tap_n = (it + 1) / KG, kg_n = (it + 1) % KG;
@@ -139,11 +156,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_x3_kernel(ConvParams p) {
 #pragma unroll
                 for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) bS[nxt][ni][t] = w_frag(it + 1, ni, t);
+                    for (int t = 0; t < TERMS; ++t) bS[nxt][ni][t] = w_frag(it + 1, ni, t);
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) aS[nxt][mi][t] = lds_frag(aoff[mi] + kg_n * 16, t);
+                    for (int t = 0; t < TERMS; ++t) aS[nxt][mi][t] = lds_frag(aoff[mi] + kg_n * 16, t);
             }
             mfma_step(cur);
         }
@@ -155,13 +172,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_x3_kernel(ConvParams p) {
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) bS[0][ni][t] = w_frag(it0, ni, t);
+            for (int t = 0; t < TERMS; ++t) bS[0][ni][t] = w_frag(it0, ni, t);
         __syncthreads();                                               // staged tile visible
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
             aoff[mi] = tap_offset(tap < TAPS ? tap : 0, mi);
 #pragma unroll
-            for (int t = 0; t < 3; ++t) aS[0][mi][t] = lds_frag(aoff[mi], t);
+            for (int t = 0; t < TERMS; ++t) aS[0][mi][t] = lds_frag(aoff[mi], t);
         }
 #pragma unroll 1
         while (tap < TAPS) {
@@ -176,11 +193,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_x3_kernel(ConvParams p) {
 #pragma unroll
                 for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) bS[nxt][ni][t] = w_frag(it_n, ni, t);
+                    for (int t = 0; t < TERMS; ++t) bS[nxt][ni][t] = w_frag(it_n, ni, t);
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-                    for (int t = 0; t < 3; ++t)
+                    for (int t = 0; t < TERMS; ++t)
                         aS[nxt][mi][t] = lds_frag(kg + 1 < KG ? aoff[mi] + (kg + 1) * 16 : aoff_n[mi], t);
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_step(cur);
@@ -201,24 +218,24 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_x3_kernel(ConvParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------ dispatch
-template <int CIN, int COUT, int KS, int MT, int NT, int WM, int WN>
+template <int CIN, int COUT, int KS, int MT, int NT, int WM, int WN, int TERMS>
 static size_t x3_lds_bytes(const ConvParams& p, int* plane_out) {
     constexpr int TM = 32 * MT * WM;
     const int HW = p.H * p.W;
     const int halo_px = (TM >= HW || KS == 1) ? 0 : 2 * p.dil * p.W;
     const int plane = (TM + halo_px + 1) * (CIN + 8);
     if (plane_out) *plane_out = plane;
-    const size_t staged = (size_t)3 * plane * sizeof(unsigned short);
+    const size_t staged = (size_t)TERMS * plane * sizeof(unsigned short);
     const size_t epi = (size_t)TM * (COUT + 4) * sizeof(float);
     return staged > epi ? staged : epi;
 }
 
-template <int CIN, int COUT, int KS, int MT, int NT, int WM, int WN, bool P2>
+template <int CIN, int COUT, int KS, int MT, int NT, int WM, int WN, bool P2, int TERMS>
 static int launch_kernel(ConvParams p, hipStream_t stream, bool dry) {
     constexpr int TM = 32 * MT * WM;
-    const size_t lds = x3_lds_bytes<CIN, COUT, KS, MT, NT, WM, WN>(p, &p.plane);
+    const size_t lds = x3_lds_bytes<CIN, COUT, KS, MT, NT, WM, WN, TERMS>(p, &p.plane);
     SBC_REQUIRE(lds <= 160 * 1024, "conv tile needs %zu bytes of LDS (> 160 KiB)", lds);
-    auto kern = conv_x3_kernel<CIN, COUT, KS, MT, NT, WM, WN, P2>;
+    auto kern = conv_x3_kernel<CIN, COUT, KS, MT, NT, WM, WN, P2, TERMS>;
     { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds); if (rc) return rc; }
     if (dry) return SBC_OK;
     const int grid = (p.total_px + TM - 1) / TM;
@@ -229,8 +246,13 @@ static int launch_kernel(ConvParams p, hipStream_t stream, bool dry) {
 
 template <int CIN, int COUT, int KS, int MT, int NT, int WM, int WN>
 static int launch_variant(const ConvParams& p, hipStream_t stream, bool dry) {
-    if (p.hsh >= 0 && p.wsh >= 1) return launch_kernel<CIN, COUT, KS, MT, NT, WM, WN, true>(p, stream, dry);
-    return launch_kernel<CIN, COUT, KS, MT, NT, WM, WN, false>(p, stream, dry);
+    const bool p2 = p.hsh >= 0 && p.wsh >= 1;
+    if (p.flags & SBC_CONV_F16W) {
+        if (p2) return launch_kernel<CIN, COUT, KS, MT, NT, WM, WN, true, 1>(p, stream, dry);
+        return launch_kernel<CIN, COUT, KS, MT, NT, WM, WN, false, 1>(p, stream, dry);
+    }
+    if (p2) return launch_kernel<CIN, COUT, KS, MT, NT, WM, WN, true, 3>(p, stream, dry);
+    return launch_kernel<CIN, COUT, KS, MT, NT, WM, WN, false, 3>(p, stream, dry);
 }
 
 // Tile choice: the largest tile that fits the image, keeps >= 2 workgroups per CU worth of work (256 CUs) and leaves
@@ -243,9 +265,10 @@ static int launch_sized(const ConvParams& p, hipStream_t stream, bool dry) {
     auto fits = [&](int tm) {
         return tm % p.W == 0 && (HW % tm == 0 || tm % HW == 0) && (!(p.flags & SBC_EPI_POOL) || tm % (2 * p.W) == 0);
     };
+    const int terms = (p.flags & SBC_CONV_F16W) ? 1 : 3;
     auto lds_of = [&](int tm) -> size_t {
         const int halo_px = (tm >= HW || KS == 1) ? 0 : 2 * p.dil * p.W;
-        const size_t staged = (size_t)3 * (tm + halo_px + 1) * (CIN + 8) * 2, epi = (size_t)tm * (COUT + 4) * 4;
+        const size_t staged = (size_t)terms * (tm + halo_px + 1) * (CIN + 8) * 2, epi = (size_t)tm * (COUT + 4) * 4;
         return staged > epi ? staged : epi;
     };
     auto good = [&](int tm) { return fits(tm) && px >= (long)tm * 512 && lds_of(tm) <= 80 * 1024; };

@@ -174,8 +174,13 @@ __device__ __forceinline__ void split3(float4 x, bf16x4& h, bf16x4& m, bf16x4& l
     l[0] = (__bf16)x.x; l[1] = (__bf16)x.y; l[2] = (__bf16)x.z; l[3] = (__bf16)x.w;
 }
 
-// lds16: LDS viewed as 16-bit elements; `plane` = elements per plane
-template <int CIN, bool P2>
+// Single-term fp16 staging (conv_mode f16w, BASELINE config 5: fp16 score-network weights): the activation is rounded
+// once to fp16 (round to nearest even, v_cvt_f16_f32) and only the first plane exists.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// lds16: LDS viewed as 16-bit elements; `plane` = elements per plane; TERMS = 3 (exact bf16 split) or 1 (fp16)
+template <int CIN, bool P2, int TERMS = 3>
 __device__ __forceinline__ void stage_put_split(unsigned short* lds16, int plane, float4 x, int idx,
                                                 const float* __restrict__ stats, int flags, const TileGeom& g,
                                                 const Dims<P2>& d) {
@@ -194,15 +199,21 @@ __device__ __forceinline__ void stage_put_split(unsigned short* lds16, int plane
         x.w = (x.w - mu.w) * sc.w + sh.w;
     }
     if (flags & SBC_PRO_ELU) x = elu4(x);
-    bf16x4 h, m, l;
-    split3(x, h, m, l);
     unsigned short* dst = lds16 + pix * SH + c4 * 4;
-    *reinterpret_cast<bf16x4*>(dst) = h;
-    *reinterpret_cast<bf16x4*>(dst + plane) = m;
-    *reinterpret_cast<bf16x4*>(dst + 2 * plane) = l;
+    if constexpr (TERMS == 1) {
+        f16x4 h;
+        h[0] = (_Float16)x.x; h[1] = (_Float16)x.y; h[2] = (_Float16)x.z; h[3] = (_Float16)x.w;
+        *reinterpret_cast<f16x4*>(dst) = h;
+    } else {
+        bf16x4 h, m, l;
+        split3(x, h, m, l);
+        *reinterpret_cast<bf16x4*>(dst) = h;
+        *reinterpret_cast<bf16x4*>(dst + plane) = m;
+        *reinterpret_cast<bf16x4*>(dst + 2 * plane) = l;
+    }
 }
 
-template <int CIN, int NTHREADS, int NPF, bool P2>
+template <int CIN, int NTHREADS, int NPF, bool P2, int TERMS = 3>
 __device__ __forceinline__ void stage_tile_split(unsigned short* lds16, int plane, const float* __restrict__ in,
                                                  const float* __restrict__ stats, int flags, const TileGeom& g,
                                                  const Dims<P2>& d, int tid) {
@@ -213,13 +224,13 @@ __device__ __forceinline__ void stage_tile_split(unsigned short* lds16, int plan
 #pragma unroll
     for (int u = 0; u < NPF; ++u) {
         const int idx = u * NTHREADS + tid;
-        if (idx < total) stage_put_split<CIN, P2>(lds16, plane, pf[u], idx, stats, flags, g, d);
+        if (idx < total) stage_put_split<CIN, P2, TERMS>(lds16, plane, pf[u], idx, stats, flags, g, d);
     }
     const float* src = in + (size_t)g.rs0 * d.W * CIN;
     for (int idx = NPF * NTHREADS + tid; idx < total; idx += NTHREADS)
-        stage_put_split<CIN, P2>(lds16, plane, ld_stream(src + (size_t)idx * 4), idx, stats, flags, g, d);
+        stage_put_split<CIN, P2, TERMS>(lds16, plane, ld_stream(src + (size_t)idx * 4), idx, stats, flags, g, d);
     // the zero pixel of each plane (SH / 2 dwords each)
-    for (int i = tid; i < 3 * (SH / 2); i += NTHREADS)
+    for (int i = tid; i < TERMS * (SH / 2); i += NTHREADS)
         reinterpret_cast<unsigned*>(lds16 + (i / (SH / 2)) * plane + g.nps * SH)[i % (SH / 2)] = 0u;
 }
 

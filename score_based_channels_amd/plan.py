@@ -27,6 +27,7 @@ from typing import List, Optional
 BEGIN_CONV, INORM_STATS, CONV, MAXPOOL5, END_CONV, LANGEVIN, STEP_INC, MEASURE = 1, 2, 3, 4, 5, 6, 7, 8
 PRO_ELU, PRO_NORM = 0x001, 0x002
 EPI_RES1_ELU, EPI_POOL, EPI_UP = 0x010, 0x020, 0x040
+CONV_F16W = 0x100
 
 # profiling tag of the dominant kernel class: 3x3 convs ngf->ngf at full resolution
 TAG_CONV_TOP = 1

@@ -13,8 +13,9 @@ import torch
 
 from . import _lib
 from . import plan as P
-from .weights import (check_state_dict, get_sigmas, pack_conv_weight, pack_conv_weight_split,
-                      pack_conv_weight_winograd, pack_conv_weight_winograd_split)
+from .weights import (check_state_dict, fp16_state_dict, get_sigmas, pack_conv_weight, pack_conv_weight_f16,
+                      pack_conv_weight_split, pack_conv_weight_winograd, pack_conv_weight_winograd_f16,
+                      pack_conv_weight_winograd_split)
 
 
 def _ptr(t, offset_elems=0):
@@ -33,7 +34,7 @@ class BoundScore:
         self.keep = extra_keep
 
 
-CONV_MODES = ('bf16x3', 'f32')
+CONV_MODES = ('bf16x3', 'f32', 'f16w')
 
 
 class ScoreNet:
@@ -45,6 +46,13 @@ class ScoreNet:
                             undilated 3x3 layers (``csrc/conv_wx3.hip``), direct for the rest (``csrc/conv_x3.hip``);
     ``'f32'``               fp32 MFMA kernels (Winograd ``csrc/conv_wino.hip`` + direct ``csrc/conv_mfma.hip``).
     Both stay within the parity tolerance of the reference (tests/test_gpu_parity.py runs every case in each).
+    ``'f16w'``              BASELINE config 5, "fp16 score-net weights": every parameter is rounded to fp16 when it is
+                            loaded (``module.half()`` semantics; the sigma schedule stays fp32), the 32/64/128-channel
+                            convolutions run as single-term ``v_mfma_f32_32x32x16_f16`` (activations fp32 in HBM, rounded
+                            to fp16 as they enter the matrix cores, fp32 accumulation) in the same two kernels; begin /
+                            end convolutions and InstanceNorm++ use the fp16-rounded parameters in fp32 arithmetic.
+                            Oracle: the fp32 reference with fp16-rounded parameters (the reference itself cannot run
+                            ``.half()``, layers.py:179); tolerance stated in tests/test_gpu_parity.py.
     """
 
     def __init__(self, config, device=None, conv_mode='bf16x3'):
@@ -97,6 +105,8 @@ class ScoreNet:
               for k, v in state_dict.items()}
         if strict:
             check_state_dict(sd, self.config)
+        if self.conv_mode == 'f16w':
+            sd = fp16_state_dict(sd)
         if 'sigmas' in sd:
             self._sigmas_np = np.asarray(sd['sigmas'], np.float32)
             self._sigmas = None
@@ -117,11 +127,19 @@ class ScoreNet:
             if name == 'sigmas':
                 continue
             if name.endswith('.weight') and w.ndim == 4 and name not in ('begin_conv.weight', 'end_conv.weight'):
-                add(name, pack_conv_weight(w))
-                if w.shape[2:] == (3, 3):
-                    add(name + '#winograd', pack_conv_weight_winograd(w))
-                    add(name + '#winograd_split', pack_conv_weight_winograd_split(w).view(np.float32))
-                add(name + '#split', pack_conv_weight_split(w).view(np.float32))      # bf16 bit patterns
+                # only the forms the selected multiplier consumes (a 128 -> 128 layer is 0.6 MB per fp32 form)
+                if self.conv_mode == 'f32':
+                    add(name, pack_conv_weight(w))
+                    if w.shape[2:] == (3, 3):
+                        add(name + '#winograd', pack_conv_weight_winograd(w))
+                elif self.conv_mode == 'bf16x3':
+                    add(name + '#split', pack_conv_weight_split(w).view(np.float32))      # bf16 bit patterns
+                    if w.shape[2:] == (3, 3):
+                        add(name + '#winograd_split', pack_conv_weight_winograd_split(w).view(np.float32))
+                else:
+                    add(name + '#split', pack_conv_weight_f16(w).view(np.float32))        # fp16 bit patterns
+                    if w.shape[2:] == (3, 3):
+                        add(name + '#winograd_split', pack_conv_weight_winograd_f16(w).view(np.float32))
             elif name.endswith('.alpha'):
                 pre = name[:-len('.alpha')]
                 add(pre, np.concatenate([sd[pre + '.alpha'], sd[pre + '.gamma'], sd[pre + '.beta']]))
@@ -163,14 +181,18 @@ class ScoreNet:
             o.cin, o.cout, o.ksize, o.dil, o.tag = op.src.c, op.dst.c, op.ksize, op.dil, op.tag
             o.in_ = _ptr(slots[op.src.slot])
             o.out = _ptr(slots[op.dst.slot])
-            if op.weight is not None:
+            if op.weight is not None and op.kind != P.CONV:
                 o.weight = _ptr(self._wdev, self._woff[op.weight])
-                if op.kind == P.CONV and op.ksize == 3 and op.dil == 1 and self.conv_mode == 'f32':
+            elif op.weight is not None and self.conv_mode == 'f32':
+                o.weight = _ptr(self._wdev, self._woff[op.weight])
+                if op.ksize == 3 and op.dil == 1:
                     o.weight_wino = _ptr(self._wdev, self._woff[op.weight + '#winograd'])
-                if op.kind == P.CONV and self.conv_mode == 'bf16x3':
-                    o.weight_split = _ptr(self._wdev, self._woff[op.weight + '#split'])
-                    if op.ksize == 3 and op.dil == 1:
-                        o.weight_wino_split = _ptr(self._wdev, self._woff[op.weight + '#winograd_split'])
+            elif op.weight is not None:
+                o.weight_split = _ptr(self._wdev, self._woff[op.weight + '#split'])
+                if op.ksize == 3 and op.dil == 1:
+                    o.weight_wino_split = _ptr(self._wdev, self._woff[op.weight + '#winograd_split'])
+                if self.conv_mode == 'f16w':
+                    o.flags |= P.CONV_F16W
             if op.bias is not None:
                 o.bias = _ptr(self._wdev, self._woff[op.bias])
             if op.stats is not None:

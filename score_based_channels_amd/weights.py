@@ -201,3 +201,38 @@ def pack_conv_weight_winograd_split(w):
         raise ValueError('Winograd F(2x2,3x3) needs a 3x3 kernel, got %s' % (w.shape,))
     u = np.einsum('ij,ocjk,lk->ocil', _WINO_G, w, _WINO_G)          # [O, C, 4, 4]
     return pack_conv_weight_split(u.astype(np.float32))
+
+
+def round_fp16(x):
+    """float32 -> nearest-even float16 -> float32: what ``tensor.half().float()`` gives (BASELINE config 5, "fp16 score-net
+    weights")."""
+    return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
+
+
+def fp16_state_dict(sd):
+    """Every learnable tensor of a ``state_dict`` rounded to fp16 (``module.half()`` semantics for parameters); the
+    ``sigmas`` buffer -- the noise schedule, not a weight -- is kept in float32."""
+    return {k: (np.asarray(v, np.float32) if k == 'sigmas' else round_fp16(v)) for k, v in sd.items()}
+
+
+def pack_conv_weight_f16(w):
+    """Single-term fp16 form of an ``[O, C, k, k]`` weight: the layout of ``pack_conv_weight_split`` without the term axis,
+    ``[k*k, C/16, O/32, 64, 8]`` uint16 (fp16 bit patterns, round to nearest even) -- the B operand of one
+    ``v_mfma_f32_32x32x16_f16`` (``SBC_CONV_F16W``)."""
+    w = np.asarray(w, np.float32)
+    o, c, kh, kw = w.shape
+    if c % 16 or o % 32:
+        raise ValueError('pack_conv_weight_f16 needs C %% 16 == 0 and O %% 32 == 0, got %s' % (w.shape,))
+    a = w.astype(np.float16).view(np.uint16).reshape(o // 32, 32, c // 16, 2, 8, kh * kw)     # [nb, l31, g, half, j, tap]
+    a = a.transpose(5, 2, 0, 3, 1, 4)                                                        # [tap, g, nb, half, l31, j]
+    return np.ascontiguousarray(a).reshape(kh * kw, c // 16, o // 32, 64, 8)
+
+
+def pack_conv_weight_winograd_f16(w):
+    """Winograd F(2x2, 3x3) weights ``U = G g G^T`` (float64, rounded to float32 and then once to fp16) in the
+    ``pack_conv_weight_f16`` layout with the 16 transform positions in place of the taps: ``[16, C/16, O/32, 64, 8]``."""
+    w = np.asarray(w, np.float64)
+    if w.shape[2:] != (3, 3):
+        raise ValueError('Winograd F(2x2,3x3) needs a 3x3 kernel, got %s' % (w.shape,))
+    u = np.einsum('ij,ocjk,lk->ocil', _WINO_G, w, _WINO_G)          # [O, C, 4, 4]
+    return pack_conv_weight_f16(u.astype(np.float32))

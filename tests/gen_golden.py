@@ -15,7 +15,7 @@ the fixtures are inputs and outputs only.  What is executed:
 * loader goldens: the reference's ``loaders.Channels`` (imported with a stand-in ``hdf5storage``
   module that returns a synthetic ``output_h``).
 
-Usage:  python tests/gen_golden.py [forward plumbing trunc big loader tune full]
+Usage:  python tests/gen_golden.py [forward plumbing trunc big f16w cross mmse loader tune full]
 """
 import os
 import sys
@@ -182,6 +182,41 @@ def gen_big():
                         Y=Y, X_final=X, nmse_log=log, snr_db=np.array([10.0]),
                         levels=np.array([0, 1000]), seed=106, weight_seed=WEIGHT_SEED)
     print('big_256x64: out absmax %g nmse %s' % (np.abs(out).max(), log[0, :, 0]))
+
+
+def gen_f16w():
+    """G6: BASELINE config 5, "fp16 score-net weights".  The reference cannot run ``.half()``
+    (``MSFBlock`` allocates ``sums`` in fp32, layers.py:179), so the stated oracle is the fp32 reference with every
+    parameter rounded to fp16 (``weights.fp16_state_dict``; the sigma buffer stays fp32)."""
+    from score_based_channels_amd.weights import fp16_state_dict
+    # 64x16: forward at three levels + a truncated schedule
+    cfg = default_config()
+    sd16 = fp16_state_dict(seeded_state_dict(cfg, WEIGHT_SEED))
+    net = reference_net(cfg, sd16)
+    g = np.load(os.path.join(GOLD, 'forward_64x16.npz'))
+    x, levels = g['x'], [int(v) for v in g['levels']]
+    with torch.no_grad():
+        outs = [net(torch.from_numpy(x), torch.full((4,), lv, dtype=torch.long)).numpy() for lv in levels]
+    H, P = case_inputs(107, 4, 64, 16, 0.6)
+    lv = list(range(0, 2311, 77)) + [2310]
+    Y, X, log = reference_ald(net, cfg, H, P, [0.0, 20.0], lv, 107)
+    np.savez_compressed(os.path.join(GOLD, 'f16w_64x16.npz'), x=x, levels=np.array(levels), out=np.stack(outs), H=H,
+                        P=P, Y=Y, X_final=X, nmse_log=log, snr_db=np.array([0.0, 20.0]), ald_levels=np.array(lv),
+                        seed=107, weight_seed=WEIGHT_SEED)
+    print('f16w_64x16: out absmax', [float(np.abs(o).max()) for o in outs], 'final nmse', log[:, -1].mean(-1))
+    # 256x64: the inputs of big_256x64 with fp16-rounded parameters
+    cfg = default_config(image_size=(64, 256))
+    sd16 = fp16_state_dict(seeded_state_dict(cfg, WEIGHT_SEED))
+    net = reference_net(cfg, sd16)
+    H, P = case_inputs(21, 1, 256, 64, 0.6, profile='ULA')
+    x = np.stack((H.real, H.imag), 1).astype(np.float32)
+    with torch.no_grad():
+        out = net(torch.from_numpy(x), torch.full((1,), 1155, dtype=torch.long)).numpy()
+    Y, X, log = reference_ald(net, cfg, H, P, [10.0], [0, 1000], 106)
+    np.savez_compressed(os.path.join(GOLD, 'f16w_256x64.npz'), x=x, out=out, level=1155, H=H, P=P, Y=Y, X_final=X,
+                        nmse_log=log, snr_db=np.array([10.0]), levels=np.array([0, 1000]), seed=106,
+                        weight_seed=WEIGHT_SEED)
+    print('f16w_256x64: out absmax %g nmse %s' % (np.abs(out).max(), log[0, :, 0]))
 
 
 def gen_loader():

@@ -67,7 +67,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize('algo', ['direct', 'winograd', 'bf16x3', 'winograd_bf16x3'])
+@pytest.mark.parametrize('algo', ['direct', 'winograd', 'bf16x3', 'winograd_bf16x3', 'f16w', 'winograd_f16w'])
 @pytest.mark.parametrize('cin,cout,k,dil,B,H,W,mode', CONV_CASES)
 def test_conv_matches_oracle(gpu, cin, cout, k, dil, B, H, W, mode, algo):
     """The three multipliers behind SBC_OP_CONV: the fp32-MFMA direct implicit GEMM (weight); when the op also carries
@@ -75,8 +75,9 @@ def test_conv_matches_oracle(gpu, cin, cout, k, dil, B, H, W, mode, algo):
     when it carries weight_split, the split-bf16 kernel (three exact bf16 terms per fp32 operand, six bf16 MFMAs)."""
     torch, _lib = gpu
     from score_based_channels_amd import plan as P
-    from score_based_channels_amd.weights import (pack_conv_weight, pack_conv_weight_split, pack_conv_weight_winograd,
-                                                  pack_conv_weight_winograd_split)
+    from score_based_channels_amd.weights import (pack_conv_weight, pack_conv_weight_f16, pack_conv_weight_split,
+                                                  pack_conv_weight_winograd, pack_conv_weight_winograd_f16,
+                                                  pack_conv_weight_winograd_split, round_fp16)
     if algo.startswith('winograd') and (k != 3 or dil != 1):
         pytest.skip('Winograd F(2x2,3x3) applies to undilated 3x3 convolutions')
     rng = np.random.default_rng(hash((cin, cout, k, dil, B, H, W)) % (2 ** 31))
@@ -96,7 +97,17 @@ def test_conv_matches_oracle(gpu, cin, cout, k, dil, B, H, W, mode, algo):
     if 'elu' in mode:
         flags |= P.PRO_ELU
         v = O.elu(v)
-    ref = O.conv2d(v.transpose(0, 3, 1, 2), w, bias, dil)
+    tol = TOL
+    if algo.endswith('f16w'):
+        # SBC_CONV_F16W: fp16 weights, activations rounded to fp16 as they enter the matrix cores, fp32 accumulation.  The
+        # direct kernel is held to the same products evaluated in fp32 (fp16 x fp16 is exact in fp32; a staged value one
+        # fp32 ulp off may round to the neighbouring fp16); the Winograd kernel rounds the TRANSFORMED operands instead
+        # (2^-11 relative each), so it is held to that rounding level.
+        w_ref, v_ref = round_fp16(w), round_fp16(v)
+        tol = 1e-4 if algo == 'f16w' else 4e-3
+    else:
+        w_ref, v_ref = w, v
+    ref = O.conv2d(v_ref.transpose(0, 3, 1, 2), w_ref, bias, dil)
     if pool:
         flags |= P.EPI_POOL
         ref = O.mean_pool2(ref)
@@ -136,10 +147,59 @@ def test_conv_matches_oracle(gpu, cin, cout, k, dil, B, H, W, mode, algo):
         ws = _dev(torch, pack_conv_weight_split(w).view(np.float32))
         op.weight_split = _p(ws)
         op.weight = None                      # the split kernel needs nothing else
+    if algo == 'f16w':
+        wf = _dev(torch, pack_conv_weight_f16(w).view(np.float32))
+        op.weight_split, op.weight, op.flags = _p(wf), None, flags | P.CONV_F16W
+    if algo == 'winograd_f16w':
+        wf = _dev(torch, pack_conv_weight_f16(w).view(np.float32))
+        wwf = _dev(torch, pack_conv_weight_winograd_f16(w).view(np.float32))
+        op.weight_split, op.weight_wino_split, op.weight, op.flags = _p(wf), _p(wwf), None, flags | P.CONV_F16W
     _launch(gpu, op)
     got = out.cpu().numpy()
     assert np.isfinite(got).all()
-    assert rel_err(got, ref) < TOL
+    assert rel_err(got, ref) < tol
+
+
+@pytest.mark.parametrize('cin,cout,B', [(128, 128, 53), (64, 128, 53), (128, 64, 53), (64, 64, 120)])
+def test_conv_two_wave_groups_are_race_free(gpu, cin, cout, B):
+    """Launches with fewer tiles than CUs run conv_wx3 with two wave groups per workgroup (output blocks dealt between
+    them, T planes per group).  The shortest epilogue (no bias / residual) leaves the least time between a group's finish
+    reads and its next T-plane writes: repeat the launch and require bit-identical, correct outputs every time."""
+    torch, _lib = gpu
+    from score_based_channels_amd import plan as P
+    from score_based_channels_amd.weights import pack_conv_weight_winograd_split
+    rng = np.random.default_rng(cin + cout)
+    H, W = 8, 2
+    x = rng.standard_normal((B, H, W, cin)).astype(F32)
+    w = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(F32)
+    ref = O.conv2d(x.transpose(0, 3, 1, 2), w, None, 1).transpose(0, 2, 3, 1)
+    dx, dw = _dev(torch, x), _dev(torch, pack_conv_weight_winograd_split(w).view(np.float32))
+    outs = [torch.full((B, H, W, cout), float('nan'), dtype=torch.float32, device='cuda') for _ in range(2)]
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    first = None
+    for rep in range(300):
+        out = outs[rep & 1]
+        op = _lib.sbc_op(kind=P.CONV, B=B, H=H, W=W, cin=cin, cout=cout, ksize=3, dil=1, in_=_p(dx), out=_p(out),
+                         weight_wino_split=_p(dw), weight_split=_p(dw))
+        _lib.check(_lib.lib().sbc_op_launch(C.byref(op), stream))
+        if rep < 2 or rep % 50 == 49:
+            torch.cuda.synchronize()
+            got = out.cpu().numpy()
+            if first is None:
+                first = got
+                assert rel_err(got, ref) < TOL
+            assert np.array_equal(got, first), rep
+    # every launch of the burst: accumulate a checksum on the device instead of copying 300 tensors back
+    sums = []
+    for rep in range(200):
+        out = outs[rep & 1]
+        out.fill_(float('nan'))
+        op = _lib.sbc_op(kind=P.CONV, B=B, H=H, W=W, cin=cin, cout=cout, ksize=3, dil=1, in_=_p(dx), out=_p(out),
+                         weight_wino_split=_p(dw), weight_split=_p(dw))
+        _lib.check(_lib.lib().sbc_op_launch(C.byref(op), stream))
+        sums.append((out.view(torch.int32).to(torch.int64)).sum())
+    sums = torch.stack(sums).cpu().numpy()
+    assert (sums == sums[0]).all()
 
 
 def test_conv_rejects_unsupported_shapes(gpu):

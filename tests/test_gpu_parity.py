@@ -200,6 +200,90 @@ def test_big_array_forward_and_ald(weights64):
     assert rel_err(X, g['X_final']) < 1e-5
 
 
+# conv_mode 'f16w' (BASELINE config 5, "fp16 score-net weights").  Oracle: the fp32 reference with fp16-rounded
+# parameters (goldens f16w_*.npz; the reference cannot run .half() itself, layers.py:179).  The HIP path additionally
+# rounds the activations to fp16 where they enter the matrix cores (11-bit significands, fp32 accumulation), so the
+# tolerance is looser than the fp32 contract.  Measured on MI355X: score error 0.92e-3 (64x16) / 1.8e-3 (256x64) of the
+# largest score value, NMSE within 4.4e-6 / 1.1e-6 relative at every logged step (93-step truncated schedule / 6 steps);
+# asserted with margin:
+F16W_FWD_TOL = 4e-3        # score, max-abs error over max-abs value
+F16W_NMSE_RTOL = 1e-4      # NMSE at every logged step, relative
+
+
+def _f16w_net(cfg, sd):
+    from score_based_channels_amd.scorenet import ScoreNet
+    return ScoreNet(cfg, conv_mode='f16w').cuda().load_state_dict(sd).eval()
+
+
+def test_f16w_matches_reference_with_fp16_weights(weights64):
+    import torch
+    cfg, sd = weights64
+    net = _f16w_net(cfg, sd)
+    g = load_golden('f16w_64x16.npz')
+    x = torch.from_numpy(g['x']).cuda()
+    errs = []
+    for i, lv in enumerate(g['levels']):
+        out = net(x, torch.full((4,), int(lv), dtype=torch.long, device='cuda'))
+        errs.append(rel_err(out.cpu().numpy(), g['out'][i]))
+    ga = dict(g, levels=g['ald_levels'], steps_each=3, alpha_step=3e-11, beta_noise=0.01)
+    _, X, log = _run_golden_ald(net, ga)
+    dev = float(np.max(np.abs(log / g['nmse_log'] - 1)))
+    print('f16w 64x16: forward errors %s, NMSE deviation %.2e, X %.2e' % (errs, dev, rel_err(X, g['X_final'])))
+    assert max(errs) < F16W_FWD_TOL and dev < F16W_NMSE_RTOL
+
+
+def test_f16w_big_array_matches_reference_with_fp16_weights():
+    """256 x 64 antennas with fp16 weights: golden G6 (forward + 6 Langevin steps)."""
+    import torch
+    from score_based_channels_amd.config import default_config
+    from score_based_channels_amd.weights import seeded_state_dict
+    cfg = default_config(image_size=(64, 256))
+    net = _f16w_net(cfg, seeded_state_dict(cfg, 2024))
+    g = load_golden('f16w_256x64.npz')
+    out = net(torch.from_numpy(g['x']).cuda(), torch.full((1,), int(g['level']), dtype=torch.long))
+    e = rel_err(out.cpu().numpy(), g['out'])
+    _, X, log = _run_golden_ald(net, dict(g, steps_each=3, alpha_step=3e-11, beta_noise=0.01))
+    dev = float(np.max(np.abs(log / g['nmse_log'] - 1)))
+    print('f16w 256x64: forward error %.2e, NMSE deviation %.2e' % (e, dev))
+    assert e < F16W_FWD_TOL and dev < F16W_NMSE_RTOL
+
+
+def test_config5_full_batch_is_the_sum_of_its_trajectories():
+    """BASELINE config 5 at full size: 1024 lock-step trajectories on 256 x 64 arrays (153 pilots) with fp16 weights --
+    16 GB of activation slots.  Size-independent property: a trajectory's estimate and NMSE log are bit-identical to the
+    same trajectory run in a batch of three; with the 256x64 goldens above this pins the full-size run."""
+    import torch
+    from score_based_channels_amd import synth
+    from score_based_channels_amd.ald import AldBatch, snr_to_noise
+    from score_based_channels_amd.config import default_config
+    from score_based_channels_amd.weights import seeded_state_dict
+    cfg = default_config(image_size=(64, 256))
+    net = _f16w_net(cfg, seeded_state_dict(cfg, 2024))
+    nch, nt, nr, npil = 64, 256, 64, 153
+    raw = synth.generate_channels('ULA', nch, nt, nr, 0.5, seed=31)
+    H = np.conj(np.transpose(raw / np.std(raw), (0, 2, 1))).astype(np.complex64)
+    Pm = np.conj(np.transpose(synth.qpsk_pilots(np.random.default_rng(32), nch, nt, npil), (0, 2, 1)))
+    snr = np.arange(-10, 30, 2.5)                                        # 16 SNR points x 64 channels = 1024
+    idx = np.tile(np.arange(nch), len(snr))
+    ln = np.repeat(snr_to_noise(snr, nt), nch)
+    init = torch.randn(nch, nt, nr, dtype=torch.complex64, generator=torch.Generator().manual_seed(6))
+
+    def run(sel):
+        ald = AldBatch(net, H, Pm, idx[sel], idx[sel], ln[sel], levels=[0, 1155], steps_each=2, seed=9, traj_id=sel)
+        ald.set_init(init[torch.from_numpy(idx[sel])])
+        ald.synthesize_measurements()
+        ald.run()
+        torch.cuda.synchronize()
+        out = ald.X.cpu().numpy(), ald.nmse_log().cpu().numpy()
+        ald.close()
+        return out
+    Xa, La = run(np.arange(1024))
+    assert np.isfinite(La).all() and La.shape == (4, 1024)
+    pick = np.array([0, 511, 1023])
+    Xb, Lb = run(pick)
+    assert np.array_equal(Xa[pick], Xb) and np.array_equal(La[:, pick], Lb)
+
+
 def test_cli_test_score_drop_in_outputs(net64, tmp_path, monkeypatch):
     """``python -m score_based_channels_amd.test_score`` keeps the reference's result file (test_score.py:192-200)."""
     import torch

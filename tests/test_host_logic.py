@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     h = _lib.lib()
     for name in declared:
         assert hasattr(h, name), name
-    assert h.sbc_abi_version() == 4
+    assert h.sbc_abi_version() == 5
 
 
 def test_pack_conv_weight_c_matches_python():
@@ -68,6 +68,30 @@ def test_pack_conv_weight_winograd_and_split_c_match_python():
             _lib.check(_lib.lib().sbc_pack_conv_weight_winograd_split(w.ctypes.data, o, c, dsts.ctypes.data))
             assert np.array_equal(dsts, refs)
     assert _lib.lib().sbc_pack_conv_weight_split(w.ctypes.data, 32, 24, 3, dst.ctypes.data) == -1
+
+
+def test_pack_conv_weight_f16_c_matches_python():
+    """fp16 weight forms of conv_mode f16w (BASELINE config 5): C packers == Python packers, values == w.half()."""
+    from score_based_channels_amd import _lib
+    from score_based_channels_amd.weights import (fp16_state_dict, pack_conv_weight_f16, pack_conv_weight_winograd_f16,
+                                                  round_fp16)
+    rng = np.random.default_rng(12)
+    for o, c, k in [(32, 32, 3), (64, 32, 1), (128, 64, 3)]:
+        w = (rng.standard_normal((o, c, k, k)) * np.exp(rng.uniform(-6, 1, (o, c, k, k)))).astype(np.float32)
+        ref = pack_conv_weight_f16(w)
+        dst = np.zeros(ref.shape, np.uint16)
+        _lib.check(_lib.lib().sbc_pack_conv_weight_f16(w.ctypes.data, o, c, k, dst.ctypes.data))
+        assert ref.shape == (k * k, c // 16, o // 32, 64, 8) and np.array_equal(dst, ref)
+        # lane l of block (t, g, n) holds fp16(w[n*32 + l%32, g*16 + 8*(l//32) + j, kh, kw])
+        assert ref[k * k - 1, 1, 0, 37, 2] == np.float16(w[5, 16 + 8 + 2, k - 1, k - 1]).view(np.uint16)
+        if k == 3:
+            refw = pack_conv_weight_winograd_f16(w)
+            dstw = np.zeros(refw.shape, np.uint16)
+            _lib.check(_lib.lib().sbc_pack_conv_weight_winograd_f16(w.ctypes.data, o, c, dstw.ctypes.data))
+            assert np.array_equal(dstw, refw)
+    sd = fp16_state_dict({'a.weight': w, 'sigmas': np.array([0.1234567], np.float32)})
+    assert np.array_equal(sd['a.weight'], round_fp16(w)) and sd['sigmas'][0] == np.float32(0.1234567)
+    assert _lib.lib().sbc_pack_conv_weight_f16(w.ctypes.data, 32, 24, 3, dst.ctypes.data) == -1
 
 
 def test_config_is_dotmap_like():

@@ -83,6 +83,24 @@ def test_big_array_forward_matches_reference():
     assert rel_err(out, g['out']) < 2e-5
 
 
+def test_fp16_weight_goldens_match_oracle_with_rounded_parameters(weights64):
+    """G6 / BASELINE config 5: the reference with fp16-rounded parameters == the oracle fed ``fp16_state_dict`` weights
+    (fp32 arithmetic on both sides, so the fp32 tolerance applies); this is what conv_mode f16w is held against."""
+    from score_based_channels_amd.config import default_config
+    from score_based_channels_amd.weights import fp16_state_dict, seeded_state_dict
+    _, sd = weights64
+    sd16 = fp16_state_dict(sd)
+    g = load_golden('f16w_64x16.npz')
+    for i, lv in enumerate(g['levels']):
+        out = ncsnv2_oracle.score_forward(sd16, g['x'], np.full((4,), lv))
+        assert rel_err(out, g['out'][i]) < 2e-5, lv
+        assert rel_err(out, load_golden('forward_64x16.npz')['out'][i]) > 1e-4      # and it is a different network
+    cfg = default_config(image_size=(64, 256))
+    gb = load_golden('f16w_256x64.npz')
+    out = ncsnv2_oracle.score_forward(fp16_state_dict(seeded_state_dict(cfg, 2024)), gb['x'], np.array([int(gb['level'])]))
+    assert rel_err(out, gb['out']) < 2e-5
+
+
 def test_loader_pieces_match_reference():
     g = load_golden('loader.npz')
     ch, mean, std, pil = ald_oracle.channels_dataset(g['output_h'], 64, 38, 'global',
