@@ -126,8 +126,9 @@ typedef struct sbc_endconv {
  *   P      [nP][Np][Nt] conj-transposed pilots, sample b uses P[p_index[b]] (b if p_index NULL)   (:109-111)
  *   Y      [B][Np][Nr]  measurements                                   (:122-124)
  *   Htrue  [nH][Nt][Nr] ground truth, sample b uses Htrue[h_index[b]]  (:112-113,131)
- *   sched  [G][n_steps][4] float32 (alpha, dc_div, noise_scale, unused) of group `group[b]` at step k,
- *          i.e. the float64 python scalars of :143-144,160,165 rounded to float32
+ *   sched  [G][n_steps][4] float32 (alpha, dc_div, noise_scale, dc_boost) of group `group[b]` at step k,
+ *          i.e. the float64 python scalars of :143-144,160,165 rounded to float32; dc_boost (1 for test_score,
+ *          --dc_boost of test_mmse.py:231-233) multiplies the data-consistency gradient before the division
  *   noise  [n_steps][B][Nt][Nr] CN(0,1) draws or NULL -> in-kernel Philox4x32-10 keyed by
  *          (seed, traj_id[b], step, element)                            (:160-161)
  *   nmse   [n_steps][B] float32 log, row *step is written               (:168-170)

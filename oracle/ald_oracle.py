@@ -52,10 +52,13 @@ def step_scalars(sigma_f32, sigma_end, alpha_step, beta_noise, local_noise):
     return F32(alpha), F32(dc_div), F32(noise_scale)
 
 
-def langevin_step(current, score, P, Y, alpha32, dc_div32, noise_scale32, noise):
-    """One update of test_score.py:156-165.  All tensors complex64."""
+def langevin_step(current, score, P, Y, alpha32, dc_div32, noise_scale32, noise, dc_boost32=None):
+    """One update of test_score.py:156-165.  All tensors complex64.  ``dc_boost32``: the factor of
+    test_mmse.py:231-233, ``alpha * (score - dc_boost * meas_grad / (...))`` -- multiplied into the gradient first."""
     P_h = np.conj(np.transpose(P, (0, 2, 1)))
     meas_grad = np.matmul(P_h, np.matmul(P, current) - Y)          # :157-158
+    if dc_boost32 is not None:
+        meas_grad = F32(dc_boost32) * meas_grad
     grad_noise = noise_scale32 * noise                             # :160-161
     return (current + alpha32 * (score - meas_grad / dc_div32) + grad_noise).astype(C64)
 
@@ -94,6 +97,38 @@ def ald_run(score_fn, sigmas, sigma_end, P, Y, H_true, init, step_noise, local_n
             log[k] = nmse(current, H_true)                          # :168-170
             k += 1
     return current, log
+
+
+def mmse_run(score_fn, sigmas, sigma_end, P, Y, H_true, init, step_noise, local_noise, step_size, noise_boost,
+             target_stop, mmse_avg, dc_boost=1.0, steps_each=3, levels=None):
+    """Posterior sampling of ONE SNR point, ``src/score_based_channels/test_mmse.py:182-262``: every kept sample is
+    repeated ``mmse_avg`` times (chains share the sample's measurement, :185-193), walked with that SNR's tuned
+    ``step_size`` / ``noise_boost`` (:171-172,216-228), the data-consistency gradient scaled by ``dc_boost`` (:231-233), and
+    stopped after step index ``target_stop`` (:246-250).
+
+    P ``[kept, Np, Nt]``, Y ``[kept, Np, Nr]``, H_true ``[kept, Nt, Nr]``; ``init`` ``[kept * mmse_avg, Nt, Nr]`` (chain
+    ``c`` of sample ``s`` is row ``s * mmse_avg + c``); ``step_noise(k)`` the CN(0,1) draw of step ``k`` for all chains.
+    Returns (``oracle_log`` ``[total_steps, kept, mmse_avg]`` float32, zero beyond the stop; final estimates
+    ``[kept, mmse_avg, Nt, Nr]``)."""
+    levels = range(len(sigmas)) if levels is None else list(levels)
+    kept = H_true.shape[0]
+    gY, gP, gH = (np.repeat(a, mmse_avg, axis=0) for a in (Y, P, H_true))      # tile per sample (:185-193)
+    current = init.astype(C64).copy()
+    log = np.zeros((len(levels) * steps_each, kept, mmse_avg), F32)
+    k = 0
+    for step_idx in levels:
+        a32, d32, n32 = step_scalars(sigmas[step_idx], sigma_end, step_size, noise_boost, local_noise)
+        labels = np.full((current.shape[0],), step_idx, np.int64)
+        for _ in range(steps_each):
+            current_real = np.stack((current.real, current.imag), axis=1).astype(F32)
+            score_real = score_fn(current_real, labels)
+            score = (score_real[:, 0] + 1j * score_real[:, 1]).astype(C64)
+            current = langevin_step(current, score, gP, gY, a32, d32, n32, step_noise(k), dc_boost32=dc_boost)
+            log[k] = nmse(current, gH).reshape(kept, mmse_avg)                   # :238-244
+            if k == target_stop:                                                 # :246-250
+                return log, current.reshape((kept, mmse_avg) + H_true.shape[1:])
+            k += 1
+    return log, current.reshape((kept, mmse_avg) + H_true.shape[1:])
 
 
 def reduce_nmse(nmse_log):

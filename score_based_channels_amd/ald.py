@@ -30,16 +30,15 @@ def schedule_tables(sigmas_f32, sigma_end, levels, steps_each, alpha_step, beta_
     test_score.py:137-165 and rounded to float32 where they meet a complex64 tensor.
 
     ``alpha_step``, ``beta_noise``, ``local_noise``: float64 arrays of equal length G (one row per distinct
-    scalar group).  Returns (``sched`` float32 ``[G, n_steps, 4]`` = (alpha, dc_div, noise_scale, 0),
-    ``sigma_of_step`` float32 ``[n_steps]``)."""
+    scalar group).  Returns (``sched`` float32 ``[G, n_steps, 4]`` = (alpha, dc_div, noise_scale, dc_boost),
+    ``sigma_of_step`` float32 ``[n_steps]``).  ``dc_boost`` (test_mmse.py:231-233) stays a separate factor: the reference
+    evaluates ``dc_boost * meas_grad / (...)`` left to right, so the kernel multiplies the gradient first."""
     levels = np.asarray(levels, np.int64)
     sig = np.asarray(sigmas_f32, np.float32)[levels].astype(np.float64)        # .item() of a float32 tensor
     alpha = np.asarray(alpha_step, np.float64)[:, None] * (sig[None, :] / float(sigma_end)) ** 2     # :143-144
     nscale = np.sqrt(2 * alpha * np.asarray(beta_noise, np.float64)[:, None])                        # :160
     dc_div = np.asarray(local_noise, np.float64)[:, None] / 2. + sig[None, :] ** 2                   # :165
-    if dc_boost != 1.0:                      # test_mmse.py:231-233 multiplies the gradient by dc_boost instead
-        dc_div = dc_div / float(dc_boost)
-    per_level = np.stack((alpha, dc_div, nscale, np.zeros_like(alpha)), axis=-1).astype(np.float32)
+    per_level = np.stack((alpha, dc_div, nscale, np.full_like(alpha, float(dc_boost))), axis=-1).astype(np.float32)
     sched = np.repeat(per_level, steps_each, axis=1)
     sigma_of_step = np.repeat(np.asarray(sigmas_f32, np.float32)[levels], steps_each)
     return np.ascontiguousarray(sched), np.ascontiguousarray(sigma_of_step)
@@ -61,7 +60,7 @@ class AldBatch:
     ``levels``: noise-level indices to walk (default: the full schedule), ``steps_each``: Langevin steps per
     level (test_score.py:56).  Noise: ``seed`` keys the in-kernel Philox stream of trajectory ``traj_id[t]``
     (independent of batching / world size); pass ``step_noise`` ``[n_steps, T, Nt, Nr]`` complex64 to replay
-    externally drawn noise instead (parity runs).
+    externally drawn noise instead (parity runs; fewer rows than ``n_steps`` are allowed when the run stops early).
     """
 
     def __init__(self, net, Htrue, P_pilots, h_index, p_index, local_noise, alpha_step=3e-11, beta_noise=0.01,
@@ -107,8 +106,9 @@ class AldBatch:
         self.step_noise = None
         if step_noise is not None:
             self.step_noise = _as_c64(step_noise, dev)
-            if tuple(self.step_noise.shape) != (self.n_steps, T, self.nt, self.nr):
-                raise ValueError('step_noise must be [n_steps=%d, T=%d, Nt, Nr]' % (self.n_steps, T))
+            if tuple(self.step_noise.shape[1:]) != (T, self.nt, self.nr) or not 0 < self.step_noise.shape[0] <= self.n_steps:
+                raise ValueError('step_noise must be [k <= n_steps=%d, T=%d, Nt, Nr] (rows = steps that will be run)'
+                                 % (self.n_steps, T))
         # score network bound to this batch: its input buffer IS the current estimate X (complex64 view)
         self.bound = net.bind(T, self.nt, self.nr, step=self.d_step, sigma_of_step=self.d_sigma_of_step,
                               use_labels=False)
@@ -166,6 +166,8 @@ class AldBatch:
         n = self.n_steps - done if n_steps is None else int(n_steps)
         if n < 0 or done + n > self.n_steps:
             raise ValueError('schedule has %d steps, %d already done, %d requested' % (self.n_steps, done, n))
+        if self.step_noise is not None and done + n > self.step_noise.shape[0]:
+            raise ValueError('replayed noise covers %d steps, %d requested' % (self.step_noise.shape[0], done + n))
         if use_graph:
             # hipGraph capture is not allowed on the legacy default stream: replay on a private stream that is
             # ordered after / before the caller's current stream

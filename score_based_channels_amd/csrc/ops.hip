@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void langevin_kernel(sbc_langevin a, int B, in
     }
     __syncthreads();
     const float* sc = a.sched + ((size_t)(a.group ? a.group[b] : 0) * a.n_steps + step) * 4;
-    const float alpha = sc[0], dc_div = sc[1], nscale = sc[2];
+    const float alpha = sc[0], dc_div = sc[1], nscale = sc[2], dcb = sc[3];     // dcb: dc_boost of test_mmse.py:231-233
     const float2* ext = a.noise ? reinterpret_cast<const float2*>(a.noise) + ((size_t)step * B + b) * Nt * Nr : nullptr;
     const int64_t traj = a.traj_id ? a.traj_id[b] : b;
     float err = 0.f, den = 0.f;
@@ -458,8 +458,8 @@ __global__ __launch_bounds__(256) void langevin_kernel(sbc_langevin a, int B, in
         const float2 s = Sc[e], x = Xs[e], h = Ht[e];
         const float2 n = ext ? ext[e] : complex_normal(a.seed, traj, step, e);
         float2 u;
-        u.x = x.x + alpha * (s.x - gacc.x / dc_div) + nscale * n.x;
-        u.y = x.y + alpha * (s.y - gacc.y / dc_div) + nscale * n.y;
+        u.x = x.x + alpha * (s.x - (dcb * gacc.x) / dc_div) + nscale * n.x;      // x * 1.0f is exact: test_score semantics
+        u.y = x.y + alpha * (s.y - (dcb * gacc.y) / dc_div) + nscale * n.y;
         X[e] = u;
         const float dx = u.x - h.x, dy = u.y - h.y;
         err += dx * dx + dy * dy;

@@ -41,9 +41,23 @@ def batch_limit(net, nt, nr, requested, reserve=0.25):
     return max(1, min(int(requested), by_mem, by_index))
 
 
+def host_noise_streams(seed, combo, shape, n_snr, n_steps, meas_shape):
+    """The Gaussian draws of one (spacing, pilot_alpha) combination from the keyed host streams of ``noise.HostNoise``
+    -- the reference's draw order: one initial estimate shared by all SNR points, then per SNR point
+    one measurement-noise draw and one draw per Langevin step -- laid out for the lock-step batch ``t = snr * B + b``.
+    Returns (init ``[B, Nt, Nr]`` torch, meas ``[S*B, Np, Nr]``, steps ``[n_steps, S*B, Nt, Nr]``)."""
+    from .noise import HostNoise
+    noise = HostNoise(seed, combo)
+    init = torch.from_numpy(noise.init(shape))
+    meas = np.concatenate([noise.measurement(s, meas_shape) for s in range(n_snr)], axis=0)
+    steps = np.concatenate([noise.step_block(s, shape, n_steps) for s in range(n_snr)], axis=1)
+    return init, meas, steps
+
+
 def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, beta_noise, levels, steps_each,
                      seed, init, traj_base=0, max_batch=4096, use_graph=True, rank=0, world=1, n_streams=1,
-                     return_final=False, n_steps=None, dc_boost=1.0, init_index=None, Y=None, y_index=None):
+                     return_final=False, n_steps=None, dc_boost=1.0, init_index=None, Y=None, y_index=None,
+                     step_noise=None, meas_noise=None):
     """Run ``T = len(h_index)`` trajectories, sharded over ``world`` ranks; returns the full NMSE log
     ``[n_steps, T]`` (float32 numpy, identical on every rank).  ``init``: ``[nH, Nt, Nr]`` complex64 initial
     estimates indexed by ``h_index``.  Trajectory ``t`` draws its noise from Philox stream ``traj_base + t``.
@@ -56,7 +70,10 @@ def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, b
     ``init_index`` (default ``h_index``) selects the initial estimate of each trajectory; ``Y`` ``[nY, Np, Nr]`` with
     ``y_index`` supplies measurements shared by several trajectories instead of synthesising one per trajectory
     (the 50 chains per sample of ``test_mmse.py:185-193``).  ``return_final``: also return the final estimates ``[T, Nt, Nr]`` complex64 (``--save_channels``); ``n_steps``: stop
-    after that many Langevin steps (early stop of ``test_mmse.py:246-250``)"""
+    after that many Langevin steps (early stop of ``test_mmse.py:246-250``).
+
+    ``step_noise`` ``[n_steps, T, Nt, Nr]`` / ``meas_noise`` ``[T, Np, Nr]`` complex64 (host arrays) replay externally
+    drawn CN(0,1) noise instead of the in-kernel Philox streams (``--noise host`` parity runs against the reference)."""
     h_index = np.asarray(h_index, np.int64)
     T = len(h_index)
     bc = lambda a: np.broadcast_to(np.asarray(a), (T,))            # noqa: E731
@@ -79,12 +96,13 @@ def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, b
                 continue
             st.wait_stream(cur)
             with torch.cuda.stream(st):
+                sn = None if step_noise is None else torch.from_numpy(np.ascontiguousarray(step_noise[:n_steps, part]))
                 ald = AldBatch(net, Htrue, P, h_index[part], p_index[part], local_noise[part], alpha_step[part],
                                beta_noise[part], levels=levels, steps_each=steps_each, seed=seed,
-                               traj_id=traj_base + part, dc_boost=dc_boost)
+                               traj_id=traj_base + part, dc_boost=dc_boost, step_noise=sn)
                 ald.set_init(init[torch.from_numpy(init_index[part])])
                 if Y is None:
-                    ald.synthesize_measurements()
+                    ald.synthesize_measurements(None if meas_noise is None else torch.from_numpy(meas_noise[part]))
                 else:
                     ald.set_measurements(Y[torch.from_numpy(np.asarray(y_index)[part])])
                 ald.run(n_steps, use_graph=use_graph)

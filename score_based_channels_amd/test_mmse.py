@@ -23,6 +23,7 @@ from .checkpoint import load_checkpoint
 from .config import default_config
 from .driver import level_subset, run_trajectories
 from .loaders import Channels
+from .noise import HostNoise
 from .scorenet import ScoreNet
 from .shard import init_distributed
 from .weights import get_sigmas, seeded_state_dict
@@ -67,7 +68,9 @@ def parse_args(argv=None):
                    help='[added] tuned per-SNR hyper-parameters (default ./our_hyperparams_<model>.pt, test_mmse.py:123)')
     p.add_argument('--synthetic', action='store_true', help='[added] generated CDL-like channels instead of ./data')
     p.add_argument('--synthetic_weights', type=int, default=None, metavar='SEED', help='[added] seed-derived weights')
-    p.add_argument('--conv_mode', type=str, default='bf16x3', choices=['bf16x3', 'f32'], help='[added]')
+    p.add_argument('--conv_mode', type=str, default='bf16x3', choices=['bf16x3', 'f32', 'f16w'], help='[added]')
+    p.add_argument('--noise', type=str, default='device', choices=['device', 'host'],
+                   help='[added] in-kernel Philox noise, or the keyed host streams of noise.HostNoise (parity runs)')
     p.add_argument('--no_graph', action='store_true', help='[added] eager launches instead of hipGraph replay')
     p.add_argument('--result_dir', type=str, default=None, help='[added] default TWC_rebuttal_MMSE_aug6_seed4321')
     return p.parse_args(argv)
@@ -85,6 +88,41 @@ def start_points(kind, P_herm, Y, n_chains, nt, nr, seed, key):
     else:                                                 # 'LS': minimum-norm least squares per sample
         x = np.stack([np.linalg.lstsq(P_herm[b], Y[b], rcond=None)[0] for b in range(B)])
     return torch.from_numpy(np.repeat(x.astype(np.complex64), n_chains, axis=0))
+
+
+def posterior_chains(diffuser, val_H, val_P, local_noise, step, noise_boost, n_run, levels, steps_each, navg,
+                     start_point='Noise', seed=0, key=0, dc_boost=1.0, use_graph=True, rank=0, world=1, host_noise=None):
+    """All chains of ONE SNR point (test_mmse.py:170-262): one measurement per kept sample shared by its ``navg`` chains
+    (:176-193), start points (:196-203), ``n_run`` Langevin steps with that SNR's (step, noise) pair and ``dc_boost``
+    (:216-233), early stop (:246-250).  ``val_H`` ``[kept, Nt, Nr]``, ``val_P`` ``[kept, Np, Nt]`` complex64 numpy.
+
+    Noise: in-kernel Philox streams keyed by (``seed``, ``key``), or -- ``host_noise`` = a ``noise.HostNoise`` -- that
+    object's measurement draw 0, ``init`` draw (start point 'Noise') and step stream 0, i.e. the draws the reference
+    goldens were generated with.  Returns (Y ``[kept, Np, Nr]`` torch, log ``[n_run, kept, navg]``, estimates
+    ``[kept, navg, Nt, Nr]``)."""
+    kept, nt, nr = val_H.shape
+    npil = val_P.shape[1]
+    h_index = np.repeat(np.arange(kept), navg)                          # trajectory = sample * mmse_avg + chain
+    base = key * kept * (navg + 1)
+    # one measurement per sample (measure kernel), shared by its chains
+    meas = AldBatch(diffuser, val_H, val_P, np.arange(kept), np.arange(kept), local_noise, levels=levels[:1],
+                    steps_each=1, seed=seed, traj_id=base + np.arange(kept))
+    mz = None if host_noise is None else torch.from_numpy(host_noise.measurement(0, (kept, npil, nr)))
+    Y = meas.synthesize_measurements(mz).clone()
+    meas.close()
+    step_noise = None
+    if host_noise is not None:
+        step_noise = host_noise.step_block(0, (kept * navg, nt, nr), n_run)
+    if host_noise is not None and start_point == 'Noise':
+        init = torch.from_numpy(host_noise.init((kept * navg, nt, nr)))
+    else:
+        init = start_points(start_point, val_P, Y.cpu().numpy(), navg, nt, nr, seed, key)
+    log, est = run_trajectories(
+        diffuser, val_H, val_P, h_index, h_index, local_noise, step, noise_boost, levels, steps_each, seed,
+        init, traj_base=base + kept, max_batch=8192, use_graph=use_graph, rank=rank, world=world, return_final=True,
+        n_steps=n_run, dc_boost=float(dc_boost), init_index=np.arange(kept * navg), Y=Y, y_index=h_index,
+        step_noise=step_noise)
+    return Y, log.reshape(n_run, kept, navg), est.reshape(kept, navg, nt, nr)
 
 
 def main(argv=None):
@@ -167,25 +205,17 @@ def main(argv=None):
         val_P = np.conj(np.transpose(sample['P'], (0, 2, 1)))           # [B, Np, Nt]
         val_H = sample['H_herm'][:, 0] + 1j * sample['H_herm'][:, 1]     # [B, Nt, Nr]
         oracle_H = val_H
-        h_index = np.repeat(np.arange(kept), navg)                      # trajectory = sample * mmse_avg + chain
         for snr_idx, local_noise in enumerate(noise_range):
             step = float(best_step[pilot_alpha_idx, snr_idx])
             noise_boost = float(best_noise[pilot_alpha_idx, snr_idx])
             n_run = min(int(best_stop[pilot_alpha_idx, snr_idx]) + 1, total_steps)     # early stop (:246-250)
             key = (meta_idx * S + snr_idx)
-            # one measurement per sample (measure kernel), shared by its chains
-            meas = AldBatch(diffuser, val_H, val_P, np.arange(kept), np.arange(kept), local_noise, levels=levels,
-                            steps_each=steps_each, seed=seed, traj_id=key * kept * (navg + 1) + np.arange(kept))
-            Y = meas.synthesize_measurements().clone()
-            del meas
-            init = start_points(args.start_point, val_P, Y.cpu().numpy(), navg, nt, nr, seed, key)
-            log, est = run_trajectories(
-                diffuser, val_H, val_P, h_index, h_index, local_noise, step, noise_boost, levels, steps_each, seed,
-                init, traj_base=key * kept * (navg + 1) + kept, max_batch=8192, use_graph=not args.no_graph,
-                rank=rank, world=world, return_final=True, n_steps=n_run, dc_boost=float(args.dc_boost),
-                init_index=np.arange(kept * navg), Y=Y, y_index=h_index)
-            oracle_log[spacing_idx, pilot_alpha_idx, snr_idx, :n_run] = log.reshape(n_run, kept, navg)
-            saved_H[spacing_idx, pilot_alpha_idx, snr_idx] = est.reshape(kept, navg, nt, nr)
+            host = HostNoise(seed, combo=1 + key) if args.noise == 'host' else None
+            _, log, est = posterior_chains(diffuser, val_H, val_P, local_noise, step, noise_boost, n_run, levels,
+                                           steps_each, navg, args.start_point, seed, key, args.dc_boost,
+                                           not args.no_graph, rank, world, host)
+            oracle_log[spacing_idx, pilot_alpha_idx, snr_idx, :n_run] = log
+            saved_H[spacing_idx, pilot_alpha_idx, snr_idx] = est
             if rank == 0:
                 print('SNR %.1f dB: early stopping at step %d' % (snr_range[snr_idx], n_run - 1))
 

@@ -36,9 +36,14 @@ def parse_args(argv=None):
     p.add_argument('--synthetic', action='store_true', help='generate CDL-like channels instead of reading ./data')
     p.add_argument('--synthetic_weights', type=int, default=None, metavar='SEED',
                    help='seed-derived random weights instead of ./models/score/<train>/final_model.pt')
+    p.add_argument('--noise', type=str, default='device', choices=['device', 'host'],
+                   help="Gaussian draws: in-kernel Philox streams keyed by (seed, trajectory, step) [device, default], or "
+                        "the keyed host streams of noise.HostNoise replayed from memory [host] -- the streams the "
+                        "reference goldens were generated with (parity runs; needs n_steps x T x Nt x Nr x 8 bytes)")
     p.add_argument('--no_plot', action='store_true')
-    p.add_argument('--conv_mode', type=str, default='bf16x3', choices=['bf16x3', 'f32'],
-                   help='convolution multiplier: split-bf16 matrix cores (fp32-accurate, default) or fp32 MFMA')
+    p.add_argument('--conv_mode', type=str, default='bf16x3', choices=['bf16x3', 'f32', 'f16w'],
+                   help='convolution multiplier: split-bf16 matrix cores (fp32-accurate, default), fp32 MFMA, or fp16 '
+                        'weights on the fp16 matrix cores (BASELINE config 5; looser tolerance)')
     p.add_argument('--no_graph', action='store_true', help='launch kernels eagerly instead of hipGraph replay')
     return p.parse_args(argv)
 
@@ -49,7 +54,7 @@ def main(argv=None):
     from . import shard
     from .checkpoint import load_checkpoint
     from .config import default_config
-    from .driver import level_subset, run_trajectories, shared_init
+    from .driver import host_noise_streams, level_subset, run_trajectories, shared_init
     from .loaders import Channels
     from .scorenet import ScoreNet
     from .weights import seeded_state_dict
@@ -107,13 +112,19 @@ def main(argv=None):
         val_P = np.conj(np.transpose(sample['P'], (0, 2, 1)))           # Hermitian pilots [B, Np, Nt] (:109-111)
         val_H = sample['H_herm'][:, 0] + 1j * sample['H_herm'][:, 1]     # [B, Nt, Nr] (:112-113)
         nr = val_H.shape[-1]
-        init = shared_init(num_channels, nt, nr, seed, meta_idx)        # one init for all SNR points (:115,126)
         S = len(snr_range)
+        step_noise = meas_noise = None
+        if args.noise == 'host':
+            init, meas_noise, step_noise = host_noise_streams(seed, meta_idx, val_H.shape, S, n_steps,
+                                                              (num_channels, val_P.shape[1], nr))
+        else:
+            init = shared_init(num_channels, nt, nr, seed, meta_idx)    # one init for all SNR points (:115,126)
         idx = np.tile(np.arange(num_channels), S)                       # trajectory t = snr * B + channel
         out = run_trajectories(diffuser, val_H, val_P, idx, idx, np.repeat(noise_range, num_channels), alpha_step,
                                beta_noise, levels, config.sampling.steps_each, seed, init,
                                traj_base=meta_idx * S * num_channels, use_graph=not args.no_graph,
-                               rank=rank, world=world, return_final=bool(args.save_channels))
+                               rank=rank, world=world, return_final=bool(args.save_channels),
+                               step_noise=step_noise, meas_noise=meas_noise)
         if args.save_channels:
             log, est = out
             if saved_H is None:

@@ -37,8 +37,11 @@ def parse_args(argv=None):
     p.add_argument('--synthetic', action='store_true')
     p.add_argument('--synthetic_weights', type=int, default=None, metavar='SEED')
     p.add_argument('--no_plot', action='store_true')
-    p.add_argument('--conv_mode', type=str, default='bf16x3', choices=['bf16x3', 'f32'],
-                   help='convolution multiplier: split-bf16 matrix cores (fp32-accurate, default) or fp32 MFMA')
+    p.add_argument('--conv_mode', type=str, default='bf16x3', choices=['bf16x3', 'f32', 'f16w'],
+                   help='convolution multiplier: split-bf16 matrix cores (fp32-accurate, default), fp32 MFMA, or fp16 '
+                        'weights on the fp16 matrix cores (looser tolerance)')
+    p.add_argument('--noise', type=str, default='device', choices=['device', 'host'],
+                   help='in-kernel Philox noise [device] or the keyed host streams of noise.HostNoise [host, parity runs]')
     p.add_argument('--no_graph', action='store_true')
     return p.parse_args(argv)
 
@@ -60,7 +63,7 @@ def main(argv=None):
     from . import shard
     from .checkpoint import load_checkpoint
     from .config import default_config
-    from .driver import level_subset, run_trajectories, shared_init
+    from .driver import host_noise_streams, level_subset, run_trajectories, shared_init
     from .loaders import Channels
     from .scorenet import ScoreNet
     from .weights import seeded_state_dict
@@ -102,7 +105,7 @@ def main(argv=None):
 
     # one validation dataset / pilot draw / initial estimate per grid cell, in the reference's order
     cells = list(itertools.product(alpha_step_range, beta_noise_range))
-    Hs, Ps, inits = [], [], []
+    Hs, Ps, inits, meas_nz, step_nz = [], [], [], [], []
     for meta_idx, _ in enumerate(cells):
         val_config = copy.deepcopy(config)
         val_config.data.channel = args.channel
@@ -112,8 +115,14 @@ def main(argv=None):
         sample = val_dataset.batch(B)
         Ps.append(np.conj(np.transpose(sample['P'], (0, 2, 1))))
         Hs.append(sample['H_herm'][:, 0] + 1j * sample['H_herm'][:, 1])
-        inits.append(shared_init(B, nt, Hs[-1].shape[-1], seed, meta_idx))
+        if args.noise == 'host':                          # draw order of the reference: init, then per SNR (Y noise, steps)
+            i0, m0, s0 = host_noise_streams(seed, meta_idx, Hs[-1].shape, S, n_steps, (B, Ps[-1].shape[1], Hs[-1].shape[-1]))
+            inits.append(i0); meas_nz.append(m0); step_nz.append(s0)
+        else:
+            inits.append(shared_init(B, nt, Hs[-1].shape[-1], seed, meta_idx))
     H_all, P_all, init_all = np.concatenate(Hs), np.concatenate(Ps), torch.cat(inits)
+    meas_noise = np.concatenate(meas_nz, axis=0) if meas_nz else None
+    step_noise = np.concatenate(step_nz, axis=1) if step_nz else None
     # trajectory t = (cell * S + snr) * B + channel
     cell_of = np.repeat(np.arange(len(cells)), S * B)
     chan_of = np.tile(np.arange(B), len(cells) * S)
@@ -122,7 +131,8 @@ def main(argv=None):
     a0 = np.asarray([c[0] for c in cells])[cell_of]
     be = np.asarray([c[1] for c in cells])[cell_of]
     log = run_trajectories(diffuser, H_all, P_all, h_index, h_index, ln, a0, be, levels, steps_each, seed, init_all,
-                           use_graph=not args.no_graph, rank=rank, world=world)
+                           use_graph=not args.no_graph, rank=rank, world=world, step_noise=step_noise,
+                           meas_noise=meas_noise)
     nmse_log = log.reshape(n_steps, len(alpha_step_range), len(beta_noise_range), S, B).transpose(1, 2, 3, 0, 4)
     nmse_log = nmse_log.astype(np.float64)
 

@@ -61,10 +61,10 @@ def case_inputs(seed, B, nt, nr, pilot_alpha, profile='CDL-C'):
 
 
 def reference_ald(net, config, H, P, snr_db, levels, seed, steps_each=3, alpha_step=3e-11,
-                  beta_noise=0.01):
+                  beta_noise=0.01, combo=0):
     """test_score.py:115-171 with keyed noise; returns Y, final estimates and the NMSE log."""
     nt = H.shape[1]
-    noise = HostNoise(seed)
+    noise = HostNoise(seed, combo)
     val_P, val_H = torch.from_numpy(P), torch.from_numpy(H)
     init_val_H = torch.from_numpy(noise.init(H.shape))
     noise_range = 10 ** (-np.asarray(snr_db, np.float64) / 10.) * nt
@@ -217,6 +217,159 @@ def gen_f16w():
                         nmse_log=log, snr_db=np.array([10.0]), levels=np.array([0, 1000]), seed=106,
                         weight_seed=WEIGHT_SEED)
     print('f16w_256x64: out absmax %g nmse %s' % (np.abs(out).max(), log[0, :, 0]))
+
+
+def _reference_datasets(train_profile, test_profile, legacy_seed, num_pilots_val, spacing=0.5):
+    """The data path of the reference scripts (test_score.py:62-113 / tune_hparams_score.py:48-97), executed with the
+    reference's own ``loaders.Channels`` and ``DataLoader``: training-profile dataset for the normalisation constants,
+    then a factory for validation datasets (the tuner re-creates one per grid cell, drawing fresh pilots from numpy's
+    global RNG).  The ``.mat`` reader is replaced by the build's synthetic generator -- the same arrays
+    ``Channels(..., synthetic=True)`` of this repo produces for those file names."""
+    import re
+    from torch.utils.data import DataLoader
+    fake = types.ModuleType('hdf5storage')
+
+    def loadmat(fn):
+        m = re.match(r'(.+)_Nt(\d+)_Nr(\d+)_ULA([0-9.]+)_seed(\d+)\.mat', os.path.basename(fn))
+        prof, nt, nr, sp, seed = m.group(1), int(m.group(2)), int(m.group(3)), float(m.group(4)), int(m.group(5))
+        return {'output_h': synth.generate_output_h(prof, 200, nt, nr, sp, seed, n_sym=1)}
+    fake.loadmat = loadmat
+    sys.modules['hdf5storage'] = fake
+    from score_based_channels.loaders import Channels
+    import copy
+    cfg = default_config(train_profile)
+    np.random.seed(legacy_seed % (2 ** 32))
+    cfg.data.channel = train_profile
+    dataset = Channels(1234, cfg, norm=cfg.data.norm_channels)
+    def make_val():
+        val_config = copy.deepcopy(cfg)
+        val_config.data.channel = test_profile
+        val_config.data.spacing_list = [spacing]
+        val_config.data.num_pilots = num_pilots_val
+        return Channels(4321, val_config, norm=[dataset.mean, dataset.std])
+    # created lazily: numpy's global RNG is consumed in script order (dataset -> its batch -> next dataset)
+    return cfg, dataset, make_val, DataLoader
+
+
+def _first_batch(val_dataset, DataLoader, n):
+    """test_score.py:102-113: first batch, Hermitian pilots, complex normalised Hermitian channels."""
+    sample = next(iter(DataLoader(val_dataset, batch_size=n, shuffle=False, num_workers=0, drop_last=True)))
+    val_P = torch.conj(torch.transpose(sample['P'], -1, -2))
+    val_H = sample['H_herm'][:, 0] + 1j * sample['H_herm'][:, 1]
+    return val_H.numpy().astype(np.complex64), val_P.resolve_conj().numpy().astype(np.complex64)
+
+
+def gen_cross():
+    """BASELINE config 4 end to end: ``--train CDL-C --test CDL-D`` (normalisation constants from the TRAIN profile's
+    seed-1234 dataset, test_score.py:68-69,101), 4 channels x 17 SNR points x the first 2 noise levels, seed 3.
+    The build's CLI must reproduce ``nmse_log`` from the same command line with ``--noise host``."""
+    seed, B = 3, 4
+    cfg, dataset, make_val, DataLoader = _reference_datasets('CDL-C', 'CDL-D', seed, 38)
+    H, P = _first_batch(make_val(), DataLoader, B)
+    net = reference_net(cfg, seeded_state_dict(cfg, WEIGHT_SEED))
+    snr = np.arange(-10, 32.5, 2.5)
+    Y, X, log = reference_ald(net, cfg, H, P, snr, [0, 1], seed)
+    np.savez_compressed(os.path.join(GOLD, 'cli_cross_cdlc_cdld.npz'), H=H, P=P, nmse_log=log, X_final=X, snr_db=snr,
+                        train_std=np.float64(dataset.std), seed=seed, weight_seed=WEIGHT_SEED,
+                        argv=np.array('--train CDL-C --test CDL-D --synthetic --synthetic_weights 2024 --num_levels 2 '
+                                      '--num_channels 4 --seed 3 --noise host --no_plot'))
+    print('cli_cross: std(train)=%g |H| rms %g nmse[0,-1]=%s' % (dataset.std, np.sqrt(np.mean(np.abs(H) ** 2)), log[0, -1]))
+
+
+def gen_tunecli():
+    """BASELINE config 3 end to end at reduced size: a 2 x 2 (alpha, beta) grid, 3 channels, first noise level; every cell
+    re-creates the validation dataset and draws its own noise streams (tune_hparams_score.py:71-97)."""
+    seed, B = 4, 3
+    alphas, betas = [3e-11, 3e-10], [0.1, 0.01]
+    cfg, dataset, make_val, DataLoader = _reference_datasets('CDL-C', 'CDL-C', seed, 38)
+    net = reference_net(cfg, seeded_state_dict(cfg, WEIGHT_SEED))
+    snr = np.arange(-10, 32.5, 2.5)
+    logs = np.zeros((2, 2, len(snr), 3, B), np.float32)
+    for meta_idx, (a, b) in enumerate([(a, b) for a in alphas for b in betas]):
+        # the reference batches the whole validation set (batch_size=len(val_dataset), tune_hparams_score.py:84-85) and
+        # its log has room for exactly 100 channels (:63); here the first B items play that role
+        H, P = _first_batch(make_val(), DataLoader, B)
+        # HostNoise(seed, combo=meta_idx): reference_ald keys its streams by seed only, so fold the cell into the call
+        _, _, log = reference_ald(net, cfg, H, P, snr, [0], seed, alpha_step=a, beta_noise=b, combo=meta_idx)
+        logs[meta_idx // 2, meta_idx % 2] = log
+    np.savez_compressed(os.path.join(GOLD, 'cli_tune_grid.npz'), nmse_log=logs, snr_db=snr, alpha_step_range=alphas,
+                        beta_noise_range=betas, seed=seed, weight_seed=WEIGHT_SEED)
+    print('cli_tune: nmse[...,0,-1,0] =', logs[..., 0, -1, 0])
+
+
+def reference_mmse(net, config, H, P, snr_db, levels, seed, best_step, best_noise, best_stop, mmse_avg, dc_boost,
+                   start_point, steps_each=3):
+    """test_mmse.py:166-277 around the imported network, with keyed noise.  Two stale lines of the script are written as
+    they are meant: the per-SNR collections are re-created for every SNR point (the script appends to tensors from the
+    second point on, :185-193), and the NMSE vector is reshaped to (kept_samples, mmse_avg) directly (the script's
+    ``.view(len(snr_range), -1)`` only works when 19 divides the batch, :238-244)."""
+    kept = H.shape[0]
+    noise_range = 10 ** (-np.asarray(snr_db, np.float64) / 10.)          # no Nt factor here (:100)
+    val_P, val_H = torch.from_numpy(P), torch.from_numpy(H)
+    total_steps = len(levels) * steps_each
+    oracle_log = np.zeros((len(noise_range), total_steps, kept, mmse_avg))
+    saved_H = np.zeros((len(noise_range), kept, mmse_avg) + H.shape[1:], np.complex64)
+    Ys = []
+    for snr_idx, local_noise in enumerate(noise_range):
+        noise = HostNoise(seed, combo=1 + snr_idx)
+        step_size = 1. * best_step[snr_idx]                              # fixed_step_size * best_step (:171)
+        noise_boost, target_stop = best_noise[snr_idx], best_stop[snr_idx]
+        local_Y = torch.matmul(val_P, val_H)
+        local_Y = local_Y + np.sqrt(local_noise) * torch.from_numpy(noise.measurement(0, tuple(local_Y.shape)))
+        global_Y = torch.cat([torch.tile(local_Y[i][None, ...].clone(), (mmse_avg, 1, 1)) for i in range(kept)])
+        global_P = torch.cat([torch.tile(val_P[i][None, ...].clone(), (mmse_avg, 1, 1)) for i in range(kept)])
+        global_H = torch.cat([torch.tile(val_H[i][None, ...].clone(), (mmse_avg, 1, 1)) for i in range(kept)])
+        if start_point == 'Noise':
+            current = torch.from_numpy(noise.init(tuple(global_H.shape)))
+        elif start_point == 'Adjoint':
+            current = torch.matmul(torch.conj(torch.transpose(global_P, -1, -2)), global_Y)
+        y, forward, forward_h, oracle = global_Y, global_P, torch.conj(torch.transpose(global_P, -1, -2)), global_H
+        draw = noise.step_stream(0, tuple(global_H.shape))
+        trailing_idx, mark_break = 0, False
+        with torch.no_grad():
+            for step_idx in levels:
+                current_sigma = net.sigmas[step_idx].item()
+                labels = (torch.ones(global_H.shape[0]) * step_idx).long()
+                for inner_idx in range(steps_each):
+                    current_real = torch.view_as_real(current).permute(0, 3, 1, 2)
+                    score = net(current_real, labels)
+                    score = torch.view_as_complex(score.permute(0, 2, 3, 1).contiguous())
+                    alpha = step_size * (current_sigma / config.model.sigma_end) ** 2
+                    meas_term = torch.matmul(forward, current) - y
+                    meas_grad = torch.matmul(forward_h, meas_term)
+                    grad_noise = np.sqrt(2 * alpha * noise_boost) * torch.from_numpy(draw(trailing_idx))
+                    current = current + alpha * (score - dc_boost * meas_grad /
+                                                 (local_noise / 2. + current_sigma ** 2)) + grad_noise
+                    oracle_log[snr_idx, trailing_idx] = np.reshape(
+                        (torch.sum(torch.square(torch.abs(current - oracle)), dim=(-1, -2)) /
+                         torch.sum(torch.square(torch.abs(oracle)), dim=(-1, -2))).numpy(), (kept, mmse_avg))
+                    if trailing_idx == target_stop:
+                        mark_break = True
+                        break
+                    trailing_idx = trailing_idx + 1
+                if mark_break:
+                    saved_H[snr_idx] = torch.reshape(current, (kept, mmse_avg) + H.shape[1:]).numpy()
+                    break
+        Ys.append(local_Y.numpy())
+    return np.stack(Ys), oracle_log, saved_H
+
+
+def gen_mmse():
+    """F2: posterior-mean sampling (test_mmse.py): 2 kept samples x 3 chains, two SNR points with their own (step, noise,
+    stop) triple, dc_boost = 2, start points Noise and Adjoint."""
+    cfg = default_config()
+    net = reference_net(cfg, seeded_state_dict(cfg, WEIGHT_SEED))
+    H, P = case_inputs(108, 2, 64, 16, 0.6)
+    snr, levels = [-10.0, 10.0], [0, 1000, 2000]
+    best_step, best_noise, best_stop = [3e-11, 6e-11], [0.01, 0.1], [3, 4]
+    out = {}
+    for sp in ('Noise', 'Adjoint'):
+        Y, log, saved = reference_mmse(net, cfg, H, P, snr, levels, 108, best_step, best_noise, best_stop, 3, 2.0, sp)
+        out.update({'Y': Y, 'oracle_log_' + sp: log, 'saved_H_' + sp: saved})
+        print('mmse %s: log at stop' % sp, log[0, 3].ravel()[:3], log[1, 4].ravel()[:3])
+    np.savez_compressed(os.path.join(GOLD, 'mmse.npz'), H=H, P=P, snr_db=np.array(snr), levels=np.array(levels), seed=108,
+                        best_step=np.array(best_step), best_noise=np.array(best_noise), best_stop=np.array(best_stop),
+                        mmse_avg=3, dc_boost=2.0, weight_seed=WEIGHT_SEED, **out)
 
 
 def gen_loader():

@@ -142,7 +142,7 @@ def test_langevin_kernel_matches_oracle_step(net64):
     def cn(*s):
         return (rng.standard_normal(s) + 1j * rng.standard_normal(s)).astype(np.complex64)
     X, S, H, Y, Pm, nz = cn(T, nt, nr), cn(T, nt, nr), cn(T, nt, nr), cn(T, npil, nr), cn(T, npil, nt) / 8, cn(T, nt, nr)
-    sched = np.array([[[0.3, 7.0, 0.05, 0]], [[1e-3, 0.2, 0.01, 0]]], np.float32)
+    sched = np.array([[[0.3, 7.0, 0.05, 1.0]], [[1e-3, 0.2, 0.01, 2.5]]], np.float32)     # (alpha, dc_div, noise, dc_boost)
     group = np.array([0, 1, 0, 1, 1, 0], np.int32)
     d = {k: torch.from_numpy(v).cuda() for k, v in dict(X=X, S=S, H=H, Y=Y, P=Pm, nz=nz[None], sched=sched, group=group).items()}
     nm = torch.zeros(1, T, device='cuda')
@@ -156,8 +156,8 @@ def test_langevin_kernel_matches_oracle_step(net64):
     _lib.check(_lib.lib().sbc_op_launch(C.byref(op), None))
     torch.cuda.synchronize()
     for t in range(T):
-        a, dv, ns = sched[group[t], 0, :3]
-        ref = A.langevin_step(X[t:t + 1], S[t:t + 1], Pm[t:t + 1], Y[t:t + 1], a, dv, ns, nz[t:t + 1])
+        a, dv, ns, dcb = sched[group[t], 0]
+        ref = A.langevin_step(X[t:t + 1], S[t:t + 1], Pm[t:t + 1], Y[t:t + 1], a, dv, ns, nz[t:t + 1], dc_boost32=dcb)
         assert rel_err(d['X'][t].cpu().numpy(), ref[0]) < 1e-5
         assert abs(nm[0, t].item() / A.nmse(ref, H[t:t + 1])[0] - 1) < 1e-5
 
@@ -343,6 +343,61 @@ def test_cli_test_mmse_posterior_mean(net64, tmp_path, monkeypatch):
     assert not np.allclose(saved[0, 0, 0, 0, 0], saved[0, 0, 0, 0, 1])                # chains differ (own start + noise)
     adj, _, _ = test_mmse.main(argv + ['--start_point', 'Adjoint', '--no_graph'])
     assert np.isfinite(adj).all() and not np.array_equal(adj, log)
+
+
+@pytest.mark.parametrize('start', ['Noise', 'Adjoint'])
+def test_posterior_mean_chains_match_reference_golden(net64, start):
+    """F2 parity: ``test_mmse.posterior_chains`` (chains sharing a measurement, per-SNR step / noise / stop, dc_boost,
+    start points) against the golden produced by the transcription of test_mmse.py:166-277 around the reference network."""
+    from score_based_channels_amd.noise import HostNoise
+    from score_based_channels_amd.test_mmse import posterior_chains
+    g = load_golden('mmse.npz')
+    H, P, navg = g['H'], g['P'], int(g['mmse_avg'])
+    levels = [int(v) for v in g['levels']]
+    for s, snr in enumerate(g['snr_db']):
+        stop = int(g['best_stop'][s])
+        Y, log, est = posterior_chains(net64, H, P, 10 ** (-snr / 10.), float(g['best_step'][s]), float(g['best_noise'][s]),
+                                       stop + 1, levels, 3, navg, start_point=start, dc_boost=float(g['dc_boost']),
+                                       use_graph=bool(s), host_noise=HostNoise(int(g['seed']), combo=1 + s))
+        ref = g['oracle_log_' + start][s]
+        assert rel_err(Y.cpu().numpy(), g['Y'][s]) < 1e-6
+        assert log.shape == (stop + 1, 2, navg) and np.max(np.abs(log / ref[:stop + 1] - 1)) < NMSE_RTOL
+        assert rel_err(est, g['saved_H_' + start][s]) < 1e-5
+
+
+def test_cli_cross_profile_matches_reference_pipeline(net64, tmp_path, monkeypatch):
+    """BASELINE config 4 (``--train CDL-C --test CDL-D``) end to end: the golden ran the reference's own loader
+    (normalisation constants from the TRAIN profile, test_score.py:68-69,101), DataLoader batch and sampling loop on the
+    same synthetic files and keyed noise; the CLI must reproduce its NMSE log from the same command line."""
+    from score_based_channels_amd import test_score
+    g = load_golden('cli_cross_cdlc_cdld.npz')
+    monkeypatch.chdir(tmp_path)
+    argv = str(g['argv']).split() + ['--conv_mode', net64.conv_mode]
+    nmse_log, _, _ = test_score.main(argv)
+    assert nmse_log.shape == (1, 1, 17, 6, 4)
+    assert np.max(np.abs(nmse_log[0, 0] / g['nmse_log'] - 1)) < NMSE_RTOL
+    est = test_score.main(argv + ['--save_channels', '1', '--no_graph'])
+    import torch
+    res = torch.load(tmp_path / 'results/score/train-CDL-C_test-CDL-D/results.pt', weights_only=False)
+    assert rel_err(res['saved_H'][0, 0], g['X_final']) < 1e-5
+    # the same channels normalised by their OWN profile would differ: the train-profile constants really are used
+    same, _, _ = test_score.main([a if a != 'CDL-C' else 'CDL-D' for a in argv])
+    assert np.max(np.abs(same[0, 0] / g['nmse_log'] - 1)) > 1e-3
+
+
+def test_cli_tuner_matches_reference_pipeline(net64, tmp_path, monkeypatch):
+    """BASELINE config 3 at reduced size: a 2 x 2 (alpha, beta) grid through the tuner CLI vs the reference pipeline
+    (one validation dataset, pilot draw and noise stream per cell, tune_hparams_score.py:71-97)."""
+    from score_based_channels_amd import tune_hparams_score
+    g = load_golden('cli_tune_grid.npz')
+    monkeypatch.chdir(tmp_path)
+    nmse_log, ba, bb = tune_hparams_score.main(
+        ['--synthetic', '--synthetic_weights', '2024', '--num_levels', '1', '--num_channels', '3', '--seed', str(int(g['seed'])),
+         '--no_plot', '--noise', 'host', '--conv_mode', net64.conv_mode,
+         '--alpha_step_range'] + [repr(float(a)) for a in g['alpha_step_range']] +
+        ['--beta_noise_range'] + [repr(float(b)) for b in g['beta_noise_range']])
+    assert nmse_log.shape == (2, 2, 17, 3, 3)
+    assert np.max(np.abs(nmse_log / g['nmse_log'] - 1)) < NMSE_RTOL
 
 
 @pytest.mark.parametrize('nt,nr', [(16, 64), (32, 32), (128, 8)])

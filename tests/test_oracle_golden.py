@@ -101,6 +101,35 @@ def test_fp16_weight_goldens_match_oracle_with_rounded_parameters(weights64):
     assert rel_err(out, gb['out']) < 2e-5
 
 
+@pytest.mark.parametrize('start', ['Noise', 'Adjoint'])
+def test_posterior_mean_loop_matches_reference(weights64, start):
+    """F2: ``ald_oracle.mmse_run`` against the transcription of test_mmse.py:166-277 run around the reference network
+    (2 samples x 3 chains sharing a measurement, per-SNR (step, noise, stop), dc_boost 2, both start points)."""
+    cfg, sd = weights64
+    g = load_golden('mmse.npz')
+    H, P, navg = g['H'], g['P'], int(g['mmse_avg'])
+    levels = [int(v) for v in g['levels']]
+    for s, snr in enumerate(g['snr_db']):
+        noise = HostNoise(int(g['seed']), combo=1 + s)
+        local_noise = 10 ** (-snr / 10.)                                   # test_mmse.py:100, no Nt factor
+        Y = ald_oracle.make_measurements(P, H, local_noise, noise.measurement(0, g['Y'][s].shape))
+        assert rel_err(Y, g['Y'][s]) < 1e-6
+        if start == 'Noise':
+            init = noise.init((H.shape[0] * navg,) + H.shape[1:])
+        else:
+            init = np.repeat(np.matmul(np.conj(np.transpose(P, (0, 2, 1))), Y), navg, axis=0)
+        stop = int(g['best_stop'][s])
+        log, est = ald_oracle.mmse_run(lambda x, lab: ncsnv2_oracle.score_forward(sd, x, lab), sd['sigmas'],
+                                       cfg.model.sigma_end, P, Y, H, init,
+                                       noise.step_stream(0, (H.shape[0] * navg,) + H.shape[1:]), local_noise,
+                                       float(g['best_step'][s]), float(g['best_noise'][s]), stop, navg,
+                                       dc_boost=float(g['dc_boost']), levels=levels)
+        ref = g['oracle_log_' + start][s]
+        assert np.all(log[stop + 1:] == 0) and np.all(ref[stop + 1:] == 0)
+        assert np.max(np.abs(log[:stop + 1] / ref[:stop + 1] - 1)) < 1e-5
+        assert rel_err(est, g['saved_H_' + start][s]) < 1e-5
+
+
 def test_loader_pieces_match_reference():
     g = load_golden('loader.npz')
     ch, mean, std, pil = ald_oracle.channels_dataset(g['output_h'], 64, 38, 'global',
