@@ -1,23 +1,30 @@
 #!/usr/bin/env python3
 """Throughput of the annealed-Langevin channel-estimation hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): CDL-C-like Nt64 x Nr16 channels, pilot fraction 0.6 (38 pilots), batch of
+Default workload (BASELINE.json configs[1]): CDL-C-like Nt64 x Nr16 channels, pilot fraction 0.6 (38 pilots), batch of
 100 channels x 17 SNR points (-10..30 dB) = 1700 lock-step trajectories per GPU, full schedule of
 2311 noise levels x 3 steps = 6933 Langevin steps per trajectory (test_score.py:56,72,77; train_score.py:42).
 
-A benchmark "step" is ONE Langevin step of the whole 1700-trajectory batch: score network forward (113 convs),
-data-consistency gradient, noise, update, NMSE log.  Every one of the 6933 steps of the schedule is the same
-work (the noise level only changes three scalars), so
+A benchmark "step" is ONE Langevin step of the whole batch: score network forward (113 convs), data-consistency
+gradient, noise, update, NMSE log.  Every one of the 6933 steps of the schedule is the same work (the noise level only
+changes three scalars), so
     channels/s = trajectories / (6933 * seconds_per_step)
-is the full-schedule rate; `--full-schedule` walks all 6933 steps instead of K to confirm it.
+is the full-schedule rate; `--full-schedule` walks all 6933 steps instead of K to confirm it, and every default run also
+times a sustained segment (`--sustained`, 1000 steps) after the K-step window and reports it next to the headline.
 
-One process per GPU (torch.distributed / RCCL when WORLD_SIZE > 1): trajectories are independent, each rank
-runs its own 1700 (weak scaling), the only collective is the final gather of the per-step NMSE curves.
-Prints ONE JSON line on rank 0.
+`python bench.py --gpus N` starts its own N ranks (one process per GPU, torch.distributed over RCCL) when it is not
+already running under torch.distributed.run; the parent never touches the GPU.  Trajectories are independent: the weak
+number gives every rank its own 1700 trajectories, and the same run also times the STRONG-scaling workload -- the
+20 400 trajectories of the tune_hparams_score grid (12 (alpha, beta) cells x 17 SNR x 100 channels, BASELINE configs[2])
+sharded over the ranks by shard.my_block -- reported as the `strong` object.  The only collective is the final gather of
+the per-step NMSE curves.  `--workload big` runs BASELINE configs[4] instead (Nt256 x Nr64, 1024 trajectories, fp16
+weights).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,9 +33,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
-PEAK_BF16_MFMA_TFLOPS = 2516.6     # same guide: v_mfma_f32_32x32x16_bf16 dense, 16x the fp32 MFMA rate ("~2.5 PF")
+# /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_MFMA_TFLOPS = 157.3       # v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2516.6     # v_mfma_f32_32x32x16_bf16 / _f16 dense ("~2.5 PF"), 16x the fp32 MFMA rate
+PEAK_HBM_TBS = 8.0                 # HBM3E spec (6.3 TB/s achievable by a float4 copy)
 STEPS_PER_CHANNEL = 2311 * 3
+PROFILE_ROUND = 'r02'
 
 
 def _cpu_worker(job):
@@ -78,25 +88,55 @@ def cpu_baseline(n_steps=20, per_worker=8):
                       'schedule' % (n_steps, n, W, dt, wall)}
 
 
-def main():
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a CHILD process tree (this process
+    has not imported torch or touched the GPU, and never will) and pass the children's exit code on."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % n_gpus,
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--channels', type=int, default=100, help='channel realisations per GPU (test_score.py:77)')
-    ap.add_argument('--snr-points', type=int, default=17)
-    ap.add_argument('--graph', type=int, default=0, help='replay the step as a hipGraph (no per-kernel timing)')
+    ap.add_argument('--workload', default='cdlc', choices=['cdlc', 'big'],
+                    help='cdlc: BASELINE configs[1] (Nt64xNr16, 1700 trajectories); big: configs[4] (Nt256xNr64, 1024 '
+                         'trajectories, fp16 weights)')
+    ap.add_argument('--channels', type=int, default=None, help='channel realisations per GPU (test_score.py:77)')
+    ap.add_argument('--snr-points', type=int, default=None)
+    ap.add_argument('--graph', type=int, default=None,
+                    help='1: replay each step as a hipGraph, 0: eager launches; default: what the CLIs default to '
+                         '(driver.DEFAULT_USE_GRAPH)')
     ap.add_argument('--full-schedule', action='store_true', help='time all 6933 steps instead of --steps')
+    ap.add_argument('--sustained', type=int, default=None,
+                    help='steps of the sustained segment timed after the K-step window (default 1000; 0 disables)')
+    ap.add_argument('--no-strong', action='store_true', help='skip the strong-scaling (tuner grid) measurement')
+    ap.add_argument('--no-other-mode', action='store_true', help='skip timing the non-default launch mode')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--conv-mode', default='bf16x3', choices=['bf16x3', 'f32'],
-                    help='convolution multiplier (scorenet.CONV_MODES)')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='with --gpus 1: still create a one-rank RCCL process group and route the barrier / max / gather through it')
+    ap.add_argument('--conv-mode', default=None, choices=['bf16x3', 'f32', 'f16w'],
+                    help='convolution multiplier (scorenet.CONV_MODES); default bf16x3, f16w for --workload big')
     ap.add_argument('--streams', type=int, default=1,
                     help='split the trajectories into this many concurrent sub-batch streams (DESIGN.md section 7)')
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     # CPU baseline first: its worker processes are spawned, which must happen before this process touches the GPU
     cpu_base = None
-    if int(os.environ.get('WORLD_SIZE', '1')) == 1 and not args.no_cpu_baseline:
+    if int(os.environ.get('WORLD_SIZE', '1')) == 1 and not args.no_cpu_baseline and args.workload == 'cdlc':
         cpu_base = cpu_baseline()
 
     import torch
@@ -105,142 +145,262 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
-    local %= max(1, torch.cuda.device_count())           # identity on a full node; lets 2 ranks share 1 GPU in a smoke test
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    n_dev = max(1, torch.cuda.device_count())
+    local %= n_dev                                       # identity on a full node; lets 2 ranks share 1 GPU in a smoke test
     torch.cuda.set_device(local)
-    if world > 1:
-        backend = os.environ.get('SBC_DIST_BACKEND', 'nccl')   # 'nccl' is RCCL on ROCm
+    use_dist = world > 1 or args.force_dist
+    backend = None
+    if use_dist:
+        # 'nccl' is RCCL on ROCm.  RCCL refuses two ranks on one device ("Duplicate GPU detected"), so a smoke run with more
+        # ranks than GPUs (2 ranks on the 1-GPU dev box) falls back to gloo for the barrier / max / gather.
+        backend = os.environ.get('SBC_DIST_BACKEND', 'nccl' if world <= n_dev else 'gloo')
+        if world == 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29533')
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
         kw = {'device_id': torch.device('cuda', local)} if backend == 'nccl' else {}
         dist.init_process_group(backend, **kw)
 
-    from score_based_channels_amd import plan as P, synth
+    from score_based_channels_amd import plan as P, shard, synth
     from score_based_channels_amd.ald import AldBatch, snr_to_noise
     from score_based_channels_amd.config import default_config
+    from score_based_channels_amd.driver import DEFAULT_USE_GRAPH
     from score_based_channels_amd.scorenet import ScoreNet
     from score_based_channels_amd.weights import seeded_state_dict
 
-    cfg = default_config('CDL-C')
+    big = args.workload == 'big'
+    conv_mode = args.conv_mode or ('f16w' if big else 'bf16x3')
+    nt, nr = (256, 64) if big else (64, 16)
+    npil = int(np.floor(nt * 0.6))
+    nch = args.channels or (64 if big else 100)
+    nsnr = args.snr_points or (16 if big else 17)
+    profile = 'ULA' if big else 'CDL-C'
+    cfg = default_config('CDL-C', image_size=(nr, nt)) if big else default_config('CDL-C')
     sd = seeded_state_dict(cfg, 2024)                     # random-init weights of the reference architecture
-    net = ScoreNet(cfg, 'cuda:%d' % local, conv_mode=args.conv_mode).load_state_dict(sd)
-    nt, nr, npil = 64, 16, int(np.floor(64 * 0.6))
-    nch, nsnr = args.channels, args.snr_points
-    raw = synth.generate_channels('CDL-C', nch, nt, nr, 0.5, seed=4321 + rank)       # per-rank channel batch
-    H = np.conj(np.transpose(raw / np.std(raw), (0, 2, 1))).astype(np.complex64)
-    pil = synth.qpsk_pilots(np.random.default_rng([4321, rank]), nch, nt, npil)
-    Pm = np.conj(np.transpose(pil, (0, 2, 1)))
+    net = ScoreNet(cfg, 'cuda:%d' % local, conv_mode=conv_mode).load_state_dict(sd)
+    use_graph = DEFAULT_USE_GRAPH if args.graph is None else bool(args.graph)
     snr = np.arange(-10, 32.5, 2.5)[:nsnr]
-    T = nch * len(snr)
-    idx = np.tile(np.arange(nch), len(snr))
-    ln = np.repeat(snr_to_noise(snr, nt), nch)
-    traj = rank * T + np.arange(T)
-    init = torch.randn(nch, nt, nr, dtype=torch.complex64, device=net.device,
-                       generator=torch.Generator(net.device).manual_seed(rank))
-    init = init.repeat(len(snr), 1, 1)                   # one initial estimate shared by all SNR points (:115)
-    # the trajectory list may be split over several HIP streams: independent sub-batches whose kernels the GPU
-    # interleaves (fills the tail of one launch with the head of another, overlaps memory-bound with MFMA-bound ones)
-    parts = np.array_split(np.arange(T), args.streams)
-    alds, streams = [], []
-    for part in parts:
-        a = AldBatch(net, H, Pm, idx[part], idx[part], ln[part], alpha_step=3e-11, beta_noise=0.01, seed=1234,
-                     traj_id=traj[part])
-        a.set_init(init[torch.from_numpy(part)])
-        a.synthesize_measurements()
-        alds.append(a)
-        streams.append(torch.cuda.Stream(net.device) if args.streams > 1 else torch.cuda.current_stream(net.device))
-    ald = alds[0]
 
-    def run_all(n, graph):
+    cdev = net.device if backend != 'gloo' else torch.device('cpu')      # where collective payloads live
+
+    def sync():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device=cdev)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def make_batches(H, Pm, h_idx, p_idx, ln, a0, be, traj, init, n_streams=1):
+        """The trajectory list as `n_streams` AldBatch objects (independent sub-batches on their own HIP streams)."""
+        alds, streams = [], []
+        for part in np.array_split(np.arange(len(h_idx)), n_streams):
+            a = AldBatch(net, H, Pm, h_idx[part], p_idx[part], ln[part], alpha_step=a0[part], beta_noise=be[part],
+                         seed=1234, traj_id=traj[part])
+            a.set_init(init[torch.from_numpy(h_idx[part])])
+            a.synthesize_measurements()
+            alds.append(a)
+            streams.append(torch.cuda.Stream(net.device) if n_streams > 1 else torch.cuda.current_stream(net.device))
+        return alds, streams
+
+    def run_all(alds, streams, n, graph):
         for a, st in zip(alds, streams):
             with torch.cuda.stream(st):
                 a.run(n, use_graph=graph)
 
+    logged = [0]                 # rows of the NMSE log the most recent timed() call wrote
+
+    def timed(alds, streams, n, graph, warm):
+        """`warm` untimed steps, then exactly `n` steps between barrier + synchronize pairs; max over ranks (seconds)."""
+        for a in alds:
+            a.rewind()
+        logged[0] = warm + n
+        run_all(alds, streams, warm, graph)
+        sync()
+        t0 = time.perf_counter()
+        run_all(alds, streams, n, graph)
+        sync()
+        return max_over_ranks(time.perf_counter() - t0)
+
+    # ---------------------------------------------------------------- weak workload: this rank's own trajectories
+    raw = synth.generate_channels(profile, nch, nt, nr, 0.5, seed=4321 + rank)        # per-rank channel batch
+    H = np.conj(np.transpose(raw / np.std(raw), (0, 2, 1))).astype(np.complex64)
+    Pm = np.conj(np.transpose(synth.qpsk_pilots(np.random.default_rng([4321, rank]), nch, nt, npil), (0, 2, 1)))
+    T = nch * len(snr)
+    idx = np.tile(np.arange(nch), len(snr))
+    ln = np.repeat(snr_to_noise(snr, nt), nch)
+    init = torch.randn(nch, nt, nr, dtype=torch.complex64, device=net.device,
+                       generator=torch.Generator(net.device).manual_seed(rank))   # one init shared by all SNR points (:115)
+    alds, streams = make_batches(H, Pm, idx, idx, ln, np.full(T, 3e-11), np.full(T, 0.01), rank * T + np.arange(T), init,
+                                 args.streams)
+    ald = alds[0]
+
     K = STEPS_PER_CHANNEL - args.warmup if args.full_schedule else args.steps
-    use_graph = bool(args.graph)
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-
-    run_all(args.warmup, use_graph)
+    # headline: the launch mode the CLIs default to.  Per-kernel hipEvent timing needs eager launches: it brackets the
+    # timed region itself when that is eager, otherwise it is taken in an extra eager segment right after it.
     if not use_graph:
         ald.plan.profile(P.TAG_CONV_TOP)
-    sync()
-    t0 = time.perf_counter()
-    run_all(K, use_graph)
-    sync()
-    dt = time.perf_counter() - t0
-    kern_ms, kern_n = ald.plan.profile_read() if not use_graph else (0.0, 0)
+    dt = timed(alds, streams, K, use_graph, args.warmup)
+    if use_graph:
+        ald.plan.profile(P.TAG_CONV_TOP)
+        timed(alds, streams, min(K, 30), False, 1)
+    kern_ms, kern_n = ald.plan.profile_read()
     ald.plan.profile(-1)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=net.device)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    other = None
+    if not args.no_other_mode and not args.full_schedule:
+        other = timed(alds, streams, K, not use_graph, args.warmup)
+    n_sus = (0 if args.full_schedule else 1000 if not big else 40) if args.sustained is None else args.sustained
+    n_sus = min(n_sus, STEPS_PER_CHANNEL - args.warmup)
+    dt_sus = timed(alds, streams, n_sus, use_graph, args.warmup) if n_sus > 0 else None
 
     # the one collective of the path: gather the per-step mean NMSE curves of every rank (RCCL over xGMI)
-    curves = torch.cat([a.nmse_log()[:args.warmup + K] for a in alds], dim=1).view(-1, len(snr), nch).mean(-1)
+    curves = torch.cat([a.nmse_log()[:logged[0]] for a in alds], dim=1).view(-1, len(snr), nch).mean(-1)
     t_g = time.perf_counter()
-    if world > 1:
+    if use_dist:
+        curves = curves.to(cdev)
         gathered = [torch.empty_like(curves) for _ in range(world)]
         dist.all_gather(gathered, curves)
         curves = torch.stack(gathered).mean(0)
     torch.cuda.synchronize()
     gather_ms = (time.perf_counter() - t_g) * 1e3
     finite = bool(torch.isfinite(curves).all().item())
+    T0 = alds[0].T
+    for a in alds:
+        a.close()
+    del alds, ald
+
+    # ---------------------------------------------------------------- strong workload: the tuner grid, sharded
+    strong = None
+    if not args.no_strong and not big and not args.full_schedule:
+        cells = [(a, b) for a in (3e-11, 6e-11, 1e-10, 3e-10) for b in (0.1, 0.01, 0.001)]     # tune_hparams_score.py:20-23
+        nC, nS, nB = len(cells), 17, 100
+        Ttot = nC * nS * nB
+        raw = synth.generate_channels('CDL-C', nB, nt, nr, 0.5, seed=4321)
+        Hs = np.conj(np.transpose(raw / np.std(raw), (0, 2, 1))).astype(np.complex64)
+        Ps = np.conj(np.transpose(synth.qpsk_pilots(np.random.default_rng(4321), nC * nB, nt, npil), (0, 2, 1)))
+        t_all = np.arange(Ttot)                                   # t = (cell * S + snr) * B + channel
+        cell_of, snr_of, ch_of = t_all // (nS * nB), (t_all // nB) % nS, t_all % nB
+        lo, hi = shard.my_block(Ttot, rank, world)
+        sel = t_all[lo:hi]
+        a0 = np.asarray([c[0] for c in cells])[cell_of[sel]]
+        be = np.asarray([c[1] for c in cells])[cell_of[sel]]
+        lns = snr_to_noise(np.arange(-10, 32.5, 2.5), nt)[snr_of[sel]]
+        init_s = torch.randn(nB, nt, nr, dtype=torch.complex64, device=net.device,
+                             generator=torch.Generator(net.device).manual_seed(99))
+        s_alds, s_streams = make_batches(Hs, Ps, ch_of[sel], (cell_of * nB + ch_of)[sel], lns, a0, be, sel, init_s)
+        Ks = max(5, min(K, 20))
+        dts = timed(s_alds, s_streams, Ks, use_graph, 2)
+        strong = {'scaling': 'strong', 'value': Ttot / (STEPS_PER_CHANNEL * dts / Ks), 'unit': 'channels/s',
+                  'ms_per_step': dts / Ks * 1e3, 'steps': Ks, 'trajectories_total': Ttot,
+                  'trajectories_per_gpu': int(hi - lo),
+                  'workload': 'tune_hparams_score grid (BASELINE configs[2]): 12 (alpha, beta) cells x 17 SNR points x 100 '
+                              'channels = 20400 trajectories in total, contiguous blocks per rank (shard.my_block)'}
+        for a in s_alds:
+            a.close()
+        del s_alds
 
     if rank == 0:
         ms_per_step = dt / K * 1e3
         value = world * T / (STEPS_PER_CHANNEL * dt / K)
         flops_fwd = P.count_conv_flops(net.score_plan(nt, nr)) * T          # conv FLOPs of one step on this GPU
+        dtype = {'f32': 'f32', 'bf16x3': 'f32 (products as exact 3-term bf16 splits on the bf16 matrix cores, fp32 accumulate)',
+                 'f16w': 'f16 weights x f16-rounded activations on the fp16 matrix cores, fp32 accumulate, fp32 tensors in HBM'}
         out = {
-            'metric': 'channels/s full ALD inference, CDL-C Nt64xNr16', 'value': value, 'unit': 'channels/s',
+            'metric': 'channels/s full ALD inference, %s Nt%dxNr%d' % ('CDL-C' if not big else 'ULA', nt, nr),
+            'value': value, 'unit': 'channels/s',
             'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if args.conv_mode == 'f32' else 'f32 (products as exact 3-term bf16 splits on the bf16 matrix cores, fp32 accumulate)',
-            'data': 'synthetic (CDL-C-like cluster channels, QPSK pilots, seed-derived random-init weights)',
-            'config': {'workload': 'CDL-C Nt64xNr16, batch=100 channels x 17 SNR points (-10..30 dB) = 1700 '
-                                   'lock-step trajectories per GPU, full 2311x3 schedule',
+            'dtype': dtype[conv_mode],
+            'data': 'synthetic (%s cluster channels, QPSK pilots, seed-derived random-init weights)'
+                    % ('CDL-C-like' if not big else 'ULA plane-wave'),
+            'config': {'workload': ('CDL-C Nt64xNr16, batch=100 channels x 17 SNR points (-10..30 dB) = 1700 lock-step '
+                                    'trajectories per GPU, full 2311x3 schedule (BASELINE configs[1])') if not big else
+                                   ('synthetic ULA Nt256xNr64, 64 channels x 16 SNR points = 1024 lock-step trajectories per '
+                                    'GPU, 153 pilots, fp16 score-net weights, full 2311x3 schedule (BASELINE configs[4])'),
                        'trajectories_per_gpu': T, 'steps_per_channel': STEPS_PER_CHANNEL, 'num_pilots': npil,
                        'step_definition': 'one Langevin step (score forward + DC gradient + update + NMSE) of all '
                                           'trajectories; channels/s = trajectories / (6933 * s_per_step)',
-                       'full_schedule_timed': bool(args.full_schedule), 'conv_mode': args.conv_mode, 'graph_replay': use_graph, 'streams': args.streams,
-                       'parallelism': 'independent trajectories sharded over %d GPU(s); one RCCL all_gather of NMSE '
-                                      'curves at the end (%.2f ms)' % (world, gather_ms),
+                       'full_schedule_timed': bool(args.full_schedule), 'conv_mode': conv_mode,
+                       'graph_replay': use_graph, 'launch_mode': 'hipGraph replay' if use_graph else 'eager launches',
+                       'launch_mode_is_cli_default': use_graph == DEFAULT_USE_GRAPH, 'streams': args.streams,
+                       'parallelism': 'independent trajectories sharded over %d rank(s) on %d device(s); one all_gather of '
+                                      'NMSE curves at the end (%.2f ms, backend %s)'
+                                      % (world, min(world, n_dev), gather_ms,
+                                         {'nccl': 'nccl = RCCL', 'gloo': 'gloo (more ranks than GPUs)', None: 'none: one rank'}[backend]),
                        'nmse_finite': finite},
             'step_conv_tflops': flops_fwd / (ms_per_step * 1e-3) / 1e12,
         }
+        if dt_sus is not None:
+            out['sustained_ms_per_step'] = dt_sus / n_sus * 1e3
+            out['sustained_value'] = world * T / (STEPS_PER_CHANNEL * dt_sus / n_sus)
+            out['sustained_steps'] = n_sus
+        if other is not None:
+            out['other_launch_mode'] = {'mode': 'eager launches' if use_graph else 'hipGraph replay',
+                                        'ms_per_step': other / K * 1e3,
+                                        'value': world * T / (STEPS_PER_CHANNEL * other / K)}
+        if strong is not None:
+            out['strong'] = strong
         if kern_n:
-            per_launch = 2.0 * alds[0].T * nt * nr * 9 * 32 * 32            # 3x3 conv 32->32 at 64x16, 2*MACs
-            ach = per_launch / (kern_ms / kern_n * 1e-3) / 1e12
-            traffic = None                  # HBM bytes per launch from the PMC passes (profiles/), same workload only
-            tfile = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-            if os.path.exists(tfile) and args.conv_mode == 'bf16x3':
+            t_k = kern_ms / kern_n * 1e-3                                   # seconds per launch
+            px = T0 * nt * nr
+            per_launch = 2.0 * px * 9 * 32 * 32                              # 3x3 conv 32->32, 2*MACs (SURVEY 8(d))
+            ach = per_launch / t_k / 1e12
+            where = 'the timed region' if not use_graph else 'an eager segment after the (graph-replayed) timed region'
+            tfile = os.path.join(ROOT, 'profiles', '%s_traffic_%s.json' % (PROFILE_ROUND, args.workload))
+            traffic, tsrc = None, None
+            if os.path.exists(tfile):
                 with open(tfile) as f:
                     tj = json.load(f)
-                if tj.get('trajectories_per_launch') == alds[0].T:
-                    traffic = tj.get('hbm_bytes_per_launch')
-            if args.conv_mode == 'bf16x3':
-                # fp32-exact products on the bf16 matrix cores: 6 bf16 MFMAs per fp32 product block, so the roofline of
-                # the instruction the kernel issues is the dense bf16 MFMA peak / 6
-                peak = PEAK_BF16_MFMA_TFLOPS / 6.0
-                kname = ('conv_wx3_kernel<32, 32, 1, true, 3, true, 1, 1>: the 18 3x3 32->32 convolutions at 64x16 of every step (%d '
-                         'tagged launches, avg %.1f us).  achieved = direct-convolution FLOPs (2*9*32*32 per pixel) / '
-                         'time; peak = dense bf16 MFMA peak %.1f / 6 (fp32 operands as three exact bf16 terms, six bf16 '
-                         'MFMAs per product block); the kernel executes 16/36 of the products (Winograd F(2x2,3x3)), '
-                         'i.e. %.0f TFLOP/s of bf16 MFMA' % (kern_n, kern_ms / kern_n * 1e3, PEAK_BF16_MFMA_TFLOPS,
-                                                            ach * 6 * 16 / 36))
+                if tj.get('trajectories_per_launch') == T0 and tj.get('conv_mode') == conv_mode:
+                    traffic, tsrc = tj.get('hbm_bytes_per_launch'), 'profiles/' + os.path.basename(tfile)
+            alg_bytes = px * 32 * 4 * 3.0                                    # input + residual + output, fp32 NHWC
+            if conv_mode == 'bf16x3':
+                # Winograd F(2x2,3x3) executes 16/36 of the direct products, each as six bf16 MFMAs (exact 3-term split):
+                # algorithmic FLOP/s at which the bf16 matrix pipe would be 100 % busy with this algorithm
+                exec_ratio = 6.0 * 16.0 / 36.0
+                peak = PEAK_BF16_MFMA_TFLOPS / exec_ratio
+                rf = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
+                      'traffic': traffic,
+                      'executed_mfma_tflops': ach * exec_ratio, 'mfma_peak_tflops': PEAK_BF16_MFMA_TFLOPS,
+                      'frac_alternatives': {'vs_bf16_peak_over_6_no_winograd_credit': ach / (PEAK_BF16_MFMA_TFLOPS / 6),
+                                            'vs_fp32_mfma_peak': ach / PEAK_F32_MFMA_TFLOPS},
+                      'hbm': {'algorithmic_bytes_per_launch': alg_bytes, 'algorithmic_TBps': alg_bytes / t_k / 1e12,
+                              'frac_of_8TBps': alg_bytes / t_k / 1e12 / PEAK_HBM_TBS},
+                      'kernel': 'conv_wx3_kernel<32, 32, 1, true, 3, true, 1, 1, false>: the 18 3x3 32->32 convolutions at '
+                                '%dx%d of every step (%d tagged launches, avg %.1f us, hipEvents on the launch stream over %s).  '
+                                'achieved = direct-convolution FLOPs (2*9*32*32 per pixel) / time; peak = dense bf16 MFMA peak '
+                                '%.1f x 36/16 / 6: the kernel executes 16/36 of the products (Winograd F(2x2,3x3)), each as six '
+                                'bf16 MFMAs (fp32 operands as three exact bf16 terms), so frac IS the busy fraction of the '
+                                'bf16 matrix pipe' % (nt, nr, kern_n, t_k * 1e6, where, PEAK_BF16_MFMA_TFLOPS)}
+            elif conv_mode == 'f16w':
+                # one fp16 MFMA per executed product: the layer is bound by streaming its fp32 tensors through HBM
+                rf = {'bound': 'hbm', 'achieved': alg_bytes / t_k / 1e9, 'peak': PEAK_HBM_TBS * 1e3, 'unit': 'GB/s',
+                      'frac': alg_bytes / t_k / 1e12 / PEAK_HBM_TBS, 'traffic': traffic,
+                      'mfma': {'algorithmic_tflops': ach, 'executed_mfma_tflops': ach * 16.0 / 36.0,
+                               'frac_of_f16_peak': ach * 16.0 / 36.0 / PEAK_BF16_MFMA_TFLOPS},
+                      'kernel': 'conv_wx3_kernel<32, 32, 1, true, 3, true, 1, 1, true>: the 18 3x3 32->32 convolutions at '
+                                '%dx%d of every step (%d tagged launches, avg %.1f us, hipEvents over %s).  achieved = '
+                                'algorithmic bytes (fp32 input + residual + output = 3 x pixels x 32 x 4 B) / time against '
+                                'the 8 TB/s HBM3E peak (6.3 TB/s achievable); Winograd F(2x2,3x3) with one fp16 MFMA per '
+                                'product' % (nt, nr, kern_n, t_k * 1e6, where)}
             else:
-                peak = PEAK_F32_MFMA_TFLOPS
-                kname = ('conv_wino_kernel<32, 32, 2, true>: the 18 3x3 32->32 convolutions at 64x16 of every step (%d '
-                         'launches, avg %.1f us).  achieved = direct-convolution FLOPs (2*9*32*32 per pixel) / time; the '
-                         'kernel executes 16/36 of them (fp32 Winograd F(2x2,3x3)), i.e. %.1f TFLOP/s on the MFMA pipe'
-                         % (kern_n, kern_ms / kern_n * 1e3, ach * 16 / 36))
-            out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
-                               'frac': ach / peak, 'traffic': traffic, 'kernel': kname}
+                rf = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS * 36 / 16, 'unit': 'TFLOP/s',
+                      'frac': ach * 16 / 36 / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
+                      'kernel': 'conv_wino_kernel<32, 32, 2, true>: the 18 3x3 32->32 convolutions at %dx%d of every step (%d '
+                                'launches, avg %.1f us); fp32 Winograd F(2x2,3x3) executes 16/36 of the algorithmic FLOPs '
+                                'on v_mfma_f32_32x32x2_f32' % (nt, nr, kern_n, t_k * 1e6)}
+            if traffic is not None:
+                rf['traffic_source'] = tsrc + ' (rocprofv3 --pmc passes of this command: FETCH_SIZE x 2 + WRITE_SIZE per launch)'
+            out['roofline'] = rf
         if cpu_base is not None:
             out['cpu_baseline'] = cpu_base
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

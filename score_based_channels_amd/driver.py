@@ -11,6 +11,23 @@ from . import shard
 from .ald import AldBatch
 
 
+# Launch mode of a Langevin step the CLIs and bench.py default to: False = eager launches, True = hipGraph replay of the
+# ~150-launch step.  Both give bit-identical results (tests/test_gpu_parity.py::test_ald_graph_replay_equals_eager); the
+# faster one on MI355X is the default -- see DESIGN.md section 5 for the measured pair.
+DEFAULT_USE_GRAPH = False
+
+
+def resolve_launch_mode(args):
+    """``--graph`` / ``--no_graph`` of the CLIs -> use_graph (default ``DEFAULT_USE_GRAPH``)."""
+    if getattr(args, 'graph', False) and getattr(args, 'no_graph', False):
+        raise SystemExit('--graph and --no_graph are mutually exclusive')
+    if getattr(args, 'graph', False):
+        return True
+    if getattr(args, 'no_graph', False):
+        return False
+    return DEFAULT_USE_GRAPH
+
+
 def level_subset(num_classes, stride=1, num_levels=None):
     """Noise levels to walk: all of them (reference behaviour), every ``stride``-th plus the last one, or the
     first ``num_levels``.  Truncation is an addition of this build for quick runs; it is never applied silently."""

@@ -21,7 +21,7 @@ import torch
 from .ald import AldBatch
 from .checkpoint import load_checkpoint
 from .config import default_config
-from .driver import level_subset, run_trajectories
+from .driver import level_subset, resolve_launch_mode, run_trajectories
 from .loaders import Channels
 from .noise import HostNoise
 from .scorenet import ScoreNet
@@ -72,6 +72,7 @@ def parse_args(argv=None):
     p.add_argument('--noise', type=str, default='device', choices=['device', 'host'],
                    help='[added] in-kernel Philox noise, or the keyed host streams of noise.HostNoise (parity runs)')
     p.add_argument('--no_graph', action='store_true', help='[added] eager launches instead of hipGraph replay')
+    p.add_argument('--graph', action='store_true', help='[added] replay each Langevin step as a hipGraph (default: driver.DEFAULT_USE_GRAPH)')
     p.add_argument('--result_dir', type=str, default=None, help='[added] default TWC_rebuttal_MMSE_aug6_seed4321')
     return p.parse_args(argv)
 
@@ -213,7 +214,7 @@ def main(argv=None):
             host = HostNoise(seed, combo=1 + key) if args.noise == 'host' else None
             _, log, est = posterior_chains(diffuser, val_H, val_P, local_noise, step, noise_boost, n_run, levels,
                                            steps_each, navg, args.start_point, seed, key, args.dc_boost,
-                                           not args.no_graph, rank, world, host)
+                                           resolve_launch_mode(args), rank, world, host)
             oracle_log[spacing_idx, pilot_alpha_idx, snr_idx, :n_run] = log
             saved_H[spacing_idx, pilot_alpha_idx, snr_idx] = est
             if rank == 0:

@@ -45,6 +45,7 @@ def parse_args(argv=None):
                    help='convolution multiplier: split-bf16 matrix cores (fp32-accurate, default), fp32 MFMA, or fp16 '
                         'weights on the fp16 matrix cores (BASELINE config 5; looser tolerance)')
     p.add_argument('--no_graph', action='store_true', help='launch kernels eagerly instead of hipGraph replay')
+    p.add_argument('--graph', action='store_true', help='[added] replay each Langevin step as a hipGraph (default: driver.DEFAULT_USE_GRAPH)')
     return p.parse_args(argv)
 
 
@@ -54,7 +55,7 @@ def main(argv=None):
     from . import shard
     from .checkpoint import load_checkpoint
     from .config import default_config
-    from .driver import host_noise_streams, level_subset, run_trajectories, shared_init
+    from .driver import host_noise_streams, level_subset, resolve_launch_mode, run_trajectories, shared_init
     from .loaders import Channels
     from .scorenet import ScoreNet
     from .weights import seeded_state_dict
@@ -122,7 +123,7 @@ def main(argv=None):
         idx = np.tile(np.arange(num_channels), S)                       # trajectory t = snr * B + channel
         out = run_trajectories(diffuser, val_H, val_P, idx, idx, np.repeat(noise_range, num_channels), alpha_step,
                                beta_noise, levels, config.sampling.steps_each, seed, init,
-                               traj_base=meta_idx * S * num_channels, use_graph=not args.no_graph,
+                               traj_base=meta_idx * S * num_channels, use_graph=resolve_launch_mode(args),
                                rank=rank, world=world, return_final=bool(args.save_channels),
                                step_noise=step_noise, meas_noise=meas_noise)
         if args.save_channels:

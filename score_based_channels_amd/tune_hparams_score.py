@@ -43,6 +43,7 @@ def parse_args(argv=None):
     p.add_argument('--noise', type=str, default='device', choices=['device', 'host'],
                    help='in-kernel Philox noise [device] or the keyed host streams of noise.HostNoise [host, parity runs]')
     p.add_argument('--no_graph', action='store_true')
+    p.add_argument('--graph', action='store_true', help='[added] replay each Langevin step as a hipGraph (default: driver.DEFAULT_USE_GRAPH)')
     return p.parse_args(argv)
 
 
@@ -63,7 +64,7 @@ def main(argv=None):
     from . import shard
     from .checkpoint import load_checkpoint
     from .config import default_config
-    from .driver import host_noise_streams, level_subset, run_trajectories, shared_init
+    from .driver import host_noise_streams, level_subset, resolve_launch_mode, run_trajectories, shared_init
     from .loaders import Channels
     from .scorenet import ScoreNet
     from .weights import seeded_state_dict
@@ -131,7 +132,7 @@ def main(argv=None):
     a0 = np.asarray([c[0] for c in cells])[cell_of]
     be = np.asarray([c[1] for c in cells])[cell_of]
     log = run_trajectories(diffuser, H_all, P_all, h_index, h_index, ln, a0, be, levels, steps_each, seed, init_all,
-                           use_graph=not args.no_graph, rank=rank, world=world, step_noise=step_noise,
+                           use_graph=resolve_launch_mode(args), rank=rank, world=world, step_noise=step_noise,
                            meas_noise=meas_noise)
     nmse_log = log.reshape(n_steps, len(alpha_step_range), len(beta_noise_range), S, B).transpose(1, 2, 3, 0, 4)
     nmse_log = nmse_log.astype(np.float64)
