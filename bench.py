@@ -166,7 +166,7 @@ def main():
     from score_based_channels_amd import plan as P, shard, synth
     from score_based_channels_amd.ald import AldBatch, snr_to_noise
     from score_based_channels_amd.config import default_config
-    from score_based_channels_amd.driver import DEFAULT_USE_GRAPH
+    from score_based_channels_amd.driver import DEFAULT_USE_GRAPH, run_concurrently
     from score_based_channels_amd.scorenet import ScoreNet
     from score_based_channels_amd.weights import seeded_state_dict
 
@@ -209,9 +209,7 @@ def main():
         return alds, streams
 
     def run_all(alds, streams, n, graph):
-        for a, st in zip(alds, streams):
-            with torch.cuda.stream(st):
-                a.run(n, use_graph=graph)
+        run_concurrently(alds, streams, n, graph)           # one host thread per stream when there are several
 
     logged = [0]                 # rows of the NMSE log the most recent timed() call wrote
 

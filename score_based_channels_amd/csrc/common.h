@@ -49,7 +49,9 @@ int launch_step_inc(const sbc_op& op, hipStream_t stream);
 // kernels evaluate it, exp(x) - 1, on the hardware exponential (v_exp_f32 of x*log2(e), ~1 ulp) rather than a
 // ~20-instruction expm1: on gfx950 fp32 VALU work and fp32 MFMA share the same ALUs (tools/mfma_valu_coissue.hip:
 // 146 TF + 130 TF alone, 83 + 42 TF together), so every vector instruction of the staging path is MFMA time.
-__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
+// The select is a median: exp(x) - 1 >= x everywhere, so for x > 0 the middle of (x, exp(x) - 1, 0) is x and for x < 0 it
+// is exp(x) - 1 -- one v_med3_f32 instead of compare + select.  (x = +inf gives med3(inf, inf, 0) = inf; NaN stays NaN.)
+__device__ __forceinline__ float elu1(float x) { return __builtin_amdgcn_fmed3f(x, __expf(x) - 1.f, 0.f); }
 __device__ __forceinline__ float4 elu4(float4 v) {
     return make_float4(elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w));
 }

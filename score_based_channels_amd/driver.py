@@ -58,6 +58,35 @@ def batch_limit(net, nt, nr, requested, reserve=0.25):
     return max(1, min(int(requested), by_mem, by_index))
 
 
+def run_concurrently(batches, streams, n_steps, use_graph=False):
+    """Advance several ``AldBatch`` objects by ``n_steps`` each, every one on its own HIP stream and fed by its own host
+    thread.  A Langevin step is ~150 dependent launches, many of them (the 8x2 / 16x4 levels) with fewer workgroups than the
+    chip has CUs; two independent sub-batches in flight let the GPU fill one's gaps with the other's kernels.  One thread
+    per stream matters: ``plan.run`` returns only when its launches are queued, so sequential calls would queue one
+    stream's whole schedule ahead of the other's (ctypes releases the GIL during the call, the threads really overlap)."""
+    import threading
+    if len(batches) == 1:
+        with torch.cuda.stream(streams[0]):
+            batches[0].run(n_steps, use_graph=use_graph)
+        return
+    errors = []
+
+    def work(b, st):
+        try:
+            torch.cuda.set_device(b.net.device)
+            with torch.cuda.stream(st):
+                b.run(n_steps, use_graph=use_graph)
+        except BaseException as e:                        # surfaced in the caller's thread
+            errors.append(e)
+    threads = [threading.Thread(target=work, args=(b, st)) for b, st in zip(batches, streams)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+
+
 def host_noise_streams(seed, combo, shape, n_snr, n_steps, meas_shape):
     """The Gaussian draws of one (spacing, pilot_alpha) combination from the keyed host streams of ``noise.HostNoise``
     -- the reference's draw order: one initial estimate shared by all SNR points, then per SNR point
@@ -79,10 +108,8 @@ def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, b
     ``[n_steps, T]`` (float32 numpy, identical on every rank).  ``init``: ``[nH, Nt, Nr]`` complex64 initial
     estimates indexed by ``h_index``.  Trajectory ``t`` draws its noise from Philox stream ``traj_base + t``.
 
-    ``n_streams`` > 1 runs a chunk as independent sub-batches on concurrent HIP streams (results do not depend on the
-    split: per-trajectory noise keys, per-sample normalisation).  Measured on MI355X: +5 % at two streams over 30
-    steps, but nothing with hipGraph replay and a loss with eager launches over hundreds of steps (the host queues one
-    stream's launches long before the other's), so the default is one stream.
+    ``n_streams`` > 1 runs a chunk as independent sub-batches on concurrent HIP streams, one host thread each
+    (``run_concurrently``; results do not depend on the split: per-trajectory noise keys, per-sample normalisation).
 
     ``init_index`` (default ``h_index``) selects the initial estimate of each trajectory; ``Y`` ``[nY, Np, Nr]`` with
     ``y_index`` supplies measurements shared by several trajectories instead of synthesising one per trajectory
@@ -112,7 +139,7 @@ def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, b
             if len(part) == 0:
                 continue
             st.wait_stream(cur)
-            with torch.cuda.stream(st):
+            with torch.cuda.stream(st):                     # set-up on the sub-batch's stream; the walk itself below
                 sn = None if step_noise is None else torch.from_numpy(np.ascontiguousarray(step_noise[:n_steps, part]))
                 ald = AldBatch(net, Htrue, P, h_index[part], p_index[part], local_noise[part], alpha_step[part],
                                beta_noise[part], levels=levels, steps_each=steps_each, seed=seed,
@@ -122,8 +149,8 @@ def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, b
                     ald.synthesize_measurements(None if meas_noise is None else torch.from_numpy(meas_noise[part]))
                 else:
                     ald.set_measurements(Y[torch.from_numpy(np.asarray(y_index)[part])])
-                ald.run(n_steps, use_graph=use_graph)
             running.append((part, ald, st))
+        run_concurrently([r[1] for r in running], [r[2] for r in running], n_steps, use_graph)
         for part, ald, st in running:
             cur.wait_stream(st)
             local[:, part[0] - lo:part[-1] + 1 - lo] = ald.nmse_log()[:n_steps]
