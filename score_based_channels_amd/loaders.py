@@ -8,8 +8,9 @@ rules (:40-49), QPSK pilots drawn from numpy's legacy global RNG with two ``bino
 reference.  The per-item 64x64 ``eigvals`` (:83-85) is not on the estimation path and only computed on request.
 
 Reading the data: the reference uses ``hdf5storage`` (MATLAB v7.3 = HDF5).  Here ``h5py`` is used when it is
-installed; a sibling ``.npz`` / ``.npy`` file with the same stem (key ``output_h``) is accepted as an
-equivalent; ``synthetic=True`` generates CDL-like channels with ``synth.generate_output_h`` instead (the
+installed, otherwise the package's own dependency-free reader (``mat73.py``: super block, old-style groups, compound
+``{real, imag}``, contiguous / chunked + deflate layouts -- what ``save -v7.3`` writes); a sibling ``.npz`` / ``.npy``
+file with the same stem (key ``output_h``) is accepted as an equivalent; ``synthetic=True`` generates CDL-like channels with ``synth.generate_output_h`` instead (the
 reference's data blobs are not distributed).
 """
 import os
@@ -31,9 +32,10 @@ def read_output_h(filename):
                                 'generate them with matlab/generate_data.m or pass synthetic=True' % (filename, stem))
     try:
         import h5py
-    except ImportError as e:
-        raise ImportError('reading MATLAB v7.3 file %s needs h5py; alternatively convert it once to %s.npz with key '
-                          "'output_h'" % (filename, stem)) from e
+    except ImportError:
+        # no HDF5 library in this environment: the package's own reader for MATLAB's subset of the format
+        from .mat73 import loadmat_variable
+        return loadmat_variable(filename, 'output_h')
     with h5py.File(filename, 'r') as f:
         d = f['output_h'][()]
     if d.dtype.names:                                  # MATLAB stores complex as a compound {real, imag}
