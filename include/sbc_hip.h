@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SBC_ABI_VERSION 5
+#define SBC_ABI_VERSION 6
 
 typedef enum sbc_status {
     SBC_OK = 0,
@@ -198,6 +198,38 @@ int sbc_pack_conv_weight_split(const float* src, int32_t cout, int32_t cin, int3
 /* Winograd form U = G g G^T (double, rounded once to float) of a 3x3 weight, split like sbc_pack_conv_weight_split with
  * the 16 transform positions in place of the taps: [16][cin/16][cout/32][3][64][8] uint16. */
 int sbc_pack_conv_weight_winograd_split(const float* src, int32_t cout, int32_t cin, uint16_t* dst);
+
+/* --- the whole score network behind one call (hosts that are not Python) -------------------------------
+ * The Python host (score_based_channels_amd/plan.py, scorenet.py) wires NCSNv2Deepest.forward
+ * (ncsnv2/models/ncsnv2.py:269-300) into ~150 sbc_op records, shares activation storage, packs the weights and binds
+ * device memory.  sbc_score_create does all of that inside the library from the tensors of the reference checkpoint's
+ * `model_state` (names as in NCSNv2Deepest.state_dict(): "res2.0.conv2.conv.weight", "normalizer.alpha", ...; HOST
+ * pointers, float32, torch layouts).  The handle owns its device memory (weights, activation slots for `batch` samples,
+ * labels).  conv_mode: 0 = split-bf16 (fp32-accurate, default of the Python host), 1 = fp32 MFMA, 2 = fp16 weights
+ * (SBC_CONV_F16W; every parameter is rounded to fp16 first).
+ *   sbc_score_buffers      device pointers of the input x [batch][Nt][Nr][2], the output score (same shape) and the
+ *                          int64 noise-level labels [batch] (ncsnv2.py:295-298); fill x / labels, then
+ *   sbc_score_forward      one score evaluation, asynchronous on `stream`;
+ *   sbc_score_level_source inside an annealed-Langevin plan: take sigma from sigma_of_step[*step] (device) instead of
+ *                          the labels (both NULL switches back);
+ *   sbc_score_ops          the bound records, e.g. to append SBC_OP_LANGEVIN + SBC_OP_STEP_INC (X = the x buffer,
+ *                          score = the out buffer) and build a full Langevin-step plan with sbc_plan_create. */
+typedef struct sbc_tensor_ref { const char* name; const float* data; int64_t numel; } sbc_tensor_ref;
+typedef struct sbc_score_desc {
+    int32_t ngf, channels;       /* 32, 2 (train_score.py:37,59) */
+    int32_t nt, nr;              /* array size; multiples of 8 */
+    int32_t batch;
+    int32_t conv_mode;
+    const float* sigmas;         /* HOST [num_classes] (models/__init__.py:4-8) */
+    int32_t num_classes;
+} sbc_score_desc;
+typedef struct sbc_score sbc_score;
+int sbc_score_create(const sbc_score_desc* desc, const sbc_tensor_ref* tensors, int32_t n_tensors, sbc_score** out);
+int sbc_score_buffers(sbc_score* score, float** x, float** out, int64_t** labels);
+int sbc_score_ops(sbc_score* score, const sbc_op** ops, int32_t* n_ops);
+int sbc_score_level_source(sbc_score* score, const float* sigma_of_step, const int32_t* step);
+int sbc_score_forward(sbc_score* score, void* stream);
+void sbc_score_destroy(sbc_score* score);
 
 /* fp16 weight forms for SBC_CONV_F16W (round to nearest even): the layouts of sbc_pack_conv_weight_split /
  * sbc_pack_conv_weight_winograd_split with a single fp16 term, [k*k | 16][cin/16][cout/32][64 lanes][8] uint16.  The

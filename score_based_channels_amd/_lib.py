@@ -8,13 +8,15 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SBC_LIB_PATH') or os.path.join(_HERE, 'libsbc_hip.so')   # env override: A/B builds (tools/)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 EXPORTS = ('sbc_abi_version', 'sbc_last_error', 'sbc_device_count', 'sbc_op_launch', 'sbc_plan_create',
            'sbc_plan_run', 'sbc_plan_destroy', 'sbc_plan_profile', 'sbc_plan_profile_read',
            'sbc_pack_conv_weight', 'sbc_pack_conv_weight_winograd',
            'sbc_pack_conv_weight_split', 'sbc_pack_conv_weight_winograd_split',
-           'sbc_pack_conv_weight_f16', 'sbc_pack_conv_weight_winograd_f16')
+           'sbc_pack_conv_weight_f16', 'sbc_pack_conv_weight_winograd_f16',
+           'sbc_score_create', 'sbc_score_buffers', 'sbc_score_ops', 'sbc_score_level_source', 'sbc_score_forward',
+           'sbc_score_destroy')
 
 
 class SbcError(RuntimeError):
@@ -45,6 +47,15 @@ class sbc_langevin(C.Structure):
                 ('n_steps', C.c_int32), ('Nt', C.c_int32), ('Nr', C.c_int32), ('Np', C.c_int32)]
 
 
+class sbc_tensor_ref(C.Structure):
+    _fields_ = [('name', C.c_char_p), ('data', C.c_void_p), ('numel', C.c_int64)]
+
+
+class sbc_score_desc(C.Structure):
+    _fields_ = [('ngf', C.c_int32), ('channels', C.c_int32), ('nt', C.c_int32), ('nr', C.c_int32), ('batch', C.c_int32),
+                ('conv_mode', C.c_int32), ('sigmas', C.c_void_p), ('num_classes', C.c_int32)]
+
+
 _lib = None
 
 
@@ -73,6 +84,13 @@ def lib():
     h.sbc_pack_conv_weight_winograd_split.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     h.sbc_pack_conv_weight_f16.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     h.sbc_pack_conv_weight_winograd_f16.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    h.sbc_score_create.argtypes = [C.POINTER(sbc_score_desc), C.POINTER(sbc_tensor_ref), C.c_int32, C.POINTER(C.c_void_p)]
+    h.sbc_score_buffers.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    h.sbc_score_ops.argtypes = [C.c_void_p, C.POINTER(C.POINTER(sbc_op)), C.POINTER(C.c_int32)]
+    h.sbc_score_level_source.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    h.sbc_score_forward.argtypes = [C.c_void_p, C.c_void_p]
+    h.sbc_score_destroy.argtypes = [C.c_void_p]
+    h.sbc_score_destroy.restype = None
     if h.sbc_abi_version() != ABI_VERSION:
         raise SbcError('libsbc_hip.so ABI %d != expected %d' % (h.sbc_abi_version(), ABI_VERSION))
     _lib = h

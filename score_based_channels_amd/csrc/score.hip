@@ -1,0 +1,367 @@
+// sbc_score_*: the whole NCSNv2Deepest score network behind ONE C call, for hosts that are not Python.
+//
+// score_based_channels_amd/plan.py + scorenet.py (the product's Python host) wire ncsnv2/models/ncsnv2.py:269-300 into ~150
+// fused operator records, share activation storage between tensors with disjoint lifetimes, re-order the weights and bind
+// everything to device memory.  This file does the same inside the library -- same fusion rules, same slot assignment, same
+// packers -- so that a C / C++ / Go / Rust host gets a score evaluation from (state_dict tensors, batch size) without
+// re-implementing any of it: sbc_score_create -> sbc_score_buffers -> sbc_score_forward, or sbc_score_ops to extend the
+// record list with SBC_OP_LANGEVIN / SBC_OP_STEP_INC into a full annealed-Langevin step plan (sbc_plan_create).
+// tests/test_gpu_capi.py holds it to the Python host: identical records, bit-identical outputs.
+#include <string.h>
+#include <map>
+#include <string>
+#include <vector>
+#include "common.h"
+
+namespace {
+
+using namespace sbc;
+
+struct Tn { std::string name; int h, w, c; int slot = -1; };
+
+struct POp {
+    int kind = 0, flags = 0, ksize = 3, dil = 1, tag = 0;
+    int src = -1, dst = -1, stats = -1, res1 = -1, res2 = -1, up = -1;       // tensor indices
+    std::string weight, bias;
+};
+
+// ---- wiring: a transcription of plan.py's _Builder (reference lines cited there) --------------------------------
+struct Builder {
+    int ngf, nt, nr;
+    std::vector<Tn> t;
+    std::vector<POp> ops;
+    int tensor(const std::string& n, int h, int w, int c) { t.push_back({n, h, w, c}); return (int)t.size() - 1; }
+    int conv(const std::string& name, int src, const std::string& wkey, int cout, bool bias = true, int flags = 0,
+             int stats = -1, int res1 = -1, int res2 = -1, int up = -1, int ksize = 3, int dil = 1) {
+        const bool pool = flags & SBC_EPI_POOL;
+        const int sh = t[src].h, sw = t[src].w, sc = t[src].c;
+        const int dst = tensor(name, pool ? sh / 2 : sh, pool ? sw / 2 : sw, cout);
+        POp o;
+        o.kind = SBC_OP_CONV; o.src = src; o.dst = dst; o.weight = wkey + ".weight";
+        if (bias) o.bias = wkey + ".bias";
+        o.stats = stats; o.res1 = res1; o.res2 = res2; o.up = up;
+        o.flags = flags | (up >= 0 ? SBC_EPI_UP : 0); o.ksize = ksize; o.dil = dil;
+        o.tag = (ksize == 3 && sc == ngf && cout == ngf && sh == nt) ? 1 : 0;
+        ops.push_back(o);
+        return dst;
+    }
+    int stats(const std::string& name, int src, const std::string& nkey) {
+        const int dst = tensor(name, 1, 3, t[src].c);
+        POp o; o.kind = SBC_OP_INORM_STATS; o.src = src; o.dst = dst; o.weight = nkey;
+        ops.push_back(o);
+        return dst;
+    }
+    int maxpool(const std::string& name, int src, bool elu) {
+        const int dst = tensor(name, t[src].h, t[src].w, t[src].c);
+        POp o; o.kind = SBC_OP_MAXPOOL5; o.src = src; o.dst = dst; o.flags = elu ? SBC_PRO_ELU : 0;
+        ops.push_back(o);
+        return dst;
+    }
+    int residual_block(const std::string& p, int x, int cout, bool down, int dilation) {      // layers.py:443-456
+        const int d = dilation ? dilation : 1;
+        const bool pooled = down && !dilation;
+        const int c1 = down ? t[x].c : cout;
+        const int s1 = stats(p + "normalize1", x, p + "normalize1");
+        const int a = conv(p + "conv1", x, p + "conv1", c1, true, SBC_PRO_NORM | SBC_PRO_ELU, s1, -1, -1, -1, 3, d);
+        const int s2 = stats(p + "normalize2", a, p + "normalize2");
+        if (pooled) {
+            const int sc = conv(p + "shortcut", x, p + "shortcut.conv", cout, true, SBC_EPI_POOL, -1, -1, -1, -1, 1, 1);
+            return conv(p + "conv2", a, p + "conv2.conv", cout, true, SBC_PRO_NORM | SBC_PRO_ELU | SBC_EPI_POOL, s2, sc);
+        }
+        int sc = x;
+        if (t[x].c != cout || down) sc = conv(p + "shortcut", x, p + "shortcut", cout, true, 0, -1, -1, -1, -1, 3, d);
+        return conv(p + "conv2", a, p + "conv2", cout, true, SBC_PRO_NORM | SBC_PRO_ELU, s2, sc, -1, -1, 3, d);
+    }
+    int rcu(const std::string& p, int x, int n_blocks) {                                        // layers.py:126-134
+        for (int i = 1; i <= n_blocks; ++i) {
+            const std::string a = p + std::to_string(i) + "_1_conv", b = p + std::to_string(i) + "_2_conv";
+            const int tt = conv(a, x, a, t[x].c, false, SBC_PRO_ELU);
+            x = conv(b, tt, b, t[x].c, false, SBC_PRO_ELU, -1, x);
+        }
+        return x;
+    }
+    int crp(const std::string& p, int x) {                                                     // layers.py:76-83
+        const int p0 = maxpool(p + "pool0", x, true);
+        const int path0 = conv(p + "convs.0", p0, p + "convs.0", t[x].c, false);
+        const int p1 = maxpool(p + "pool1", path0, false);
+        return conv(p + "convs.1", p1, p + "convs.1", t[x].c, false, SBC_EPI_RES1_ELU, -1, x, path0);
+    }
+    int msf(const std::string& p, int h0, int h1, int features) {                              // layers.py:178-184
+        const int t1 = conv(p + "convs.1", h1, p + "convs.1", features);
+        return conv(p + "convs.0", h0, p + "convs.0", features, true, 0, -1, -1, -1, t1);
+    }
+    int refine(const std::string& p, const std::vector<int>& xs, int features, bool end = false) {   // layers.py:234-249
+        std::vector<int> hs;
+        for (size_t i = 0; i < xs.size(); ++i) hs.push_back(rcu(p + "adapt_convs." + std::to_string(i) + ".", xs[i], 2));
+        int h = xs.size() > 1 ? msf(p + "msf.", hs[0], hs[1], features) : hs[0];
+        h = crp(p + "crp.", h);
+        return rcu(p + "output_convs.", h, end ? 3 : 1);
+    }
+};
+
+}  // namespace
+
+struct sbc_score {
+    sbc_score_desc desc;
+    std::vector<Tn> tensors;
+    std::vector<POp> pops;
+    std::vector<size_t> slot_elems;
+    std::vector<float*> slots;           // device, [B * slot_elems]
+    float* wdev = nullptr;               // all parameters, packed
+    float* sigmas = nullptr;             // device [num_classes]
+    int64_t* labels = nullptr;           // device [B]
+    sbc_endconv endc;
+    std::vector<sbc_op> ops;
+    sbc_plan* plan = nullptr;
+    int x_t = -1, out_t = -1;
+};
+
+namespace {
+
+void assign_slots(sbc_score& s) {       // plan.assign_slots: linear scan, outputs never alias inputs of their own op
+    const int n_ops = (int)s.pops.size();
+    std::vector<int> last_use(s.tensors.size(), -1);
+    for (int i = 0; i < n_ops; ++i)
+        for (int id : {s.pops[i].src, s.pops[i].stats, s.pops[i].res1, s.pops[i].res2, s.pops[i].up})
+            if (id >= 0) last_use[id] = i;
+    std::map<size_t, std::vector<int>> free_slots;
+    std::vector<int> live;
+    auto elems = [&](int id) { return (size_t)s.tensors[id].h * s.tensors[id].w * s.tensors[id].c; };
+    auto pinned = [&](int id) { return id == s.x_t || id == s.out_t; };
+    auto alloc = [&](int id) {
+        auto& pool = free_slots[elems(id)];
+        if (!pool.empty() && !pinned(id)) { s.tensors[id].slot = pool.back(); pool.pop_back(); }
+        else { s.tensors[id].slot = (int)s.slot_elems.size(); s.slot_elems.push_back(elems(id)); }
+    };
+    alloc(s.x_t);
+    for (int i = 0; i < n_ops; ++i) {
+        const int dst = s.pops[i].dst;
+        alloc(dst);
+        live.push_back(dst);
+        for (size_t k = 0; k < live.size();) {
+            const int id = live[k];
+            if (!pinned(id) && id != dst && last_use[id] <= i) {
+                free_slots[elems(id)].push_back(s.tensors[id].slot);
+                live.erase(live.begin() + k);
+            } else {
+                ++k;
+            }
+        }
+    }
+}
+
+float round_f16(float f) { return (float)(_Float16)f; }
+
+}  // namespace
+
+extern "C" {
+
+int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int32_t n_tensors, sbc_score** out) {
+    SBC_REQUIRE(d && tensors && out && n_tensors > 0, "sbc_score_create: bad arguments");
+    SBC_REQUIRE(d->ngf == 32 && d->channels == 2, "sbc_score_create: kernels are instantiated for ngf = 32, 2 channels");
+    SBC_REQUIRE(d->nt > 0 && d->nr > 0 && d->nt % 8 == 0 && d->nr % 8 == 0,
+                "sbc_score_create: Nt and Nr must be multiples of 8 (three 2x mean pools), got %dx%d", d->nt, d->nr);
+    SBC_REQUIRE(d->batch > 0 && d->conv_mode >= 0 && d->conv_mode <= 2 && d->sigmas && d->num_classes > 0,
+                "sbc_score_create: batch, conv_mode in {0 bf16x3, 1 f32, 2 f16w}, sigmas required");
+    std::map<std::string, const sbc_tensor_ref*> sd;
+    for (int i = 0; i < n_tensors; ++i) {
+        SBC_REQUIRE(tensors[i].name && tensors[i].data, "sbc_score_create: tensor %d has no name / data", i);
+        sd[tensors[i].name] = &tensors[i];
+    }
+    sbc_score* s = new sbc_score();
+    s->desc = *d;
+    const int ngf = d->ngf, nt = d->nt, nr = d->nr, B = d->batch;
+    // ---- wiring (plan.build_score_plan)
+    Builder b{ngf, nt, nr};
+    const int x = b.tensor("x", nt, nr, d->channels);
+    int h = b.tensor("begin_conv", nt, nr, ngf);
+    { POp o; o.kind = SBC_OP_BEGIN_CONV; o.src = x; o.dst = h; o.weight = "begin_conv.weight"; o.bias = "begin_conv.bias"; b.ops.push_back(o); }
+    struct Stage { const char* name; int cout; bool down; int dil; };
+    const Stage stages[6] = {{"res1", ngf, false, 0}, {"res2", 2 * ngf, true, 0}, {"res3", 2 * ngf, true, 0},
+                             {"res31", 2 * ngf, true, 0}, {"res4", 4 * ngf, true, 2}, {"res5", 4 * ngf, true, 4}};
+    int layers[6];
+    for (int i = 0; i < 6; ++i) {
+        h = b.residual_block(std::string(stages[i].name) + ".0.", h, stages[i].cout, stages[i].down, stages[i].dil);
+        h = b.residual_block(std::string(stages[i].name) + ".1.", h, stages[i].cout, false, stages[i].dil);
+        layers[i] = h;
+    }
+    const int ref1 = b.refine("refine1.", {layers[5]}, 4 * ngf);
+    const int ref2 = b.refine("refine2.", {layers[4], ref1}, 2 * ngf);
+    const int ref31 = b.refine("refine31.", {layers[3], ref2}, 2 * ngf);
+    const int ref3 = b.refine("refine3.", {layers[2], ref31}, 2 * ngf);
+    const int ref4 = b.refine("refine4.", {layers[1], ref3}, ngf);
+    const int ref5 = b.refine("refine5.", {layers[0], ref4}, ngf, true);
+    const int sn = b.stats("normalizer", ref5, "normalizer");
+    const int o_t = b.tensor("score", nt, nr, d->channels);
+    { POp o; o.kind = SBC_OP_END_CONV; o.src = ref5; o.dst = o_t; o.weight = "end_conv.weight"; o.bias = "end_conv.bias"; o.stats = sn; b.ops.push_back(o); }
+    s->tensors = b.t; s->pops = b.ops; s->x_t = x; s->out_t = o_t;
+    assign_slots(*s);
+
+    // ---- parameters: one flat host image (16-byte aligned entries), packed by the library's own packers
+    const bool f16w = d->conv_mode == 2;
+    std::vector<float> host;
+    std::map<std::string, size_t> off;
+    auto reserve = [&](const std::string& key, size_t n) {
+        host.resize((host.size() + 3) / 4 * 4);
+        off[key] = host.size();
+        host.resize(host.size() + n);
+        return host.data() + off[key];
+    };
+    auto find = [&](const std::string& key, int64_t numel) -> const float* {
+        auto it = sd.find(key);
+        if (it == sd.end()) { set_error("sbc_score_create: tensor '%s' missing from the state dict", key.c_str()); return nullptr; }
+        if (it->second->numel != numel) {
+            set_error("sbc_score_create: tensor '%s' has %lld elements, expected %lld", key.c_str(),
+                      (long long)it->second->numel, (long long)numel);
+            return nullptr;
+        }
+        return it->second->data;
+    };
+    auto fail = [&]() { sbc_score_destroy(s); return SBC_ERR_INVALID; };
+    std::vector<float> tmp;
+    auto rounded = [&](const float* p, size_t n) {      // fp16 parameters for conv_mode f16w (module.half() semantics)
+        if (!f16w) return p;
+        tmp.assign(p, p + n);
+        for (auto& v : tmp) v = round_f16(v);
+        return (const float*)tmp.data();
+    };
+    for (const POp& o : s->pops) {
+        const Tn& src = s->tensors[o.src];
+        const Tn& dst = s->tensors[o.dst];
+        if (o.kind == SBC_OP_INORM_STATS) {
+            if (off.count(o.weight)) continue;
+            for (int k = 0; k < 3; ++k) {
+                const char* suffix[3] = {".alpha", ".gamma", ".beta"};
+                const float* v = find(o.weight + suffix[k], src.c);
+                if (!v) return fail();
+                if (k == 0) reserve(o.weight, 3 * (size_t)src.c);
+                v = rounded(v, src.c);
+                memcpy(host.data() + off[o.weight] + (size_t)k * src.c, v, sizeof(float) * src.c);
+            }
+            continue;
+        }
+        if (o.weight.empty()) continue;                  // max pooling has no parameters
+        const int k = o.ksize, cin = src.c, cout = dst.c;
+        const size_t wn = (size_t)cout * cin * k * k;
+        if (!off.count(o.weight) && !off.count(o.weight + "#split")) {
+            const float* w = find(o.weight, (int64_t)wn);
+            if (!w) return fail();
+            w = rounded(w, wn);
+            std::vector<float> wkeep(w, w + wn);          // `tmp` is reused below
+            if (o.kind != SBC_OP_CONV) {
+                memcpy(reserve(o.weight, wn), wkeep.data(), sizeof(float) * wn);
+            } else if (d->conv_mode == 1) {
+                sbc_pack_conv_weight(wkeep.data(), cout, cin, k, reserve(o.weight, wn));
+                if (k == 3) sbc_pack_conv_weight_winograd(wkeep.data(), cout, cin, reserve(o.weight + "#winograd", (size_t)cout * cin * 16));
+            } else if (d->conv_mode == 0) {
+                sbc_pack_conv_weight_split(wkeep.data(), cout, cin, k, (uint16_t*)reserve(o.weight + "#split", wn * 3 / 2));
+                if (k == 3) sbc_pack_conv_weight_winograd_split(wkeep.data(), cout, cin,
+                                                               (uint16_t*)reserve(o.weight + "#winograd_split", (size_t)cout * cin * 16 * 3 / 2));
+            } else {
+                sbc_pack_conv_weight_f16(wkeep.data(), cout, cin, k, (uint16_t*)reserve(o.weight + "#split", (wn + 1) / 2));
+                if (k == 3) sbc_pack_conv_weight_winograd_f16(wkeep.data(), cout, cin,
+                                                             (uint16_t*)reserve(o.weight + "#winograd_split", (size_t)cout * cin * 16 / 2));
+            }
+        }
+        if (!o.bias.empty() && !off.count(o.bias)) {
+            const float* bv = find(o.bias, cout);
+            if (!bv) return fail();
+            bv = rounded(bv, cout);
+            memcpy(reserve(o.bias, cout), bv, sizeof(float) * cout);
+        }
+    }
+    // ---- device memory
+    auto hip_fail = [&](hipError_t e, const char* what) {
+        set_error("sbc_score_create: %s failed: %s", what, hipGetErrorString(e));
+        sbc_score_destroy(s);
+        return SBC_ERR_HIP;
+    };
+    hipError_t e;
+    if ((e = hipMalloc((void**)&s->wdev, host.size() * sizeof(float))) != hipSuccess) return hip_fail(e, "hipMalloc(weights)");
+    if ((e = hipMemcpy(s->wdev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) return hip_fail(e, "hipMemcpy(weights)");
+    if ((e = hipMalloc((void**)&s->sigmas, d->num_classes * sizeof(float))) != hipSuccess) return hip_fail(e, "hipMalloc(sigmas)");
+    if ((e = hipMemcpy(s->sigmas, d->sigmas, d->num_classes * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) return hip_fail(e, "hipMemcpy(sigmas)");
+    if ((e = hipMalloc((void**)&s->labels, B * sizeof(int64_t))) != hipSuccess) return hip_fail(e, "hipMalloc(labels)");
+    if ((e = hipMemset(s->labels, 0, B * sizeof(int64_t))) != hipSuccess) return hip_fail(e, "hipMemset(labels)");
+    s->slots.assign(s->slot_elems.size(), nullptr);
+    for (size_t i = 0; i < s->slot_elems.size(); ++i)
+        if ((e = hipMalloc((void**)&s->slots[i], (size_t)B * s->slot_elems[i] * sizeof(float))) != hipSuccess)
+            return hip_fail(e, "hipMalloc(activation slot)");
+    s->endc.sigmas = s->sigmas; s->endc.labels = s->labels; s->endc.sigma_of_step = nullptr; s->endc.step = nullptr;
+    // ---- records (scorenet.ScoreNet.bind)
+    for (const POp& o : s->pops) {
+        sbc_op r;
+        memset(&r, 0, sizeof(r));
+        const Tn& src = s->tensors[o.src];
+        const Tn& dst = s->tensors[o.dst];
+        r.kind = o.kind; r.flags = o.flags; r.B = B; r.H = src.h; r.W = src.w;
+        r.cin = src.c; r.cout = dst.c; r.ksize = o.ksize; r.dil = o.dil; r.tag = o.tag;
+        r.in = s->slots[src.slot]; r.out = s->slots[dst.slot];
+        auto wp = [&](const std::string& key) -> const void* { return off.count(key) ? s->wdev + off[key] : nullptr; };
+        if (o.kind != SBC_OP_CONV) {
+            r.weight = wp(o.weight);
+        } else if (d->conv_mode == 1) {
+            r.weight = wp(o.weight);
+            if (o.ksize == 3 && o.dil == 1) r.weight_wino = wp(o.weight + "#winograd");
+        } else {
+            r.weight_split = wp(o.weight + "#split");
+            if (o.ksize == 3 && o.dil == 1) r.weight_wino_split = wp(o.weight + "#winograd_split");
+            if (f16w) r.flags |= SBC_CONV_F16W;
+        }
+        if (!o.bias.empty()) r.bias = wp(o.bias);
+        if (o.stats >= 0) r.stats = s->slots[s->tensors[o.stats].slot];
+        if (o.res1 >= 0) r.res1 = s->slots[s->tensors[o.res1].slot];
+        if (o.res2 >= 0) r.res2 = s->slots[s->tensors[o.res2].slot];
+        if (o.up >= 0) { r.up = s->slots[s->tensors[o.up].slot]; r.up_h = s->tensors[o.up].h; r.up_w = s->tensors[o.up].w; }
+        if (o.kind == SBC_OP_END_CONV) r.ext = &s->endc;
+        s->ops.push_back(r);
+    }
+    const int rc = sbc_plan_create(s->ops.data(), (int32_t)s->ops.size(), &s->plan);
+    if (rc) { sbc_score_destroy(s); return rc; }
+    *out = s;
+    return SBC_OK;
+}
+
+int sbc_score_buffers(sbc_score* s, float** x, float** out, int64_t** labels) {
+    SBC_REQUIRE(s, "sbc_score_buffers: handle is NULL");
+    if (x) *x = s->slots[s->tensors[s->x_t].slot];
+    if (out) *out = s->slots[s->tensors[s->out_t].slot];
+    if (labels) *labels = s->labels;
+    return SBC_OK;
+}
+
+int sbc_score_ops(sbc_score* s, const sbc_op** ops, int32_t* n_ops) {
+    SBC_REQUIRE(s && ops && n_ops, "sbc_score_ops: bad arguments");
+    *ops = s->ops.data();
+    *n_ops = (int32_t)s->ops.size();
+    return SBC_OK;
+}
+
+int sbc_score_level_source(sbc_score* s, const float* sigma_of_step, const int32_t* step) {
+    SBC_REQUIRE(s, "sbc_score_level_source: handle is NULL");
+    SBC_REQUIRE((sigma_of_step == nullptr) == (step == nullptr), "sbc_score_level_source: both pointers or neither");
+    s->endc.sigma_of_step = sigma_of_step;
+    s->endc.step = step;
+    s->endc.labels = step ? nullptr : s->labels;
+    // the score plan holds a copy of the end-conv extension: rebuild it
+    sbc_plan_destroy(s->plan);
+    s->plan = nullptr;
+    return sbc_plan_create(s->ops.data(), (int32_t)s->ops.size(), &s->plan);
+}
+
+int sbc_score_forward(sbc_score* s, void* stream) {
+    SBC_REQUIRE(s && s->plan, "sbc_score_forward: handle is NULL");
+    return sbc_plan_run(s->plan, stream, 1, 0);
+}
+
+void sbc_score_destroy(sbc_score* s) {
+    if (!s) return;
+    if (s->plan) sbc_plan_destroy(s->plan);
+    for (float* p : s->slots) if (p) (void)hipFree(p);
+    if (s->wdev) (void)hipFree(s->wdev);
+    if (s->sigmas) (void)hipFree(s->sigmas);
+    if (s->labels) (void)hipFree(s->labels);
+    delete s;
+}
+
+}  // extern "C"

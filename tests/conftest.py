@@ -32,3 +32,12 @@ def rel_err(a, b):
     a = np.asarray(a, ctype)
     b = np.asarray(b, ctype)
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30))
+
+
+def rel_err_elementwise(a, b, floor=0.05):
+    """Largest element-wise relative error over the elements of the reference that are at least ``floor`` of its largest
+    magnitude (``rel_err`` is norm-wise: it does not bound the error of individual small-but-significant elements)."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    sel = np.abs(b) >= floor * np.max(np.abs(b))
+    return float(np.max(np.abs(a[sel] - b[sel]) / np.abs(b[sel])))

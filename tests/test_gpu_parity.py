@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import load_golden, rel_err
+from conftest import load_golden, rel_err, rel_err_elementwise
 from plan_interp import exec_op
 
 pytestmark = pytest.mark.gpu
@@ -59,6 +59,7 @@ def test_forward_matches_reference_golden(net64):
         out = net64(x, torch.full((4,), int(lv), dtype=torch.long, device='cuda'))
         assert tuple(out.shape) == (4, 2, 64, 16)
         assert rel_err(out.cpu().numpy(), g['out'][i]) < 2e-5, lv
+        assert rel_err_elementwise(out.cpu().numpy(), g['out'][i], 0.02) < 1e-4, lv    # every element >= 2 % of the peak
 
 
 def test_forward_accepts_reference_call_pattern(net64):
