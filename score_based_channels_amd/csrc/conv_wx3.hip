@@ -16,8 +16,9 @@
 
 namespace sbc {
 
-// WPE: waves per SIMD the register allocation must allow (2 = 256 registers, 3 = 168).  A third resident workgroup per CU
-// is worth ~20 % where the kernel fits without spilling (32 -> 32 with 128-pixel tiles); the wider variants would spill.
+// WPE: waves per SIMD the register allocation must allow (2 = 256 registers, 3 = 168, 4 = 128).  More resident workgroups
+// per CU are worth ~20 % (third) and ~4 % (fourth) where the kernel fits without spilling (32 -> 32 with 128-pixel tiles);
+// the wider variants would spill.
 // TOP: instantiation tag without effect on the code -- launches on images of >= 1024 pixels (the full-resolution level
 // of the score network) get their own kernel symbol, so per-symbol profiler statistics (rocprofv3 --stats) separate them from
 // the same channel configuration at 32x8, and bench.py's hipEvent average of that level can be checked against them.
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
         // ring of SETS statically indexed register sets over the sequence g = step * 4 + nu), so their L2 latency hides
         // behind the MFMAs and splits in between: three columns ahead with one output block per phase, one column
         // ahead with two (twice the MFMAs per column; 48 registers either way).
-        constexpr int SETS = NBP == 1 ? 4 : 2, D = SETS - 1, NSEQ = MB * KG * 4;
+        constexpr int SETS = (NBP == 1 && WPE < 4) ? 4 : 2, D = SETS - 1, NSEQ = MB * KG * 4;
         uint4 uB[SETS][NBP][NTERM];                                   // 8 x 16-bit fragments (bf16 terms or fp16)
         auto u_load = [&](int gq) {                                   // gq is a compile-time constant at every call
             const int gg = gq % NSEQ, nu_g = gg & 3, kg_g = (gg >> 2) % KG;
@@ -361,7 +362,9 @@ static int launch_wx3(const ConvParams& p, hipStream_t stream, bool dry) {
     const size_t stats_off = lds / sizeof(float);
     const size_t lds_all = lds + ((p.flags & SBC_PRO_NORM) ? nsamp * 3 * CIN * sizeof(float) : 0);
     if (lds_all > 160 * 1024) return 1;
-    constexpr int WPE = (CIN == 32 && COUT == 32 && MB == 1) ? 3 : 2;
+    // 32 -> 32 with 128-pixel tiles: four waves per SIMD (128 registers) with the filter ring one column deep measure 4 %
+    // faster per launch than three waves (168 registers) with the ring three columns deep; deeper rings at four waves spill
+    constexpr int WPE = (CIN == 32 && COUT == 32 && MB == 1) ? 4 : 2;
     constexpr int NBP_BIG = NBLK == 2 ? 2 : 1;
     const bool top = (CIN == 32 && COUT == 32) && p.H * p.W >= 1024;
     auto kern = ng == 2 ? conv_wx3_kernel<CIN, COUT, MB, true, 2, false, (NBLK == 4 ? 2 : 1), NGMAX, F16>

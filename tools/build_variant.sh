@@ -6,7 +6,7 @@ name=$1; src=$2; shift 2
 root=$(cd "$(dirname "$0")/.." && pwd)
 csrc=$root/score_based_channels_amd/csrc
 mkdir -p /tmp/var_$name $root/tools/var
-for f in conv_mfma conv_wino conv_x3 conv_wx3 ops api; do cp $csrc/build/$f.o /tmp/var_$name/; done
+cp $csrc/build/*.o /tmp/var_$name/
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c $csrc/$src -o /tmp/var_$name/${src%.hip}.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/var_$name/*.o -o $root/tools/var/libsbc_$name.so
 echo built tools/var/libsbc_$name.so
