@@ -84,7 +84,9 @@ typedef struct sbc_op {
     int32_t B, H, W;
     int32_t cin, cout, ksize, dil;
     int32_t up_h, up_w;
-    int32_t tag;                 /* free label; sbc_plan_profile times all ops carrying a given tag */
+    int32_t tag;                 /* free label; sbc_plan_profile times all ops carrying a given tag.  tag 1 = the 3x3 ngf -> ngf
+                                    layers at full resolution: they also run under their own kernel symbol so that profilers
+                                    report them separately */
     const void* in;
     void* out;
     const void* weight;

@@ -19,6 +19,7 @@ struct ConvParams {
     int hsh, wsh;         // log2(H), log2(W) for the power-of-two builds
     int plane;            // conv_x3: 16-bit elements per LDS plane
     int stats_off;        // conv_wx3: float offset of the statistics copy in LDS
+    int top;              // op.tag == 1: a full-resolution ngf -> ngf layer (own kernel symbol for per-kernel profiles)
 };
 
 

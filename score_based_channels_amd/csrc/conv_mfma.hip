@@ -243,7 +243,7 @@ int launch_conv(const sbc_op& op, hipStream_t stream, bool dry) {
     p.B = op.B; p.H = op.H; p.W = op.W; p.dil = op.dil; p.flags = op.flags;
     p.up_h = op.up_h; p.up_w = op.up_w; p.total_px = op.B * op.H * op.W;
     p.hsh = log2_exact(op.H); p.wsh = log2_exact(op.W);
-    p.plane = 0; p.stats_off = 0;
+    p.plane = 0; p.stats_off = 0; p.top = op.tag == 1;
     if (op.weight_wino_split && !f32_only && op.ksize == 3 && op.dil == 1) {
         ConvParams pw = p;
         pw.wpk = (const float4*)op.weight_wino_split;

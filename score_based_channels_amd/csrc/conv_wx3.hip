@@ -19,8 +19,8 @@ namespace sbc {
 // WPE: waves per SIMD the register allocation must allow (2 = 256 registers, 3 = 168, 4 = 128).  More resident workgroups
 // per CU are worth ~20 % (third) and ~4 % (fourth) where the kernel fits without spilling (32 -> 32 with 128-pixel tiles);
 // the wider variants would spill.
-// TOP: instantiation tag without effect on the code -- launches on images of >= 1024 pixels (the full-resolution level
-// of the score network) get their own kernel symbol, so per-symbol profiler statistics (rocprofv3 --stats) separate them from
+// TOP: instantiation tag without effect on the code -- the ngf -> ngf layers of the score network's full-resolution level
+// (sbc_op.tag == 1) get their own kernel symbol, so per-symbol profiler statistics (rocprofv3 --stats) separate them from
 // the same channel configuration at 32x8, and bench.py's hipEvent average of that level can be checked against them.
 // NBP: output blocks (32 channels) per phase.  (One workgroup per (tile, phase) was tried for the low-resolution
 // levels, where a launch has fewer tiles than the chip has CUs: slower, because staging the 128-channel tile dominates
@@ -366,7 +366,7 @@ static int launch_wx3(const ConvParams& p, hipStream_t stream, bool dry) {
     // faster per launch than three waves (168 registers) with the ring three columns deep; deeper rings at four waves spill
     constexpr int WPE = (CIN == 32 && COUT == 32 && MB == 1) ? 4 : 2;
     constexpr int NBP_BIG = NBLK == 2 ? 2 : 1;
-    const bool top = (CIN == 32 && COUT == 32) && p.H * p.W >= 1024;
+    const bool top = (CIN == 32 && COUT == 32) && p.top;
     auto kern = ng == 2 ? conv_wx3_kernel<CIN, COUT, MB, true, 2, false, (NBLK == 4 ? 2 : 1), NGMAX, F16>
               : top     ? conv_wx3_kernel<CIN, COUT, MB, true, WPE, (CIN == 32 && COUT == 32), NBP_BIG, 1, F16>
                         : conv_wx3_kernel<CIN, COUT, MB, true, WPE, false, NBP_BIG, 1, F16>;

@@ -228,19 +228,23 @@ __global__ __launch_bounds__(256) void maxpool5_kernel(const float* __restrict__
     }
 }
 
-// Separable variant for images at least 16 rows high and up to 16 columns wide (the 64x16 and 32x8 levels, where the
-// tensor is far larger than the caches): a workgroup owns 16 rows of one sample.  Pass 1: thread (row, quad) reads its
+// Separable variant for images at least 16 rows high (the 64x16 and 32x8 levels, and every level of a 256x64 array, where
+// the tensor is far larger than the caches): a workgroup owns 16 rows x up to 16 columns of one sample.  Pass 1: thread (row, quad) reads its
 // row straight from global memory (every element once per workgroup, 128-byte segments) and writes the horizontal
 // 5-max to LDS; pass 2: thread (row group, column, quad) slides the vertical 5-window over LDS and stores.  1.25 global
 // loads per output instead of ~7 through the vector cache.
 template <int WMAX>
 __global__ __launch_bounds__(256) void maxpool5_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int H,
-                                                             int W, int C4, int flags) {
+                                                             int W, int C4, int flags, int wtiles) {
+    // a workgroup owns R rows x WT = min(W, WMAX) columns of one sample; wider images are tiled along W with a
+    // two-column halo on each side (wtiles column tiles per row block)
     constexpr int R = 16, RH = R + 4;
-    extern __shared__ __attribute__((aligned(16))) float4 hm[];       // [RH][W][C4] horizontal maxima
+    extern __shared__ __attribute__((aligned(16))) float4 hm[];       // [RH][WT][C4] horizontal maxima
     const int tid = threadIdx.x;
-    const int tiles_per_sample = H / R;
-    const int n = blockIdx.x / tiles_per_sample, r0 = (blockIdx.x % tiles_per_sample) * R;
+    const int tiles_per_sample = (H / R) * wtiles;
+    const int n = blockIdx.x / tiles_per_sample, rem = blockIdx.x % tiles_per_sample;
+    const int r0 = (rem / wtiles) * R, w0 = (rem % wtiles) * WMAX;
+    const int WT = min(WMAX, W - w0);
     const size_t row_stride = (size_t)W * C4 * 4;
     const float* base = in + (size_t)n * H * row_stride;
     const float NEG = -INFINITY;
@@ -248,34 +252,36 @@ __global__ __launch_bounds__(256) void maxpool5_rows_kernel(const float* __restr
     // pass 1: RH rows x C4 quads
     for (int t = tid; t < RH * C4; t += 256) {
         const int c4 = t % C4, rr = t / C4, r = r0 - 2 + rr;
-        float4 x[WMAX + 4];
+        float4 x[WMAX + 4];                                            // x[k] = column w0 - 2 + k
 #pragma unroll
-        for (int w = 0; w < WMAX + 4; ++w) x[w] = ninf;
+        for (int k = 0; k < WMAX + 4; ++k) x[k] = ninf;
         if (r >= 0 && r < H) {
             const float* q = base + (size_t)r * row_stride + c4 * 4;
 #pragma unroll
-            for (int w = 0; w < WMAX; ++w)
-                if (w < W) x[w + 2] = *reinterpret_cast<const float4*>(q + (size_t)w * C4 * 4);
+            for (int k = 0; k < WMAX + 4; ++k) {
+                const int col = w0 - 2 + k;
+                if (col >= 0 && col < W && k < WT + 4) x[k] = *reinterpret_cast<const float4*>(q + (size_t)col * C4 * 4);
+            }
         }
 #pragma unroll
         for (int w = 0; w < WMAX; ++w)
-            if (w < W) hm[(rr * W + w) * C4 + c4] = max4(max4(max4(x[w], x[w + 1]), max4(x[w + 2], x[w + 3])), x[w + 4]);
+            if (w < WT) hm[(rr * WT + w) * C4 + c4] = max4(max4(max4(x[w], x[w + 1]), max4(x[w + 2], x[w + 3])), x[w + 4]);
     }
     __syncthreads();
     // pass 2: (row group of 4, column, quad)
     float* obase = out + (size_t)n * H * row_stride;
-    for (int t = tid; t < (R / 4) * W * C4; t += 256) {
-        const int c4 = t % C4, w = (t / C4) % W, g = t / (C4 * W);
+    for (int t = tid; t < (R / 4) * WT * C4; t += 256) {
+        const int c4 = t % C4, w = (t / C4) % WT, g = t / (C4 * WT);
         const float4* col = hm + w * C4 + c4;
         const int rr0 = g * 4;                                            // hm row rr corresponds to image row r0 - 2 + rr
-        float4 m0 = col[(rr0 + 0) * W * C4], m1 = col[(rr0 + 1) * W * C4], m2 = col[(rr0 + 2) * W * C4],
-               m3 = col[(rr0 + 3) * W * C4];
+        float4 m0 = col[(rr0 + 0) * WT * C4], m1 = col[(rr0 + 1) * WT * C4], m2 = col[(rr0 + 2) * WT * C4],
+               m3 = col[(rr0 + 3) * WT * C4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float4 m4 = col[(rr0 + 4 + k) * W * C4];
+            const float4 m4 = col[(rr0 + 4 + k) * WT * C4];
             float4 m = max4(max4(max4(m0, m1), max4(m2, m3)), m4);
             if (flags & SBC_PRO_ELU) m = elu4(m);
-            st_stream(obase + (size_t)(r0 + rr0 + k) * row_stride + ((size_t)w * C4 + c4) * 4, m);
+            st_stream(obase + (size_t)(r0 + rr0 + k) * row_stride + ((size_t)(w0 + w) * C4 + c4) * 4, m);
             m0 = m1; m1 = m2; m2 = m3; m3 = m4;
         }
     }
@@ -284,15 +290,17 @@ __global__ __launch_bounds__(256) void maxpool5_rows_kernel(const float* __restr
 int launch_maxpool5(const sbc_op& op, hipStream_t stream) {
     SBC_REQUIRE(op.in && op.out && op.cin % 4 == 0, "maxpool5: in/out must be set, channels %% 4 == 0");
     const int C4 = op.cin / 4;
-    if (op.H % 16 == 0 && op.W <= 16 && (size_t)20 * op.W * C4 * 16 <= 64 * 1024) {
-        const size_t lds = (size_t)20 * op.W * C4 * sizeof(float4);
-        const int grid = op.B * (op.H / 16);
+    const int wt = op.W <= 8 ? op.W : 16;                              // column tile
+    if (op.H % 16 == 0 && (op.W <= 16 || op.W % 16 == 0) && (size_t)20 * wt * C4 * 16 <= 64 * 1024) {
+        const size_t lds = (size_t)20 * wt * C4 * sizeof(float4);
+        const int wtiles = (op.W + wt - 1) / wt;
+        const int grid = op.B * (op.H / 16) * wtiles;
         if (op.W <= 8)
             hipLaunchKernelGGL(maxpool5_rows_kernel<8>, dim3(grid), dim3(256), lds, stream, (const float*)op.in,
-                               (float*)op.out, op.H, op.W, C4, op.flags);
+                               (float*)op.out, op.H, op.W, C4, op.flags, wtiles);
         else
             hipLaunchKernelGGL(maxpool5_rows_kernel<16>, dim3(grid), dim3(256), lds, stream, (const float*)op.in,
-                               (float*)op.out, op.H, op.W, C4, op.flags);
+                               (float*)op.out, op.H, op.W, C4, op.flags, wtiles);
         SBC_CHECK_HIP(hipGetLastError());
         return SBC_OK;
     }
@@ -478,6 +486,116 @@ __global__ __launch_bounds__(256) void langevin_kernel(sbc_langevin a, int B, in
     }
 }
 
+// Large arrays (256 x 64: X alone is 128 KB): the two products are register-blocked and K-chunked instead.  512 threads;
+// thread (g, r) = (tid / Nr, tid % Nr) owns column r of up to J output rows g, g + G, g + 2G, ... (G = 512 / Nr groups) in
+// registers; per K chunk the P slab [rows][KC] and the X (or R) slab [KC][Nr] go through LDS, so each complex FMA costs one
+// broadcast LDS read of P (all lanes of a wave share the row) -- the X / R element is read once per chunk row and reused for
+// all J rows.  R = P X - Y stays in LDS for the second product.  The summation order over Nt / Np is the same ascending
+// order as langevin_kernel's, so both kernels agree to rounding of identical operation sequences.
+template <int J, int KC>
+__global__ __launch_bounds__(512) void langevin_tiled_kernel(sbc_langevin a, int B) {
+    extern __shared__ __attribute__((aligned(16))) float2 sm[];
+    constexpr int NT_ = 512;
+    const int Nt = a.Nt, Nr = a.Nr, Np = a.Np;
+    const int G = NT_ / Nr;                               // row groups
+    float2* Rs = sm;                                      // [Np][Nr]
+    float2* Ps = Rs + Np * Nr;                            // phase 1: [G*J][KC] (zero rows beyond Np); phase 2: [KC][G*J]
+    float2* Xs = Ps + G * J * KC;                         // phase 1: [KC][Nr]
+    __shared__ float red[2][8];
+    const int b = blockIdx.x, tid = threadIdx.x, r = tid % Nr, g = tid / Nr;
+    const int step = *a.step;
+    float2* X = reinterpret_cast<float2*>(a.X) + (size_t)b * Nt * Nr;
+    const float2* P = reinterpret_cast<const float2*>(a.P) + (size_t)(a.p_index ? a.p_index[b] : b) * Np * Nt;
+    const float2* Y = reinterpret_cast<const float2*>(a.Y) + (size_t)b * Np * Nr;
+    const float2* Ht = reinterpret_cast<const float2*>(a.Htrue) + (size_t)(a.h_index ? a.h_index[b] : b) * Nt * Nr;
+    const float2* Sc = reinterpret_cast<const float2*>(a.score) + (size_t)b * Nt * Nr;
+    // ---- R = P X - Y: output rows m = g + G*j (+ pass offset), K = Nt
+    for (int m0 = 0; m0 < Np; m0 += G * J) {
+        float2 acc[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) acc[j] = make_float2(0.f, 0.f);
+        for (int t0 = 0; t0 < Nt; t0 += KC) {
+            __syncthreads();
+            for (int e = tid; e < G * J * KC; e += NT_) {
+                const int mm = e / KC, tt = e - mm * KC;
+                Ps[e] = (m0 + mm < Np && t0 + tt < Nt) ? P[(size_t)(m0 + mm) * Nt + t0 + tt] : make_float2(0.f, 0.f);
+            }
+            for (int e = tid; e < KC * Nr; e += NT_) {
+                const int tt = e / Nr;
+                Xs[e] = t0 + tt < Nt ? X[(size_t)(t0 + tt) * Nr + (e - tt * Nr)] : make_float2(0.f, 0.f);
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int tt = 0; tt < KC; ++tt) {
+                const float2 x = Xs[tt * Nr + r];
+#pragma unroll
+                for (int j = 0; j < J; ++j) acc[j] = cfma(Ps[(g + G * j) * KC + tt], x, acc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int m = m0 + g + G * j;
+            if (m < Np) {
+                const float2 y = Y[m * Nr + r];
+                Rs[m * Nr + r] = make_float2(acc[j].x - y.x, acc[j].y - y.y);
+            }
+        }
+    }
+    // ---- G = P^H R: output rows t = g + G*j, K = Np; then the update and the NMSE terms of those elements
+    const float* sc = a.sched + ((size_t)(a.group ? a.group[b] : 0) * a.n_steps + step) * 4;
+    const float alpha = sc[0], dc_div = sc[1], nscale = sc[2], dcb = sc[3];
+    const float2* ext = a.noise ? reinterpret_cast<const float2*>(a.noise) + ((size_t)step * B + b) * Nt * Nr : nullptr;
+    const int64_t traj = a.traj_id ? a.traj_id[b] : b;
+    float err = 0.f, den = 0.f;
+    for (int q0 = 0; q0 < Nt; q0 += G * J) {
+        float2 acc[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) acc[j] = make_float2(0.f, 0.f);
+        for (int k0 = 0; k0 < Np; k0 += KC) {
+            __syncthreads();                              // also orders the Rs writes above before the first read
+            for (int e = tid; e < KC * G * J; e += NT_) {
+                const int mm = e / (G * J), tt = e - mm * (G * J);
+                Ps[e] = (k0 + mm < Np && q0 + tt < Nt) ? P[(size_t)(k0 + mm) * Nt + q0 + tt] : make_float2(0.f, 0.f);
+            }
+            __syncthreads();
+            const int kn = min(KC, Np - k0);
+            for (int mm = 0; mm < kn; ++mm) {
+                const float2 rv = Rs[(k0 + mm) * Nr + r];
+#pragma unroll
+                for (int j = 0; j < J; ++j) acc[j] = cfma_conj(Ps[mm * (G * J) + g + G * j], rv, acc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int t = q0 + g + G * j;
+            if (t < Nt) {
+                const int e = t * Nr + r;
+                const float2 s = Sc[e], x = X[e], h = Ht[e];
+                const float2 n = ext ? ext[e] : complex_normal(a.seed, traj, step, e);
+                float2 u;
+                u.x = x.x + alpha * (s.x - (dcb * acc[j].x) / dc_div) + nscale * n.x;
+                u.y = x.y + alpha * (s.y - (dcb * acc[j].y) / dc_div) + nscale * n.y;
+                X[e] = u;
+                const float dx = u.x - h.x, dy = u.y - h.y;
+                err += dx * dx + dy * dy;
+                den += h.x * h.x + h.y * h.y;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        err += __shfl_down(err, off);
+        den += __shfl_down(den, off);
+    }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = err; red[1][tid >> 6] = den; }
+    __syncthreads();
+    if (tid == 0) {
+        float e8 = 0.f, d8 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { e8 += red[0][w]; d8 += red[1][w]; }
+        a.nmse[(size_t)step * B + b] = e8 / d8;
+    }
+}
+
 static int check_langevin(const sbc_op& op, const sbc_langevin& a, bool measure) {
     SBC_REQUIRE(a.P && a.Y && a.Htrue, "langevin/measure: P, Y, Htrue must be set");
     SBC_REQUIRE(a.Nt > 0 && a.Nr > 0 && a.Np > 0 && op.B > 0, "langevin/measure: bad sizes");
@@ -500,6 +618,20 @@ int launch_langevin(const sbc_op& op, const sbc_langevin& a, hipStream_t stream,
     const size_t lds_p = (size_t)a.Np * a.Nt * sizeof(float2);
     const int p_in_lds = x_in_lds && (a.Np * a.Nt) % 2 == 0 && lds_all + lds_p <= 40 * 1024;   // keeps 4 workgroups per CU
     const size_t lds = (x_in_lds ? lds_all : (size_t)a.Np * a.Nr * sizeof(float2)) + (p_in_lds ? lds_p : 0);
+    if (!x_in_lds && 512 % a.Nr == 0) {
+        // large arrays: register-blocked, K-chunked products (langevin_tiled_kernel)
+        constexpr int J = 32, KC = 16;
+        const int G = 512 / a.Nr;
+        const size_t lds_t = ((size_t)a.Np * a.Nr + (size_t)G * J * KC + (size_t)KC * a.Nr) * sizeof(float2);
+        if (lds_t <= 156 * 1024) {
+            auto kern = langevin_tiled_kernel<J, KC>;
+            { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds_t); if (rc) return rc; }
+            if (dry) return SBC_OK;
+            hipLaunchKernelGGL(kern, dim3(op.B), dim3(512), lds_t, stream, a, op.B);
+            SBC_CHECK_HIP(hipGetLastError());
+            return SBC_OK;
+        }
+    }
     { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(langevin_kernel), lds); if (rc) return rc; }
     if (dry) return SBC_OK;
     hipLaunchKernelGGL(langevin_kernel, dim3(op.B), dim3(256), lds, stream, a, op.B, x_in_lds, p_in_lds);

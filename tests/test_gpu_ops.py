@@ -237,7 +237,8 @@ def test_inorm_stats_matches_oracle(gpu, C_, B, H, W):
 
 
 @pytest.mark.parametrize('C_,B,H,W,elu', [(32, 3, 64, 16, True), (64, 5, 16, 4, False), (128, 9, 8, 2, True),
-                                          (64, 4, 32, 8, True), (32, 2, 32, 8, False), (32, 1, 256, 64, True)])
+                                          (64, 4, 32, 8, True), (32, 2, 32, 8, False), (32, 1, 256, 64, True),
+                                          (64, 2, 128, 32, False), (128, 3, 32, 16, True), (32, 2, 48, 24, True)])
 def test_maxpool5_matches_oracle(gpu, C_, B, H, W, elu):
     torch, _lib = gpu
     from score_based_channels_amd import plan as P

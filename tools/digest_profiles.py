@@ -1,23 +1,36 @@
-"""Turn gpurun_out/profile_passes/ (tools/profile_passes.sh) into the committed summaries under profiles/."""
-import collections, csv, json, os
+"""Turn gpurun_out/profile_passes_<workload>/ (tools/profile_passes.sh) into the committed summaries under profiles/.
+usage: digest_profiles.py [cdlc|big] [round tag, default r02]"""
+import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = os.path.join(ROOT, 'gpurun_out', 'profile_passes') + '/'
+W = sys.argv[1] if len(sys.argv) > 1 else 'cdlc'
+TAG = sys.argv[2] if len(sys.argv) > 2 else 'r02'
+R = os.path.join(ROOT, 'gpurun_out', 'profile_passes_' + W) + '/'
 P = os.path.join(ROOT, 'profiles') + '/'
-DOMINANT = 'conv_wx3_kernel<32, 32, 1, true, 3, true, 1, 1>'
+BIG = W == 'big'
+DOMINANT = 'conv_wx3_kernel<32, 32, 1, true, 4, true, 1, 1, %s>' % ('true' if BIG else 'false')
+PX = (256 * 64) if BIG else (64 * 16)
+CMD = '--workload %s --no-cpu-baseline --no-strong --no-other-mode --sustained 0' % W
+DESC = ('conv_mode f16w, one stream, T=1024 (256x64 arrays)' if BIG else 'conv_mode bf16x3, one stream, T=1700')
 
-rows = list(csv.reader(open(R + 'stats/s_kernel_stats.csv')))
-with open(P + 'r01_kernel_stats_bench_steps10.csv', 'w', newline='') as f:
-    f.write('# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 10 --no-cpu-baseline '
-            '(13 steps incl. 3 warm-up), 1x MI355X, defaults: conv_mode bf16x3, one stream, T=1700\n')
+
+def find(d, suffix):
+    hits = glob.glob(R + d + '/**/*' + suffix, recursive=True)
+    assert hits, (d, suffix)
+    return hits[0]
+
+rows = list(csv.reader(open(find('stats', 'kernel_stats.csv'))))
+with open(P + '%s_kernel_stats_%s_steps10.csv' % (TAG, W), 'w', newline='') as f:
+    f.write('# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 10 %s '
+            '(13 steps incl. 3 warm-up), 1x MI355X, %s\n' % (CMD, DESC))
     w = csv.writer(f, quoting=csv.QUOTE_ALL)
     for r in rows:
         w.writerow(r)
 
 
 def load(d):
-    kt = {r['Dispatch_Id']: r for r in csv.DictReader(open(R + d + '/p_kernel_trace.csv'))}
+    kt = {r['Dispatch_Id']: r for r in csv.DictReader(open(find(d, 'kernel_trace.csv')))}
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(R + d + '/p_counter_collection.csv')):
+    for r in csv.DictReader(open(find(d, 'counter_collection.csv'))):
         k = kt[r['Dispatch_Id']]
         name = r['Kernel_Name'].split('(')[0].replace('void sbc::', '').replace('sbc::', '')
         if 'at::native' in name or 'rocclr' in name:
@@ -28,9 +41,9 @@ def load(d):
 
 
 a1 = load('pmc1')
-with open(P + 'r01_pmc_mfma_util.csv', 'w') as f:
+with open(P + '%s_pmc_mfma_util_%s.csv' % (TAG, W), 'w') as f:
     f.write('# rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY\n'
-            '#   -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline; per (kernel, grid) mean over dispatches.  clock = GRBM_GUI_ACTIVE / 8 XCDs / duration\n'
+            '#   -- python3 bench.py --steps 2 --warmup 1 %s; per (kernel, grid) mean over dispatches.  clock = GRBM_GUI_ACTIVE / 8 XCDs / duration\n' % CMD +
             '#   (over-estimates for kernels < 60 us: the counter runs a little before/after the dispatch); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * cycles).\n'
             'kernel,grid_threads,dispatches,avg_dur_us,clock_ghz,mfma_busy_frac,wait_inst_any_frac,active_inst_frac\n')
     for key, d in sorted(a1.items(), key=lambda kv: -sum(t for _, t in kv[1]['GRBM_GUI_ACTIVE'])):
@@ -43,8 +56,8 @@ with open(P + 'r01_pmc_mfma_util.csv', 'w') as f:
                 m('SQ_ACTIVE_INST_ANY') / m('SQ_WAVE_CYCLES')))
 a2, a3 = load('pmc2'), load('pmc3')
 tr = {}
-with open(P + 'r01_pmc_hbm_traffic.csv', 'w') as f:
-    f.write('# rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes) of bench.py --steps 2 --warmup 1 --no-cpu-baseline, T=1700.\n'
+with open(P + '%s_pmc_hbm_traffic_%s.csv' % (TAG, W), 'w') as f:
+    f.write('# rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes) of bench.py --steps 2 --warmup 1 %s; %s.\n' % (CMD, DESC) +
             '# Raw counter values are KB per dispatch.  Per MI355X_MICROARCH.md FETCH_SIZE reports half of the bytes of wide coalesced (16 B/lane) reads on gfx950,\n'
             '# so hbm_read_MB = 2 * FETCH_SIZE / 1024; WRITE_SIZE is uncalibrated (it matches the algorithmic output bytes here).  MALL hits are counted as traffic.\n'
             'kernel,grid_threads,dispatches,avg_dur_us,FETCH_SIZE_KB_raw,WRITE_SIZE_KB_raw,hbm_read_MB_corrected,hbm_write_MB,GBps_corrected\n')
@@ -54,19 +67,21 @@ with open(P + 'r01_pmc_hbm_traffic.csv', 'w') as f:
         fs = sum(v for v, _ in d['FETCH_SIZE']) / n
         ws = sum(v for v, _ in a3[key]['WRITE_SIZE']) / max(1, len(a3[key]['WRITE_SIZE']))
         rd, wr = 2 * fs / 1024, ws / 1024
-        tr[key[0]] = (fs, ws, dur, key[1])
+        if key[0] not in tr or key[1] > tr[key[0]][3]:
+            tr[key[0]] = (fs, ws, dur, key[1])
         f.write('"%s",%d,%d,%.1f,%.0f,%.0f,%.1f,%.1f,%.0f\n' % (key[0], key[1], n, dur / 1e3, fs, ws, rd, wr, (rd + wr) * 1e6 / dur))
 fs, ws, dur, grid = tr[DOMINANT]
+traj = grid // 256 * 128 // PX
 json.dump({
-    'kernel': '%s: 3x3 32->32 at 64x16 (grid %d threads = %d trajectories per launch)' % (DOMINANT, grid, grid // 256 * 128 // 1024),
-    'trajectories_per_launch': grid // 256 * 128 // 1024,
-    'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), profiles/r01_pmc_hbm_traffic.csv',
+    'kernel': '%s: 3x3 32->32 at full resolution (grid %d threads = %d trajectories per launch)' % (DOMINANT, grid, traj),
+    'trajectories_per_launch': traj, 'conv_mode': 'f16w' if BIG else 'bf16x3',
+    'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), profiles/%s_pmc_hbm_traffic_%s.csv' % (TAG, W),
     'fetch_size_kb_raw': round(fs), 'write_size_kb': round(ws),
     'correction': 'FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B for wide coalesced reads, '
                   'MI355X_MICROARCH.md); WRITE_SIZE as reported',
     'hbm_bytes_per_launch': int(round((2 * fs + ws) * 1024)),
-    'algorithmic_bytes_per_launch': 'input + residual (15 of 18 launches) + output, 131072 B per trajectory each'},
-    open(P + 'r01_traffic.json', 'w'), indent=1)
+    'algorithmic_bytes_per_launch': 'input + residual (15 of 18 launches) + output, %d B per trajectory each' % (PX * 128)},
+    open(P + '%s_traffic_%s.json' % (TAG, W), 'w'), indent=1)
 for r in rows[1:6]:
     print(r[0][:70], r[1], '%.1f us' % (float(r[3]) / 1e3))
-print(open(P + 'r01_traffic.json').read())
+print(open(P + '%s_traffic_%s.json' % (TAG, W)).read())
