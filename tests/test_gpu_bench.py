@@ -1,0 +1,48 @@
+"""bench.py keeps the driver's contract: one JSON line with the headline keys, the roofline and (N = 1) cpu_baseline objects,
+and it starts its own ranks for --gpus N.  Short runs on the GPU box (``pytest -m gpu``)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+KEYS = {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+        'dtype', 'data', 'config', 'roofline'}
+
+
+def _run(*args):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(args), capture_output=True, text=True,
+                       timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract_single_gpu():
+    d = _run('--steps', '4', '--warmup', '1', '--channels', '8', '--snr-points', '4', '--sustained', '6', '--no-cpu-baseline')
+    assert KEYS <= set(d) and d['n_gpus'] == 1 and d['steps'] == 4 and d['scaling'] == 'weak' and d['vs_baseline'] is None
+    assert d['value'] > 0 and abs(d['value'] - 32 / (6933 * d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+    assert 'workload' in d['config'] and 'model' not in d['config'] and d['config']['nmse_finite']
+    r = d['roofline']
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+    assert d['sustained_steps'] == 6 and d['sustained_ms_per_step'] > 0 and 'other_launch_mode' in d
+    assert d['strong']['scaling'] == 'strong' and d['strong']['trajectories_total'] == 20400
+
+
+def test_bench_self_launches_its_ranks():
+    """``python bench.py --gpus 2`` with no torchrun environment: the parent starts the ranks as children (gloo here: RCCL
+    refuses two ranks on the one GPU of this box) and rank 0 prints the line with the aggregate over both."""
+    env_clean = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--channels', '8', '--snr-points', '4', '--sustained', '0', '--no-strong', '--no-other-mode'],
+                       capture_output=True, text=True, timeout=900, env=env_clean)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    assert d['n_gpus'] == 2 and d['config']['trajectories_per_gpu'] == 32
+    assert abs(d['value'] - 2 * 32 / (6933 * d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']

@@ -401,6 +401,27 @@ def test_cli_tuner_matches_reference_pipeline(net64, tmp_path, monkeypatch):
     assert np.max(np.abs(nmse_log / g['nmse_log'] - 1)) < NMSE_RTOL
 
 
+def test_concurrent_sub_batch_streams_do_not_change_results(net64):
+    """``run_trajectories(n_streams=2)``: two sub-batches on their own HIP streams, one host thread each
+    (driver.run_concurrently).  Per-trajectory noise keys and per-sample normalisation make the split invisible."""
+    import torch
+    from score_based_channels_amd import synth
+    from score_based_channels_amd.ald import snr_to_noise
+    from score_based_channels_amd.driver import run_trajectories
+    nch, nt, nr, npil = 24, 64, 16, 38
+    raw = synth.generate_channels('CDL-C', nch, nt, nr, 0.5, seed=41)
+    H = np.conj(np.transpose(raw / np.std(raw), (0, 2, 1))).astype(np.complex64)
+    Pm = np.conj(np.transpose(synth.qpsk_pilots(np.random.default_rng(42), nch, nt, npil), (0, 2, 1)))
+    snr = np.array([-10.0, 0.0, 12.5, 30.0])
+    idx = np.tile(np.arange(nch), len(snr))
+    ln = np.repeat(snr_to_noise(snr, nt), nch)
+    init = torch.randn(nch, nt, nr, dtype=torch.complex64, generator=torch.Generator().manual_seed(7))
+    out = [run_trajectories(net64, H, Pm, idx, idx, ln, 3e-11, 0.01, [0, 1155, 2310], 3, 11, init, n_streams=n,
+                            use_graph=g, return_final=True) for n, g in ((1, False), (2, False), (3, True))]
+    for log, est in out[1:]:
+        assert np.array_equal(log, out[0][0]) and np.array_equal(est, out[0][1])
+
+
 @pytest.mark.parametrize('nt,nr', [(16, 64), (32, 32), (128, 8)])
 def test_forward_other_geometries_match_oracle(nt, nr, weights64):
     """Array shapes the reference goldens do not cover (wide images, square images, 8-column images): every level still
