@@ -247,3 +247,44 @@ def test_product_fails_loudly_without_the_library(monkeypatch):
     monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libsbc_hip.so')
     with pytest.raises(_lib.SbcError, match='no CPU fallback'):
         _lib.lib()
+
+
+def test_launch_mode_flags_and_default():
+    from types import SimpleNamespace as NS
+    from score_based_channels_amd import driver
+    assert driver.resolve_launch_mode(NS(graph=False, no_graph=False)) is driver.DEFAULT_USE_GRAPH
+    assert driver.resolve_launch_mode(NS(graph=True, no_graph=False)) is True
+    assert driver.resolve_launch_mode(NS(graph=False, no_graph=True)) is False
+    with pytest.raises(SystemExit):
+        driver.resolve_launch_mode(NS(graph=True, no_graph=True))
+
+
+def test_host_noise_streams_follow_the_reference_draw_order():
+    """``--noise host``: one init per combination shared by all SNR points, then per SNR point its measurement draw and its
+    step draws, laid out for the lock-step batch t = snr * B + channel."""
+    from score_based_channels_amd.driver import host_noise_streams
+    from score_based_channels_amd.noise import HostNoise
+    B, nt, nr, npil, S, n_steps = 3, 8, 4, 5, 2, 4
+    init, meas, steps = host_noise_streams(17, 2, (B, nt, nr), S, n_steps, (B, npil, nr))
+    ref = HostNoise(17, 2)
+    assert np.array_equal(init.numpy(), ref.init((B, nt, nr)))
+    assert meas.shape == (S * B, npil, nr) and steps.shape == (n_steps, S * B, nt, nr)
+    for s_ in range(S):
+        assert np.array_equal(meas[s_ * B:(s_ + 1) * B], ref.measurement(s_, (B, npil, nr)))
+        draw = ref.step_stream(s_, (B, nt, nr))
+        for k in range(n_steps):
+            assert np.array_equal(steps[k, s_ * B:(s_ + 1) * B], draw(k))
+    other = host_noise_streams(17, 3, (B, nt, nr), S, n_steps, (B, npil, nr))
+    assert not np.array_equal(other[0].numpy(), init.numpy())                 # another combination / grid cell: other streams
+
+
+def test_schedule_tables_keep_dc_boost_as_its_own_factor():
+    """test_mmse.py:231-233 evaluates ``dc_boost * meas_grad / (...)`` left to right: the kernel gets the un-boosted divisor
+    and the factor separately (column 3), not a pre-divided divisor."""
+    from score_based_channels_amd.ald import schedule_tables
+    cfg = default_config()
+    from score_based_channels_amd.weights import get_sigmas
+    sig = get_sigmas(cfg)
+    a, _ = schedule_tables(sig, cfg.model.sigma_end, [0, 1000], 2, [3e-11], [0.01], [0.1], dc_boost=1.0)
+    b, _ = schedule_tables(sig, cfg.model.sigma_end, [0, 1000], 2, [3e-11], [0.01], [0.1], dc_boost=2.5)
+    assert np.array_equal(a[..., :3], b[..., :3]) and np.all(a[..., 3] == 1.0) and np.all(b[..., 3] == np.float32(2.5))
