@@ -244,7 +244,8 @@ int launch_conv(const sbc_op& op, hipStream_t stream, bool dry) {
     p.up_h = op.up_h; p.up_w = op.up_w; p.total_px = op.B * op.H * op.W;
     p.hsh = log2_exact(op.H); p.wsh = log2_exact(op.W);
     p.plane = 0; p.stats_off = 0; p.top = op.tag == 1;
-    if (op.weight_wino_split && !f32_only && op.ksize == 3 && op.dil == 1) {
+    static const bool no_wx3 = getenv("SBC_NO_WX3") != nullptr;                    // A/B aid: direct split-bf16 kernel everywhere
+    if (op.weight_wino_split && !f32_only && !no_wx3 && op.ksize == 3 && op.dil == 1) {
         ConvParams pw = p;
         pw.wpk = (const float4*)op.weight_wino_split;
         const int rc = launch_conv_wx3(pw, op.cin, op.cout, stream, dry);

@@ -16,9 +16,8 @@
 
 namespace sbc {
 
-// WPE: waves per SIMD the register allocation must allow (2 = 256 registers, 3 = 168, 4 = 128).  More resident workgroups
-// per CU are worth ~20 % (third) and ~4 % (fourth) where the kernel fits without spilling (32 -> 32 with 128-pixel tiles);
-// the wider variants would spill.
+// WPE: waves per SIMD the register allocation must allow (2 = 256 registers, 3 = 168).  A third resident workgroup per CU
+// is worth ~20 % where the kernel fits without spilling (32 -> 32 with 128-pixel tiles); the wider variants would spill.
 // TOP: instantiation tag without effect on the code -- the ngf -> ngf layers of the score network's full-resolution level
 // (sbc_op.tag == 1) get their own kernel symbol, so per-symbol profiler statistics (rocprofv3 --stats) separate them from
 // the same channel configuration at 32x8, and bench.py's hipEvent average of that level can be checked against them.
@@ -362,19 +361,21 @@ static int launch_wx3(const ConvParams& p, hipStream_t stream, bool dry) {
     const size_t stats_off = lds / sizeof(float);
     const size_t lds_all = lds + ((p.flags & SBC_PRO_NORM) ? nsamp * 3 * CIN * sizeof(float) : 0);
     if (lds_all > 160 * 1024) return 1;
-    // 32 -> 32 with 128-pixel tiles: four waves per SIMD (128 registers) with the filter ring one column deep measure 4 %
-    // faster per launch than three waves (168 registers) with the ring three columns deep; deeper rings at four waves spill
-    constexpr int WPE = (CIN == 32 && COUT == 32 && MB == 1) ? 4 : 2;
+    // 32 -> 32 with 128-pixel tiles: three waves per SIMD (168 registers), filter ring three columns deep.  (Four waves at 128
+    // registers with a one-column ring measured 4 % faster per launch, but only with the packed-fp32 instructions the build
+    // no longer allows -- see the Makefile; without them that variant spills.)
+    constexpr int WPE = (CIN == 32 && COUT == 32 && MB == 1) ? 3 : 2;
     constexpr int NBP_BIG = NBLK == 2 ? 2 : 1;
     const bool top = (CIN == 32 && COUT == 32) && p.top;
     auto kern = ng == 2 ? conv_wx3_kernel<CIN, COUT, MB, true, 2, false, (NBLK == 4 ? 2 : 1), NGMAX, F16>
               : top     ? conv_wx3_kernel<CIN, COUT, MB, true, WPE, (CIN == 32 && COUT == 32), NBP_BIG, 1, F16>
                         : conv_wx3_kernel<CIN, COUT, MB, true, WPE, false, NBP_BIG, 1, F16>;
-    { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds_all); if (rc) return rc; }
+    static const size_t pad = getenv("SBC_LDS_PAD") ? atoi(getenv("SBC_LDS_PAD")) : 0;   // debugging aid
+    { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds_all + pad); if (rc) return rc; }
     if (dry) return SBC_OK;
     ConvParams q = p;
     q.stats_off = (int)stats_off;
-    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256 * ng), lds_all, stream, q);
+    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256 * ng), lds_all + pad, stream, q);
     SBC_CHECK_HIP(hipGetLastError());
     return SBC_OK;
 }

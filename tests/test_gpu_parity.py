@@ -403,7 +403,9 @@ def test_cli_tuner_matches_reference_pipeline(net64, tmp_path, monkeypatch):
 
 def test_concurrent_sub_batch_streams_do_not_change_results(net64):
     """``run_trajectories(n_streams=2)``: two sub-batches on their own HIP streams, one host thread each
-    (driver.run_concurrently).  Per-trajectory noise keys and per-sample normalisation make the split invisible."""
+    (driver.run_concurrently).  Per-trajectory noise keys and per-sample normalisation make the split invisible -- and so
+    must the hardware: with packed-fp32 instructions in the build, concurrently running kernels of different kinds corrupted
+    each other's results here in 8 of 12 runs (csrc/Makefile)."""
     import torch
     from score_based_channels_amd import synth
     from score_based_channels_amd.ald import snr_to_noise
@@ -416,10 +418,11 @@ def test_concurrent_sub_batch_streams_do_not_change_results(net64):
     idx = np.tile(np.arange(nch), len(snr))
     ln = np.repeat(snr_to_noise(snr, nt), nch)
     init = torch.randn(nch, nt, nr, dtype=torch.complex64, generator=torch.Generator().manual_seed(7))
+    modes = [(1, False)] + [(2 + k % 2, bool(k & 2)) for k in range(8)]       # repeated: the hazard this guards is sporadic
     out = [run_trajectories(net64, H, Pm, idx, idx, ln, 3e-11, 0.01, [0, 1155, 2310], 3, 11, init, n_streams=n,
-                            use_graph=g, return_final=True) for n, g in ((1, False), (2, False), (3, True))]
-    for log, est in out[1:]:
-        assert np.array_equal(log, out[0][0]) and np.array_equal(est, out[0][1])
+                            use_graph=g, return_final=True) for n, g in modes]
+    for (n, g), (log, est) in zip(modes[1:], out[1:]):
+        assert np.array_equal(log, out[0][0]) and np.array_equal(est, out[0][1]), (n, g)
 
 
 @pytest.mark.parametrize('nt,nr', [(16, 64), (32, 32), (128, 8)])
