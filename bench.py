@@ -369,7 +369,7 @@ def main():
                                             'vs_fp32_mfma_peak': ach / PEAK_F32_MFMA_TFLOPS},
                       'hbm': {'algorithmic_bytes_per_launch': alg_bytes, 'algorithmic_TBps': alg_bytes / t_k / 1e12,
                               'frac_of_8TBps': alg_bytes / t_k / 1e12 / PEAK_HBM_TBS},
-                      'kernel': 'conv_wx3_kernel<32, 32, 1, true, 4, true, 1, 1, false>: the 18 3x3 32->32 convolutions at '
+                      'kernel': 'conv_wx3_kernel<32, 32, 1, true, 3, true, 1, 1, false>: the 18 3x3 32->32 convolutions at '
                                 '%dx%d of every step (%d tagged launches, avg %.1f us, hipEvents on the launch stream over %s).  '
                                 'achieved = direct-convolution FLOPs (2*9*32*32 per pixel) / time; peak = dense bf16 MFMA peak '
                                 '%.1f x 36/16 / 6: the kernel executes 16/36 of the products (Winograd F(2x2,3x3)), each as six '
@@ -381,7 +381,7 @@ def main():
                       'frac': alg_bytes / t_k / 1e12 / PEAK_HBM_TBS, 'traffic': traffic,
                       'mfma': {'algorithmic_tflops': ach, 'executed_mfma_tflops': ach * 16.0 / 36.0,
                                'frac_of_f16_peak': ach * 16.0 / 36.0 / PEAK_BF16_MFMA_TFLOPS},
-                      'kernel': 'conv_wx3_kernel<32, 32, 1, true, 4, true, 1, 1, true>: the 18 3x3 32->32 convolutions at '
+                      'kernel': 'conv_wx3_kernel<32, 32, 1, true, 3, true, 1, 1, true>: the 18 3x3 32->32 convolutions at '
                                 '%dx%d of every step (%d tagged launches, avg %.1f us, hipEvents over %s).  achieved = '
                                 'algorithmic bytes (fp32 input + residual + output = 3 x pixels x 32 x 4 B) / time against '
                                 'the 8 TB/s HBM3E peak (6.3 TB/s achievable); Winograd F(2x2,3x3) with one fp16 MFMA per '

@@ -7,7 +7,7 @@ TAG = sys.argv[2] if len(sys.argv) > 2 else 'r02'
 R = os.path.join(ROOT, 'gpurun_out', 'profile_passes_' + W) + '/'
 P = os.path.join(ROOT, 'profiles') + '/'
 BIG = W == 'big'
-DOMINANT = 'conv_wx3_kernel<32, 32, 1, true, 4, true, 1, 1, %s>' % ('true' if BIG else 'false')
+DOMINANT = 'conv_wx3_kernel<32, 32, 1, true, 3, true, 1, 1, %s>' % ('true' if BIG else 'false')
 PX = (256 * 64) if BIG else (64 * 16)
 CMD = '--workload %s --no-cpu-baseline --no-strong --no-other-mode --sustained 0' % W
 DESC = ('conv_mode f16w, one stream, T=1024 (256x64 arrays)' if BIG else 'conv_mode bf16x3, one stream, T=1700')
