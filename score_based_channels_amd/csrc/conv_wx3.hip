@@ -370,12 +370,11 @@ static int launch_wx3(const ConvParams& p, hipStream_t stream, bool dry) {
     auto kern = ng == 2 ? conv_wx3_kernel<CIN, COUT, MB, true, 2, false, (NBLK == 4 ? 2 : 1), NGMAX, F16>
               : top     ? conv_wx3_kernel<CIN, COUT, MB, true, WPE, (CIN == 32 && COUT == 32), NBP_BIG, 1, F16>
                         : conv_wx3_kernel<CIN, COUT, MB, true, WPE, false, NBP_BIG, 1, F16>;
-    static const size_t pad = getenv("SBC_LDS_PAD") ? atoi(getenv("SBC_LDS_PAD")) : 0;   // debugging aid
-    { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds_all + pad); if (rc) return rc; }
+    { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds_all); if (rc) return rc; }
     if (dry) return SBC_OK;
     ConvParams q = p;
     q.stats_off = (int)stats_off;
-    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256 * ng), lds_all + pad, stream, q);
+    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256 * ng), lds_all, stream, q);
     SBC_CHECK_HIP(hipGetLastError());
     return SBC_OK;
 }

@@ -236,11 +236,10 @@ static int launch_kernel(ConvParams p, hipStream_t stream, bool dry) {
     const size_t lds = x3_lds_bytes<CIN, COUT, KS, MT, NT, WM, WN, TERMS>(p, &p.plane);
     SBC_REQUIRE(lds <= 160 * 1024, "conv tile needs %zu bytes of LDS (> 160 KiB)", lds);
     auto kern = conv_x3_kernel<CIN, COUT, KS, MT, NT, WM, WN, P2, TERMS>;
-    static const size_t pad = getenv("SBC_LDS_PAD") ? atoi(getenv("SBC_LDS_PAD")) : 0;   // debugging aid
-    { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds + pad); if (rc) return rc; }
+    { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds); if (rc) return rc; }
     if (dry) return SBC_OK;
     const int grid = (p.total_px + TM - 1) / TM;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), lds + pad, stream, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), lds, stream, p);
     SBC_CHECK_HIP(hipGetLastError());
     return SBC_OK;
 }

@@ -73,6 +73,9 @@ def parse_args(argv=None):
                    help='[added] in-kernel Philox noise, or the keyed host streams of noise.HostNoise (parity runs)')
     p.add_argument('--no_graph', action='store_true', help='[added] eager launches instead of hipGraph replay')
     p.add_argument('--graph', action='store_true', help='[added] replay each Langevin step as a hipGraph (default: driver.DEFAULT_USE_GRAPH)')
+    p.add_argument('--streams', type=int, default=1,
+                   help='[added] run each lock-step batch as this many concurrent sub-batches on their own HIP streams '
+                        '(bit-identical results; +7 %% at 2 on MI355X for 1700 trajectories)')
     p.add_argument('--result_dir', type=str, default=None, help='[added] default TWC_rebuttal_MMSE_aug6_seed4321')
     return p.parse_args(argv)
 
@@ -92,7 +95,8 @@ def start_points(kind, P_herm, Y, n_chains, nt, nr, seed, key):
 
 
 def posterior_chains(diffuser, val_H, val_P, local_noise, step, noise_boost, n_run, levels, steps_each, navg,
-                     start_point='Noise', seed=0, key=0, dc_boost=1.0, use_graph=True, rank=0, world=1, host_noise=None):
+                     start_point='Noise', seed=0, key=0, dc_boost=1.0, use_graph=True, rank=0, world=1, host_noise=None,
+                     n_streams=1):
     """All chains of ONE SNR point (test_mmse.py:170-262): one measurement per kept sample shared by its ``navg`` chains
     (:176-193), start points (:196-203), ``n_run`` Langevin steps with that SNR's (step, noise) pair and ``dc_boost``
     (:216-233), early stop (:246-250).  ``val_H`` ``[kept, Nt, Nr]``, ``val_P`` ``[kept, Np, Nt]`` complex64 numpy.
@@ -122,7 +126,7 @@ def posterior_chains(diffuser, val_H, val_P, local_noise, step, noise_boost, n_r
         diffuser, val_H, val_P, h_index, h_index, local_noise, step, noise_boost, levels, steps_each, seed,
         init, traj_base=base + kept, max_batch=8192, use_graph=use_graph, rank=rank, world=world, return_final=True,
         n_steps=n_run, dc_boost=float(dc_boost), init_index=np.arange(kept * navg), Y=Y, y_index=h_index,
-        step_noise=step_noise)
+        step_noise=step_noise, n_streams=n_streams)
     return Y, log.reshape(n_run, kept, navg), est.reshape(kept, navg, nt, nr)
 
 
@@ -214,7 +218,7 @@ def main(argv=None):
             host = HostNoise(seed, combo=1 + key) if args.noise == 'host' else None
             _, log, est = posterior_chains(diffuser, val_H, val_P, local_noise, step, noise_boost, n_run, levels,
                                            steps_each, navg, args.start_point, seed, key, args.dc_boost,
-                                           resolve_launch_mode(args), rank, world, host)
+                                           resolve_launch_mode(args), rank, world, host, args.streams)
             oracle_log[spacing_idx, pilot_alpha_idx, snr_idx, :n_run] = log
             saved_H[spacing_idx, pilot_alpha_idx, snr_idx] = est
             if rank == 0:

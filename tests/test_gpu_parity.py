@@ -305,6 +305,8 @@ def test_cli_test_score_drop_in_outputs(net64, tmp_path, monkeypatch):
     assert np.isfinite(res['saved_H'].view(np.float32)).all()
     # low SNR must not beat high SNR after the same number of steps on the same channels (sanity of per-SNR scalars)
     assert not np.array_equal(nmse_log[0, 0, 0], nmse_log[0, 0, -1])
+    split, _, _ = test_score.main(argv + ['--streams', '2'])                        # ... or as two concurrent sub-batches
+    assert np.array_equal(split, nmse_log)
 
 
 def test_cli_tune_hparams_drop_in_outputs(net64, tmp_path, monkeypatch):
@@ -344,6 +346,8 @@ def test_cli_test_mmse_posterior_mean(net64, tmp_path, monkeypatch):
     assert not np.allclose(saved[0, 0, 0, 0, 0], saved[0, 0, 0, 0, 1])                # chains differ (own start + noise)
     adj, _, _ = test_mmse.main(argv + ['--start_point', 'Adjoint', '--no_graph'])
     assert np.isfinite(adj).all() and not np.array_equal(adj, log)
+    split, saved2, _ = test_mmse.main(argv + ['--streams', '2'])
+    assert np.array_equal(split, log) and np.array_equal(saved2, saved)
 
 
 @pytest.mark.parametrize('start', ['Noise', 'Adjoint'])
@@ -392,13 +396,15 @@ def test_cli_tuner_matches_reference_pipeline(net64, tmp_path, monkeypatch):
     from score_based_channels_amd import tune_hparams_score
     g = load_golden('cli_tune_grid.npz')
     monkeypatch.chdir(tmp_path)
-    nmse_log, ba, bb = tune_hparams_score.main(
-        ['--synthetic', '--synthetic_weights', '2024', '--num_levels', '1', '--num_channels', '3', '--seed', str(int(g['seed'])),
-         '--no_plot', '--noise', 'host', '--conv_mode', net64.conv_mode,
-         '--alpha_step_range'] + [repr(float(a)) for a in g['alpha_step_range']] +
-        ['--beta_noise_range'] + [repr(float(b)) for b in g['beta_noise_range']])
+    argv = (['--synthetic', '--synthetic_weights', '2024', '--num_levels', '1', '--num_channels', '3',
+             '--seed', str(int(g['seed'])), '--no_plot', '--noise', 'host', '--conv_mode', net64.conv_mode,
+             '--alpha_step_range'] + [repr(float(a)) for a in g['alpha_step_range']] +
+            ['--beta_noise_range'] + [repr(float(b)) for b in g['beta_noise_range']])
+    nmse_log, ba, bb = tune_hparams_score.main(argv)
     assert nmse_log.shape == (2, 2, 17, 3, 3)
     assert np.max(np.abs(nmse_log / g['nmse_log'] - 1)) < NMSE_RTOL
+    split, _, _ = tune_hparams_score.main(argv + ['--streams', '2'])
+    assert np.array_equal(split, nmse_log)
 
 
 def test_concurrent_sub_batch_streams_do_not_change_results(net64):
