@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SBC_ABI_VERSION 6
+#define SBC_ABI_VERSION 7
 
 typedef enum sbc_status {
     SBC_OK = 0,
@@ -52,7 +52,21 @@ typedef enum sbc_op_kind {
     SBC_OP_END_CONV = 5,     /* normalizer -> ELU -> end_conv ngf->2 -> / sigma   ncsnv2.py:291-298           */
     SBC_OP_LANGEVIN = 6,     /* P^H(PX-Y), noise, Langevin update, NMSE           test_score.py:156-170       */
     SBC_OP_STEP_INC = 7,     /* advance the device-side step counter (trailing_idx, test_score.py:171)        */
-    SBC_OP_MEASURE = 8       /* Y = P H + sqrt(noise) n                           test_score.py:122-124       */
+    SBC_OP_MEASURE = 8,      /* Y = P H + sqrt(noise) n                           test_score.py:122-124       */
+    /* --- denoising-score-matching training step: ncsnv2/losses/dsm.py:6-32,
+     *     train_score.py:145-173.  Reverse-mode counterparts of the operators above; see "Training operators". */
+    SBC_OP_DSM_PERTURB = 9,  /* x~ = x + sigma_b z, z ~ N(0,1)                    dsm.py:14-17                */
+    SBC_OP_DSM_LOSS = 10,    /* 1/2 |s + z/sigma|^2 sigma^p per sample (+ d/ds)   dsm.py:19-32                */
+    SBC_OP_GRAD_ADD = 11,    /* out (+)= grad [* ELU'(in)]                        backward of +, of nn.ELU    */
+    SBC_OP_INORM_BWD = 12,   /* backward of InstanceNorm2dPlus (+ ELU)            normalization.py:163-176    */
+    SBC_OP_MAXPOOL5_BWD = 13,/* backward of nn.MaxPool2d(5,1,2) (+ ELU of input)  layers.py:69,77-80          */
+    SBC_OP_UPSAMPLE_BWD = 14,/* adjoint of the bilinear(align_corners) resize     layers.py:182               */
+    SBC_OP_POOL_BWD = 15,    /* adjoint of the 2x2 mean pool of ConvMeanPool      layers.py:311-312           */
+    SBC_OP_CONV_WGRAD = 16,  /* d loss / d weight, d bias of an SBC_OP_CONV       layers.py:28-60             */
+    SBC_OP_PACK_WEIGHT = 17, /* torch-layout weight (device) -> split-bf16 fragments, optionally of the adjoint conv */
+    SBC_OP_END_CONV_BWD = 18,/* backward of SBC_OP_END_CONV up to the ELU output  ncsnv2.py:291-298           */
+    SBC_OP_BEGIN_CONV_BWD = 19, /* weight / bias gradient of SBC_OP_BEGIN_CONV    ncsnv2.py:270-275           */
+    SBC_OP_ADAM_EMA = 20     /* torch.optim.Adam step + EMAHelper.update          losses/__init__.py:3-7, ema.py:17-22 */
 } sbc_op_kind;
 
 /* sbc_op.flags for SBC_OP_CONV / SBC_OP_MAXPOOL5 */
@@ -61,6 +75,10 @@ typedef enum sbc_op_kind {
 #define SBC_EPI_RES1_ELU 0x010  /* ELU the res1 operand before adding (CRP: x = act(x))                    */
 #define SBC_EPI_POOL     0x020  /* 2x2 mean pool of (conv + bias), then + res1 (ConvMeanPool)               */
 #define SBC_EPI_UP       0x040  /* + bilinear(align_corners) resize of `up` [B][up_h][up_w][cout] (MSF)     */
+#define SBC_BWD_ACCUM     0x200  /* training operators: add to `out` instead of overwriting it (a tensor with several
+                                   consumers collects one gradient term per consumer)                            */
+#define SBC_PACK_ADJOINT  0x400  /* SBC_OP_PACK_WEIGHT: pack w'[ci][co][kh][kw] = w[co][ci][k-1-kh][k-1-kw], the weight of
+                                   the adjoint (input-gradient) convolution, which then runs as an ordinary SBC_OP_CONV */
 #define SBC_CONV_F16W    0x100  /* fp16 weights (BASELINE config 5): `weight_split` / `weight_wino_split` hold ONE
                                    fp16 term per weight (sbc_pack_conv_weight_f16 / _winograd_f16) instead of
                                    three bf16 terms; activations are rounded to fp16 as they enter the matrix
@@ -112,7 +130,59 @@ typedef struct sbc_op {
                                     (uint16): Winograd F(2x2,3x3) with its 16 products on the bf16 matrix cores
                                     (csrc/conv_wx3.hip).  Used for undilated 3x3 convolutions on power-of-two images,
                                     ahead of `weight_split`. */
+    /* --- training operators only (ABI 7; NULL / unused on the inference path) --- */
+    const void* grad;            /* incoming gradient: d loss / d (this operator's forward output) */
+    void* aux;                   /* kind-specific second output or scratch (see "Training operators") */
+    void* wgrad;                 /* parameter-gradient output: conv weight in torch layout, or alpha|gamma|beta [3][cin] */
+    void* bgrad;                 /* bias-gradient output [cout] or NULL */
 } sbc_op;
+
+/* Training operators.  The reverse of a forward record `y = epi(conv(pro(x)))` is built by the host
+ * (score_based_channels_amd/train.py) from these pieces; every tensor is NHWC float32 like its forward counterpart, `grad`
+ * always has the shape of the forward OUTPUT of the operator being reversed, `out` the shape of its forward INPUT.
+ *   DSM_PERTURB   in = samples [B][n] (n = H*W*cin), ext = sbc_dsm; out = samples + sigmas[labels[b]] * z;
+ *                 aux = the scaled noise sigma_b * z [B][n] (kept for the loss).  z = ext.noise (standard normal draws,
+ *                 replay) or in-kernel Philox keyed by (seed, sample_id[b] or b, offset, element).
+ *   DSM_LOSS      in = scores [B][n], grad = scaled noise [B][n], ext = sbc_dsm; out = per-sample loss [B]:
+ *                 1/2 * sum_n (s - t)^2 * sigma^p with t = -1/sigma^2 * noise (dsm.py:20-30; the batch mean of :32 is the
+ *                 caller's); aux (optional) = d mean-loss / d scores = (s - t) * sigma^p / B.
+ *   GRAD_ADD      out (+)= grad, or grad * ELU'(in) with SBC_PRO_ELU (in = the tensor the forward ELU was applied to).
+ *   INORM_BWD     reverse of stats -> affine -> ELU: in = x, stats [B][3][cin] (forward), weight = alpha|gamma|beta,
+ *                 grad = d / d ELU-output (or d / d norm-output without SBC_PRO_ELU); out (+)= d / d x through the
+ *                 normalised value, the spatial mean / variance and the cross-channel mean term; wgrad = d alpha|gamma|beta
+ *                 [3][cin] summed over the batch (written); aux = scratch, >= B*6*cin floats.
+ *   MAXPOOL5_BWD  in = forward input, grad = d / d output; out (+)= the gradient routed to each window's first maximum in
+ *                 row-major order (times ELU'(in) with SBC_PRO_ELU); aux = scratch, >= B*H*W*cin bytes.
+ *   UPSAMPLE_BWD  grad = [B][H][W][cin]; out (+)= [B][up_h][up_w][cin], the transpose of the resize of SBC_EPI_UP.
+ *   POOL_BWD      grad = [B][H/2][W/2][cin]; out = [B][H][W][cin] = grad[h/2][w/2] / 4.
+ *   CONV_WGRAD    in/stats/flags(PRO_*)/ksize/dil as in the forward CONV, grad = d / d (conv + bias) [B][H][W][cout];
+ *                 wgrad = [cout][cin][k][k] (torch layout, written), bgrad = [cout] or NULL; aux = scratch (float),
+ *                 >= sbc_wgrad_scratch_floats(B, H, W, cin, cout, ksize).
+ *   PACK_WEIGHT   in = [cout][cin][k][k] float32 DEVICE, out = the sbc_pack_conv_weight_split layout (of the adjoint
+ *                 convolution cout -> cin with SBC_PACK_ADJOINT).
+ *   END_CONV_BWD  in/stats/weight/ext as in END_CONV, grad = d / d score [B][H][W][2]; out = d / d ELU-output
+ *                 [B][H][W][cin] (written); wgrad [2][cin][3][3], bgrad [2]; aux = scratch >= sbc_wgrad_scratch_floats.
+ *   BEGIN_CONV_BWD in = x [B][H][W][2], grad = d / d output [B][H][W][cout]; wgrad [cout][2][3][3], bgrad [cout]; aux.
+ *   ADAM_EMA      ext = sbc_adam; in = gradients [n], out = parameters [n] (updated in place), aux = state [3][n]:
+ *                 exp_avg | exp_avg_sq | EMA shadow.
+ */
+typedef struct sbc_dsm {
+    const float* sigmas;         /* [num_classes] device */
+    const int64_t* labels;       /* [B] device: noise level of each sample (dsm.py:9-12) */
+    const float* noise;          /* [B][n] device standard-normal draws to replay, or NULL -> Philox */
+    const int64_t* sample_id;    /* [B] device Philox stream ids or NULL (= b) */
+    uint64_t seed;
+    int32_t offset;              /* Philox counter word 1: the optimiser step */
+    float anneal_power;          /* dsm.py:7 (2 in train_score.py:55) */
+} sbc_dsm;
+
+typedef struct sbc_adam {
+    int64_t n;                   /* elements */
+    double lr, beta1, beta2, eps; /* torch.optim.Adam(lr, betas, eps), weight_decay = 0, amsgrad = False.  double: torch
+                                    forms 1 - beta and the bias corrections from python floats before rounding to fp32 */
+    double ema_mu;               /* EMAHelper(mu): shadow = (1 - mu) * p + mu * shadow; < 0 disables the shadow update */
+    const int32_t* step;         /* device counter: number of optimiser steps already taken (t - 1) */
+} sbc_adam;
 
 /* Extension of SBC_OP_END_CONV: where the noise level comes from (ncsnv2.py:295-298). */
 typedef struct sbc_endconv {
@@ -238,6 +308,9 @@ void sbc_score_destroy(sbc_score* score);
  * Winograd form rounds U = G g G^T (double) once to fp16. */
 int sbc_pack_conv_weight_f16(const float* src, int32_t cout, int32_t cin, int32_t ksize, uint16_t* dst);
 int sbc_pack_conv_weight_winograd_f16(const float* src, int32_t cout, int32_t cin, uint16_t* dst);
+
+/* scratch floats SBC_OP_CONV_WGRAD / END_CONV_BWD / BEGIN_CONV_BWD need in `aux` for this shape */
+int64_t sbc_wgrad_scratch_floats(int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t ksize);
 
 #ifdef __cplusplus
 }

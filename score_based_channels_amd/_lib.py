@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SBC_LIB_PATH') or os.path.join(_HERE, 'libsbc_hip.so')   # env override: A/B builds (tools/)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 EXPORTS = ('sbc_abi_version', 'sbc_last_error', 'sbc_device_count', 'sbc_op_launch', 'sbc_plan_create',
            'sbc_plan_run', 'sbc_plan_destroy', 'sbc_plan_profile', 'sbc_plan_profile_read',
@@ -16,7 +16,7 @@ EXPORTS = ('sbc_abi_version', 'sbc_last_error', 'sbc_device_count', 'sbc_op_laun
            'sbc_pack_conv_weight_split', 'sbc_pack_conv_weight_winograd_split',
            'sbc_pack_conv_weight_f16', 'sbc_pack_conv_weight_winograd_f16',
            'sbc_score_create', 'sbc_score_buffers', 'sbc_score_ops', 'sbc_score_level_source', 'sbc_score_forward',
-           'sbc_score_destroy')
+           'sbc_score_destroy', 'sbc_wgrad_scratch_floats')
 
 
 class SbcError(RuntimeError):
@@ -31,7 +31,9 @@ class sbc_op(C.Structure):
                 ('in_', C.c_void_p), ('out', C.c_void_p), ('weight', C.c_void_p), ('bias', C.c_void_p),
                 ('stats', C.c_void_p), ('res1', C.c_void_p), ('res2', C.c_void_p), ('up', C.c_void_p),
                 ('ext', C.c_void_p), ('weight_wino', C.c_void_p), ('weight_split', C.c_void_p),
-                ('weight_wino_split', C.c_void_p)]
+                ('weight_wino_split', C.c_void_p),
+                # training operators (ABI 7)
+                ('grad', C.c_void_p), ('aux', C.c_void_p), ('wgrad', C.c_void_p), ('bgrad', C.c_void_p)]
 
 
 class sbc_endconv(C.Structure):
@@ -45,6 +47,16 @@ class sbc_langevin(C.Structure):
                 ('group', C.c_void_p), ('noise', C.c_void_p), ('nmse', C.c_void_p), ('step', C.c_void_p),
                 ('traj_id', C.c_void_p), ('meas_scale', C.c_void_p), ('seed', C.c_uint64),
                 ('n_steps', C.c_int32), ('Nt', C.c_int32), ('Nr', C.c_int32), ('Np', C.c_int32)]
+
+
+class sbc_dsm(C.Structure):
+    _fields_ = [('sigmas', C.c_void_p), ('labels', C.c_void_p), ('noise', C.c_void_p), ('sample_id', C.c_void_p),
+                ('seed', C.c_uint64), ('offset', C.c_int32), ('anneal_power', C.c_float)]
+
+
+class sbc_adam(C.Structure):
+    _fields_ = [('n', C.c_int64), ('lr', C.c_double), ('beta1', C.c_double), ('beta2', C.c_double), ('eps', C.c_double),
+                ('ema_mu', C.c_double), ('step', C.c_void_p)]
 
 
 class sbc_tensor_ref(C.Structure):
@@ -91,6 +103,8 @@ def lib():
     h.sbc_score_forward.argtypes = [C.c_void_p, C.c_void_p]
     h.sbc_score_destroy.argtypes = [C.c_void_p]
     h.sbc_score_destroy.restype = None
+    h.sbc_wgrad_scratch_floats.argtypes = [C.c_int32] * 6
+    h.sbc_wgrad_scratch_floats.restype = C.c_int64
     if h.sbc_abi_version() != ABI_VERSION:
         raise SbcError('libsbc_hip.so ABI %d != expected %d' % (h.sbc_abi_version(), ABI_VERSION))
     _lib = h

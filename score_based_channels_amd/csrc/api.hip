@@ -33,14 +33,47 @@ int ensure_dyn_lds(const void* kernel, size_t bytes) {
     return SBC_OK;
 }
 
-struct PlanOp {
-    sbc_op op;
-    sbc_langevin lang;     // valid for LANGEVIN / MEASURE
-    sbc_endconv endc;      // valid for END_CONV
+// kind-specific extension structs, copied at plan creation (sbc_op.ext is host memory the caller may free)
+union OpExt {
+    sbc_langevin lang;     // LANGEVIN / MEASURE
+    sbc_endconv endc;      // END_CONV / END_CONV_BWD
+    sbc_dsm dsm;           // DSM_PERTURB / DSM_LOSS
+    sbc_adam adam;         // ADAM_EMA
 };
 
-static int dispatch(const sbc_op& op, const sbc_langevin* lang, const sbc_endconv* endc, hipStream_t s) {
+struct PlanOp {
+    sbc_op op;
+    OpExt ext;
+};
+
+// size of the extension struct an op kind carries (0 = none)
+static size_t ext_size(int kind) {
+    switch (kind) {
+        case SBC_OP_LANGEVIN: case SBC_OP_MEASURE: return sizeof(sbc_langevin);
+        case SBC_OP_END_CONV: case SBC_OP_END_CONV_BWD: return sizeof(sbc_endconv);
+        case SBC_OP_DSM_PERTURB: case SBC_OP_DSM_LOSS: return sizeof(sbc_dsm);
+        case SBC_OP_ADAM_EMA: return sizeof(sbc_adam);
+        default: return 0;
+    }
+}
+
+static int dispatch(const sbc_op& op, const void* ext, hipStream_t s) {
+    const sbc_langevin* lang = (const sbc_langevin*)ext;
+    const sbc_endconv* endc = (const sbc_endconv*)ext;
+    SBC_REQUIRE(ext || ext_size(op.kind) == 0, "op kind %d: ext must be set", op.kind);
     switch (op.kind) {
+        case SBC_OP_DSM_PERTURB: return launch_dsm_perturb(op, *(const sbc_dsm*)ext, s);
+        case SBC_OP_DSM_LOSS: return launch_dsm_loss(op, *(const sbc_dsm*)ext, s);
+        case SBC_OP_GRAD_ADD: return launch_grad_add(op, s);
+        case SBC_OP_INORM_BWD: return launch_inorm_bwd(op, s);
+        case SBC_OP_MAXPOOL5_BWD: return launch_maxpool5_bwd(op, s);
+        case SBC_OP_UPSAMPLE_BWD: return launch_upsample_bwd(op, s);
+        case SBC_OP_POOL_BWD: return launch_pool_bwd(op, s);
+        case SBC_OP_CONV_WGRAD: return launch_conv_wgrad(op, s);
+        case SBC_OP_PACK_WEIGHT: return launch_pack_weight(op, s);
+        case SBC_OP_END_CONV_BWD: return launch_end_conv_bwd(op, *endc, s);
+        case SBC_OP_BEGIN_CONV_BWD: return launch_begin_conv_bwd(op, s);
+        case SBC_OP_ADAM_EMA: return launch_adam_ema(op, *(const sbc_adam*)ext, s);
         case SBC_OP_BEGIN_CONV: return launch_begin_conv(op, s);
         case SBC_OP_INORM_STATS: return launch_inorm_stats(op, s);
         case SBC_OP_CONV: return launch_conv(op, s);
@@ -106,7 +139,7 @@ static int run_eager(sbc_plan* plan, hipStream_t s) {
             }
             SBC_CHECK_HIP(hipEventRecord(plan->ev_pool[plan->ev_used], s));
         }
-        const int rc = dispatch(po.op, &po.lang, &po.endc, s);
+        const int rc = dispatch(po.op, ext_size(po.op.kind) ? &po.ext : nullptr, s);
         if (rc) return rc;
         if (timed) {
             SBC_CHECK_HIP(hipEventRecord(plan->ev_pool[plan->ev_used + 1], s));
@@ -130,7 +163,7 @@ int sbc_device_count(void) {
 
 int sbc_op_launch(const sbc_op* op, void* stream) {
     SBC_REQUIRE(op, "sbc_op_launch: op is NULL");
-    return dispatch(*op, (const sbc_langevin*)op->ext, (const sbc_endconv*)op->ext, (hipStream_t)stream);
+    return dispatch(*op, op->ext, (hipStream_t)stream);
 }
 
 int sbc_plan_create(const sbc_op* ops, int32_t n_ops, sbc_plan** out_plan) {
@@ -140,21 +173,17 @@ int sbc_plan_create(const sbc_op* ops, int32_t n_ops, sbc_plan** out_plan) {
     for (int i = 0; i < n_ops; ++i) {
         PlanOp& po = plan->ops[i];
         po.op = ops[i];
-        memset(&po.lang, 0, sizeof(po.lang));
-        memset(&po.endc, 0, sizeof(po.endc));
-        if (ops[i].kind == SBC_OP_LANGEVIN || ops[i].kind == SBC_OP_MEASURE) {
-            if (!ops[i].ext) { delete plan; set_error("op %d: ext (sbc_langevin) is NULL", i); return SBC_ERR_INVALID; }
-            po.lang = *(const sbc_langevin*)ops[i].ext;
-        } else if (ops[i].kind == SBC_OP_END_CONV) {
-            if (!ops[i].ext) { delete plan; set_error("op %d: ext (sbc_endconv) is NULL", i); return SBC_ERR_INVALID; }
-            po.endc = *(const sbc_endconv*)ops[i].ext;
+        memset(&po.ext, 0, sizeof(po.ext));
+        if (const size_t es = ext_size(ops[i].kind)) {
+            if (!ops[i].ext) { delete plan; set_error("op %d (kind %d): ext is NULL", i, ops[i].kind); return SBC_ERR_INVALID; }
+            memcpy(&po.ext, ops[i].ext, es);
         }
         po.op.ext = nullptr;
         // resolve kernel variants / set function attributes now, so a later hipGraph capture sees launches only
         int rc = SBC_OK;
         if (po.op.kind == SBC_OP_CONV) rc = launch_conv(po.op, nullptr, true);
-        else if (po.op.kind == SBC_OP_END_CONV) rc = launch_end_conv(po.op, po.endc, nullptr, true);
-        else if (po.op.kind == SBC_OP_LANGEVIN) rc = launch_langevin(po.op, po.lang, nullptr, true);
+        else if (po.op.kind == SBC_OP_END_CONV) rc = launch_end_conv(po.op, po.ext.endc, nullptr, true);
+        else if (po.op.kind == SBC_OP_LANGEVIN) rc = launch_langevin(po.op, po.ext.lang, nullptr, true);
         if (rc) { delete plan; return rc; }
     }
     *out_plan = plan;

@@ -43,6 +43,19 @@ int launch_end_conv(const sbc_op& op, const sbc_endconv& ext, hipStream_t stream
 int launch_langevin(const sbc_op& op, const sbc_langevin& ext, hipStream_t stream, bool dry = false);
 int launch_measure(const sbc_op& op, const sbc_langevin& ext, hipStream_t stream);
 int launch_step_inc(const sbc_op& op, hipStream_t stream);
+// training operators (train.hip, train_conv.hip)
+int launch_dsm_perturb(const sbc_op& op, const sbc_dsm& ext, hipStream_t stream);
+int launch_dsm_loss(const sbc_op& op, const sbc_dsm& ext, hipStream_t stream);
+int launch_grad_add(const sbc_op& op, hipStream_t stream);
+int launch_inorm_bwd(const sbc_op& op, hipStream_t stream);
+int launch_maxpool5_bwd(const sbc_op& op, hipStream_t stream);
+int launch_upsample_bwd(const sbc_op& op, hipStream_t stream);
+int launch_pool_bwd(const sbc_op& op, hipStream_t stream);
+int launch_conv_wgrad(const sbc_op& op, hipStream_t stream);
+int launch_pack_weight(const sbc_op& op, hipStream_t stream);
+int launch_end_conv_bwd(const sbc_op& op, const sbc_endconv& ext, hipStream_t stream);
+int launch_begin_conv_bwd(const sbc_op& op, hipStream_t stream);
+int launch_adam_ema(const sbc_op& op, const sbc_adam& ext, hipStream_t stream);
 
 #if defined(__HIPCC__)
 // nn.ELU(alpha=1): x > 0 ? x : exp(x) - 1   (ncsnv2/models/layers.py:12-13).  Written the way PyTorch's own ELU

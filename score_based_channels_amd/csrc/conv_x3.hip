@@ -301,6 +301,7 @@ int launch_conv_x3(const ConvParams& p, int cin, int cout, int ksize, hipStream_
         case 64 * 100000 + 64 * 100 + 3: return launch_sized<64, 64, 3>(p, stream, dry);
         case 64 * 100000 + 64 * 100 + 1: return launch_sized<64, 64, 1>(p, stream, dry);
         case 64 * 100000 + 32 * 100 + 3: return launch_sized<64, 32, 3>(p, stream, dry);
+        case 64 * 100000 + 32 * 100 + 1: return launch_sized<64, 32, 1>(p, stream, dry);     // adjoint of the 32 -> 64 shortcut
         case 64 * 100000 + 128 * 100 + 3: return launch_sized<64, 128, 3>(p, stream, dry);
         case 128 * 100000 + 128 * 100 + 3: return launch_sized<128, 128, 3>(p, stream, dry);
         case 128 * 100000 + 64 * 100 + 3: return launch_sized<128, 64, 3>(p, stream, dry);

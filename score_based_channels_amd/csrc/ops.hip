@@ -2,6 +2,7 @@
 // vector ALU, InstanceNorm++ statistics, 5x5 max pooling, and the fused data-consistency gradient + Langevin
 // update + NMSE kernel.  All activations NHWC float32; complex tensors are interleaved (re, im) pairs.
 #include "tile.h"
+#include "philox.h"
 
 namespace sbc {
 
@@ -392,18 +393,6 @@ __device__ __forceinline__ float2 cfma_conj(float2 a, float2 b, float2 c) {  // 
     return make_float2(fmaf(a.x, b.x, fmaf(a.y, b.y, c.x)), fmaf(a.x, b.y, fmaf(-a.y, b.x, c.y)));
 }
 
-// Philox4x32-10 (Salmon et al. 2011), counter (c0..c3), key (k0, k1)
-__device__ __forceinline__ uint4 philox4x32(uint4 c, uint2 k) {
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
-        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
-        k.x += 0x9E3779B9u;
-        k.y += 0xBB67AE85u;
-    }
-    return c;
-}
 // one CN(0,1) sample (re, im each N(0, 1/2)) per (trajectory, step, element): Box-Muller on two uniforms
 __device__ __forceinline__ float2 complex_normal(uint64_t seed, int64_t traj, int step, int elem) {
     const uint4 r = philox4x32(make_uint4((uint32_t)elem, (uint32_t)step, (uint32_t)traj, (uint32_t)((uint64_t)traj >> 32)),
