@@ -172,8 +172,9 @@ typedef struct sbc_dsm {
     const float* noise;          /* [B][n] device standard-normal draws to replay, or NULL -> Philox */
     const int64_t* sample_id;    /* [B] device Philox stream ids or NULL (= b) */
     uint64_t seed;
-    int32_t offset;              /* Philox counter word 1: the optimiser step */
+    int32_t offset;              /* Philox counter word 1 (the optimiser step) = offset + *step */
     float anneal_power;          /* dsm.py:7 (2 in train_score.py:55) */
+    const int32_t* step;         /* device step counter or NULL (= 0): lets a replayed plan draw fresh noise every step */
 } sbc_dsm;
 
 typedef struct sbc_adam {

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void dsm_perturb_kernel(const float* __restric
     const float sigma = e.sigmas[e.labels[b]];
     float2 z;
     if (e.noise) z = *reinterpret_cast<const float2*>(e.noise + (size_t)b * n + 2 * k);
-    else z = normal_pair(e.seed, e.sample_id ? e.sample_id[b] : b, e.offset, k);
+    else z = normal_pair(e.seed, e.sample_id ? e.sample_id[b] : b, e.offset + (e.step ? *e.step : 0), k);
     const float2 xv = *reinterpret_cast<const float2*>(x + (size_t)b * n + 2 * k);
     const float2 nv = make_float2(z.x * sigma, z.y * sigma);
     *reinterpret_cast<float2*>(nz + (size_t)b * n + 2 * k) = nv;

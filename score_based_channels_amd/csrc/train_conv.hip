@@ -186,6 +186,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const float* __restric
     }
     float inv_sigma = 1.f;
     if (MODE == 1) inv_sigma = 1.f / (e.labels ? e.sigmas[e.labels[n]] : e.sigma_of_step[*e.step]);
+#pragma clang loop vectorize(disable)                    // no packed-fp32 instructions in this library (Makefile)
     for (int i = tid; i < npx * CD; i += 256) {
         float v = grad[((size_t)n * H + r0) * W * CD + i];
         if (MODE == 1) v = v * inv_sigma;                // d (out / sigma) / d out  (reference: tensor / sigma)

@@ -157,8 +157,10 @@ class _Builder:
         return self.rcu(p + 'output_convs.', h, 3 if end else 1)
 
 
-def build_score_plan(ngf=32, nt=64, nr=16, channels=2):
-    """Op list of one ``NCSNv2Deepest.forward`` for ``[B, 2, nt, nr]`` inputs (ncsnv2.py:269-300)."""
+def build_score_plan(ngf=32, nt=64, nr=16, channels=2, share_slots=True):
+    """Op list of one ``NCSNv2Deepest.forward`` for ``[B, 2, nt, nr]`` inputs (ncsnv2.py:269-300).
+    ``share_slots=False`` gives every logical tensor its own storage (a training step reads every activation again on
+    the way back, ``train.py``)."""
     if nt % 8 or nr % 8:
         raise ValueError('Nt and Nr must be multiples of 8 (three 2x mean-pools), got %dx%d' % (nt, nr))
     b = _Builder(ngf, nt, nr)
@@ -184,7 +186,12 @@ def build_score_plan(ngf=32, nt=64, nr=16, channels=2):
     b.ops.append(Op(END_CONV, 'end_conv', src=ref5, dst=out, weight='end_conv.weight', bias='end_conv.bias',
                     stats=sn))
     plan = ScorePlan(b.ops, x, out, b.tensors)
-    assign_slots(plan)
+    if share_slots:
+        assign_slots(plan)
+    else:
+        for i, t in enumerate(plan.tensors):
+            t.slot = i
+        plan.slot_elems = [t.elems for t in plan.tensors]
     return plan
 
 

@@ -15,7 +15,7 @@ the fixtures are inputs and outputs only.  What is executed:
 * loader goldens: the reference's ``loaders.Channels`` (imported with a stand-in ``hdf5storage``
   module that returns a synthetic ``output_h``).
 
-Usage:  python tests/gen_golden.py [forward plumbing trunc big f16w cross mmse loader tune full]
+Usage:  python tests/gen_golden.py [forward plumbing trunc big f16w cross mmse loader tune train full]
 """
 import os
 import sys
@@ -412,6 +412,90 @@ def gen_tune():
     np.savez_compressed(os.path.join(GOLD, 'tune_post.npz'), nmse_log=nmse_log, avg_nmse=avg_nmse,
                         best_nmse=best_nmse, best_alpha_snr=np.array(ba), best_beta_snr=np.array(bb),
                         alpha_step_range=alpha_range, beta_noise_range=beta_range)
+
+
+def _train_batch(seed, B, config):
+    """Normalised Hermitian channels as the real view train_score.py:151-153 feeds the loss, labels and N(0,1) draws."""
+    H, _ = case_inputs(seed, B, 64, 16, 0.6)
+    x = np.stack([H.real, H.imag], axis=1).astype(np.float32)            # [B, 2, Nt, Nr]
+    rng = np.random.default_rng([seed, 5])
+    labels = rng.integers(0, config.model.num_classes, size=B).astype(np.int64)
+    z = rng.standard_normal(x.shape).astype(np.float32)
+    return x, labels, z
+
+
+def _reference_dsm(net, sigmas, x, labels, z):
+    """ncsnv2/losses/dsm.py:6-32 called as train_score.py:151-153 does, with ``torch.randn_like`` returning ``z``."""
+    from ncsnv2.losses import dsm
+    real = torch.randn_like
+    torch.randn_like = lambda t: torch.from_numpy(z)
+    try:
+        return dsm.anneal_dsm_score_estimation(net, torch.from_numpy(x), sigmas, torch.from_numpy(labels), 2.)
+    finally:
+        torch.randn_like = real
+
+
+def gen_train():
+    """SURVEY 8(f) F4.  (1) loss and every parameter gradient of one DSM batch through the reference network (autograd);
+    (2) three optimiser steps of train_score.py:145-173 (Adam lr 1e-4, betas (0.9, 0.999), eps 1e-3; EMA 0.999) on three
+    different batches.  5.9 M values per tensor set do not fit a fixture: gradients / updates are stored as per-tensor
+    digests (conftest.tensor_digest), small tensors in full."""
+    from conftest import tensor_digest
+    from ncsnv2.models import get_sigmas
+    from ncsnv2.models.ema import EMAHelper
+    cfg = default_config()
+    sd = seeded_state_dict(cfg, WEIGHT_SEED)
+    net = reference_net(cfg, sd).train()
+    sigmas = get_sigmas(net.config)
+    B = 4
+    x, labels, z = _train_batch(31, B, cfg)
+    labels[:2] = [0, cfg.model.num_classes - 1]                          # both ends of the noise schedule
+    t0 = time.time()
+    loss = _reference_dsm(net, sigmas, x, labels, z)
+    loss.backward()
+    out = dict(x=x, labels=labels, z=z, loss=np.float64(loss.item()), weight_seed=WEIGHT_SEED)
+    names = []
+    for name, p in net.named_parameters():
+        g = p.grad.numpy()
+        names.append(name)
+        out['gd_' + name] = tensor_digest(name, g)
+        if g.size <= 4096:
+            out['g_' + name] = g.copy()
+    # per-sample losses (the mean of :32 hides which sample is off)
+    with torch.no_grad():
+        used = sigmas[torch.from_numpy(labels)].view(B, 1, 1, 1)
+        noise = torch.from_numpy(z) * used
+        scores = net(torch.from_numpy(x) + noise, torch.from_numpy(labels))
+        per = 0.5 * ((scores + noise / used ** 2).reshape(B, -1) ** 2).sum(-1) * used.squeeze() ** 2
+    out['loss_per_sample'] = per.numpy()
+    print('train gradients: loss %.6g, %d tensors, %.1f s' % (loss.item(), len(names), time.time() - t0))
+
+    # (2) the optimiser loop
+    net = reference_net(cfg, sd).train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, weight_decay=0.0, betas=(0.9, 0.999), amsgrad=False, eps=1e-3)
+    ema = EMAHelper(mu=0.999)
+    ema.register(net)
+    before = {n: p.detach().clone() for n, p in net.named_parameters()}
+    K = 3
+    xs, ls, zs, losses = [], [], [], []
+    for k in range(K):
+        xk, lk, zk = _train_batch(40 + k, B, cfg)
+        lo = _reference_dsm(net, sigmas, xk, lk, zk)
+        opt.zero_grad()
+        lo.backward()
+        opt.step()
+        ema.update(net)
+        xs.append(xk); ls.append(lk); zs.append(zk); losses.append(lo.item())
+    out.update(steps_x=np.stack(xs), steps_labels=np.stack(ls), steps_z=np.stack(zs), steps_loss=np.array(losses))
+    for name, p in net.named_parameters():
+        out['ud_' + name] = tensor_digest(name, (p.detach() - before[name]).numpy())
+        out['ed_' + name] = tensor_digest(name, (ema.shadow[name] - before[name]).numpy())
+    # validation-style loss of the EMA copy on the first batch (train_score.py:172-185)
+    val = ema.ema_copy(net)
+    with torch.no_grad():
+        out['ema_loss'] = np.float64(_reference_dsm(val, sigmas, x, labels, z).item())
+    print('train loop: losses', losses, 'ema loss', out['ema_loss'])
+    np.savez_compressed(os.path.join(GOLD, 'train_dsm.npz'), **out)
 
 
 if __name__ == '__main__':

@@ -298,3 +298,41 @@ def test_library_contains_no_packed_fp32_instructions():
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_no_packed.py')], capture_output=True, text=True)
     assert p.returncode == 0, p.stdout + p.stderr
     assert 'no packed-fp32 arithmetic' in p.stdout
+
+
+def test_training_plan_covers_every_parameter_exactly_once():
+    """train.TrainNet without a GPU: the flat parameter layout round-trips a state_dict, and the reverse
+    records write the gradient of every parameter tensor exactly once (conv weights / biases through CONV_WGRAD or the
+    begin / end conv records, alpha|gamma|beta triples through INORM_BWD)."""
+    from score_based_channels_amd import plan as P
+    from score_based_channels_amd.config import default_config
+    from score_based_channels_amd.train import TrainNet
+    from score_based_channels_amd.weights import seeded_state_dict, state_dict_spec
+    cfg = default_config()
+    net = TrainNet(cfg, batch=2, device='cpu')
+    sd = seeded_state_dict(cfg, 7)
+    net.load_state_dict(sd)
+    back = net.state_dict()
+    assert set(back) == set(sd) and all(np.array_equal(back[k], sd[k]) for k in sd)
+    assert all(np.array_equal(net.ema_state_dict()[k], sd[k]) for k in sd)           # EMAHelper.register: shadow = clone
+    keep = []
+    ops = net._backward_ops(keep)
+    base = net.grads.data_ptr()
+    written = {}
+    for o in ops:
+        for ptr, is_norm in ((o.wgrad, o.kind == P.INORM_BWD), (o.bgrad, False)):
+            if ptr:
+                off = (ptr - base) // 4
+                written[off] = written.get(off, 0) + 1
+    expect = {}
+    for name, shape in state_dict_spec():
+        if name == 'sigmas' or name.endswith('.gamma') or name.endswith('.beta'):
+            continue                                               # gamma / beta ride with alpha: one [3][C] write
+        expect[net.off[name]] = 1
+    assert written == expect
+    kinds = [o.kind for o in ops]
+    n_conv = sum(op.kind == P.CONV for op in net.plan.ops)
+    assert kinds.count(P.CONV_WGRAD) == n_conv == 111 and kinds.count(P.CONV) == n_conv       # one adjoint conv each
+    assert kinds.count(P.INORM_BWD) == 25 and kinds.count(P.MAXPOOL5_BWD) == 12
+    assert kinds.count(P.END_CONV_BWD) == 1 and kinds.count(P.BEGIN_CONV_BWD) == 1 and kinds.count(P.UPSAMPLE_BWD) == 5
+    assert kinds.count(P.POOL_BWD) == 6

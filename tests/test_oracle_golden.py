@@ -149,3 +149,35 @@ def test_tune_postprocessing_matches_reference():
     assert np.array_equal(avg, g['avg_nmse']) and np.array_equal(best, g['best_nmse'])
     ba, bb = ald_oracle.tune_select(best, g['alpha_step_range'], g['beta_noise_range'])
     assert np.array_equal(ba, g['best_alpha_snr']) and np.array_equal(bb, g['best_beta_snr'])
+
+
+def test_dsm_loss_restatement_matches_reference(weights64):
+    """oracle/dsm_oracle.py (ncsnv2/losses/dsm.py:6-32) around the numpy score network against the loss the reference's own
+    ``anneal_dsm_score_estimation`` returned for the same samples, labels and noise (tests/golden/train_dsm.npz)."""
+    from oracle import dsm_oracle as D
+    g = load_golden('train_dsm.npz')
+    _, sd = weights64
+    pert, noise, used = D.perturb(g['x'], sd['sigmas'], g['labels'], g['z'])
+    scores = ncsnv2_oracle.score_forward(sd, pert, g["labels"])
+    per = D.loss_per_sample(scores, noise, used)
+    assert np.max(np.abs(per / g['loss_per_sample'] - 1)) < 2e-5
+    assert abs(per.astype(np.float64).mean() / g['loss'] - 1) < 2e-5
+
+
+def test_adam_ema_restatement_matches_torch():
+    """oracle adam_ema_step against torch.optim.Adam + the EMAHelper update rule (models/ema.py:17-22) on CPU."""
+    import torch
+    from oracle import dsm_oracle as D
+    rng = np.random.default_rng(3)
+    p0 = rng.standard_normal(500).astype(np.float32)
+    pt = torch.from_numpy(p0.copy()).requires_grad_(True)
+    opt = torch.optim.Adam([pt], lr=1e-4, weight_decay=0.0, betas=(0.9, 0.999), amsgrad=False, eps=1e-3)
+    shadow_t = pt.data.clone()
+    p, m, v, sh = p0, np.zeros_like(p0), np.zeros_like(p0), p0.copy()
+    for t in range(1, 4):
+        gk = (rng.standard_normal(500) * 10.0 ** rng.uniform(-4, 1, 500)).astype(np.float32)
+        pt.grad = torch.from_numpy(gk.copy())
+        opt.step()
+        shadow_t = (1. - 0.999) * pt.data + 0.999 * shadow_t
+        p, m, v, sh = D.adam_ema_step(p, gk, m, v, sh, t)
+    assert np.max(np.abs(p - pt.data.numpy())) < 5e-7 and np.max(np.abs(sh - shadow_t.numpy())) < 5e-7
