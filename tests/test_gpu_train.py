@@ -117,3 +117,34 @@ def test_step_with_device_noise_and_graph_replay(trainer, golden):
         g2 = trainer.step(x, labels, use_graph=True).clone()
         torch.cuda.synchronize()
     assert torch.equal(g1, l1) and torch.equal(g2, l2) and torch.equal(trainer.params, p_eager)
+
+
+def test_cli_train_score_writes_a_checkpoint_the_estimator_loads(tmp_path, monkeypatch):
+    """``python -m score_based_channels_amd.train_score`` (train_score.py:20-23,145-216): the loss falls, the run is
+    reproducible from its seed (eager or hipGraph replay), and ``final_model.pt`` has the reference's keys and feeds
+    ``test_score`` unchanged."""
+    import torch
+    from score_based_channels_amd import test_score, train_score
+    from score_based_channels_amd.checkpoint import load_checkpoint
+    monkeypatch.chdir(tmp_path)
+    argv = ['--synthetic', '--max_steps', '40', '--batch_size', '16', '--val_every', '20', '--seed', '5']
+    tl, vl = train_score.main(argv)
+    assert len(tl) == 40 and len(vl) == 2 and np.isfinite(tl).all()
+    assert np.mean(tl[-8:]) < 0.8 * np.mean(tl[:8]) and vl[1][0] < vl[0][0]
+    ck = load_checkpoint(tmp_path / 'models/score/CDL-C/final_model.pt')
+    assert {'model_state', 'optim_state', 'config', 'train_loss', 'val_loss'} <= set(ck) and ck['train_loss'] == tl
+    assert len(ck['model_state']) == 230 and ck['config'].model.num_classes == 2311 and ck['config'].optim.eps == 0.001
+    opt = ck['optim_state']
+    assert len(opt['state']) == 229 and float(opt['state'][0]['step']) == 40 and opt['param_groups'][0]['lr'] == 1e-4
+    assert opt['state'][0]['exp_avg'].shape == ck['model_state']['begin_conv.weight'].shape
+    # torch's own optimiser accepts the stored state (same parameter order and shapes as named_parameters())
+    params = [torch.nn.Parameter(v.clone()) for k, v in ck['model_state'].items() if k != 'sigmas']
+    torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.999), eps=1e-3).load_state_dict(opt)
+    tl2, _ = train_score.main(argv + ['--graph', '--out_dir', str(tmp_path / 'again')])
+    assert tl2 == tl
+    # continue from the checkpoint; then estimate channels with the trained weights
+    tl3, _ = train_score.main(['--synthetic', '--max_steps', '3', '--batch_size', '16', '--seed', '6', '--init',
+                               str(tmp_path / 'models/score/CDL-C/final_model.pt'), '--out_dir', str(tmp_path / 'more')])
+    assert np.mean(tl3) < np.mean(tl[:3])
+    nmse_log, _, _ = test_score.main(['--synthetic', '--num_levels', '2', '--num_channels', '4', '--seed', '3', '--no_plot'])
+    assert nmse_log.shape == (1, 1, 17, 6, 4) and np.isfinite(nmse_log).all()
