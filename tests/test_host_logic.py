@@ -17,7 +17,7 @@ from score_based_channels_amd.config import Config, default_config
 def test_library_exports_every_declared_symbol():
     from score_based_channels_amd import _lib
     header = open(os.path.join(ROOT, 'include', 'sbc_hip.h')).read()
-    declared = set(re.findall(r'^\s*(?:int|void|const char\*)\s+(sbc_\w+)\s*\(', header, re.M))
+    declared = set(re.findall(r'^\s*(?:int|int64_t|void|const char\*)\s+(sbc_\w+)\s*\(', header, re.M))
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     h = _lib.lib()
     for name in declared:
