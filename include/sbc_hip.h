@@ -159,7 +159,9 @@ typedef struct sbc_op {
  *                 wgrad = [cout][cin][k][k] (torch layout, written), bgrad = [cout] or NULL; aux = scratch (float),
  *                 >= sbc_wgrad_scratch_floats(B, H, W, cin, cout, ksize).
  *   PACK_WEIGHT   in = [cout][cin][k][k] float32 DEVICE, out = the sbc_pack_conv_weight_split layout (of the adjoint
- *                 convolution cout -> cin with SBC_PACK_ADJOINT).
+ *                 convolution cout -> cin with SBC_PACK_ADJOINT).  Batched form (aux != NULL): aux = device int32 table
+ *                 [B][6] = (source offset from `in` in floats, destination offset from `out` in uint16, cout, cin, k*k,
+ *                 adjoint) and cin/cout/ksize = those of the largest entry: every weight of a network in one launch.
  *   END_CONV_BWD  in/stats/weight/ext as in END_CONV, grad = d / d score [B][H][W][2]; out = d / d ELU-output
  *                 [B][H][W][cin] (written); wgrad [2][cin][3][3], bgrad [2]; aux = scratch >= sbc_wgrad_scratch_floats.
  *   BEGIN_CONV_BWD in = x [B][H][W][2], grad = d / d output [B][H][W][cout]; wgrad [cout][2][3][3], bgrad [cout]; aux.

@@ -416,8 +416,15 @@ __device__ __forceinline__ unsigned short bf16_bits(float v) {
     return __builtin_bit_cast(unsigned short, b);
 }
 
+// `table` != NULL: one launch packs many weights, blockIdx.y = entry, 6 int32 per entry:
+// (source offset in floats from w, destination offset in uint16 from dst, cout, cin, taps, adjoint)
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst,
-                                                           int cout, int cin, int taps, int adjoint) {
+                                                           int cout, int cin, int taps, int adjoint,
+                                                           const int* __restrict__ table) {
+    if (table) {
+        const int* e = table + 6 * blockIdx.y;
+        w += e[0]; dst += e[1]; cout = e[2]; cin = e[3]; taps = e[4]; adjoint = e[5];
+    }
     const int co_p = adjoint ? cin : cout, ci_p = adjoint ? cout : cin;      // packed (cout', cin')
     const int KG = ci_p / 16, NB = co_p / 32;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -444,11 +451,20 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
 
 int launch_pack_weight(const sbc_op& op, hipStream_t stream) {
     SBC_REQUIRE(op.in && op.out, "pack_weight: in/out must be set");
+    if (op.aux) {
+        // batched form: B entries of the device table in `aux`; cin/cout/ksize = the LARGEST weight (sizes the grid)
+        SBC_REQUIRE(op.B > 0 && op.cin > 0 && op.cout > 0 && op.ksize > 0, "pack_weight (batched): B, cin, cout, ksize must be set");
+        const long n = (long)op.ksize * op.ksize * (op.cin / 16) * (op.cout / 16) * 64;     // upper bound for either form
+        hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((n + 255) / 256), op.B), dim3(256), 0, stream,
+                           (const float*)op.in, (unsigned short*)op.out, 0, 0, 0, 0, (const int*)op.aux);
+        SBC_CHECK_HIP(hipGetLastError());
+        return SBC_OK;
+    }
     SBC_REQUIRE(op.cin % 32 == 0 && op.cout % 32 == 0 && (op.ksize == 1 || op.ksize == 3), "pack_weight: cin, cout %% 32, ksize in {1, 3}");
     const int taps = op.ksize * op.ksize, adj = (op.flags & SBC_PACK_ADJOINT) ? 1 : 0;
     const long n = (long)taps * (op.cin / (adj ? 32 : 16)) * (op.cout / (adj ? 16 : 32)) * 64;
     hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const float*)op.in,
-                       (unsigned short*)op.out, op.cout, op.cin, taps, adj);
+                       (unsigned short*)op.out, op.cout, op.cin, taps, adj, (const int*)nullptr);
     SBC_CHECK_HIP(hipGetLastError());
     return SBC_OK;
 }

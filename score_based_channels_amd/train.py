@@ -102,11 +102,7 @@ class TrainNet:
         self.replay = torch.zeros(B, n, **f32)                        # standard-normal draws to replay (parity runs)
         self.labels = torch.zeros(B, dtype=torch.int64, device=dev)
         self.loss_per_sample = torch.zeros(B, **f32)
-        convs = [op for op in pl.ops if op.kind == P.CONV]
-        self.packed = {}
-        for op in convs:
-            numel = int(np.prod(self.shape[op.weight]))
-            self.packed[op.weight] = (torch.zeros(3 * numel // 2, **f32), torch.zeros(3 * numel // 2, **f32))   # uint16 x 3 terms
+        self._make_pack_table()
         big = max(t.elems for t in pl.tensors)
         self.tmp_a = torch.zeros(B * big, **f32)
         self.tmp_c = torch.zeros(B * big, **f32)
@@ -172,17 +168,29 @@ class TrainNet:
             self.gbuf[id(t)] = torch.zeros(self.B * t.elems, dtype=torch.float32, device=self.device)
         return self.gbuf[id(t)]
 
-    def _pack_ops(self, base):
-        ops = []
+    def _make_pack_table(self):
+        """Device table of SBC_OP_PACK_WEIGHT's batched form: both packed forms of every convolution weight."""
+        rows, cur, self._pack_off = [], 0, {}
         for op in self.plan.ops:
             if op.kind != P.CONV:
                 continue
             cout, cin, k, _ = self.shape[op.weight]
-            fwd, adj = self.packed[op.weight]
-            ops.append(_lib.sbc_op(kind=P.PACK_WEIGHT, cin=cin, cout=cout, ksize=k, in_=self._par(base, op.weight), out=_ptr(fwd)))
-            ops.append(_lib.sbc_op(kind=P.PACK_WEIGHT, flags=P.PACK_ADJOINT, cin=cin, cout=cout, ksize=k,
-                                   in_=self._par(base, op.weight), out=_ptr(adj)))
-        return ops
+            n16 = 3 * cout * cin * k * k                                   # uint16 elements per packed form
+            self._pack_off[op.weight] = (cur, cur + n16)
+            rows.append((self.off[op.weight], cur, cout, cin, k * k, 0))
+            rows.append((self.off[op.weight], cur + n16, cout, cin, k * k, 1))
+            cur += 2 * n16
+        self._pack_table = torch.tensor(rows, dtype=torch.int32, device=self.device)
+        self._pack_buf = torch.zeros(cur // 2, dtype=torch.float32, device=self.device)
+        self._pack_max = (max(r[2] for r in rows), max(r[3] for r in rows))
+
+    def _pack_ops(self, base):
+        """ONE launch that re-packs every convolution weight (forward + adjoint form) from the flat parameter buffer."""
+        return [_lib.sbc_op(kind=P.PACK_WEIGHT, B=self._pack_table.shape[0], cout=self._pack_max[0], cin=self._pack_max[1],
+                            ksize=3, in_=_ptr(base), out=_ptr(self._pack_buf), aux=C.c_void_p(self._pack_table.data_ptr()))]
+
+    def _packed(self, wkey, adjoint):
+        return C.c_void_p(self._pack_buf.data_ptr() + 2 * self._pack_off[wkey][1 if adjoint else 0])
 
     def _forward_ops(self, base, keep):
         """The forward records of plan.py bound to private activation slots; conv weights come from the packed copies."""
@@ -194,7 +202,7 @@ class TrainNet:
             o = _lib.sbc_op(kind=op.kind, flags=op.flags, B=B, H=op.src.h, W=op.src.w, cin=op.src.c, cout=op.dst.c,
                             ksize=op.ksize, dil=op.dil, tag=op.tag, in_=_ptr(sl[op.src.slot]), out=_ptr(sl[op.dst.slot]))
             if op.kind == P.CONV:
-                o.weight_split = _ptr(self.packed[op.weight][0])
+                o.weight_split = self._packed(op.weight, False)
             elif op.kind == P.INORM_STATS:
                 o.weight = self._par(base, op.weight + '.alpha')
             elif op.weight is not None:
@@ -289,7 +297,7 @@ class TrainNet:
                 direct = pro == 0 and id(src) not in done
                 target = self._grad_of(src) if direct else self.tmp_a
                 ops.append(_lib.sbc_op(kind=P.CONV, B=B, H=src.h, W=src.w, cin=dst.c, cout=src.c, ksize=op.ksize, dil=op.dil,
-                                       in_=_ptr(dc), out=_ptr(target), weight_split=_ptr(self.packed[op.weight][1])))
+                                       in_=_ptr(dc), out=_ptr(target), weight_split=self._packed(op.weight, True)))
                 if direct:
                     done.add(id(src))
                 elif pro == 0:
@@ -326,6 +334,7 @@ class TrainNet:
             ops.append(_lib.sbc_op(kind=P.DSM_LOSS, B=self.B, H=self.nt, W=self.nr, cin=self.channels,
                                    in_=_ptr(self.slots[pl.out.slot]), grad=_ptr(self.noise), out=_ptr(self.loss_per_sample),
                                    aux=_ptr(self._grad_of(pl.out)) if want_grad else None, ext=ep))
+            n_fwd = len(ops)
             if want_grad:
                 ops += self._backward_ops(keep)
             if mode == 'step':
@@ -335,6 +344,9 @@ class TrainNet:
                 ops.append(_lib.sbc_op(kind=P.ADAM_EMA, in_=_ptr(self.grads), out=_ptr(self.params), aux=_ptr(self.state),
                                        ext=C.cast(C.pointer(adam), C.c_void_p)))
                 ops.append(_lib.sbc_op(kind=P.STEP_INC, out=C.c_void_p(self.step_count.data_ptr())))
+            # profiling tags (sbc_plan_profile): 100 + kind for the packing / forward part, 200 + kind for the rest
+            for i, o in enumerate(ops):
+                o.tag = (100 if i < n_fwd else 200) + o.kind
             plans[replay] = _lib.Plan(ops, keepalive=keep)
         return plans
 
@@ -362,6 +374,23 @@ class TrainNet:
             self.replay.copy_(z.to(self.device, torch.float32).reshape(self.B, -1))
         self._plans[mode][replay].run(cur.cuda_stream, 1, use_graph)
         return self.loss_per_sample
+
+    def profile_step(self, samples, labels, repeats=5):
+        """Per-operator-class GPU time of one optimiser step: {tag: (ms per step, launches per step)} by hipEvents around
+        every launch carrying the tag (eager runs; tags: 100 + kind forward / packing, 200 + kind reverse)."""
+        self._run('step', samples, labels, None)
+        plan = self._plans['step'][False]
+        tags = sorted({(100 if forward else 200) + k for forward in (True, False) for k in range(1, 21)})
+        out = {}
+        for tag in tags:
+            plan.profile(tag)
+            for _ in range(repeats):
+                self._run('step', samples, labels, None)
+            ms, n = plan.profile_read()
+            if n:
+                out[tag] = (ms / repeats, n // repeats)
+        plan.profile(-1)
+        return out
 
     def step(self, samples, labels, noise=None, use_graph=False):
         """One optimiser step (train_score.py:145-173); returns the per-sample losses (device tensor)."""
