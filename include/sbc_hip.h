@@ -157,7 +157,7 @@ typedef struct sbc_op {
  *   POOL_BWD      grad = [B][H/2][W/2][cin]; out = [B][H][W][cin] = grad[h/2][w/2] / 4.
  *   CONV_WGRAD    in/stats/flags(PRO_*)/ksize/dil as in the forward CONV, grad = d / d (conv + bias) [B][H][W][cout];
  *                 wgrad = [cout][cin][k][k] (torch layout, written), bgrad = [cout] or NULL; aux = scratch (float),
- *                 >= sbc_wgrad_scratch_floats(B, H, W, cin, cout, ksize).
+ *                 >= sbc_wgrad_scratch_floats(B, H, W, cin, cout, ksize) (one buffer serves all launches of a stream).
  *   PACK_WEIGHT   in = [cout][cin][k][k] float32 DEVICE, out = the sbc_pack_conv_weight_split layout (of the adjoint
  *                 convolution cout -> cin with SBC_PACK_ADJOINT).  Batched form (aux != NULL): aux = device int32 table
  *                 [B][6] = (source offset from `in` in floats, destination offset from `out` in uint16, cout, cin, k*k,

@@ -5,9 +5,8 @@
 //   dW[co][ci][tap] = sum_{b,h,w} a[b][h + dh(tap)][w + dw(tap)][ci] * dC[b][h][w][co],   a = pro(x) (IN++ affine, ELU),
 //   db[co] = sum dC[b][h][w][co]
 // is a [k*k*cin] x [cout] product with B*H*W as the contraction.  conv_wgrad_kernel: a workgroup owns one tap and a chunk
-// of the 64-pixel tiles; per tile it stages a (with halo, through the forward prologue) and dC in LDS and every thread
-// keeps a (cin*cout/1024) x 4 block of that tap's outputs in registers across its tiles.  Partial results go to scratch
-// [chunk][tap][ci][co] and a second kernel sums the chunks in ascending order (no atomics) into the torch layout.
+// of the 64-pixel tiles; per tile it stages a (with halo, through the forward prologue) and dC in LDS and its four waves
+// accumulate 32 x 32 blocks of that tap's outputs on the fp32 matrix cores across the tiles.
 #include "tile.h"
 
 namespace sbc {
@@ -20,18 +19,29 @@ static int wgrad_chunks(long total_px) {
     return (int)(tiles < WG_MAX_CHUNKS ? tiles : WG_MAX_CHUNKS);
 }
 
-template <int CIN, int COUT, int KS>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Wave layout: WM x WN waves tile the [CIN] x [COUT] output blocks of 32 x 32, WK waves split the pixels of a tile (the
+// contraction); WM * WN * WK = 4.  Each wave holds (CIN/32/WM) x (COUT/32/WN) accumulator blocks (v_mfma_f32_32x32x2_f32:
+// exact fp32 products, fp32 accumulation; A = a[pixel][ci] with M = ci, B = dC[pixel][co] with N = co, K = 2 pixels per
+// instruction, both operands one conflict-free ds_read_b32 per lane).  Partials go to scratch
+// [chunk * WK + wk][tap][ci][co]; wgrad_reduce_kernel sums them in ascending order and writes the torch layout.  (A
+// single-launch variant in which the last workgroup of a tap reduces it was 3x SLOWER: the device-scope fence it needs
+// writes back the whole L2 of the XCD, once per workgroup.)
+template <int CIN, int COUT, int KS, int WM, int WN, int WK>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ stats,
                                                           const float* __restrict__ dC, float* __restrict__ scratch,
                                                           int B, int H, int W, int dil, int flags, int nchunks) {
+    static_assert(WM * WN * WK == 4, "four waves");
     constexpr int S = CIN + 4, DS = COUT + 4;
-    constexpr int CO4 = COUT / 4;                 // float4 column groups
-    constexpr int NCG = 256 / CO4;                // input-channel groups
-    constexpr int CI_T = CIN / NCG;               // input channels per thread
-    static_assert(CIN % NCG == 0 && CI_T >= 1, "wgrad: channel blocking");
+    constexpr int MB = CIN / 32 / WM, NB = COUT / 32 / WN;       // accumulator blocks per wave
+    static_assert(MB >= 1 && NB >= 1, "wgrad: wave tiling");
     constexpr int TAPS = KS * KS;
+    constexpr int PXW = WG_TM / WK;                              // pixels of a tile per K-split wave
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, tap = blockIdx.y, chunk = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
+    const int tap = blockIdx.y, chunk = blockIdx.x;
     const Dims<false> d{H, W, H * W, 0, 0};
     const int total_px = B * H * W, ntiles = (total_px + WG_TM - 1) / WG_TM;
     const int halo_rows = KS == 3 ? dil : 0;
@@ -39,18 +49,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
     float* at = lds;                                   // [max_nps + 1][S]
     float* dt = at + (size_t)(max_nps + 1) * S;        // [WG_TM][DS]
     int* aidx = reinterpret_cast<int*>(dt + (size_t)WG_TM * DS);   // [WG_TM] staged-pixel index of this tap, per pixel
-    const int co4 = tid % CO4, cg = tid / CO4;
     const int dh = KS == 3 ? (tap / 3 - 1) * dil : 0, dw = KS == 3 ? (tap % 3 - 1) * dil : 0;
-    float4 acc[CI_T];
+    f32x16 acc[MB][NB];
 #pragma unroll
-    for (int i = 0; i < CI_T; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     float bacc = 0.f;
+    const int half = lane >> 5, col = lane & 31;
     for (int tile = chunk; tile < ntiles; tile += nchunks) {
         const TileGeom g = tile_geom(tile, WG_TM, B, d, halo_rows);
         __syncthreads();                                // previous tile fully consumed
         stage_tile<CIN, 256, 4, false>(at, in, stats, flags & (SBC_PRO_NORM | SBC_PRO_ELU), g, d, tid);
-        for (int i = tid; i < WG_TM * CO4; i += 256) {
-            const int pl = i / CO4, c = i % CO4;
+        for (int i = tid; i < WG_TM * (COUT / 4); i += 256) {
+            const int pl = i / (COUT / 4), c = i % (COUT / 4);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (g.p0 + pl < total_px) v = *reinterpret_cast<const float4*>(dC + (size_t)(g.p0 + pl) * COUT + c * 4);
             *reinterpret_cast<float4*>(dt + pl * DS + c * 4) = v;
@@ -67,47 +81,72 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
         }
         __syncthreads();
 #pragma unroll 2
-        for (int pl = 0; pl < WG_TM; ++pl) {
-            const float4 dv = *reinterpret_cast<const float4*>(dt + pl * DS + co4 * 4);
-            const float* ap = at + aidx[pl] * S + cg * CI_T;
+        for (int p2 = 0; p2 < PXW; p2 += 2) {
+            const int pl = wk * PXW + p2 + half;
+            const float* ap = at + aidx[pl] * S + wm * MB * 32 + col;
+            const float* bp = dt + pl * DS + wn * NB * 32 + col;
+            float av[MB], bv[NB];
 #pragma unroll
-            for (int i = 0; i < CI_T; ++i) {
-                const float a = ap[i];
-                acc[i].x = fmaf(a, dv.x, acc[i].x); acc[i].y = fmaf(a, dv.y, acc[i].y);
-                acc[i].z = fmaf(a, dv.z, acc[i].z); acc[i].w = fmaf(a, dv.w, acc[i].w);
-            }
+            for (int i = 0; i < MB; ++i) av[i] = ap[i * 32];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) bv[j] = bp[j * 32];
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
         if (tap == 0 && tid < COUT) {
             for (int pl = 0; pl < WG_TM; ++pl) bacc += dt[pl * DS + tid];
         }
     }
-    // scratch: [chunk][tap][ci][co], then [nchunks][COUT] bias partials
-    float* o = scratch + (((size_t)chunk * TAPS + tap) * CIN + cg * CI_T) * COUT + co4 * 4;
+    // scratch layout: 16 unused floats | partials [nchunks * WK][TAPS][CIN][COUT] | bias [nchunks][COUT]
+    float* part = scratch + 16;
+    const int per_tap = CIN * COUT, nparts = nchunks * WK;
+    float* o = part + (((size_t)(chunk * WK + wk) * TAPS + tap) * CIN) * COUT;
 #pragma unroll
-    for (int i = 0; i < CI_T; ++i) *reinterpret_cast<float4*>(o + (size_t)i * COUT) = acc[i];
-    if (tap == 0 && tid < COUT) scratch[(size_t)nchunks * TAPS * CIN * COUT + (size_t)chunk * COUT + tid] = bacc;
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = (wm * MB + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                o[(size_t)ci * COUT + (wn * NB + j) * 32 + col] = acc[i][j][r];
+            }
+    float* bpart = part + (size_t)nparts * TAPS * per_tap;
+    if (tap == 0 && tid < COUT) bpart[(size_t)chunk * COUT + tid] = bacc;
 }
 
-// sum the chunk partials in ascending order; write torch layout [co][ci][tap]
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ scratch, float* __restrict__ dW,
-                                                            float* __restrict__ db, int nchunks, int taps, int cin, int cout) {
+// sum the partials in ascending order (fixed order, no atomics); write the torch layout [co][ci][tap]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW,
+                                                            float* __restrict__ db, int nparts, int nchunks, int taps, int cin,
+                                                            int cout) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int per = taps * cin * cout;
     if (i < per) {
         float s = 0.f;
-        for (int c = 0; c < nchunks; ++c) s += scratch[(size_t)c * per + i];
+#pragma unroll 8
+        for (int c = 0; c < nparts; ++c) s += part[(size_t)c * per + i];
         const int co = i % cout, ci = (i / cout) % cin, tap = i / (cout * cin);
         dW[((size_t)co * cin + ci) * taps + tap] = s;
     } else if (db && i < per + cout) {
         const int co = i - per;
         float s = 0.f;
-        for (int c = 0; c < nchunks; ++c) s += scratch[(size_t)nchunks * per + (size_t)c * cout + co];
+        for (int c = 0; c < nchunks; ++c) s += part[(size_t)nparts * per + (size_t)c * cout + co];
         db[co] = s;
     }
 }
 
+template <int CIN, int COUT>
+struct WgradWaves {        // (WM, WN, WK): blocks of 32 x 32 per wave <= 2 x 2, the rest of the four waves split the pixels
+    static constexpr int WM = CIN >= 64 ? 2 : 1;
+    static constexpr int WN = COUT >= 64 ? 2 : 1;
+    static constexpr int WK = 4 / (WM * WN);
+};
+
 template <int CIN, int COUT, int KS>
 static int launch_wgrad_t(const sbc_op& op, hipStream_t stream) {
+    using Wv = WgradWaves<CIN, COUT>;
     const long total_px = (long)op.B * op.H * op.W;
     const int HW = op.H * op.W;
     SBC_REQUIRE(WG_TM % op.W == 0 && (HW % WG_TM == 0 || WG_TM % HW == 0), "conv_wgrad: image %dx%d does not tile by %d pixels",
@@ -117,14 +156,14 @@ static int launch_wgrad_t(const sbc_op& op, hipStream_t stream) {
     const int max_nps = WG_TM >= HW ? WG_TM : WG_TM + 2 * halo_rows * op.W;
     const size_t lds = ((size_t)(max_nps + 1) * (CIN + 4) + (size_t)WG_TM * (COUT + 4)) * sizeof(float) + WG_TM * sizeof(int);
     SBC_REQUIRE(lds <= 160 * 1024, "conv_wgrad: tile needs %zu bytes of LDS", lds);
-    auto kern = conv_wgrad_kernel<CIN, COUT, KS>;
+    auto kern = conv_wgrad_kernel<CIN, COUT, KS, Wv::WM, Wv::WN, Wv::WK>;
     { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds); if (rc) return rc; }
     hipLaunchKernelGGL(kern, dim3(nchunks, KS * KS), dim3(256), lds, stream, (const float*)op.in, (const float*)op.stats,
                        (const float*)op.grad, (float*)op.aux, op.B, op.H, op.W, op.dil, op.flags, nchunks);
     SBC_CHECK_HIP(hipGetLastError());
     const int outs = KS * KS * CIN * COUT + COUT;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((outs + 255) / 256), dim3(256), 0, stream, (const float*)op.aux,
-                       (float*)op.wgrad, (float*)op.bgrad, nchunks, KS * KS, CIN, COUT);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((outs + 255) / 256), dim3(256), 0, stream, (const float*)op.aux + 16,
+                       (float*)op.wgrad, (float*)op.bgrad, nchunks * Wv::WK, nchunks, KS * KS, CIN, COUT);
     SBC_CHECK_HIP(hipGetLastError());
     return SBC_OK;
 }
@@ -194,7 +233,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const float* __restric
     }
     __syncthreads();
     constexpr int NOUT = 9 * CA * CD;                    // 576
-    float* o = scratch + (size_t)blockIdx.x * (NOUT + CD);
+    float* o = scratch + 16 + (size_t)blockIdx.x * (NOUT + CD);     // the first 16 words belong to conv_wgrad_kernel's counters
     for (int q = tid; q < NOUT + CD; q += 256) {
         float s = 0.f;
         if (q < NOUT) {
@@ -217,7 +256,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* __
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= nout + cd) return;
     float s = 0.f;
-    for (int g = 0; g < nwg; ++g) s += scratch[(size_t)g * (nout + cd) + q];
+    for (int g = 0; g < nwg; ++g) s += scratch[16 + (size_t)g * (nout + cd) + q];
     if (q < nout) dW[q] = s;
     else if (db) db[q - nout] = s;
 }
@@ -302,8 +341,8 @@ extern "C" int64_t sbc_wgrad_scratch_floats(int32_t B, int32_t H, int32_t W, int
     if (B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0 || ksize <= 0) return 0;
     if (cin == 2 || cout == 2) {                                             // begin / end conv: one partial per workgroup
         const int rows = sbc::small_rows(H, W);
-        return (int64_t)B * (H / rows) * (9 * cin * cout + (cin == 2 ? cout : 2));
+        return 16 + (int64_t)B * (H / rows) * (9 * cin * cout + (cin == 2 ? cout : 2));
     }
     const int chunks = sbc::wgrad_chunks((long)B * H * W);
-    return (int64_t)chunks * ((int64_t)ksize * ksize * cin * cout + cout);
+    return 16 + (int64_t)chunks * 4 * ((int64_t)ksize * ksize * cin * cout) + (int64_t)chunks * cout;   // <= 4 pixel splits
 }

@@ -215,7 +215,7 @@ def test_conv_weight_gradient_matches_autograd(gpu, cin, cout, k, dil, B, H, W, 
     y.backward(torch.from_numpy(g.transpose(0, 3, 1, 2).copy()).double())
     n_scr = int(_lib.lib().sbc_wgrad_scratch_floats(B, H, W, cin, cout, k))
     assert n_scr > 0
-    aux = torch.empty(n_scr, dtype=torch.float32, device='cuda')
+    aux = torch.zeros(n_scr, dtype=torch.float32, device='cuda')
     dw = torch.full((cout, cin, k, k), float('nan'), dtype=torch.float32, device='cuda')
     db = torch.full((cout,), float('nan'), dtype=torch.float32, device='cuda')
     op = _lib.sbc_op(kind=P.CONV_WGRAD, flags=flags, B=B, H=H, W=W, cin=cin, cout=cout, ksize=k, dil=dil, in_=_p(dx),
@@ -223,6 +223,10 @@ def test_conv_weight_gradient_matches_autograd(gpu, cin, cout, k, dil, B, H, W, 
     _launch(gpu, op)
     assert rel_err(dw.cpu().numpy(), w.grad.numpy()) < TOL
     assert rel_err(db.cpu().numpy(), b.grad.numpy()) < TOL
+    first = dw.clone()
+    dw.fill_(float('nan'))
+    _launch(gpu, op)                                   # same scratch again: the arrival counters were left at zero
+    assert torch.equal(dw, first)
 
 
 @pytest.mark.parametrize('cin,cout,k', [(32, 32, 3), (32, 64, 3), (32, 64, 1), (64, 64, 1), (64, 128, 3), (128, 64, 3),
@@ -290,7 +294,7 @@ def test_end_conv_backward_matches_autograd(gpu):
     dsig, dlab = _dev(torch, sigmas), _dev(torch, labels)
     st = _forward_stats(gpu, dx, dagb)
     ext = _lib.sbc_endconv(sigmas=_p(dsig), labels=_p(dlab))
-    aux = torch.empty(int(_lib.lib().sbc_wgrad_scratch_floats(B, H, W, Cc, 2, 3)), dtype=torch.float32, device='cuda')
+    aux = torch.zeros(int(_lib.lib().sbc_wgrad_scratch_floats(B, H, W, Cc, 2, 3)), dtype=torch.float32, device='cuda')
     out = torch.full((B, H, W, Cc), float('nan'), dtype=torch.float32, device='cuda')
     gw = torch.full((2, Cc, 3, 3), float('nan'), dtype=torch.float32, device='cuda')
     gb = torch.full((2,), float('nan'), dtype=torch.float32, device='cuda')
@@ -316,7 +320,7 @@ def test_begin_conv_backward_matches_autograd(gpu):
     y = torch.nn.functional.conv2d(2 * torch.from_numpy(x.transpose(0, 3, 1, 2).copy()).double() - 1, wt, bt, padding=1)
     y.backward(torch.from_numpy(g.transpose(0, 3, 1, 2).copy()).double())
     dx, dg = _dev(torch, x), _dev(torch, g)
-    aux = torch.empty(int(_lib.lib().sbc_wgrad_scratch_floats(B, H, W, 2, 32, 3)), dtype=torch.float32, device='cuda')
+    aux = torch.zeros(int(_lib.lib().sbc_wgrad_scratch_floats(B, H, W, 2, 32, 3)), dtype=torch.float32, device='cuda')
     gw = torch.full((32, 2, 3, 3), float('nan'), dtype=torch.float32, device='cuda')
     gb = torch.full((32,), float('nan'), dtype=torch.float32, device='cuda')
     op = _lib.sbc_op(kind=P.BEGIN_CONV_BWD, B=B, H=H, W=W, cin=2, cout=32, ksize=3, dil=1, in_=_p(dx), grad=_p(dg),
