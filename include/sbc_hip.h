@@ -79,6 +79,12 @@ typedef enum sbc_op_kind {
                                    consumers collects one gradient term per consumer)                            */
 #define SBC_PACK_ADJOINT  0x400  /* SBC_OP_PACK_WEIGHT: pack w'[ci][co][kh][kw] = w[co][ci][k-1-kh][k-1-kw], the weight of
                                    the adjoint (input-gradient) convolution, which then runs as an ordinary SBC_OP_CONV */
+#define SBC_OP_SIDE       0x800  /* any kind, inside a plan: this launch may overlap the launches that follow it.  The plan
+                                   runs it on a stream of its own that first waits for everything issued before it; side
+                                   launches keep their order among themselves.  The caller guarantees that no later launch
+                                   writes what it reads or reads what it writes before the next SBC_OP_JOIN             */
+#define SBC_OP_JOIN       0x1000 /* this launch (and everything after it) waits for all side launches issued so far; the
+                                   end of the plan always joins                                                       */
 #define SBC_CONV_F16W    0x100  /* fp16 weights (BASELINE config 5): `weight_split` / `weight_wino_split` hold ONE
                                    fp16 term per weight (sbc_pack_conv_weight_f16 / _winograd_f16) instead of
                                    three bf16 terms; activations are rounded to fp16 as they enter the matrix

@@ -99,6 +99,9 @@ struct sbc_plan {
     // hipGraph replay
     hipGraphExec_t exec = nullptr;
     hipStream_t graph_stream = nullptr;
+    // side stream for ops flagged SBC_OP_SIDE (created on first use; forked from / joined into the run stream by events)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // per-tag timing
     int prof_tag = -1;
     std::vector<hipEvent_t> ev_pool;     // pairs
@@ -121,8 +124,31 @@ static int drain_events(sbc_plan* plan) {
     return SBC_OK;
 }
 
+static int join_side(sbc_plan* plan, hipStream_t s) {
+    SBC_CHECK_HIP(hipEventRecord(plan->ev_join, plan->side));
+    SBC_CHECK_HIP(hipStreamWaitEvent(s, plan->ev_join, 0));
+    return SBC_OK;
+}
+
 static int run_eager(sbc_plan* plan, hipStream_t s) {
+    bool side_busy = false;
     for (auto& po : plan->ops) {
+        hipStream_t os = s;                              // the stream this op runs on
+        if (po.op.flags & SBC_OP_SIDE) {
+            if (!plan->side) {
+                SBC_CHECK_HIP(hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking));
+                SBC_CHECK_HIP(hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming));
+                SBC_CHECK_HIP(hipEventCreateWithFlags(&plan->ev_join, hipEventDisableTiming));
+            }
+            SBC_CHECK_HIP(hipEventRecord(plan->ev_fork, s));         // everything issued so far happens before the side op
+            SBC_CHECK_HIP(hipStreamWaitEvent(plan->side, plan->ev_fork, 0));
+            os = plan->side;
+            side_busy = true;
+        } else if ((po.op.flags & SBC_OP_JOIN) && side_busy) {
+            const int rc = join_side(plan, s);
+            if (rc) return rc;
+            side_busy = false;
+        }
         const bool timed = plan->prof_tag >= 0 && po.op.tag == plan->prof_tag;
         if (timed) {
             if (plan->ev_used + 2 > plan->ev_pool.size()) {
@@ -137,15 +163,16 @@ static int run_eager(sbc_plan* plan, hipStream_t s) {
                     plan->ev_pool.push_back(b);
                 }
             }
-            SBC_CHECK_HIP(hipEventRecord(plan->ev_pool[plan->ev_used], s));
+            SBC_CHECK_HIP(hipEventRecord(plan->ev_pool[plan->ev_used], os));
         }
-        const int rc = dispatch(po.op, ext_size(po.op.kind) ? &po.ext : nullptr, s);
+        const int rc = dispatch(po.op, ext_size(po.op.kind) ? &po.ext : nullptr, os);
         if (rc) return rc;
         if (timed) {
-            SBC_CHECK_HIP(hipEventRecord(plan->ev_pool[plan->ev_used + 1], s));
+            SBC_CHECK_HIP(hipEventRecord(plan->ev_pool[plan->ev_used + 1], os));
             plan->ev_used += 2;
         }
     }
+    if (side_busy) return join_side(plan, s);            // never return with side work the run stream does not wait for
     return SBC_OK;
 }
 
@@ -221,6 +248,9 @@ void sbc_plan_destroy(sbc_plan* plan) {
     if (!plan) return;
     if (plan->exec) (void)hipGraphExecDestroy(plan->exec);
     for (hipEvent_t e : plan->ev_pool) (void)hipEventDestroy(e);
+    if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
+    if (plan->ev_join) (void)hipEventDestroy(plan->ev_join);
+    if (plan->side) (void)hipStreamDestroy(plan->side);
     delete plan;
 }
 

@@ -105,7 +105,6 @@ class TrainNet:
         self._make_pack_table()
         big = max(t.elems for t in pl.tensors)
         self.tmp_a = torch.zeros(B * big, **f32)
-        self.tmp_c = torch.zeros(B * big, **f32)
         self.inorm_aux = torch.zeros(B * 6 * 4 * self.ngf, **f32)
         self.pool_aux = torch.zeros(B * big, dtype=torch.uint8, device=dev)
         lib = _lib.lib()
@@ -113,8 +112,9 @@ class TrainNet:
         for op in pl.ops:
             if op.kind in (P.CONV, P.BEGIN_CONV, P.END_CONV):
                 scr = max(scr, int(lib.sbc_wgrad_scratch_floats(B, op.src.h, op.src.w, op.src.c, op.dst.c, op.ksize)))
-        self.scratch = torch.zeros(scr, **f32)
-        self.gbuf = {}
+        self.scratch = torch.zeros(scr, **f32)                        # weight-gradient partials (side stream, in order)
+        self.scratch_main = torch.zeros(int(lib.sbc_wgrad_scratch_floats(B, self.nt, self.nr, self.ngf, self.channels, 3)), **f32)
+        self.gbuf, self.pool_grad = {}, {}
 
     # --- checkpoint grammar -----------------------------------------------------------------------------------------
     def load_state_dict(self, state_dict, strict=True):
@@ -167,6 +167,11 @@ class TrainNet:
         if id(t) not in self.gbuf:
             self.gbuf[id(t)] = torch.zeros(self.B * t.elems, dtype=torch.float32, device=self.device)
         return self.gbuf[id(t)]
+
+    def _pool_grad(self, op):
+        if op.name not in self.pool_grad:
+            self.pool_grad[op.name] = torch.zeros(self.B * op.src.h * op.src.w * op.dst.c, dtype=torch.float32, device=self.device)
+        return self.pool_grad[op.name]
 
     def _make_pack_table(self):
         """Device table of SBC_OP_PACK_WEIGHT's batched form: both packed forms of every convolution weight."""
@@ -259,7 +264,7 @@ class TrainNet:
             if op.kind == P.END_CONV:
                 ops.append(_lib.sbc_op(kind=P.END_CONV_BWD, B=B, H=src.h, W=src.w, cin=src.c, cout=op.dst.c, ksize=3, dil=1,
                                        in_=_ptr(sl[src.slot]), stats=_ptr(sl[op.stats.slot]), weight=self._par(base, op.weight),
-                                       grad=_ptr(dy), out=_ptr(self.tmp_a), aux=_ptr(self.scratch),
+                                       grad=_ptr(dy), out=_ptr(self.tmp_a), aux=_ptr(self.scratch_main),
                                        wgrad=self._par(gr, op.weight), bgrad=self._par(gr, op.bias),
                                        ext=C.cast(C.pointer(ext), C.c_void_p)))
                 inorm_bwd(src, op.stats, self.tmp_a)
@@ -268,7 +273,7 @@ class TrainNet:
                                        cin=src.c, in_=_ptr(sl[src.slot]), grad=_ptr(dy), out=_ptr(self._grad_of(src)),
                                        aux=C.c_void_p(self.pool_aux.data_ptr())))
             elif op.kind == P.BEGIN_CONV:
-                ops.append(_lib.sbc_op(kind=P.BEGIN_CONV_BWD, B=B, H=src.h, W=src.w, cin=src.c, cout=op.dst.c, ksize=3, dil=1,
+                ops.append(_lib.sbc_op(kind=P.BEGIN_CONV_BWD, flags=P.OP_SIDE, B=B, H=src.h, W=src.w, cin=src.c, cout=op.dst.c, ksize=3, dil=1,
                                        in_=_ptr(sl[src.slot]), grad=_ptr(dy), aux=_ptr(self.scratch),
                                        wgrad=self._par(gr, op.weight), bgrad=self._par(gr, op.bias)))
             elif op.kind == P.CONV:
@@ -285,10 +290,11 @@ class TrainNet:
                                            up_h=op.up.h, up_w=op.up.w, grad=_ptr(dy), out=_ptr(self._grad_of(op.up))))
                 dc = dy
                 if op.flags & P.EPI_POOL:
-                    ops.append(_lib.sbc_op(kind=P.POOL_BWD, B=B, H=src.h, W=src.w, cin=dst.c, grad=_ptr(dy), out=_ptr(self.tmp_c)))
-                    dc = self.tmp_c
+                    dc = self._pool_grad(op)              # private buffer: the weight gradient reads it from the side stream
+                    ops.append(_lib.sbc_op(kind=P.POOL_BWD, B=B, H=src.h, W=src.w, cin=dst.c, grad=_ptr(dy), out=_ptr(dc)))
                 pro = op.flags & (P.PRO_NORM | P.PRO_ELU)
-                ops.append(_lib.sbc_op(kind=P.CONV_WGRAD, flags=pro, B=B, H=src.h, W=src.w, cin=src.c, cout=dst.c,
+                # weight gradients are off the critical path (nothing before the optimiser reads them): side stream
+                ops.append(_lib.sbc_op(kind=P.CONV_WGRAD, flags=pro | P.OP_SIDE, B=B, H=src.h, W=src.w, cin=src.c, cout=dst.c,
                                        ksize=op.ksize, dil=op.dil, in_=_ptr(sl[src.slot]),
                                        stats=_ptr(sl[op.stats.slot]) if op.stats is not None else None, grad=_ptr(dc),
                                        aux=_ptr(self.scratch), wgrad=self._par(gr, op.weight),
@@ -341,7 +347,7 @@ class TrainNet:
                 adam = _lib.sbc_adam(n=self.n_params, lr=self.lr, beta1=self.beta1, beta2=0.999, eps=self.eps,
                                      ema_mu=self.ema_mu, step=_ptr(self.step_count))
                 keep.append(adam)
-                ops.append(_lib.sbc_op(kind=P.ADAM_EMA, in_=_ptr(self.grads), out=_ptr(self.params), aux=_ptr(self.state),
+                ops.append(_lib.sbc_op(kind=P.ADAM_EMA, flags=P.OP_JOIN, in_=_ptr(self.grads), out=_ptr(self.params), aux=_ptr(self.state),
                                        ext=C.cast(C.pointer(adam), C.c_void_p)))
                 ops.append(_lib.sbc_op(kind=P.STEP_INC, out=C.c_void_p(self.step_count.data_ptr())))
             # profiling tags (sbc_plan_profile): 100 + kind for the packing / forward part, 200 + kind for the rest
