@@ -106,9 +106,11 @@ def parse_args():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default='cdlc', choices=['cdlc', 'big'],
+    ap.add_argument('--workload', default='cdlc', choices=['cdlc', 'big', 'train'],
                     help='cdlc: BASELINE configs[1] (Nt64xNr16, 1700 trajectories); big: configs[4] (Nt256xNr64, 1024 '
-                         'trajectories, fp16 weights)')
+                         'trajectories, fp16 weights); train: one DSM optimiser step of train_score.py (SURVEY 8(f) F4; its '
+                         'own metric, not the BASELINE one; single GPU)')
+    ap.add_argument('--batch', type=int, default=32, help='--workload train: batch size (train_score.py:52)')
     ap.add_argument('--channels', type=int, default=None, help='channel realisations per GPU (test_score.py:77)')
     ap.add_argument('--snr-points', type=int, default=None)
     ap.add_argument('--graph', type=int, default=None,
@@ -129,8 +131,64 @@ def parse_args():
     return ap.parse_args()
 
 
+def bench_train(args):
+    """--workload train: one step = perturbation + forward + DSM loss + backward + Adam + EMA on a batch of synthetic
+    channels (train_score.py:145-173), everything resident on the device; prints one JSON line in the format of the
+    main bench."""
+    import torch
+    from score_based_channels_amd import plan as P, synth
+    from score_based_channels_amd.train import TrainNet
+    from score_based_channels_amd.train_score import fresh_state_dict, training_config
+    if args.gpus != 1:
+        raise SystemExit('--workload train runs on one GPU (the reference trains on one device, train_score.py:31)')
+    torch.cuda.set_device(0)
+    B = args.batch
+    cfg = training_config('CDL-C')
+    net = TrainNet(cfg, batch=B, device='cuda:0', seed=1)
+    net.load_state_dict(fresh_state_dict(cfg, 1))
+    raw = synth.generate_channels('CDL-C', max(B, 16), 64, 16, 0.5, seed=1234)[:B]
+    h = np.conj(np.transpose(raw / np.std(raw), (0, 2, 1)))
+    x = np.stack((h.real, h.imag), axis=1).astype(np.float32)
+    gen = torch.Generator().manual_seed(0)
+    labels = [torch.randint(0, cfg.model.num_classes, (B,), generator=gen) for _ in range(args.warmup + args.steps)]
+    graph = bool(args.graph) if args.graph is not None else False
+    with torch.cuda.stream(torch.cuda.Stream()):
+        for k in range(args.warmup):
+            net.step(x, labels[k], use_graph=graph)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            net.step(x, labels[args.warmup + k], use_graph=graph)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        loss = float(net.loss_per_sample.mean().item())
+        prof = net.profile_step(x, labels[0], repeats=3)
+    flops = 3 * P.count_conv_flops(net.plan) * B                 # forward + input-gradient + weight-gradient convolutions
+    names = {P.CONV: 'conv', P.CONV_WGRAD: 'conv_wgrad', P.GRAD_ADD: 'grad_add', P.INORM_BWD: 'inorm_bwd'}
+    classes = {('forward ' if t < 200 else 'reverse ') + names.get(t % 100, 'kind %d' % (t % 100)): round(ms, 3)
+               for t, (ms, n) in sorted(prof.items(), key=lambda kv: -kv[1][0])[:6]}
+    out = {'metric': 'samples/s DSM training step (train_score.py), CDL-C Nt64xNr16', 'value': B / dt, 'unit': 'samples/s',
+           'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt * 1e3, 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None,
+           'dtype': 'f32 (forward / input-gradient convolutions as exact 3-term bf16 splits, weight gradients on fp32 MFMA)',
+           'data': 'synthetic (CDL-C-like cluster channels, fresh nn.Conv2d-style initial weights)',
+           'config': {'workload': 'DSM optimiser step: batch %d of Nt64xNr16 channels, 2311 noise levels, Adam lr 1e-4 eps 1e-3, '
+                                  'EMA 0.999 (train_score.py:34-67); %s launches' % (B, 'hipGraph' if graph else 'eager')},
+           'final_loss': loss,
+           'roofline': {'bound': 'launch latency at this batch size (about 720 launches per step)', 'achieved': flops / dt / 1e12,
+                        'peak': 157.3, 'unit': 'TFLOP/s', 'frac': flops / dt / 1e12 / 157.3, 'traffic': None,
+                        'note': 'algorithmic conv FLOPs of the step (3 x forward) against the fp32 MFMA peak',
+                        'ms_by_operator_class': classes},
+           'cpu_baseline': {'value': None, 'note': 'the reference step (autograd, Adam, EMA) was timed in the build container '
+                                                   'only: 0.26-0.33 s per step of 32 on 8 cores (DESIGN.md section 10); there '
+                                                   'is no CPU port of the backward pass to time on this host'}}
+    print(json.dumps(out))
+
+
 def main():
     args = parse_args()
+    if args.workload == 'train':
+        return bench_train(args)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(args.gpus))
 
