@@ -148,3 +148,33 @@ def test_cli_train_score_writes_a_checkpoint_the_estimator_loads(tmp_path, monke
     assert np.mean(tl3) < np.mean(tl[:3])
     nmse_log, _, _ = test_score.main(['--synthetic', '--num_levels', '2', '--num_channels', '4', '--seed', '3', '--no_plot'])
     assert nmse_log.shape == (1, 1, 17, 6, 4) and np.isfinite(nmse_log).all()
+
+
+def test_training_step_on_a_large_array(weights64):
+    """Nt256 x Nr64 (the array of BASELINE config 5): one optimiser step runs, is finite, reproducible, and its loss equals
+    the forward-only loss of the same batch; the gradient of a small step along -grad lowers the loss."""
+    import torch
+    from score_based_channels_amd.config import default_config
+    from score_based_channels_amd.train import TrainNet
+    from score_based_channels_amd.weights import seeded_state_dict
+    cfg = default_config('CDL-C', image_size=(64, 256))
+    sd = seeded_state_dict(cfg, 2024)
+    rng = np.random.default_rng(0)
+    B = 2
+    x = rng.standard_normal((B, 2, 256, 64)).astype(np.float32)
+    z = rng.standard_normal((B, 2, 256, 64)).astype(np.float32)
+    labels = np.array([100, 2000])
+    net = TrainNet(cfg, batch=B).load_state_dict(sd)
+    fwd = net.loss(x, labels, z).clone()
+    bwd = net.backward(x, labels, z).clone()
+    assert torch.isfinite(fwd).all() and torch.equal(fwd, bwd)
+    g = net.grads.clone()
+    assert torch.isfinite(g).all() and float(g.abs().max()) > 0
+    net.backward(x, labels, z)
+    assert torch.equal(g, net.grads)
+    # first-order check of the whole gradient: loss(p) - loss(p - h g) ~= h |g|^2, with h chosen for a 0.1 % decrease
+    L0 = fwd.double().mean().item()
+    h = 1e-3 * L0 / float((g.double() ** 2).sum())
+    net.params.sub_(h * g)
+    dec = (L0 - net.loss(x, labels, z).double().mean().item()) / L0
+    assert 0.7e-3 < dec < 1.3e-3, dec

@@ -86,7 +86,8 @@ def test_grad_add(gpu, elu, accum):
 
 @pytest.mark.parametrize('C_,B,H,W,elu,accum', [(32, 3, 64, 16, True, False), (64, 5, 32, 8, True, True),
                                                  (64, 4, 16, 4, True, False), (128, 7, 8, 2, True, True),
-                                                 (32, 2, 64, 16, False, False)])
+                                                 (32, 2, 64, 16, False, False), (32, 1, 256, 64, True, False),
+                                                 (128, 2, 32, 8, True, True)])
 def test_inorm_backward_matches_autograd(gpu, C_, B, H, W, elu, accum):
     """d/dx and d/d(alpha, gamma, beta) of ELU(InstanceNorm2dPlus(x)) (normalization.py:163-176, layers.py:444-449)."""
     torch, _lib = gpu
@@ -187,6 +188,10 @@ WGRAD_CASES = [
     (128, 64, 3, 1, 6, 8, 2, ''),
     (64, 32, 3, 1, 2, 32, 8, ''),
     (32, 32, 3, 1, 70, 64, 16, 'elu'),          # more tiles than chunks: workgroups walk several tiles
+    (32, 32, 3, 1, 1, 256, 64, 'norm_elu'),     # large-array config (Nt256 x Nr64): one image row per tile, halo rows
+    (64, 64, 3, 1, 1, 128, 32, 'elu'),
+    (128, 128, 3, 4, 1, 32, 8, 'norm_elu'),     # dilation 4 with a real halo (tiles of 8 rows inside a 32-row image)
+    (64, 128, 3, 2, 2, 32, 8, 'norm_elu'),
 ]
 
 
