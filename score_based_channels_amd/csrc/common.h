@@ -65,6 +65,8 @@ int launch_adam_ema(const sbc_op& op, const sbc_adam& ext, hipStream_t stream);
 // The select is a median: exp(x) - 1 >= x everywhere, so for x > 0 the middle of (x, exp(x) - 1, 0) is x and for x < 0 it
 // is exp(x) - 1 -- one v_med3_f32 instead of compare + select.  (x = +inf gives med3(inf, inf, 0) = inf; NaN stays NaN.)
 __device__ __forceinline__ float elu1(float x) { return __builtin_amdgcn_fmed3f(x, __expf(x) - 1.f, 0.f); }
+// d ELU(x) / dx = 1 (x > 0), exp(x) (x <= 0)
+__device__ __forceinline__ float elu_grad1(float x) { return x > 0.f ? 1.f : __expf(x); }
 __device__ __forceinline__ float4 elu4(float4 v) {
     return make_float4(elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w));
 }

@@ -102,6 +102,18 @@ __device__ __forceinline__ void conv_epilogue(const float* lds, const ConvParams
             ok[i] = g.p0 + pl < p.total_px;
             o[i] = (unsigned)(g.p0 + pl) * COUT + c4 * 4;
         }
+        if (p.flags & SBC_EPI_ELUGRAD) {
+            // reverse pass: this convolution is the adjoint of a forward conv whose input went through ELU; `res2` holds that
+            // forward input: v = conv * ELU'(res2) [+ res1, the gradient collected so far -- may alias `out`]
+#pragma unroll
+            for (int i = 0; i < EC; ++i)
+                if (ok[i]) rr[i] = ld_stream(p.res2 + o[i]);
+#pragma unroll
+            for (int i = 0; i < EC; ++i) {
+                v[i].x *= elu_grad1(rr[i].x); v[i].y *= elu_grad1(rr[i].y);
+                v[i].z *= elu_grad1(rr[i].z); v[i].w *= elu_grad1(rr[i].w);
+            }
+        }
         if (p.res1) {
 #pragma unroll
             for (int i = 0; i < EC; ++i)
@@ -110,7 +122,7 @@ __device__ __forceinline__ void conv_epilogue(const float* lds, const ConvParams
 #pragma unroll
                 for (int i = 0; i < EC; ++i) rr[i] = elu4(rr[i]);
             }
-            if (p.res2) {
+            if (p.res2 && !(p.flags & SBC_EPI_ELUGRAD)) {
                 float4 r2[EC];
 #pragma unroll
                 for (int i = 0; i < EC; ++i)

@@ -230,6 +230,8 @@ int launch_conv(const sbc_op& op, hipStream_t stream, bool dry) {
     SBC_REQUIRE(op.dil >= 1, "conv: dilation %d", op.dil);
     SBC_REQUIRE(!(op.flags & SBC_PRO_NORM) || op.stats, "conv: PRO_NORM without stats");
     SBC_REQUIRE(!(op.flags & SBC_EPI_UP) || (op.up && op.up_h > 0 && op.up_w > 0), "conv: EPI_UP without up tensor");
+    SBC_REQUIRE(!(op.flags & SBC_EPI_ELUGRAD) || (op.res2 && !(op.flags & (SBC_EPI_POOL | SBC_EPI_RES1_ELU))),
+                "conv: EPI_ELUGRAD needs res2 (the forward input) and excludes EPI_POOL / EPI_RES1_ELU");
     SBC_REQUIRE(!((op.flags & SBC_EPI_POOL) && (op.res2 || (op.flags & (SBC_EPI_UP | SBC_EPI_RES1_ELU)))),
                 "conv: EPI_POOL combines only with res1");
     // pixel indices are int32, element offsets of the epilogues uint32: bound the larger of the two tensors
@@ -245,7 +247,8 @@ int launch_conv(const sbc_op& op, hipStream_t stream, bool dry) {
     p.hsh = log2_exact(op.H); p.wsh = log2_exact(op.W);
     p.plane = 0; p.stats_off = 0; p.top = op.tag == 1;
     static const bool no_wx3 = getenv("SBC_NO_WX3") != nullptr;                    // A/B aid: direct split-bf16 kernel everywhere
-    if (op.weight_wino_split && !f32_only && !no_wx3 && op.ksize == 3 && op.dil == 1) {
+    const bool direct_only = (op.flags & SBC_EPI_ELUGRAD) != 0;       // the Winograd kernels have their own epilogues
+    if (op.weight_wino_split && !f32_only && !no_wx3 && !direct_only && op.ksize == 3 && op.dil == 1) {
         ConvParams pw = p;
         pw.wpk = (const float4*)op.weight_wino_split;
         const int rc = launch_conv_wx3(pw, op.cin, op.cout, stream, dry);
@@ -256,7 +259,7 @@ int launch_conv(const sbc_op& op, hipStream_t stream, bool dry) {
         return launch_conv_x3(p, op.cin, op.cout, op.ksize, stream, dry);
     }
     static const bool no_wino = getenv("SBC_NO_WINO") != nullptr;                  // A/B aid
-    if (op.weight_wino && op.ksize == 3 && op.dil == 1 && !no_wino) {
+    if (op.weight_wino && op.ksize == 3 && op.dil == 1 && !no_wino && !direct_only) {
         ConvParams pw = p;
         pw.wpk = (const float4*)op.weight_wino;
         const int rc = launch_conv_wino(pw, op.cin, op.cout, stream, dry);

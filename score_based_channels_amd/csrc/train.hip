@@ -8,8 +8,7 @@
 
 namespace sbc {
 
-// d ELU(x) / dx = 1 (x > 0), exp(x) (x <= 0)    [nn.ELU(alpha = 1), layers.py:12-13]
-__device__ __forceinline__ float elu_grad1(float x) { return x > 0.f ? 1.f : __expf(x); }
+// elu_grad1 (common.h): d ELU(x) / dx    [nn.ELU(alpha = 1), layers.py:12-13]
 __device__ __forceinline__ float4 elu_grad4(float4 v) {
     return make_float4(elu_grad1(v.x), elu_grad1(v.y), elu_grad1(v.z), elu_grad1(v.w));
 }

@@ -26,7 +26,7 @@ from typing import List, Optional
 # op kinds / flags: numerically identical to include/sbc_hip.h
 BEGIN_CONV, INORM_STATS, CONV, MAXPOOL5, END_CONV, LANGEVIN, STEP_INC, MEASURE = 1, 2, 3, 4, 5, 6, 7, 8
 PRO_ELU, PRO_NORM = 0x001, 0x002
-EPI_RES1_ELU, EPI_POOL, EPI_UP = 0x010, 0x020, 0x040
+EPI_RES1_ELU, EPI_POOL, EPI_UP, EPI_ELUGRAD = 0x010, 0x020, 0x040, 0x080
 CONV_F16W = 0x100
 # training operators
 (DSM_PERTURB, DSM_LOSS, GRAD_ADD, INORM_BWD, MAXPOOL5_BWD, UPSAMPLE_BWD, POOL_BWD, CONV_WGRAD, PACK_WEIGHT, END_CONV_BWD,

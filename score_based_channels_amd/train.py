@@ -226,19 +226,50 @@ class TrainNet:
         return ops
 
     def _backward_ops(self, keep):
-        """Reverse-mode records: walk the forward list backwards; ``done`` holds the tensors whose gradient buffer already
-        has a first term (later terms are added with SBC_BWD_ACCUM)."""
+        """Reverse-mode records: walk the forward list backwards.  Per tensor the gradient is in one of three states:
+        nothing yet; ``alias`` -- exactly one plain term so far, which is simply another tensor's finished gradient buffer
+        (e.g. the ``+ x`` of a residual connection): nothing is copied until a second term arrives; ``done`` -- materialised
+        in the tensor's own buffer, further terms are added (SBC_BWD_ACCUM, or the adjoint convolution's own epilogue)."""
         B, sl, pl = self.B, self.slots, self.plan
         base, gr = self.params, self.grads
-        done = {id(pl.out)}
+        done, alias = set(), {}
         ops = []
         ext = _lib.sbc_endconv(sigmas=_ptr(self.sigmas), labels=_ptr(self.labels))
         keep.append(ext)
+        done.add(id(pl.out))                                   # written by SBC_OP_DSM_LOSS
+
+        def grad_add(t, src_buf, flags=0, x=None):
+            ops.append(_lib.sbc_op(kind=P.GRAD_ADD, flags=flags, B=B, H=t.h, W=t.w, cin=t.c,
+                                   in_=_ptr(sl[x.slot]) if x is not None else None, grad=_ptr(src_buf),
+                                   out=_ptr(self._grad_of(t))))
+
+        def materialise(t):
+            """Make the tensor's own buffer hold what has been collected so far; returns SBC_BWD_ACCUM if there is anything."""
+            if id(t) in alias:
+                grad_add(t, alias.pop(id(t)))
+                done.add(id(t))
+            return P.BWD_ACCUM if id(t) in done else 0
 
         def acc(t):
-            f = P.BWD_ACCUM if id(t) in done else 0
+            """Flag for a kernel that writes (first term) or adds to (later terms) the tensor's own buffer."""
+            f = materialise(t)
             done.add(id(t))
             return f
+
+        def add_plain(t, buf):
+            """g(t) += buf, where buf is a finished gradient buffer that nobody writes again."""
+            if id(t) not in done and id(t) not in alias:
+                alias[id(t)] = buf
+            else:
+                grad_add(t, buf, acc(t))
+
+        def current(t):
+            """The buffer that holds the complete gradient of t (call when every consumer of t has been reversed)."""
+            if id(t) in alias:
+                return alias[id(t)]
+            if id(t) not in done:
+                raise RuntimeError('no gradient reaches %s' % t.name)
+            return self._grad_of(t)
 
         def norm_params(stats_tensor):
             """state_dict prefix of the norm that produced a statistics tensor."""
@@ -257,9 +288,7 @@ class TrainNet:
         for op in reversed(pl.ops):
             if op.kind == P.INORM_STATS:
                 continue                                    # reversed together with the consumer of the statistics
-            if id(op.dst) not in done:
-                raise RuntimeError('no gradient reaches %s' % op.dst.name)
-            dy = self._grad_of(op.dst)
+            dy = current(op.dst)
             src = op.src
             if op.kind == P.END_CONV:
                 ops.append(_lib.sbc_op(kind=P.END_CONV_BWD, B=B, H=src.h, W=src.w, cin=src.c, cout=op.dst.c, ksize=3, dil=1,
@@ -273,18 +302,18 @@ class TrainNet:
                                        cin=src.c, in_=_ptr(sl[src.slot]), grad=_ptr(dy), out=_ptr(self._grad_of(src)),
                                        aux=C.c_void_p(self.pool_aux.data_ptr())))
             elif op.kind == P.BEGIN_CONV:
-                ops.append(_lib.sbc_op(kind=P.BEGIN_CONV_BWD, flags=P.OP_SIDE, B=B, H=src.h, W=src.w, cin=src.c, cout=op.dst.c, ksize=3, dil=1,
-                                       in_=_ptr(sl[src.slot]), grad=_ptr(dy), aux=_ptr(self.scratch),
+                ops.append(_lib.sbc_op(kind=P.BEGIN_CONV_BWD, flags=P.OP_SIDE, B=B, H=src.h, W=src.w, cin=src.c, cout=op.dst.c,
+                                       ksize=3, dil=1, in_=_ptr(sl[src.slot]), grad=_ptr(dy), aux=_ptr(self.scratch),
                                        wgrad=self._par(gr, op.weight), bgrad=self._par(gr, op.bias)))
             elif op.kind == P.CONV:
                 dst = op.dst
                 if op.res2 is not None:
-                    ops.append(_lib.sbc_op(kind=P.GRAD_ADD, flags=acc(op.res2), B=B, H=dst.h, W=dst.w, cin=dst.c,
-                                           grad=_ptr(dy), out=_ptr(self._grad_of(op.res2))))
+                    add_plain(op.res2, dy)
                 if op.res1 is not None:
-                    elu = P.PRO_ELU if op.flags & P.EPI_RES1_ELU else 0
-                    ops.append(_lib.sbc_op(kind=P.GRAD_ADD, flags=elu | acc(op.res1), B=B, H=dst.h, W=dst.w, cin=dst.c,
-                                           in_=_ptr(sl[op.res1.slot]), grad=_ptr(dy), out=_ptr(self._grad_of(op.res1))))
+                    if op.flags & P.EPI_RES1_ELU:
+                        grad_add(op.res1, dy, P.PRO_ELU | acc(op.res1), x=op.res1)
+                    else:
+                        add_plain(op.res1, dy)
                 if op.up is not None:
                     ops.append(_lib.sbc_op(kind=P.UPSAMPLE_BWD, flags=acc(op.up), B=B, H=dst.h, W=dst.w, cin=dst.c,
                                            up_h=op.up.h, up_w=op.up.w, grad=_ptr(dy), out=_ptr(self._grad_of(op.up))))
@@ -299,21 +328,26 @@ class TrainNet:
                                        stats=_ptr(sl[op.stats.slot]) if op.stats is not None else None, grad=_ptr(dc),
                                        aux=_ptr(self.scratch), wgrad=self._par(gr, op.weight),
                                        bgrad=self._par(gr, op.bias) if op.bias is not None else None))
-                # input gradient: the adjoint convolution dst.c -> src.c of dC, then back through the prologue
-                direct = pro == 0 and id(src) not in done
-                target = self._grad_of(src) if direct else self.tmp_a
-                ops.append(_lib.sbc_op(kind=P.CONV, B=B, H=src.h, W=src.w, cin=dst.c, cout=src.c, ksize=op.ksize, dil=op.dil,
-                                       in_=_ptr(dc), out=_ptr(target), weight_split=self._packed(op.weight, True)))
-                if direct:
-                    done.add(id(src))
-                elif pro == 0:
-                    ops.append(_lib.sbc_op(kind=P.GRAD_ADD, flags=acc(src), B=B, H=src.h, W=src.w, cin=src.c,
-                                           grad=_ptr(self.tmp_a), out=_ptr(self._grad_of(src))))
-                elif pro == P.PRO_ELU:
-                    ops.append(_lib.sbc_op(kind=P.GRAD_ADD, flags=P.PRO_ELU | acc(src), B=B, H=src.h, W=src.w, cin=src.c,
-                                           in_=_ptr(sl[src.slot]), grad=_ptr(self.tmp_a), out=_ptr(self._grad_of(src))))
-                else:
+                # input gradient: the adjoint convolution dst.c -> src.c of dC, then back through the prologue.  Without a
+                # norm in the prologue the convolution's own epilogue multiplies by ELU'(src) and adds what was collected
+                # before (an aliased buffer, or the tensor's own buffer in place)
+                adj = _lib.sbc_op(kind=P.CONV, B=B, H=src.h, W=src.w, cin=dst.c, cout=src.c, ksize=op.ksize, dil=op.dil,
+                                  in_=_ptr(dc), weight_split=self._packed(op.weight, True))
+                if pro & P.PRO_NORM:
+                    adj.out = _ptr(self.tmp_a)
+                    ops.append(adj)
                     inorm_bwd(src, op.stats, self.tmp_a)
+                else:
+                    if pro & P.PRO_ELU:
+                        adj.flags |= P.EPI_ELUGRAD
+                        adj.res2 = _ptr(sl[src.slot])
+                    if id(src) in alias:
+                        adj.res1 = _ptr(alias.pop(id(src)))
+                    elif id(src) in done:
+                        adj.res1 = _ptr(self._grad_of(src))
+                    adj.out = _ptr(self._grad_of(src))
+                    done.add(id(src))
+                    ops.append(adj)
             else:
                 raise NotImplementedError('no reverse rule for op kind %d' % op.kind)
         return ops

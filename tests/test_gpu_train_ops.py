@@ -254,27 +254,39 @@ def test_device_weight_packing_matches_host_packer(gpu, cin, cout, k):
         assert np.array_equal(out.cpu().numpy().view(np.uint16).ravel(), host.ravel()), adj
 
 
+@pytest.mark.parametrize('mode', ['plain', 'elu', 'elu_plus_other', 'elu_in_place'])
 @pytest.mark.parametrize('cin,cout,k,dil,B,H,W', [(32, 64, 1, 1, 2, 64, 16), (32, 64, 3, 1, 2, 64, 16), (64, 128, 3, 2, 5, 8, 2),
-                                                   (128, 64, 3, 1, 5, 8, 2), (64, 64, 3, 1, 3, 16, 4), (128, 128, 3, 4, 5, 8, 2)])
-def test_input_gradient_is_a_conv_with_adjoint_weights(gpu, cin, cout, k, dil, B, H, W):
-    """dL/d(conv input) = SBC_OP_CONV(grad, adjoint-packed weight): the route train.py takes for every convolution."""
+                                                   (128, 64, 3, 1, 5, 8, 2), (64, 64, 3, 1, 3, 16, 4), (128, 128, 3, 4, 5, 8, 2),
+                                                   (32, 32, 3, 1, 3, 64, 16)])
+def test_input_gradient_is_a_conv_with_adjoint_weights(gpu, cin, cout, k, dil, B, H, W, mode):
+    """dL/d(conv input) = SBC_OP_CONV(grad, adjoint-packed weight): the route train.py takes for every convolution.  With
+    SBC_EPI_ELUGRAD the epilogue also goes back through the forward ELU prologue (times ELU'(x)) and adds the gradient
+    collected so far, from another buffer or from the output buffer itself."""
     torch, _lib = gpu
     from score_based_channels_amd import plan as P
     rng = np.random.default_rng(cin * 3 + cout + k)
     w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(F32)
     g = rng.standard_normal((B, H, W, cout)).astype(F32)
-    a = torch.zeros(B, cin, H, W, dtype=torch.float64, requires_grad=True)
+    x = (rng.standard_normal((B, H, W, cin)) * 1.5).astype(F32)
+    other = rng.standard_normal((B, H, W, cin)).astype(F32)
+    xt = _nchw(torch, x)
+    a = torch.nn.functional.elu(xt) if mode != 'plain' else xt
     y = torch.nn.functional.conv2d(a, torch.from_numpy(w).double(), None, padding=dil * (k // 2), dilation=dil)
     y.backward(torch.from_numpy(g.transpose(0, 3, 1, 2).copy()).double())
-    dw, dg = _dev(torch, w), _dev(torch, g)
+    ref = _nhwc(xt.grad) + (other if mode in ('elu_plus_other', 'elu_in_place') else 0.0)
+    dw, dg, dx, dother = _dev(torch, w), _dev(torch, g), _dev(torch, x), _dev(torch, other)
     packed = torch.zeros(w.size * 3, dtype=torch.int16, device='cuda')
     op = _lib.sbc_op(kind=P.PACK_WEIGHT, flags=P.PACK_ADJOINT, cin=cin, cout=cout, ksize=k, in_=_p(dw), out=_p(packed))
     _launch(gpu, op)
-    out = torch.full((B, H, W, cin), float('nan'), dtype=torch.float32, device='cuda')
+    out = dother if mode == 'elu_in_place' else torch.full((B, H, W, cin), float('nan'), dtype=torch.float32, device='cuda')
     op = _lib.sbc_op(kind=P.CONV, B=B, H=H, W=W, cin=cout, cout=cin, ksize=k, dil=dil, in_=_p(dg), out=_p(out),
                      weight_split=_p(packed))
+    if mode != 'plain':
+        op.flags, op.res2 = P.EPI_ELUGRAD, _p(dx)
+    if mode in ('elu_plus_other', 'elu_in_place'):
+        op.res1 = _p(dother)
     _launch(gpu, op)
-    assert rel_err(out.cpu().numpy(), _nhwc(a.grad)) < TOL
+    assert rel_err(out.cpu().numpy(), ref) < TOL
 
 
 def test_end_conv_backward_matches_autograd(gpu):
