@@ -126,6 +126,9 @@ def parse_args():
                     help='with --gpus 1: still create a one-rank RCCL process group and route the barrier / max / gather through it')
     ap.add_argument('--conv-mode', default=None, choices=['bf16x3', 'f32', 'f16w'],
                     help='convolution multiplier (scorenet.CONV_MODES); default bf16x3, f16w for --workload big')
+    ap.add_argument('--overlap', type=int, default=None,
+                    help='1: independent low-resolution branches of the network on the plan side stream, 0: strictly '
+                         'sequential launches; default: scorenet.DEFAULT_OVERLAP')
     ap.add_argument('--streams', type=int, default=1,
                     help='split the trajectories into this many concurrent sub-batch streams (DESIGN.md section 7)')
     return ap.parse_args()
@@ -237,7 +240,8 @@ def main():
     profile = 'ULA' if big else 'CDL-C'
     cfg = default_config('CDL-C', image_size=(nr, nt)) if big else default_config('CDL-C')
     sd = seeded_state_dict(cfg, 2024)                     # random-init weights of the reference architecture
-    net = ScoreNet(cfg, 'cuda:%d' % local, conv_mode=conv_mode).load_state_dict(sd)
+    net = ScoreNet(cfg, 'cuda:%d' % local, conv_mode=conv_mode,
+                   overlap=None if args.overlap is None else bool(args.overlap)).load_state_dict(sd)
     use_graph = DEFAULT_USE_GRAPH if args.graph is None else bool(args.graph)
     snr = np.arange(-10, 32.5, 2.5)[:nsnr]
 

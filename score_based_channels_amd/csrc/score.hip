@@ -86,14 +86,18 @@ struct Builder {
         const int p1 = maxpool(p + "pool1", path0, false);
         return conv(p + "convs.1", p1, p + "convs.1", t[x].c, false, SBC_EPI_RES1_ELU, -1, x, path0);
     }
-    int msf(const std::string& p, int h0, int h1, int features) {                              // layers.py:178-184
-        const int t1 = conv(p + "convs.1", h1, p + "convs.1", features);
-        return conv(p + "convs.0", h0, p + "convs.0", features, true, 0, -1, -1, -1, t1);
-    }
-    int refine(const std::string& p, const std::vector<int>& xs, int features, bool end = false) {   // layers.py:234-249
-        std::vector<int> hs;
-        for (size_t i = 0; i < xs.size(); ++i) hs.push_back(rcu(p + "adapt_convs." + std::to_string(i) + ".", xs[i], 2));
-        int h = xs.size() > 1 ? msf(p + "msf.", hs[0], hs[1], features) : hs[0];
+    // layers.py:234-249 with MSF (layers.py:178-184): the second input's adapt convolutions and its MSF convolution come
+    // first (they do not depend on the first input's; plan.py issues them as side records when asked to overlap)
+    int refine(const std::string& p, const std::vector<int>& xs, int features, bool end = false) {
+        int h;
+        if (xs.size() == 1) {
+            h = rcu(p + "adapt_convs.0.", xs[0], 2);
+        } else {
+            const int h1 = rcu(p + "adapt_convs.1.", xs[1], 2);
+            const int t1 = conv(p + "msf.convs.1", h1, p + "msf.convs.1", features);
+            const int h0 = rcu(p + "adapt_convs.0.", xs[0], 2);
+            h = conv(p + "msf.convs.0", h0, p + "msf.convs.0", features, true, 0, -1, -1, -1, t1);
+        }
         h = crp(p + "crp.", h);
         return rcu(p + "output_convs.", h, end ? 3 : 1);
     }

@@ -67,6 +67,8 @@ class Op:
     ksize: int = 3
     dil: int = 1
     tag: int = 0
+    side: bool = False        # may overlap the records that follow it, up to the next ``join`` record (SBC_OP_SIDE)
+    join: bool = False        # waits for every side record issued before it (SBC_OP_JOIN)
 
     def inputs(self):
         return [t for t in (self.src, self.stats, self.res1, self.res2, self.up) if t is not None]
@@ -82,9 +84,11 @@ class ScorePlan:
 
 
 class _Builder:
-    def __init__(self, ngf, nt, nr):
+    def __init__(self, ngf, nt, nr, overlap=False):
         self.ngf, self.nt, self.nr = ngf, nt, nr
         self.ops, self.tensors = [], []
+        self.overlap = overlap      # mark independent low-resolution branches as side records
+        self.side_now = False       # records appended while set carry ``side``
 
     def t(self, name, h, w, c):
         x = Tensor(name, h, w, c)
@@ -98,8 +102,14 @@ class _Builder:
         tag = TAG_CONV_TOP if (ksize == 3 and src.c == self.ngf and cout == self.ngf and src.h == self.nt) else 0
         self.ops.append(Op(CONV, name, src=src, dst=dst, weight=wkey + '.weight',
                            bias=(wkey + '.bias') if bias else None, stats=stats, res1=res1, res2=res2, up=up,
-                           flags=flags | (EPI_UP if up is not None else 0), ksize=ksize, dil=dil, tag=tag))
+                           flags=flags | (EPI_UP if up is not None else 0), ksize=ksize, dil=dil, tag=tag,
+                           side=self.side_now))
         return dst
+
+    def low_res(self, t):
+        """Branches are overlapped only below full resolution: full-resolution launches fill the chip on their own, and the
+        dominant kernel's per-launch time (the roofline entry of bench.py) stays the time it runs alone."""
+        return self.overlap and t.h < self.nt
 
     def stats(self, name, src, nkey):
         dst = self.t(name, 1, 3, src.c)
@@ -120,15 +130,24 @@ class _Builder:
         s1 = self.stats(p + 'normalize1', x, p + 'normalize1')
         a = self.conv(p + 'conv1', x, p + 'conv1', c1, flags=PRO_NORM | PRO_ELU, stats=s1, dil=d)
         s2 = self.stats(p + 'normalize2', a, p + 'normalize2')
-        if pooled:
-            sc = self.conv(p + 'shortcut', x, p + 'shortcut.conv', cout, flags=EPI_POOL, ksize=1)
-            return self.conv(p + 'conv2', a, p + 'conv2.conv', cout, flags=PRO_NORM | PRO_ELU | EPI_POOL,
-                             stats=s2, res1=sc)
-        if x.c != cout or resample is not None:
-            sc = self.conv(p + 'shortcut', x, p + 'shortcut', cout, dil=d)
+        has_sc = pooled or x.c != cout or resample is not None
+        if has_sc:
+            # the shortcut convolution only meets the main branch again at conv2's residual add
+            self.side_now = self.low_res(x)
+            if pooled:
+                sc = self.conv(p + 'shortcut', x, p + 'shortcut.conv', cout, flags=EPI_POOL, ksize=1)
+            else:
+                sc = self.conv(p + 'shortcut', x, p + 'shortcut', cout, dil=d)
+            joined = self.side_now
+            self.side_now = False
         else:
-            sc = x
-        return self.conv(p + 'conv2', a, p + 'conv2', cout, flags=PRO_NORM | PRO_ELU, stats=s2, res1=sc, dil=d)
+            sc, joined = x, False
+        if pooled:
+            out = self.conv(p + 'conv2', a, p + 'conv2.conv', cout, flags=PRO_NORM | PRO_ELU | EPI_POOL, stats=s2, res1=sc)
+        else:
+            out = self.conv(p + 'conv2', a, p + 'conv2', cout, flags=PRO_NORM | PRO_ELU, stats=s2, res1=sc, dil=d)
+        self.ops[-1].join = joined
+        return out
 
     def rcu(self, p, x, n_blocks):
         """layers.py:126-134 (n_stages = 2, no bias)."""
@@ -144,26 +163,32 @@ class _Builder:
         p1 = self.maxpool(p + 'pool1', path0, elu=False)
         return self.conv(p + 'convs.1', p1, p + 'convs.1', x.c, bias=False, flags=EPI_RES1_ELU, res1=x, res2=path0)
 
-    def msf(self, p, hs, features):
-        """layers.py:178-184 for two inputs; the second may be at half resolution."""
-        t1 = self.conv(p + 'convs.1', hs[1], p + 'convs.1', features)
-        return self.conv(p + 'convs.0', hs[0], p + 'convs.0', features, up=t1)
-
     def refine(self, p, xs, features, end=False):
-        """layers.py:234-249."""
-        hs = [self.rcu(p + 'adapt_convs.%d.' % i, x, 2) for i, x in enumerate(xs)]
-        h = self.msf(p + 'msf.', hs, features) if len(xs) > 1 else hs[0]
+        """layers.py:234-249; MSF (layers.py:178-184) for two inputs, the second may be at half resolution.  The second
+        input's adapt convolutions and its MSF convolution do not depend on the first input's: with ``overlap`` they are
+        issued first as side records and the first input's MSF convolution (which adds their result) joins them."""
+        if len(xs) == 1:
+            h = self.rcu(p + 'adapt_convs.0.', xs[0], 2)
+        else:
+            self.side_now = self.low_res(xs[0])
+            h1 = self.rcu(p + 'adapt_convs.1.', xs[1], 2)
+            t1 = self.conv(p + 'msf.convs.1', h1, p + 'msf.convs.1', features)
+            joined = self.side_now
+            self.side_now = False
+            h0 = self.rcu(p + 'adapt_convs.0.', xs[0], 2)
+            h = self.conv(p + 'msf.convs.0', h0, p + 'msf.convs.0', features, up=t1)
+            self.ops[-1].join = joined
         h = self.crp(p + 'crp.', h)
         return self.rcu(p + 'output_convs.', h, 3 if end else 1)
 
 
-def build_score_plan(ngf=32, nt=64, nr=16, channels=2, share_slots=True):
+def build_score_plan(ngf=32, nt=64, nr=16, channels=2, share_slots=True, overlap=False):
     """Op list of one ``NCSNv2Deepest.forward`` for ``[B, 2, nt, nr]`` inputs (ncsnv2.py:269-300).
     ``share_slots=False`` gives every logical tensor its own storage (a training step reads every activation again on
     the way back, ``train.py``)."""
     if nt % 8 or nr % 8:
         raise ValueError('Nt and Nr must be multiples of 8 (three 2x mean-pools), got %dx%d' % (nt, nr))
-    b = _Builder(ngf, nt, nr)
+    b = _Builder(ngf, nt, nr, overlap)
     x = b.t('x', nt, nr, channels)
     h = b.t('begin_conv', nt, nr, ngf)
     b.ops.append(Op(BEGIN_CONV, 'begin_conv', src=x, dst=h, weight='begin_conv.weight', bias='begin_conv.bias'))
@@ -198,10 +223,16 @@ def build_score_plan(ngf=32, nt=64, nr=16, channels=2, share_slots=True):
 def assign_slots(plan):
     """Share storage between logical tensors with disjoint lifetimes (linear-scan over the op list).
     The network input and output keep private slots (they are caller-visible)."""
+    # a side record may still be running until the next join record: what it reads stays live until then
+    done_at, nxt = [0] * len(plan.ops), len(plan.ops) - 1
+    for i in range(len(plan.ops) - 1, -1, -1):
+        if plan.ops[i].join:
+            nxt = i
+        done_at[i] = nxt if plan.ops[i].side else i
     last_use = {}
     for i, op in enumerate(plan.ops):
         for t in op.inputs():
-            last_use[id(t)] = i
+            last_use[id(t)] = max(last_use.get(id(t), -1), done_at[i])
     pinned = {id(plan.x), id(plan.out)}
     free = {}                     # elems -> [slot]
     slot_elems = []

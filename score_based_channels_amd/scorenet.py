@@ -35,6 +35,7 @@ class BoundScore:
 
 
 CONV_MODES = ('bf16x3', 'f32', 'f16w')
+DEFAULT_OVERLAP = False
 
 
 class ScoreNet:
@@ -55,10 +56,14 @@ class ScoreNet:
                             ``.half()``, layers.py:179); tolerance stated in tests/test_gpu_parity.py.
     """
 
-    def __init__(self, config, device=None, conv_mode='bf16x3'):
+    def __init__(self, config, device=None, conv_mode='bf16x3', overlap=None):
         if conv_mode not in CONV_MODES:
             raise ValueError('conv_mode must be one of %s, got %r' % (CONV_MODES, conv_mode))
         self.conv_mode = conv_mode
+        # overlap: run the independent low-resolution branches of the network (shortcut convolutions, the second input's
+        # adapt / MSF convolutions of a RefineBlock) on the plan's side stream (plan.py, SBC_OP_SIDE); same arithmetic,
+        # bit-identical results
+        self.overlap = DEFAULT_OVERLAP if overlap is None else bool(overlap)
         self.config = config
         m, d = config.model, config.data
         if str(m.normalization) != 'InstanceNorm++' or str(m.nonlinearity).lower() != 'elu':
@@ -157,7 +162,7 @@ class ScoreNet:
     def score_plan(self, nt, nr):
         key = (nt, nr)
         if key not in self._plans:
-            self._plans[key] = P.build_score_plan(self.ngf, nt, nr, self.channels)
+            self._plans[key] = P.build_score_plan(self.ngf, nt, nr, self.channels, overlap=self.overlap)
         return self._plans[key]
 
     def bind(self, B, nt, nr, *, step=None, sigma_of_step=None, use_labels=True):
@@ -178,6 +183,7 @@ class ScoreNet:
         for op in pl.ops:
             o = _lib.sbc_op()
             o.kind, o.flags, o.B, o.H, o.W = op.kind, op.flags, B, op.src.h, op.src.w
+            o.flags |= (P.OP_SIDE if op.side else 0) | (P.OP_JOIN if op.join else 0)
             o.cin, o.cout, o.ksize, o.dil, o.tag = op.src.c, op.dst.c, op.ksize, op.dil, op.tag
             o.in_ = _ptr(slots[op.src.slot])
             o.out = _ptr(slots[op.dst.slot])

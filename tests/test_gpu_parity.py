@@ -479,3 +479,21 @@ def test_full_batch_is_the_sum_of_its_trajectories(net64):
     pick = np.array([0, 777, 1203, 1699])
     Xb, Lb = run(pick)
     assert np.array_equal(Xa[pick], Xb) and np.array_equal(La[:, pick], Lb)
+
+
+def test_overlapped_branches_do_not_change_results(weights64):
+    """``ScoreNet(overlap=True)``: shortcut convolutions and the second input's adapt / MSF convolutions of the low-resolution
+    RefineBlocks run on the plan's side stream (SBC_OP_SIDE / SBC_OP_JOIN), with activation slots kept live until the join.
+    Same kernels on the same data: the score must be bit-identical to the sequential plan, launch after launch."""
+    import torch
+    from score_based_channels_amd.scorenet import ScoreNet
+    cfg, sd = weights64
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(rng.standard_normal((96, 2, 64, 16)).astype(np.float32))
+    labels = torch.from_numpy(rng.integers(0, 2311, 96))
+    seq = ScoreNet(cfg, overlap=False).cuda().load_state_dict(sd)
+    ovl = ScoreNet(cfg, overlap=True).cuda().load_state_dict(sd)
+    ref = seq(x, labels)
+    assert sum(o.side for o in ovl.score_plan(64, 16).ops) == 24
+    for rep in range(6):
+        assert torch.equal(ovl(x, labels), ref), rep
