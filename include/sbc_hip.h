@@ -186,6 +186,8 @@ typedef struct sbc_dsm {
     int32_t offset;              /* Philox counter word 1 (the optimiser step) = offset + *step */
     float anneal_power;          /* dsm.py:7 (2 in train_score.py:55) */
     const int32_t* step;         /* device step counter or NULL (= 0): lets a replayed plan draw fresh noise every step */
+    float grad_scale;            /* DSM_LOSS: extra factor on d loss / d scores; 0 means 1.  1 / world_size makes the SUM
+                                    all-reduce of data-parallel ranks the gradient of the mean over the global batch */
 } sbc_dsm;
 
 typedef struct sbc_adam {

@@ -51,7 +51,8 @@ class sbc_langevin(C.Structure):
 
 class sbc_dsm(C.Structure):
     _fields_ = [('sigmas', C.c_void_p), ('labels', C.c_void_p), ('noise', C.c_void_p), ('sample_id', C.c_void_p),
-                ('seed', C.c_uint64), ('offset', C.c_int32), ('anneal_power', C.c_float), ('step', C.c_void_p)]
+                ('seed', C.c_uint64), ('offset', C.c_int32), ('anneal_power', C.c_float), ('step', C.c_void_p),
+                ('grad_scale', C.c_float)]
 
 
 class sbc_adam(C.Structure):

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void dsm_loss_kernel(const float* __restrict__
     const float sigma = e.sigmas[e.labels[b]];
     const float inv = -(1.f / (sigma * sigma));
     const float wp = e.anneal_power == 2.f ? sigma * sigma : powf(sigma, e.anneal_power);
-    const float gs = wp / (float)B;
+    const float gs = wp / (float)B * (e.grad_scale != 0.f ? e.grad_scale : 1.f);
     float acc = 0.f;
     for (int i = tid; i < n; i += 256) {
         const float d = s[(size_t)b * n + i] - inv * nz[(size_t)b * n + i];

@@ -60,3 +60,18 @@ def gather_trajectory_logs(local_log, n_items, rank, world):
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad)
     return torch.cat([parts[r][:, :int(b[r + 1] - b[r])] for r in range(world)], dim=1)
+
+
+def all_reduce_sum_(t, world):
+    """In-place SUM all-reduce of a device tensor (the flat gradient buffer of data-parallel training, train.py).  RCCL
+    reduces it where it lies; a gloo group (CPU tests, more ranks than GPUs) takes it through host memory."""
+    if world == 1:
+        return t
+    import torch.distributed as dist
+    if dist.get_backend() == 'nccl' or not t.is_cuda:
+        dist.all_reduce(t)
+    else:
+        h = t.cpu()
+        dist.all_reduce(h)
+        t.copy_(h)
+    return t

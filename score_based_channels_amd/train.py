@@ -38,7 +38,7 @@ class TrainNet:
     ``loss(samples, labels, noise, ema=False)`` evaluates the loss only (validation, ``train_score.py:178-185``);
     ``backward(samples, labels, noise)`` stops after the gradients (parity tests)."""
 
-    def __init__(self, config, batch, nt=None, nr=None, device=None, seed=0):
+    def __init__(self, config, batch, nt=None, nr=None, device=None, seed=0, rank=0, world=1):
         m, d, o, tr = config.model, config.data, config.optim, config.training
         if str(m.normalization) != 'InstanceNorm++' or str(m.nonlinearity).lower() != 'elu':
             raise NotImplementedError('the HIP path implements InstanceNorm++ / ELU (train_score.py:39-40)')
@@ -58,6 +58,10 @@ class TrainNet:
         self.ema_mu = float(m.ema_rate) if m.ema and m.ema_rate else -1.0
         self.anneal_power = float(tr.anneal_power) if tr and tr.anneal_power else 2.0
         self.seed = int(seed)
+        # data parallel: `batch` samples per rank; the loss gradient is scaled by 1 / world so that the SUM all-reduce of the
+        # flat gradient buffer is the gradient of the mean over the global batch; Philox streams are keyed by the GLOBAL
+        # sample index, so a step does not depend on how the batch is split
+        self.rank, self.world = int(rank), int(world)
         self.plan = P.build_score_plan(self.ngf, self.nt, self.nr, self.channels, share_slots=False)
         self._layout()
         self._alloc()
@@ -101,6 +105,7 @@ class TrainNet:
         self.noise = torch.zeros(B, n, **f32)                         # sigma_b * z (kept for the loss)
         self.replay = torch.zeros(B, n, **f32)                        # standard-normal draws to replay (parity runs)
         self.labels = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.sample_id = (torch.arange(B, dtype=torch.int64) + self.rank * B).to(dev)
         self.loss_per_sample = torch.zeros(B, **f32)
         self._make_pack_table()
         big = max(t.elems for t in pl.tensors)
@@ -353,31 +358,34 @@ class TrainNet:
         return ops
 
     def _build(self, mode):
-        """mode: 'step' (full optimiser step), 'backward' (gradients only), 'loss' / 'loss_ema' (forward only)."""
+        """mode: 'step' (full optimiser step), 'backward' (gradients only), 'apply' (optimiser only), 'loss' / 'loss_ema'
+        (forward only)."""
         keep = []
         base = self.state[2] if mode == 'loss_ema' else self.params
         pl = self.plan
-        dsm = _lib.sbc_dsm(sigmas=_ptr(self.sigmas), labels=_ptr(self.labels), noise=None, seed=self.seed, offset=0,
-                           anneal_power=self.anneal_power, step=_ptr(self.step_count))
-        dsm_replay = _lib.sbc_dsm(sigmas=_ptr(self.sigmas), labels=_ptr(self.labels), noise=_ptr(self.replay), seed=self.seed,
-                                  offset=0, anneal_power=self.anneal_power, step=_ptr(self.step_count))
+        common = dict(sigmas=_ptr(self.sigmas), labels=_ptr(self.labels), sample_id=_ptr(self.sample_id), seed=self.seed,
+                      offset=0, anneal_power=self.anneal_power, step=_ptr(self.step_count), grad_scale=1.0 / self.world)
+        dsm = _lib.sbc_dsm(noise=None, **common)
+        dsm_replay = _lib.sbc_dsm(noise=_ptr(self.replay), **common)
         keep += [dsm, dsm_replay]
         plans = {}
         for replay in (False, True):
             e = dsm_replay if replay else dsm
             ep = C.cast(C.pointer(e), C.c_void_p)
-            ops = self._pack_ops(base)
-            ops.append(_lib.sbc_op(kind=P.DSM_PERTURB, B=self.B, H=self.nt, W=self.nr, cin=self.channels, in_=_ptr(self.samples),
-                                   out=_ptr(self.slots[pl.x.slot]), aux=_ptr(self.noise), ext=ep))
-            ops += self._forward_ops(base, keep)
             want_grad = mode in ('step', 'backward')
-            ops.append(_lib.sbc_op(kind=P.DSM_LOSS, B=self.B, H=self.nt, W=self.nr, cin=self.channels,
-                                   in_=_ptr(self.slots[pl.out.slot]), grad=_ptr(self.noise), out=_ptr(self.loss_per_sample),
-                                   aux=_ptr(self._grad_of(pl.out)) if want_grad else None, ext=ep))
+            ops = []
+            if mode != 'apply':                                  # 'apply' = optimiser only (after the gradient all-reduce)
+                ops += self._pack_ops(base)
+                ops.append(_lib.sbc_op(kind=P.DSM_PERTURB, B=self.B, H=self.nt, W=self.nr, cin=self.channels,
+                                       in_=_ptr(self.samples), out=_ptr(self.slots[pl.x.slot]), aux=_ptr(self.noise), ext=ep))
+                ops += self._forward_ops(base, keep)
+                ops.append(_lib.sbc_op(kind=P.DSM_LOSS, B=self.B, H=self.nt, W=self.nr, cin=self.channels,
+                                       in_=_ptr(self.slots[pl.out.slot]), grad=_ptr(self.noise), out=_ptr(self.loss_per_sample),
+                                       aux=_ptr(self._grad_of(pl.out)) if want_grad else None, ext=ep))
             n_fwd = len(ops)
             if want_grad:
                 ops += self._backward_ops(keep)
-            if mode == 'step':
+            if mode in ('step', 'apply'):
                 adam = _lib.sbc_adam(n=self.n_params, lr=self.lr, beta1=self.beta1, beta2=0.999, eps=self.eps,
                                      ema_mu=self.ema_mu, step=_ptr(self.step_count))
                 keep.append(adam)
@@ -433,8 +441,17 @@ class TrainNet:
         return out
 
     def step(self, samples, labels, noise=None, use_graph=False):
-        """One optimiser step (train_score.py:145-173); returns the per-sample losses (device tensor)."""
-        return self._run('step', samples, labels, noise, use_graph)
+        """One optimiser step (train_score.py:145-173); returns the per-sample losses (device tensor) of this rank's
+        samples.  With ``world`` > 1: backward, SUM all-reduce of the flat gradient buffer (RCCL), optimiser."""
+        if self.world == 1:
+            return self._run('step', samples, labels, noise, use_graph)
+        from . import shard
+        per = self._run('backward', samples, labels, noise, use_graph)
+        shard.all_reduce_sum_(self.grads, self.world)
+        if 'apply' not in self._plans:
+            self._plans['apply'] = self._build('apply')
+        self._plans['apply'][False].run(torch.cuda.current_stream(self.device).cuda_stream, 1, use_graph)
+        return per
 
     def backward(self, samples, labels, noise=None):
         """Loss and gradients only (``loss.backward()`` without ``optimizer.step()``)."""

@@ -101,9 +101,18 @@ def main(argv=None):
     from .loaders import Channels
     from .train import TrainNet
 
-    device = 'cuda:%d' % args.gpu
+    from . import shard
+    rank, world, local = shard.init_distributed(os.environ.get('SBC_DIST_BACKEND'))
+    n_dev = max(1, torch.cuda.device_count())
+    device = 'cuda:%d' % ((local % n_dev) if world > 1 else args.gpu)
     torch.cuda.set_device(device)
     seed = int.from_bytes(os.urandom(4), 'little') if args.seed is None else args.seed
+    if world > 1:                                         # every rank must use rank 0's seed
+        import torch.distributed as dist
+        t = torch.tensor([seed], dtype=torch.int64)
+        t = t.to(device) if dist.get_backend() == 'nccl' else t
+        dist.broadcast(t, 0)
+        seed = int(t.item())
     np.random.seed(seed % (2 ** 32))                      # pilots of the datasets (loaders.py:52-55)
     gen = torch.Generator().manual_seed(seed)             # batch order and noise levels
 
@@ -114,44 +123,62 @@ def main(argv=None):
     dataset = Channels(train_seed, config, norm=config.data.norm_channels, **kw)
     val_dataset = Channels(val_seed, config, norm=[dataset.mean, dataset.std], **kw)
     train_x, val_x = herm_real_view(dataset), herm_real_view(val_dataset)
-    B = args.batch_size
-    if len(train_x) < B:
-        raise ValueError('%d training channels < batch size %d' % (len(train_x), B))
+    # data parallel (torch.distributed.run): --batch_size stays the GLOBAL batch of train_score.py:52, every rank takes a
+    # contiguous share of it; gradients are summed by one all-reduce per step (RCCL), so the run is the same optimisation
+    # as on one GPU
+    Bg = args.batch_size
+    if Bg % world:
+        raise ValueError('batch size %d is not a multiple of the world size %d' % (Bg, world))
+    B = Bg // world
+    if len(train_x) < Bg:
+        raise ValueError('%d training channels < batch size %d' % (len(train_x), Bg))
 
-    net = TrainNet(config, batch=B, device=device, seed=seed)
+    net = TrainNet(config, batch=B, device=device, seed=seed, rank=rank, world=world)
     if args.init:
         net.load_state_dict(load_checkpoint(args.init)['model_state'])
     else:
         net.load_state_dict(fresh_state_dict(config, seed))
     L = config.model.num_classes
 
+    def global_mean(per):
+        """Mean of the per-sample losses over all ranks (every rank has the same count)."""
+        t = per.double().sum().reshape(1)
+        if world > 1:
+            import torch.distributed as dist
+            t = t if dist.get_backend() == 'nccl' else t.cpu()
+            dist.all_reduce(t)
+        return float(t.item()) / (per.numel() * world)
+
     def val_loss_ema():
         """train_score.py:172-185: DSM loss of the EMA copy on the validation channels (fresh labels and noise), here in
         chunks of the training batch size; the mean over all samples."""
         tot, cnt = 0.0, 0
-        for s in range(0, len(val_x) - B + 1, B):
-            per = net.loss(val_x[s:s + B], torch.randint(0, L, (B,), generator=gen), ema=bool(config.model.ema))
-            tot, cnt = tot + float(per.sum().item()), cnt + B
+        for s in range(0, len(val_x) - Bg + 1, Bg):
+            labels = torch.randint(0, L, (Bg,), generator=gen)[rank * B:(rank + 1) * B]
+            per = net.loss(val_x[s + rank * B:s + (rank + 1) * B], labels, ema=bool(config.model.ema))
+            tot, cnt = tot + global_mean(per), cnt + 1
         return tot / max(cnt, 1)
 
     train_loss, val_loss = [], []
     step, running = 0, 0.0
     done = False
-    steps_per_epoch = len(train_x) // B                    # drop_last=True (:75)
+    steps_per_epoch = len(train_x) // Bg                   # drop_last=True (:75)
     torch.cuda.synchronize(device)
     torch.cuda.set_stream(torch.cuda.Stream(device))       # hipGraph replay needs a stream of its own
     for epoch in range(config.training.n_epochs):
         order = torch.randperm(len(train_x), generator=gen).numpy()          # shuffle=True (:74)
         for i in range(steps_per_epoch):
             step += 1
-            batch = train_x[order[i * B:(i + 1) * B]]
-            labels = torch.randint(0, L, (B,), generator=gen)                 # dsm.py:9-12
-            loss = float(net.step(batch, labels, use_graph=args.graph).mean().item())   # :151-167 (.item() as :156-159)
+            mine = slice(i * Bg + rank * B, i * Bg + (rank + 1) * B)       # this rank's share of the global batch
+            batch = train_x[order[mine]]
+            labels = torch.randint(0, L, (Bg,), generator=gen)[rank * B:(rank + 1) * B]      # dsm.py:9-12
+            loss = global_mean(net.step(batch, labels, use_graph=args.graph))       # :151-167 (.item() as :156-159)
             running = loss if step == 1 else 0.99 * running + 0.01 * loss
             train_loss.append(loss)
             if step % args.val_every == 0:
                 val_loss.append([val_loss_ema()])
-                print('Epoch %d, Step %d, Train Loss (EMA) %.3f, Val. Loss %.3f' % (epoch, step, running, val_loss[-1][0]))
+                if rank == 0:
+                    print('Epoch %d, Step %d, Train Loss (EMA) %.3f, Val. Loss %.3f' % (epoch, step, running, val_loss[-1][0]))
             if args.max_steps is not None and step >= args.max_steps:
                 done = True
                 break
@@ -160,6 +187,12 @@ def main(argv=None):
 
     torch.cuda.synchronize(device)
     torch.cuda.set_stream(torch.cuda.default_stream(device))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        if rank != 0:                                      # replicas are identical: rank 0 writes the checkpoint
+            dist.destroy_process_group()
+            return train_loss, val_loss
     out_dir = args.out_dir or './models/score/%s' % args.train
     os.makedirs(out_dir, exist_ok=True)
     config.log_path = out_dir
@@ -168,6 +201,9 @@ def main(argv=None):
                 'train_loss': train_loss, 'val_loss': val_loss,
                 'ema_state': to_t(net.ema_state_dict()), 'seed': seed},           # two additions of this build
                os.path.join(out_dir, 'final_model.pt'))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
     return train_loss, val_loss
 
 

@@ -178,3 +178,33 @@ def test_training_step_on_a_large_array(weights64):
     net.params.sub_(h * g)
     dec = (L0 - net.loss(x, labels, z).double().mean().item()) / L0
     assert 0.7e-3 < dec < 1.3e-3, dec
+
+
+def test_data_parallel_training_is_the_same_optimisation(tmp_path):
+    """``torch.distributed.run --nproc-per-node 2 -m score_based_channels_amd.train_score``: the global batch of
+    train_score.py:52 split over two ranks (both on this box's one GPU, gloo carrying the collectives; RCCL on a node with
+    a GPU per rank), gradients summed by one all-reduce per step.  Noise is keyed by the global sample index, so the run
+    must follow the single-rank run of the same seed up to the rounding of the gradient sum."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    from conftest import ROOT
+    common = ['--synthetic', '--max_steps', '12', '--batch_size', '16', '--val_every', '6', '--seed', '9']
+    env = dict(os.environ, PYTHONPATH=ROOT, SBC_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    runs = {}
+    for world in (1, 2):
+        out = tmp_path / ('w%d' % world)
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr',
+               '127.0.0.1', '--master-port', str(29610 + world), '-m', 'score_based_channels_amd.train_score'] + common + \
+              ['--out_dir', str(out)]
+        r = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs[world] = torch.load(out / 'final_model.pt', weights_only=False)
+    l1, l2 = np.array(runs[1]['train_loss']), np.array(runs[2]['train_loss'])
+    assert l1.shape == l2.shape == (12,) and np.max(np.abs(l2 / l1 - 1)) < 1e-4, (l1, l2)
+    v1, v2 = np.array(runs[1]['val_loss']), np.array(runs[2]['val_loss'])
+    assert np.max(np.abs(v2 / v1 - 1)) < 1e-4
+    diff = torch.cat([(runs[1]['model_state'][k] - runs[2]['model_state'][k]).abs().flatten() for k in runs[1]['model_state']])
+    # 12 steps of at most lr = 1e-4 each; elements with |g| ~ eps amplify the rounding of the gradient sum by lr / eps
+    assert float(diff.max()) < 1e-4 and float(diff.median()) < 1e-7, (float(diff.max()), float(diff.median()))

@@ -1,4 +1,5 @@
-"""World-size-2 test of the multi-GPU path on CPU (gloo): block sharding + the one all_gather of NMSE logs."""
+"""World-size-2 test of the multi-GPU path on CPU (gloo): block sharding + the one all_gather of NMSE logs, and the SUM
+all-reduce that data-parallel training uses for its flat gradient buffer."""
 import os
 
 import numpy as np
@@ -16,7 +17,11 @@ def _worker(rank, world, port, n_items, n_steps, q):
     lo, hi = shard.my_block(n_items, r, w)
     full = torch.arange(n_steps * n_items, dtype=torch.float32).view(n_steps, n_items)   # "NMSE of trajectory t at step k"
     got = shard.gather_trajectory_logs(full[:, lo:hi].clone(), n_items, r, w)
-    q.put((rank, bool(torch.equal(got, full)), (lo, hi)))
+    # the gradient all-reduce of data-parallel training (train.TrainNet.step with world > 1)
+    g = torch.full((1000,), float(rank + 1))
+    shard.all_reduce_sum_(g, w)
+    ok_sum = bool(torch.equal(g, torch.full((1000,), float(sum(range(1, world + 1))))))
+    q.put((rank, bool(torch.equal(got, full)) and ok_sum, (lo, hi)))
     dist.destroy_process_group()
 
 
