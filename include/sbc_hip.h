@@ -88,6 +88,8 @@ typedef enum sbc_op_kind {
                                    writes what it reads or reads what it writes before the next SBC_OP_JOIN             */
 #define SBC_OP_JOIN       0x1000 /* this launch (and everything after it) waits for all side launches issued so far; the
                                    end of the plan always joins                                                       */
+#define SBC_PACK_WINOGRAD 0x2000 /* SBC_OP_PACK_WEIGHT: the Winograd F(2x2,3x3) form (sbc_pack_conv_weight_winograd_split layout) of a
+                                   3x3 weight; combines with SBC_PACK_ADJOINT                                          */
 #define SBC_CONV_F16W    0x100  /* fp16 weights (BASELINE config 5): `weight_split` / `weight_wino_split` hold ONE
                                    fp16 term per weight (sbc_pack_conv_weight_f16 / _winograd_f16) instead of
                                    three bf16 terms; activations are rounded to fp16 as they enter the matrix
@@ -169,8 +171,9 @@ typedef struct sbc_op {
  *                 >= sbc_wgrad_scratch_floats(B, H, W, cin, cout, ksize) (one buffer serves all launches of a stream).
  *   PACK_WEIGHT   in = [cout][cin][k][k] float32 DEVICE, out = the sbc_pack_conv_weight_split layout (of the adjoint
  *                 convolution cout -> cin with SBC_PACK_ADJOINT).  Batched form (aux != NULL): aux = device int32 table
- *                 [B][6] = (source offset from `in` in floats, destination offset from `out` in uint16, cout, cin, k*k,
- *                 adjoint) and cin/cout/ksize = those of the largest entry: every weight of a network in one launch.
+ *                 [B][6] = (source offset from `in` in floats, destination offset from `out` in uint16, cout, cin, k*k
+ *                 or 16 for the Winograd form, adjoint) and cin/cout = those of the largest entry: every weight of a
+ *                 network in one launch.
  *   END_CONV_BWD  in/stats/weight/ext as in END_CONV, grad = d / d score [B][H][W][2]; out = d / d ELU-output
  *                 [B][H][W][cin] (written); wgrad [2][cin][3][3], bgrad [2]; aux = scratch >= sbc_wgrad_scratch_floats.
  *   BEGIN_CONV_BWD in = x [B][H][W][2], grad = d / d output [B][H][W][cout]; wgrad [cout][2][3][3], bgrad [cout]; aux.

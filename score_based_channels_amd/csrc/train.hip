@@ -434,7 +434,22 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int ci = g * 16 + 8 * (lane >> 5) + j;
-        const float v = adjoint ? w[((size_t)ci * cin + co) * taps + (taps - 1 - tap)] : w[((size_t)co * cin + ci) * taps + tap];
+        float v;
+        if (taps == 16) {
+            // Winograd F(2x2,3x3) form of a 3x3 weight: U = G g G^T in double, rounded once (sbc_pack_conv_weight_winograd_split);
+            // `tap` is the transform position (i, l); the adjoint convolution's filter is the flipped, transposed one
+            const float* gsrc = adjoint ? w + ((size_t)ci * cin + co) * 9 : w + ((size_t)co * cin + ci) * 9;
+            const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+            const int i = tap >> 2, q = tap & 3;
+            double acc = 0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) acc += G[i][a] * (double)gsrc[adjoint ? 8 - (a * 3 + b) : a * 3 + b] * G[q][b];
+            v = (float)acc;
+        } else {
+            v = adjoint ? w[((size_t)ci * cin + co) * taps + (taps - 1 - tap)] : w[((size_t)co * cin + ci) * taps + tap];
+        }
         const __bf16 bh = (__bf16)v;
         const float r1 = v - (float)bh;
         const __bf16 bm = (__bf16)r1;
@@ -453,14 +468,15 @@ int launch_pack_weight(const sbc_op& op, hipStream_t stream) {
     if (op.aux) {
         // batched form: B entries of the device table in `aux`; cin/cout/ksize = the LARGEST weight (sizes the grid)
         SBC_REQUIRE(op.B > 0 && op.cin > 0 && op.cout > 0 && op.ksize > 0, "pack_weight (batched): B, cin, cout, ksize must be set");
-        const long n = (long)op.ksize * op.ksize * (op.cin / 16) * (op.cout / 16) * 64;     // upper bound for either form
+        const long n = 16L * (op.cin / 16) * (op.cout / 16) * 64;     // upper bound for every form (16 Winograd positions)
         hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((n + 255) / 256), op.B), dim3(256), 0, stream,
                            (const float*)op.in, (unsigned short*)op.out, 0, 0, 0, 0, (const int*)op.aux);
         SBC_CHECK_HIP(hipGetLastError());
         return SBC_OK;
     }
     SBC_REQUIRE(op.cin % 32 == 0 && op.cout % 32 == 0 && (op.ksize == 1 || op.ksize == 3), "pack_weight: cin, cout %% 32, ksize in {1, 3}");
-    const int taps = op.ksize * op.ksize, adj = (op.flags & SBC_PACK_ADJOINT) ? 1 : 0;
+    SBC_REQUIRE(!(op.flags & SBC_PACK_WINOGRAD) || op.ksize == 3, "pack_weight: the Winograd form exists for 3x3 weights");
+    const int taps = (op.flags & SBC_PACK_WINOGRAD) ? 16 : op.ksize * op.ksize, adj = (op.flags & SBC_PACK_ADJOINT) ? 1 : 0;
     const long n = (long)taps * (op.cin / (adj ? 32 : 16)) * (op.cout / (adj ? 16 : 32)) * 64;
     hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const float*)op.in,
                        (unsigned short*)op.out, op.cout, op.cin, taps, adj, (const int*)nullptr);

@@ -31,7 +31,7 @@ CONV_F16W = 0x100
 # training operators
 (DSM_PERTURB, DSM_LOSS, GRAD_ADD, INORM_BWD, MAXPOOL5_BWD, UPSAMPLE_BWD, POOL_BWD, CONV_WGRAD, PACK_WEIGHT, END_CONV_BWD,
  BEGIN_CONV_BWD, ADAM_EMA) = range(9, 21)
-BWD_ACCUM, PACK_ADJOINT, OP_SIDE, OP_JOIN = 0x200, 0x400, 0x800, 0x1000
+BWD_ACCUM, PACK_ADJOINT, OP_SIDE, OP_JOIN, PACK_WINOGRAD = 0x200, 0x400, 0x800, 0x1000, 0x2000
 
 # profiling tag of the dominant kernel class: 3x3 convs ngf->ngf at full resolution
 TAG_CONV_TOP = 1

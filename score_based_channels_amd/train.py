@@ -179,28 +179,33 @@ class TrainNet:
         return self.pool_grad[op.name]
 
     def _make_pack_table(self):
-        """Device table of SBC_OP_PACK_WEIGHT's batched form: both packed forms of every convolution weight."""
+        """Device table of SBC_OP_PACK_WEIGHT's batched form: per convolution weight the direct split-bf16 form and its
+        adjoint, and for undilated 3x3 layers also the Winograd F(2x2,3x3) form and its adjoint (what conv_wx3 consumes)."""
         rows, cur, self._pack_off = [], 0, {}
         for op in self.plan.ops:
             if op.kind != P.CONV:
                 continue
             cout, cin, k, _ = self.shape[op.weight]
-            n16 = 3 * cout * cin * k * k                                   # uint16 elements per packed form
-            self._pack_off[op.weight] = (cur, cur + n16)
-            rows.append((self.off[op.weight], cur, cout, cin, k * k, 0))
-            rows.append((self.off[op.weight], cur + n16, cout, cin, k * k, 1))
-            cur += 2 * n16
+            forms = [('fwd', k * k, 0), ('adj', k * k, 1)]
+            if k == 3 and op.dil == 1:
+                forms += [('wfwd', 16, 0), ('wadj', 16, 1)]
+            for form, taps, adj in forms:
+                self._pack_off[(op.weight, form)] = cur
+                rows.append((self.off[op.weight], cur, cout, cin, taps, adj))
+                cur += 3 * cout * cin * taps                               # uint16 elements
         self._pack_table = torch.tensor(rows, dtype=torch.int32, device=self.device)
         self._pack_buf = torch.zeros(cur // 2, dtype=torch.float32, device=self.device)
         self._pack_max = (max(r[2] for r in rows), max(r[3] for r in rows))
 
     def _pack_ops(self, base):
-        """ONE launch that re-packs every convolution weight (forward + adjoint form) from the flat parameter buffer."""
+        """ONE launch that re-packs every convolution weight (all forms) from the flat parameter buffer."""
         return [_lib.sbc_op(kind=P.PACK_WEIGHT, B=self._pack_table.shape[0], cout=self._pack_max[0], cin=self._pack_max[1],
                             ksize=3, in_=_ptr(base), out=_ptr(self._pack_buf), aux=C.c_void_p(self._pack_table.data_ptr()))]
 
-    def _packed(self, wkey, adjoint):
-        return C.c_void_p(self._pack_buf.data_ptr() + 2 * self._pack_off[wkey][1 if adjoint else 0])
+    def _packed(self, wkey, form):
+        """Device pointer of a packed form ('fwd', 'adj', 'wfwd', 'wadj'), or None if the layer has no such form."""
+        off = self._pack_off.get((wkey, form))
+        return None if off is None else C.c_void_p(self._pack_buf.data_ptr() + 2 * off)
 
     def _forward_ops(self, base, keep):
         """The forward records of plan.py bound to private activation slots; conv weights come from the packed copies."""
@@ -212,7 +217,8 @@ class TrainNet:
             o = _lib.sbc_op(kind=op.kind, flags=op.flags, B=B, H=op.src.h, W=op.src.w, cin=op.src.c, cout=op.dst.c,
                             ksize=op.ksize, dil=op.dil, tag=op.tag, in_=_ptr(sl[op.src.slot]), out=_ptr(sl[op.dst.slot]))
             if op.kind == P.CONV:
-                o.weight_split = self._packed(op.weight, False)
+                o.weight_split = self._packed(op.weight, 'fwd')
+                o.weight_wino_split = self._packed(op.weight, 'wfwd')      # the inference kernels (conv_wx3) where they apply
             elif op.kind == P.INORM_STATS:
                 o.weight = self._par(base, op.weight + '.alpha')
             elif op.weight is not None:
@@ -337,7 +343,8 @@ class TrainNet:
                 # norm in the prologue the convolution's own epilogue multiplies by ELU'(src) and adds what was collected
                 # before (an aliased buffer, or the tensor's own buffer in place)
                 adj = _lib.sbc_op(kind=P.CONV, B=B, H=src.h, W=src.w, cin=dst.c, cout=src.c, ksize=op.ksize, dil=op.dil,
-                                  in_=_ptr(dc), weight_split=self._packed(op.weight, True))
+                                  in_=_ptr(dc), weight_split=self._packed(op.weight, 'adj'),
+                                  weight_wino_split=self._packed(op.weight, 'wadj'))   # ignored with SBC_EPI_ELUGRAD (direct only)
                 if pro & P.PRO_NORM:
                     adj.out = _ptr(self.tmp_a)
                     ops.append(adj)

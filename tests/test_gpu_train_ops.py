@@ -245,13 +245,16 @@ def test_device_weight_packing_matches_host_packer(gpu, cin, cout, k):
     rng = np.random.default_rng(cin + cout + k)
     w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(F32)
     dw = _dev(torch, w)
+    from score_based_channels_amd.weights import pack_conv_weight_winograd_split
     for adj in (False, True):
-        host = pack_conv_weight_split(np.ascontiguousarray(w[:, :, ::-1, ::-1].transpose(1, 0, 2, 3)) if adj else w)
-        out = torch.zeros(host.size, dtype=torch.int16, device='cuda')
-        op = _lib.sbc_op(kind=P.PACK_WEIGHT, flags=P.PACK_ADJOINT if adj else 0, cin=cin, cout=cout, ksize=k, in_=_p(dw),
-                         out=_p(out))
-        _launch(gpu, op)
-        assert np.array_equal(out.cpu().numpy().view(np.uint16).ravel(), host.ravel()), adj
+        wa = np.ascontiguousarray(w[:, :, ::-1, ::-1].transpose(1, 0, 2, 3)) if adj else w
+        for wino in ((False, True) if k == 3 else (False,)):
+            host = pack_conv_weight_winograd_split(wa) if wino else pack_conv_weight_split(wa)
+            out = torch.zeros(host.size, dtype=torch.int16, device='cuda')
+            op = _lib.sbc_op(kind=P.PACK_WEIGHT, flags=(P.PACK_ADJOINT if adj else 0) | (P.PACK_WINOGRAD if wino else 0),
+                             cin=cin, cout=cout, ksize=k, in_=_p(dw), out=_p(out))
+            _launch(gpu, op)
+            assert np.array_equal(out.cpu().numpy().view(np.uint16).ravel(), host.ravel()), (adj, wino)
 
 
 @pytest.mark.parametrize('mode', ['plain', 'elu', 'elu_plus_other', 'elu_in_place'])
