@@ -75,7 +75,7 @@ typedef enum sbc_op_kind {
 #define SBC_EPI_RES1_ELU 0x010  /* ELU the res1 operand before adding (CRP: x = act(x))                    */
 #define SBC_EPI_POOL     0x020  /* 2x2 mean pool of (conv + bias), then + res1 (ConvMeanPool)               */
 #define SBC_EPI_UP       0x040  /* + bilinear(align_corners) resize of `up` [B][up_h][up_w][cout] (MSF)     */
-#define SBC_EPI_ELUGRAD  0x080  /* reverse pass (direct kernels, no pool): out = conv * ELU'(res2) [+ res1]; res2 = the
+#define SBC_EPI_ELUGRAD  0x080  /* reverse pass (split-bf16 kernels, no pool): out = conv * ELU'(res2) [+ res1]; res2 = the
                                    forward input the ELU was applied to, res1 = the gradient collected so far (may be
                                    `out` itself: every element is read and written by the same thread)              */
 #define SBC_BWD_ACCUM     0x200  /* training operators: add to `out` instead of overwriting it (a tensor with several

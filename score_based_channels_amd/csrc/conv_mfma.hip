@@ -247,8 +247,8 @@ int launch_conv(const sbc_op& op, hipStream_t stream, bool dry) {
     p.hsh = log2_exact(op.H); p.wsh = log2_exact(op.W);
     p.plane = 0; p.stats_off = 0; p.top = op.tag == 1;
     static const bool no_wx3 = getenv("SBC_NO_WX3") != nullptr;                    // A/B aid: direct split-bf16 kernel everywhere
-    const bool direct_only = (op.flags & SBC_EPI_ELUGRAD) != 0;       // the Winograd kernels have their own epilogues
-    if (op.weight_wino_split && !f32_only && !no_wx3 && !direct_only && op.ksize == 3 && op.dil == 1) {
+    const bool direct_only = (op.flags & SBC_EPI_ELUGRAD) != 0;       // the fp32 Winograd kernel's epilogue does not know the flag
+    if (op.weight_wino_split && !f32_only && !no_wx3 && op.ksize == 3 && op.dil == 1) {
         ConvParams pw = p;
         pw.wpk = (const float4*)op.weight_wino_split;
         const int rc = launch_conv_wx3(pw, op.cin, op.cout, stream, dry);

@@ -272,6 +272,17 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
                     for (int b = 0; b < 2; ++b) o[a][b] = ((size_t)(grow + a) * W + 2 * tc + b) * COUT + co;
+                if (p.flags & SBC_EPI_ELUGRAD) {
+                    // reverse pass (adjoint convolution): times ELU'(forward input), res2 = that input (conv_epilogue.h)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            const float4 xv = ld_stream(p.res2 + o[a][b]);
+                            y[a][b].x *= elu_grad1(xv.x); y[a][b].y *= elu_grad1(xv.y);
+                            y[a][b].z *= elu_grad1(xv.z); y[a][b].w *= elu_grad1(xv.w);
+                        }
+                }
                 if (p.res1) {
                     float4 rr[2][2];
 #pragma unroll
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
 #pragma unroll
                             for (int b = 0; b < 2; ++b) rr[a][b] = elu4(rr[a][b]);
                     }
-                    if (p.res2) {
+                    if (p.res2 && !(p.flags & SBC_EPI_ELUGRAD)) {
 #pragma unroll
                         for (int a = 0; a < 2; ++a)
 #pragma unroll

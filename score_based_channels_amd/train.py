@@ -344,7 +344,7 @@ class TrainNet:
                 # before (an aliased buffer, or the tensor's own buffer in place)
                 adj = _lib.sbc_op(kind=P.CONV, B=B, H=src.h, W=src.w, cin=dst.c, cout=src.c, ksize=op.ksize, dil=op.dil,
                                   in_=_ptr(dc), weight_split=self._packed(op.weight, 'adj'),
-                                  weight_wino_split=self._packed(op.weight, 'wadj'))   # ignored with SBC_EPI_ELUGRAD (direct only)
+                                  weight_wino_split=self._packed(op.weight, 'wadj'))
                 if pro & P.PRO_NORM:
                     adj.out = _ptr(self.tmp_a)
                     ops.append(adj)

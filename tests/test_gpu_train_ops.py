@@ -290,6 +290,18 @@ def test_input_gradient_is_a_conv_with_adjoint_weights(gpu, cin, cout, k, dil, B
         op.res1 = _p(dother)
     _launch(gpu, op)
     assert rel_err(out.cpu().numpy(), ref) < TOL
+    if k == 3 and dil == 1:
+        # the same through the Winograd kernel (adjoint Winograd form packed on the device)
+        wpacked = torch.zeros(cout * cin * 16 * 3, dtype=torch.int16, device='cuda')
+        _launch(gpu, _lib.sbc_op(kind=P.PACK_WEIGHT, flags=P.PACK_ADJOINT | P.PACK_WINOGRAD, cin=cin, cout=cout, ksize=3,
+                                 in_=_p(dw), out=_p(wpacked)))
+        if mode == 'elu_in_place':
+            dother.copy_(_dev(torch, other))
+        else:
+            out.fill_(float('nan'))
+        op.weight_wino_split = _p(wpacked)
+        _launch(gpu, op)
+        assert rel_err(out.cpu().numpy(), ref) < TOL
 
 
 def test_end_conv_backward_matches_autograd(gpu):
