@@ -129,6 +129,9 @@ def parse_args():
     ap.add_argument('--overlap', type=int, default=None,
                     help='1: independent low-resolution branches of the network on the plan side stream, 0: strictly '
                          'sequential launches; default: scorenet.DEFAULT_OVERLAP')
+    ap.add_argument('--fold-stats', type=int, default=None,
+                    help='1: full-resolution InstanceNorm++ statistics from tile moments (no statistics launches there), '
+                         '0: a statistics launch per norm; default: scorenet.DEFAULT_FOLD_STATS')
     ap.add_argument('--streams', type=int, default=1,
                     help='split the trajectories into this many concurrent sub-batch streams (DESIGN.md section 7)')
     return ap.parse_args()
@@ -241,7 +244,8 @@ def main():
     cfg = default_config('CDL-C', image_size=(nr, nt)) if big else default_config('CDL-C')
     sd = seeded_state_dict(cfg, 2024)                     # random-init weights of the reference architecture
     net = ScoreNet(cfg, 'cuda:%d' % local, conv_mode=conv_mode,
-                   overlap=None if args.overlap is None else bool(args.overlap)).load_state_dict(sd)
+                   overlap=None if args.overlap is None else bool(args.overlap),
+                   fold_stats=None if args.fold_stats is None else bool(args.fold_stats)).load_state_dict(sd)
     use_graph = DEFAULT_USE_GRAPH if args.graph is None else bool(args.graph)
     snr = np.arange(-10, 32.5, 2.5)[:nsnr]
 

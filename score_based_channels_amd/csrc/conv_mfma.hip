@@ -246,6 +246,16 @@ int launch_conv(const sbc_op& op, hipStream_t stream, bool dry) {
     p.up_h = op.up_h; p.up_w = op.up_w; p.total_px = op.B * op.H * op.W;
     p.hsh = log2_exact(op.H); p.wsh = log2_exact(op.W);
     p.plane = 0; p.stats_off = 0; p.top = op.tag == 1;
+    p.agb = (const float*)op.grad; p.pm_out = (float*)op.aux;
+    const bool moments = (op.flags & (SBC_PRO_NORM_MOMENTS | SBC_EPI_MOMENTS_OUT)) != 0;
+    if (moments) {
+        // statistics folded into the Winograd split-bf16 kernel only (tile.h): whole 128-pixel tiles inside one sample
+        SBC_REQUIRE(op.weight_wino_split && op.ksize == 3 && op.dil == 1 && op.H * op.W == 1024 && !(op.flags & SBC_EPI_POOL && op.flags & SBC_EPI_MOMENTS_OUT),
+                    "conv: tile moments need the Winograd split-bf16 kernel, H*W == 1024 (8 tiles per sample) and an unpooled output");
+        SBC_REQUIRE(!(op.flags & SBC_PRO_NORM_MOMENTS) || ((op.flags & SBC_PRO_NORM) && op.stats && op.grad && op.cin == 32),
+                    "conv: PRO_NORM_MOMENTS needs PRO_NORM, stats = tile moments, grad = alpha|gamma|beta, 32 input channels");
+        SBC_REQUIRE(!(op.flags & SBC_EPI_MOMENTS_OUT) || (op.aux && op.cout == 32), "conv: EPI_MOMENTS_OUT needs aux and 32 output channels");
+    }
     static const bool no_wx3 = getenv("SBC_NO_WX3") != nullptr;                    // A/B aid: direct split-bf16 kernel everywhere
     const bool direct_only = (op.flags & SBC_EPI_ELUGRAD) != 0;       // the fp32 Winograd kernel's epilogue does not know the flag
     if (op.weight_wino_split && !f32_only && !no_wx3 && op.ksize == 3 && op.dil == 1) {
@@ -253,6 +263,11 @@ int launch_conv(const sbc_op& op, hipStream_t stream, bool dry) {
         pw.wpk = (const float4*)op.weight_wino_split;
         const int rc = launch_conv_wx3(pw, op.cin, op.cout, stream, dry);
         if (rc <= 0) return rc;                                                    // launched (0) or failed (< 0)
+    }
+    if (moments) {
+        set_error("conv: tile moments requested but the Winograd split-bf16 kernel does not take this shape (%dx%d, %d -> %d)",
+                  op.H, op.W, op.cin, op.cout);
+        return SBC_ERR_UNSUPPORTED;
     }
     if (x3) {
         p.wpk = (const float4*)op.weight_split;

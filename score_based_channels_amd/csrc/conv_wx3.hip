@@ -63,7 +63,13 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
         stage_issue<CIN, NTHREADS, NPF>(pf, p.in, g, W, tid);
         // InstanceNorm++ statistics of the tile's samples through LDS (behind the staged tile and the T planes)
         float* st_lds = lds + p.stats_off;
-        if (p.flags & SBC_PRO_NORM) {
+        if (p.flags & SBC_PRO_NORM_MOMENTS) {
+            // the producer left per-tile moments instead of statistics (one sample per workgroup: HW >= TM)
+            const int n = dm.div_hw(g.p0), NT = HW >> 7;
+            if constexpr (CIN == 32)
+                stats_from_moments_to_lds<CIN>(st_lds, p.stats + (size_t)n * NT * CIN * 2, p.agb, NT, 128.f, HW, tid);
+            __syncthreads();
+        } else if (p.flags & SBC_PRO_NORM) {
             stage_stats_to_lds<CIN, NTHREADS, P2>(st_lds, p.stats, g, dm, tid);
             __syncthreads();
         }
@@ -223,6 +229,9 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
                 }
             __syncthreads();
             // finish: one (tile, channel quad) per thread and round
+            float4 yk[4];                                                 // this thread's four outputs (SBC_EPI_MOMENTS_OUT)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) yk[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 1
             for (int task = gtid; task < NTW * 8; task += 256) {
                 const int t = task >> 3, c4 = task & 7;
@@ -338,10 +347,29 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
                             y[a][b].w += lh0 * (lw0 * v00.w + lw1 * v01.w) + lh1 * (lw0 * v10.w + lw1 * v11.w);
                         }
                 }
+                if ((COUT == 32 && MB == 1 && NG == 1) && (p.flags & SBC_EPI_MOMENTS_OUT)) {
+                    // no statistics launch will read this tensor back in before its consumer does: store it cacheable, so
+                    // that the consumer finds it in the last-level cache
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
+                    for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) st_stream(p.out + o[a][b], y[a][b]);
+                        for (int b = 0; b < 2; ++b) *reinterpret_cast<float4*>(p.out + o[a][b]) = y[a][b];
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) st_stream(p.out + o[a][b], y[a][b]);
+                }
+                if constexpr (COUT == 32 && MB == 1 && NG == 1) {
+                    yk[0] = y[0][0]; yk[1] = y[0][1]; yk[2] = y[1][0]; yk[3] = y[1][1];
+                }
+            }
+            if constexpr (COUT == 32 && MB == 1 && NG == 1) {
+                if (p.flags & SBC_EPI_MOMENTS_OUT) {
+                    // tile moments of the output for the InstanceNorm++ that reads it next (tile.h)
+                    __shared__ __attribute__((aligned(16))) float red[8 * 8 * 8];
+                    tile_moments_out32(yk, red, p.pm_out + (size_t)(g.p0 >> 7) * 32 * 2, gtid);
+                }
             }
             // The T planes of this GROUP are rewritten for its next block: every wave of the group must be done reading
             // them.  The condition depends only on (q, ph - grp), so both wave groups execute the same barrier sequence
@@ -354,6 +382,8 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
 // ------------------------------------------------------------------------------------------------ dispatch
 template <int CIN, int COUT, int MB, bool F16>
 static int launch_wx3(const ConvParams& p, hipStream_t stream, bool dry) {
+    SBC_REQUIRE(!(p.flags & SBC_EPI_MOMENTS_OUT) || (MB == 1 && COUT == 32),
+                "conv_wx3: tile moments are written by the 128-pixel, 32-output-channel variant only");
     constexpr int TM = 128 * MB;
     constexpr int S = CIN + 4;
     constexpr int NBLK = COUT / 32;

@@ -15,7 +15,7 @@ namespace sbc {
 // 128 bytes, and the nine taps of a pixel are 8-byte LDS reads shared by the 8 threads of the pixel.
 __global__ __launch_bounds__(256) void begin_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ out,
-                                                          int H, int W, int rows_per_wg) {
+                                                          int H, int W, int rows_per_wg, float* __restrict__ pm_out) {
     constexpr int COUT = 32;
     extern __shared__ __attribute__((aligned(16))) float2 hs[];       // [(rows_per_wg + 2)][W + 2]
     const int tid = threadIdx.x, c4 = tid & 7, slot = tid >> 3;
@@ -42,8 +42,7 @@ __global__ __launch_bounds__(256) void begin_conv_kernel(const float* __restrict
     __syncthreads();
     const int npx = rows_per_wg * W;
     float* obase = out + ((size_t)n * H + r0) * W * COUT + c4 * 4;
-#pragma unroll 2
-    for (int lp = slot; lp < npx; lp += 32) {
+    auto pixel = [&](int lp) {
         const int rr = lp / W, cc = lp - rr * W;                     // local row / column
         float4 acc = b4;
 #pragma unroll
@@ -59,20 +58,36 @@ __global__ __launch_bounds__(256) void begin_conv_kernel(const float* __restrict
             }
         }
         st_stream(obase + (size_t)lp * COUT, acc);
+        return acc;
+    };
+    if (pm_out) {
+        // SBC_EPI_MOMENTS_OUT: the workgroup is one 128-pixel tile (the host chose rows_per_wg * W == 128); every thread
+        // keeps its four outputs and the tile's per-channel (mean, M2) go to pm_out[tile][32][2] (tile.h)
+        __shared__ __attribute__((aligned(16))) float red[8 * 8 * 8];
+        float4 yk[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) yk[it] = pixel(slot + 32 * it);
+        tile_moments_out32(yk, red, pm_out + (size_t)blockIdx.x * COUT * 2, tid);
+        return;
     }
+#pragma unroll 2
+    for (int lp = slot; lp < npx; lp += 32) pixel(lp);
 }
 
 int launch_begin_conv(const sbc_op& op, hipStream_t stream) {
     SBC_REQUIRE(op.in && op.out && op.weight && op.bias, "begin_conv: in/out/weight/bias must be set");
     SBC_REQUIRE(op.cin == 2 && op.cout == 32, "begin_conv: cin=%d cout=%d (kernel is built for 2 -> 32)", op.cin, op.cout);
-    // rows per workgroup: ~256 pixels, a divisor of H
-    int rows = 256 / op.W > 0 ? 256 / op.W : 1;
+    // rows per workgroup: ~256 pixels, a divisor of H (exactly 128 pixels when the tile moments are wanted)
+    const bool moments = (op.flags & SBC_EPI_MOMENTS_OUT) != 0;
+    SBC_REQUIRE(!moments || (op.aux && 128 % op.W == 0 && op.H * op.W == 1024), "begin_conv: EPI_MOMENTS_OUT needs aux and H*W == 1024 in rows of 128 / W pixels");
+    int rows = (moments ? 128 : 256) / op.W > 0 ? (moments ? 128 : 256) / op.W : 1;
     if (rows > op.H) rows = op.H;
     while (op.H % rows) --rows;
     const size_t lds = (size_t)(rows + 2) * (op.W + 2) * sizeof(float2);
     SBC_REQUIRE(lds <= 64 * 1024, "begin_conv: image row of %d pixels too wide", op.W);
     hipLaunchKernelGGL(begin_conv_kernel, dim3(op.B * (op.H / rows)), dim3(256), lds, stream, (const float*)op.in,
-                       (const float*)op.weight, (const float*)op.bias, (float*)op.out, op.H, op.W, rows);
+                       (const float*)op.weight, (const float*)op.bias, (float*)op.out, op.H, op.W, rows,
+                       moments ? (float*)op.aux : (float*)nullptr);
     SBC_CHECK_HIP(hipGetLastError());
     return SBC_OK;
 }
@@ -322,14 +337,27 @@ int launch_maxpool5(const sbc_op& op, hipStream_t stream) {
 template <int CIN>
 __global__ __launch_bounds__(256) void end_conv_kernel(const float* __restrict__ in, const float* __restrict__ stats,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
-                                                        float* __restrict__ out, sbc_endconv e, int B, int H, int W) {
+                                                        float* __restrict__ out, sbc_endconv e, int B, int H, int W,
+                                                        const float* __restrict__ agb) {
     constexpr int TM = 256, S = CIN + 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const Dims<false> d{H, W, H * W, 0, 0};
     const TileGeom g = tile_geom(blockIdx.x, TM, B, d, 1);
-    stage_tile<CIN, 256, 9, false>(lds, in, stats, SBC_PRO_NORM | SBC_PRO_ELU, g, d, tid);
     float* wl = lds + (size_t)(g.nps + 1) * S;          // [9][CIN][2]
+    if (agb) {
+        // SBC_PRO_NORM_MOMENTS: `stats` are the tile moments the producer of `in` left; (mu, scale, shift) of this
+        // workgroup's sample are formed here, behind the weights in LDS (tile.h)
+        float* st = wl + 9 * CIN * 2;
+        const int n = g.p0 / (H * W), NT = (H * W) >> 7;
+        float4 pf[9];
+        stage_issue<CIN, 256, 9>(pf, in, g, W, tid);
+        stats_from_moments_to_lds<CIN>(st, stats + (size_t)n * NT * CIN * 2, agb, NT, 128.f, H * W, tid);
+        __syncthreads();
+        stage_commit<CIN, 256, 9, false>(lds, pf, in, st, SBC_PRO_NORM | SBC_PRO_ELU, g, d, tid, 0);
+    } else {
+        stage_tile<CIN, 256, 9, false>(lds, in, stats, SBC_PRO_NORM | SBC_PRO_ELU, g, d, tid);
+    }
     for (int i = tid; i < 9 * CIN * 2; i += 256) {
         const int o = i & 1, c = (i >> 1) % CIN, tap = i / (2 * CIN);
         wl[i] = w[(o * CIN + c) * 9 + tap];             // torch [2][CIN][3][3]
@@ -370,14 +398,16 @@ int launch_end_conv(const sbc_op& op, const sbc_endconv& e, hipStream_t stream, 
     SBC_REQUIRE(TM % op.W == 0 && (HW % TM == 0 || TM % HW == 0), "end_conv: image %dx%d does not tile", op.H, op.W);
     const int total = op.B * HW;
     const int halo_px = TM >= HW ? 0 : 2 * op.W;
-    const size_t lds = ((size_t)(TM + halo_px + 1) * (op.cin + 4) + 9 * op.cin * 2) * sizeof(float);
+    const bool moments = (op.flags & SBC_PRO_NORM_MOMENTS) != 0;
+    SBC_REQUIRE(!moments || (op.grad && HW == 1024), "end_conv: PRO_NORM_MOMENTS needs grad = alpha|gamma|beta and H*W == 1024");
+    const size_t lds = ((size_t)(TM + halo_px + 1) * (op.cin + 4) + 9 * op.cin * 2 + (moments ? 3 * op.cin : 0)) * sizeof(float);
     SBC_REQUIRE(lds <= 160 * 1024, "end_conv: tile needs %zu bytes of LDS", lds);
     SBC_REQUIRE(op.cin == 32, "end_conv: %d input channels (only ngf = 32)", op.cin);
     { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(end_conv_kernel<32>), lds); if (rc) return rc; }
     if (dry) return SBC_OK;
     hipLaunchKernelGGL(end_conv_kernel<32>, dim3((total + TM - 1) / TM), dim3(256), lds, stream, (const float*)op.in,
                        (const float*)op.stats, (const float*)op.weight, (const float*)op.bias, (float*)op.out, e, op.B,
-                       op.H, op.W);
+                       op.H, op.W, moments ? (const float*)op.grad : (const float*)nullptr);
     SBC_CHECK_HIP(hipGetLastError());
     return SBC_OK;
 }

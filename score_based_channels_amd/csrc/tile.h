@@ -234,6 +234,121 @@ __device__ __forceinline__ void stage_tile_split(unsigned short* lds16, int plan
         reinterpret_cast<unsigned*>(lds16 + (i / (SH / 2)) * plane + g.nps * SH)[i % (SH / 2)] = 0u;
 }
 
+// ---- InstanceNorm++ statistics folded into the neighbouring convolutions (SBC_EPI_MOMENTS_OUT / SBC_PRO_NORM_MOMENTS) ---------
+// Instead of a statistics launch that reads the whole tensor again, the PRODUCER of a tensor writes, per 128-pixel tile and
+// channel, the tile's (mean, M2 = sum (x - mean)^2), and the CONSUMER merges the tiles of its sample in ascending order
+// (Chan et al.) and forms (mu, scale, shift) in LDS -- the values inorm_stats_kernel would have written.  Everything has a
+// fixed order, so results stay independent of batch composition and reproducible bit for bit.
+__device__ __forceinline__ void chan_merge1(float& mean_a, float& m2_a, float na, float mean_b, float m2_b, float nb) {
+    const float n = na + nb, d = mean_b - mean_a;
+    mean_a += d * (nb / n);
+    m2_a += m2_b + d * d * (na * nb / n);
+}
+__device__ __forceinline__ void merge_equal4(float4& ma, float4& qa, float4 mb, float4 qb, float n) {   // two partials of n each
+    const float hn = 0.5f * n;
+    float d;
+    d = mb.x - ma.x; ma.x += 0.5f * d; qa.x += qb.x + d * d * hn;
+    d = mb.y - ma.y; ma.y += 0.5f * d; qa.y += qb.y + d * d * hn;
+    d = mb.z - ma.z; ma.z += 0.5f * d; qa.z += qb.z + d * d * hn;
+    d = mb.w - ma.w; ma.w += 0.5f * d; qa.w += qb.w + d * d * hn;
+}
+// lane ^ 8 inside a row of 16 lanes is a rotation by 8 (one DPP move, no LDS); lane ^ 16 a swizzle inside 32 lanes
+__device__ __forceinline__ float xor8(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float xor16(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401f /* and 0x1f, xor 0x10 */));
+}
+__device__ __forceinline__ float4 xor8_4(float4 v) { return make_float4(xor8(v.x), xor8(v.y), xor8(v.z), xor8(v.w)); }
+__device__ __forceinline__ float4 xor16_4(float4 v) { return make_float4(xor16(v.x), xor16(v.y), xor16(v.z), xor16(v.w)); }
+
+// Producer side, 256 threads, 32 channels: thread (tid >> 3, tid & 7) holds four pixels of channel quad tid & 7 (any four:
+// together the threads cover the tile's 128 pixels once).  `red`: LDS scratch of 8 * 8 * 8 floats that nobody else touches;
+// `pm_tile`: this tile's [32][2] output.  Contains one workgroup barrier.
+__device__ __forceinline__ void tile_moments_out32(const float4 (&v)[4], float* red, float* __restrict__ pm_tile, int tid) {
+    float4 mean, m2;
+    mean.x = ((v[0].x + v[1].x) + (v[2].x + v[3].x)) * 0.25f; mean.y = ((v[0].y + v[1].y) + (v[2].y + v[3].y)) * 0.25f;
+    mean.z = ((v[0].z + v[1].z) + (v[2].z + v[3].z)) * 0.25f; mean.w = ((v[0].w + v[1].w) + (v[2].w + v[3].w)) * 0.25f;
+    m2 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float d;
+        d = v[i].x - mean.x; m2.x = fmaf(d, d, m2.x); d = v[i].y - mean.y; m2.y = fmaf(d, d, m2.y);
+        d = v[i].z - mean.z; m2.z = fmaf(d, d, m2.z); d = v[i].w - mean.w; m2.w = fmaf(d, d, m2.w);
+    }
+    // lanes that share the channel quad differ in lane bits 3..5: two pairwise merges of equal counts (4, 8) in registers,
+    // then the eight 16-pixel partials of a quad (two per wave) meet in LDS
+    merge_equal4(mean, m2, xor8_4(mean), xor8_4(m2), 4.f);
+    merge_equal4(mean, m2, xor16_4(mean), xor16_4(m2), 8.f);
+    const int lane = tid & 63, part = (tid >> 6) * 2 + (lane >> 5);
+    if ((lane & 31) < 8) {
+        *reinterpret_cast<float4*>(red + (part * 8 + (lane & 7)) * 8) = mean;
+        *reinterpret_cast<float4*>(red + (part * 8 + (lane & 7)) * 8 + 4) = m2;
+    }
+    __syncthreads();
+    if (tid < 32) {                                   // one channel each: the eight partials (16 pixels each) in order
+        const int c4 = tid >> 2, k = tid & 3;
+        // equal counts: mean of the means, and M2 = sum M2_w + 16 sum (mean_w - mean)^2 (fixed order, no dependent chain)
+        float mw[8], mu = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { mw[w] = red[(w * 8 + c4) * 8 + k]; mu += mw[w]; q += red[(w * 8 + c4) * 8 + 4 + k]; }
+        mu *= 0.125f;
+        float dd = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { const float d = mw[w] - mu; dd = fmaf(d, d, dd); }
+        *reinterpret_cast<float2*>(pm_tile + tid * 2) = make_float2(mu, fmaf(16.f, dd, q));
+    }
+}
+
+// Consumer side: (mu, scale, shift) of one sample into LDS st[3][C] from its NT tile moments pm[NT][C][2] (n_tile pixels
+// each) and the norm's alpha | gamma | beta -- the arithmetic of inorm_stats_kernel's last stage.  Contains one workgroup
+// barrier; the caller puts another one before st is read.
+// sum over the 32 lanes of a half wave (all lanes get the result): xor 1, 2, 4 inside quads / rows by DPP, 8 by rotation,
+// 16 by swizzle -- no LDS traffic, no barrier
+__device__ __forceinline__ float sum32(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1 /* quad_perm 1,0,3,2 */, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e /* quad_perm 2,3,0,1 */, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x101f /* xor 4 */));
+    v += xor8(v);
+    v += xor16(v);
+    return v;
+}
+
+// Consumer side (32 channels): (mu, scale, shift) of one sample into LDS st[3][32] from its NT tile moments pm[NT][32][2]
+// (n_tile pixels each, equal counts) and the norm's alpha | gamma | beta -- the arithmetic of inorm_stats_kernel's last
+// stage, entirely in the registers of the first 32 lanes.  The caller puts a barrier before st is read.
+template <int C>
+__device__ __forceinline__ void stats_from_moments_to_lds(float* st, const float* __restrict__ pm, const float* __restrict__ agb,
+                                                          int NT, float n_tile, int HW, int tid) {
+    static_assert(C == 32, "one channel per lane of a half wave");
+    if (tid < 64) {                                    // the whole first wave executes the cross-lane steps
+        const int c = tid & 31;
+        constexpr int NTC = 8;                         // tiles per sample (the host folds 1024-pixel samples only)
+        float2 mq[NTC];
+#pragma unroll
+        for (int t = 0; t < NTC; ++t) mq[t] = *reinterpret_cast<const float2*>(pm + ((size_t)t * C + c) * 2);   // all in flight
+        float mu = 0.f, q = 0.f;
+#pragma unroll
+        for (int t = 0; t < NTC; ++t) { mu += mq[t].x; q += mq[t].y; }
+        mu *= 1.f / (float)NTC;
+        float dd = 0.f;
+#pragma unroll
+        for (int t = 0; t < NTC; ++t) { const float d = mq[t].x - mu; dd = fmaf(d, d, dd); }
+        const float var = fmaf(n_tile, dd, q) * (1.f / (float)HW);
+        const float m = sum32(mu) * (1.f / (float)C);
+        const float dc = mu - m;
+        const float v = sum32(dc * dc) * (1.f / (float)(C - 1));
+        const float mhat = dc / sqrtf(v + 1e-5f);
+        const float rstd = 1.f / sqrtf(fmaxf(var, 0.f) + 1e-5f);
+        const float alpha = agb[c], gamma = agb[C + c], beta = agb[2 * C + c];
+        if (tid < 32) {
+            st[c] = mu;
+            st[C + c] = gamma * rstd;
+            st[2 * C + c] = fmaf(gamma, mhat * alpha, beta);
+        }
+    }
+}
+
 // host side: log2 of a power of two, or -1
 inline int log2_exact(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;

@@ -26,6 +26,7 @@ from typing import List, Optional
 # op kinds / flags: numerically identical to include/sbc_hip.h
 BEGIN_CONV, INORM_STATS, CONV, MAXPOOL5, END_CONV, LANGEVIN, STEP_INC, MEASURE = 1, 2, 3, 4, 5, 6, 7, 8
 PRO_ELU, PRO_NORM = 0x001, 0x002
+PRO_NORM_MOMENTS, EPI_MOMENTS_OUT = 0x4000, 0x8000
 EPI_RES1_ELU, EPI_POOL, EPI_UP, EPI_ELUGRAD = 0x010, 0x020, 0x040, 0x080
 CONV_F16W = 0x100
 # training operators
@@ -69,9 +70,14 @@ class Op:
     tag: int = 0
     side: bool = False        # may overlap the records that follow it, up to the next ``join`` record (SBC_OP_SIDE)
     join: bool = False        # waits for every side record issued before it (SBC_OP_JOIN)
+    moments: Optional[Tensor] = None    # second output: tile moments of dst (EPI_MOMENTS_OUT), [HW/128][2][C] per sample
+    norm: Optional[str] = None          # PRO_NORM_MOMENTS: state_dict prefix of the norm whose statistics this record forms
 
     def inputs(self):
         return [t for t in (self.src, self.stats, self.res1, self.res2, self.up) if t is not None]
+
+    def outputs(self):
+        return [t for t in (self.dst, self.moments) if t is not None]
 
 
 @dataclass
@@ -84,9 +90,12 @@ class ScorePlan:
 
 
 class _Builder:
-    def __init__(self, ngf, nt, nr, overlap=False):
+    def __init__(self, ngf, nt, nr, overlap=False, fold_stats=False):
         self.ngf, self.nt, self.nr = ngf, nt, nr
         self.ops, self.tensors = [], []
+        self.fold_stats = fold_stats    # full-resolution InstanceNorm++ statistics from tile moments (no statistics launch)
+        self.producer = {}              # id(tensor) -> the record that writes it
+        self.moment_norm = {}           # id(moments tensor) -> state_dict prefix of the norm it feeds
         self.overlap = overlap      # mark independent low-resolution branches as side records
         self.side_now = False       # records appended while set carry ``side``
 
@@ -100,10 +109,16 @@ class _Builder:
         pool = bool(flags & EPI_POOL)
         dst = self.t(name, src.h // 2 if pool else src.h, src.w // 2 if pool else src.w, cout)
         tag = TAG_CONV_TOP if (ksize == 3 and src.c == self.ngf and cout == self.ngf and src.h == self.nt) else 0
+        norm = None
+        if stats is not None and id(stats) in self.moment_norm:       # statistics folded: `stats` are the input's tile moments
+            assert ksize == 3 and dil == 1, name
+            flags |= PRO_NORM_MOMENTS
+            norm = self.moment_norm[id(stats)]
         self.ops.append(Op(CONV, name, src=src, dst=dst, weight=wkey + '.weight',
                            bias=(wkey + '.bias') if bias else None, stats=stats, res1=res1, res2=res2, up=up,
                            flags=flags | (EPI_UP if up is not None else 0), ksize=ksize, dil=dil, tag=tag,
-                           side=self.side_now))
+                           side=self.side_now, norm=norm))
+        self.producer[id(dst)] = self.ops[-1]
         return dst
 
     def low_res(self, t):
@@ -112,6 +127,19 @@ class _Builder:
         return self.overlap and t.h < self.nt
 
     def stats(self, name, src, nkey):
+        """InstanceNorm++ statistics of ``src`` for the norm ``nkey``.  With ``fold_stats``, at full resolution and ngf
+        channels, when ``src`` comes out of the begin convolution or an unpooled undilated 3x3 convolution: no record at all
+        -- the producer also writes the moments of its 128-pixel tiles (EPI_MOMENTS_OUT) and the consumer forms (mu, scale,
+        shift) from them in its prologue (PRO_NORM_MOMENTS; include/sbc_hip.h)."""
+        prod = self.producer.get(id(src))
+        if (self.fold_stats and prod is not None and src.c == self.ngf == 32 and src.h == self.nt and src.h * src.w == 1024
+                and (prod.kind == BEGIN_CONV or (prod.kind == CONV and prod.ksize == 3 and prod.dil == 1
+                                                 and not prod.flags & EPI_POOL))):
+            if prod.moments is None:
+                prod.moments = self.t(src.name + '.moments', src.h * src.w // 128, 2, src.c)
+                prod.flags |= EPI_MOMENTS_OUT
+            self.moment_norm[id(prod.moments)] = nkey
+            return prod.moments
         dst = self.t(name, 1, 3, src.c)
         self.ops.append(Op(INORM_STATS, name, src=src, dst=dst, weight=nkey))
         return dst
@@ -182,16 +210,17 @@ class _Builder:
         return self.rcu(p + 'output_convs.', h, 3 if end else 1)
 
 
-def build_score_plan(ngf=32, nt=64, nr=16, channels=2, share_slots=True, overlap=False):
+def build_score_plan(ngf=32, nt=64, nr=16, channels=2, share_slots=True, overlap=False, fold_stats=False):
     """Op list of one ``NCSNv2Deepest.forward`` for ``[B, 2, nt, nr]`` inputs (ncsnv2.py:269-300).
     ``share_slots=False`` gives every logical tensor its own storage (a training step reads every activation again on
     the way back, ``train.py``)."""
     if nt % 8 or nr % 8:
         raise ValueError('Nt and Nr must be multiples of 8 (three 2x mean-pools), got %dx%d' % (nt, nr))
-    b = _Builder(ngf, nt, nr, overlap)
+    b = _Builder(ngf, nt, nr, overlap, fold_stats)
     x = b.t('x', nt, nr, channels)
     h = b.t('begin_conv', nt, nr, ngf)
     b.ops.append(Op(BEGIN_CONV, 'begin_conv', src=x, dst=h, weight='begin_conv.weight', bias='begin_conv.bias'))
+    b.producer[id(h)] = b.ops[-1]
     stages = [('res1', ngf, None, None), ('res2', 2 * ngf, 'down', None), ('res3', 2 * ngf, 'down', None),
               ('res31', 2 * ngf, 'down', None), ('res4', 4 * ngf, 'down', 2), ('res5', 4 * ngf, 'down', 4)]
     layers = []
@@ -208,8 +237,9 @@ def build_score_plan(ngf=32, nt=64, nr=16, channels=2, share_slots=True, overlap
     ref5 = b.refine('refine5.', [l1, ref4], ngf, end=True)
     sn = b.stats('normalizer', ref5, 'normalizer')
     out = b.t('score', nt, nr, channels)
+    folded = id(sn) in b.moment_norm
     b.ops.append(Op(END_CONV, 'end_conv', src=ref5, dst=out, weight='end_conv.weight', bias='end_conv.bias',
-                    stats=sn))
+                    stats=sn, flags=PRO_NORM_MOMENTS if folded else 0, norm='normalizer' if folded else None))
     plan = ScorePlan(b.ops, x, out, b.tensors)
     if share_slots:
         assign_slots(plan)
@@ -249,16 +279,15 @@ def assign_slots(plan):
     alloc(plan.x)
     for i, op in enumerate(plan.ops):
         # outputs may not alias any input of the same op -> allocate before releasing
-        alloc(op.dst)
-        live.append(op.dst)
+        for o in op.outputs():
+            alloc(o)
+            live.append(o)
         for t in list(live):
             if id(t) in pinned:
                 continue
-            if last_use.get(id(t), -1) <= i and t is not op.dst:
+            if last_use.get(id(t), -1) <= i and not any(t is o for o in op.outputs()):
                 free.setdefault(t.elems, []).append(t.slot)
                 live.remove(t)
-            elif t is op.dst and id(t) not in last_use:
-                pass                                  # dead store (never happens in this network)
     plan.slot_elems = slot_elems
     return plan
 

@@ -36,6 +36,7 @@ class BoundScore:
 
 CONV_MODES = ('bf16x3', 'f32', 'f16w')
 DEFAULT_OVERLAP = False
+DEFAULT_FOLD_STATS = False
 
 
 class ScoreNet:
@@ -56,7 +57,7 @@ class ScoreNet:
                             ``.half()``, layers.py:179); tolerance stated in tests/test_gpu_parity.py.
     """
 
-    def __init__(self, config, device=None, conv_mode='bf16x3', overlap=None):
+    def __init__(self, config, device=None, conv_mode='bf16x3', overlap=None, fold_stats=None):
         if conv_mode not in CONV_MODES:
             raise ValueError('conv_mode must be one of %s, got %r' % (CONV_MODES, conv_mode))
         self.conv_mode = conv_mode
@@ -64,6 +65,10 @@ class ScoreNet:
         # adapt / MSF convolutions of a RefineBlock) on the plan's side stream (plan.py, SBC_OP_SIDE); same arithmetic,
         # bit-identical results
         self.overlap = DEFAULT_OVERLAP if overlap is None else bool(overlap)
+        # fold_stats: the full-resolution InstanceNorm++ statistics come from tile moments the producing convolution
+        # writes (plan.py `stats`): 7 of the 25 statistics launches -- each a full read of a [B][64][16][32] tensor --
+        # disappear.  Needs the Winograd split-bf16 kernels (not conv_mode 'f32').
+        self.fold_stats = (DEFAULT_FOLD_STATS if fold_stats is None else bool(fold_stats)) and conv_mode != 'f32'
         self.config = config
         m, d = config.model, config.data
         if str(m.normalization) != 'InstanceNorm++' or str(m.nonlinearity).lower() != 'elu':
@@ -162,7 +167,8 @@ class ScoreNet:
     def score_plan(self, nt, nr):
         key = (nt, nr)
         if key not in self._plans:
-            self._plans[key] = P.build_score_plan(self.ngf, nt, nr, self.channels, overlap=self.overlap)
+            fold = self.fold_stats and not (nt & (nt - 1)) and not (nr & (nr - 1))     # conv_wx3 takes power-of-two images
+            self._plans[key] = P.build_score_plan(self.ngf, nt, nr, self.channels, overlap=self.overlap, fold_stats=fold)
         return self._plans[key]
 
     def bind(self, B, nt, nr, *, step=None, sigma_of_step=None, use_labels=True):
@@ -203,6 +209,10 @@ class ScoreNet:
                 o.bias = _ptr(self._wdev, self._woff[op.bias])
             if op.stats is not None:
                 o.stats = _ptr(slots[op.stats.slot])
+            if op.moments is not None:
+                o.aux = _ptr(slots[op.moments.slot])
+            if op.norm is not None:
+                o.grad = _ptr(self._wdev, self._woff[op.norm])               # alpha | gamma | beta of the folded norm
             if op.res1 is not None:
                 o.res1 = _ptr(slots[op.res1.slot])
             if op.res2 is not None:

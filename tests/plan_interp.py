@@ -40,8 +40,26 @@ def run_plan(plan, sd, x_nhwc, labels):
 
     slots[plan.x.slot] = x_nhwc.astype(F32)
     for op in plan.ops:
-        slots[op.dst.slot] = exec_op(op, sd, get, labels)
+        out = exec_op(op, sd, get, labels)
+        slots[op.dst.slot] = out
+        if op.moments is not None:               # EPI_MOMENTS_OUT: (mean, M2) of every 128-pixel tile of the output
+            tiles = out.reshape(B, -1, 128, out.shape[-1]).astype(np.float64)
+            mean = tiles.mean(axis=2)
+            slots[op.moments.slot] = np.stack((mean, ((tiles - mean[:, :, None]) ** 2).sum(axis=2)), axis=2).astype(F32)
     return get(plan.out)
+
+
+def stats_from_moments(pm, alpha, gamma, beta, n_tile=128):
+    """(mu, scale, shift) [B,3,C] from tile moments [B,NT,2,C]: what a PRO_NORM_MOMENTS consumer forms in its prologue."""
+    pm = pm.astype(np.float64)
+    mu = pm[:, :, 0].mean(axis=1)
+    m2 = pm[:, :, 1].sum(axis=1) + n_tile * ((pm[:, :, 0] - mu[:, None]) ** 2).sum(axis=1)
+    var = m2 / (n_tile * pm.shape[1])
+    m = mu.mean(axis=-1, keepdims=True)
+    v = mu.var(axis=-1, keepdims=True, ddof=1)
+    mhat = (mu - m) / np.sqrt(v + 1e-5)
+    rstd = 1 / np.sqrt(var + 1e-5)
+    return np.stack((mu, gamma[None] * rstd, gamma[None] * (mhat * alpha[None]) + beta[None]), axis=1).astype(F32)
 
 
 def exec_op(op, sd, get, labels):
@@ -60,7 +78,10 @@ def exec_op(op, sd, get, labels):
         elif op.kind in (P.CONV, P.END_CONV):
             v = src
             flags = op.flags | ((P.PRO_NORM | P.PRO_ELU) if op.kind == P.END_CONV else 0)
-            if flags & P.PRO_NORM:
+            if flags & P.PRO_NORM_MOMENTS:
+                st = stats_from_moments(get(op.stats), sd[op.norm + '.alpha'], sd[op.norm + '.gamma'], sd[op.norm + '.beta'])
+                v = (v - st[:, None, None, 0]) * st[:, None, None, 1] + st[:, None, None, 2]
+            elif flags & P.PRO_NORM:
                 st = get(op.stats)[:, 0]
                 v = (v - st[:, None, None, 0]) * st[:, None, None, 1] + st[:, None, None, 2]
             if flags & P.PRO_ELU:

@@ -41,3 +41,24 @@ def test_plan_semantics_match_reference_forward(weights64):
     x = np.ascontiguousarray(g['x'][:2].transpose(0, 2, 3, 1))
     out = run_plan(pl, sd, x, np.full((2,), 1155))
     assert rel_err(out.transpose(0, 3, 1, 2), g['out'][1][:2]) < 2e-5
+
+
+def test_folded_statistics_plan_matches_reference_forward(weights64):
+    """``build_score_plan(fold_stats=True)``: the seven full-resolution statistics records are gone; their producers carry
+    a tile-moments output, their consumers form the statistics from it.  Interpreted on the CPU the plan still computes the
+    reference forward, and the moments tensors take part in the storage sharing like any other tensor."""
+    _, sd = weights64
+    g = load_golden('forward_64x16.npz')
+    pl = P.build_score_plan(32, 64, 16, fold_stats=True)
+    kinds = [op.kind for op in pl.ops]
+    assert kinds.count(P.INORM_STATS) == 18 and len(pl.ops) == 143
+    prod = [op for op in pl.ops if op.moments is not None]
+    cons = [op for op in pl.ops if op.flags & P.PRO_NORM_MOMENTS]
+    assert len(prod) == 7 == len(cons) and all(op.flags & P.EPI_MOMENTS_OUT for op in prod)
+    assert [c.stats for c in cons] == [q.moments for q in prod] and all(c.norm for c in cons)
+    assert all(m.elems == 8 * 2 * 32 for m in (q.moments for q in prod))
+    x = np.ascontiguousarray(g['x'][:2].transpose(0, 2, 3, 1))
+    out = run_plan(pl, sd, x, np.full((2,), 1155))
+    assert rel_err(out.transpose(0, 3, 1, 2), g['out'][1][:2]) < 2e-5
+    # nothing changes for arrays the fold does not apply to (here: not requested)
+    assert all(op.moments is None for op in P.build_score_plan(32, 64, 16).ops)
