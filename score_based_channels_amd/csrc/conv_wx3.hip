@@ -63,17 +63,25 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
         stage_issue<CIN, NTHREADS, NPF>(pf, p.in, g, W, tid);
         // InstanceNorm++ statistics of the tile's samples through LDS (behind the staged tile and the T planes)
         float* st_lds = lds + p.stats_off;
+        bool direct = false;
         if (p.flags & SBC_PRO_NORM_MOMENTS) {
             // the producer left per-tile moments instead of statistics (one sample per workgroup: HW >= TM)
             const int n = dm.div_hw(g.p0), NT = HW >> 7;
             if constexpr (CIN == 32)
                 stats_from_moments_to_lds<CIN>(st_lds, p.stats + (size_t)n * NT * CIN * 2, p.agb, NT, 128.f, HW, tid);
             __syncthreads();
+#ifndef SBC_LDS_STATS_ONLY                               // A/B aid (tools/build_variant.sh): the previous prologue
+        } else if ((p.flags & SBC_PRO_NORM) && !g.multi) {
+            // one sample per tile: statistics straight into registers, no LDS copy, no barrier (tile.h)
+            const RegStats rs = load_reg_stats<CIN, NTHREADS>(p.stats, g, tid);
+            stage_commit_reg<CIN, NTHREADS, NPF>(lds, pf, p.in, rs, p.flags, g, W, tid);
+            direct = true;
+#endif
         } else if (p.flags & SBC_PRO_NORM) {
             stage_stats_to_lds<CIN, NTHREADS, P2>(st_lds, p.stats, g, dm, tid);
             __syncthreads();
         }
-        stage_commit<CIN, NTHREADS, NPF, P2>(lds, pf, p.in, st_lds, p.flags, g, dm, tid, 0);
+        if (!direct) stage_commit<CIN, NTHREADS, NPF, P2>(lds, pf, p.in, st_lds, p.flags, g, dm, tid, 0);
     }
     // T planes [xi][b][tile][TS]: overlay the staged tile when there is a single output block, else live behind it
     float* const tl = (NBLK == 1 ? lds : lds + (size_t)(g.multi ? TM + 1 : TM + 2 * W + 1) * S) + (size_t)grp * 8 * NTW * 36;
@@ -227,6 +235,25 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) e[((r & 3) + 8 * (r >> 2)) * TS] = tv[r];
                 }
+            // One task per thread (32 output channels, 128 pixels): the residual operand is requested BEFORE the barrier, so
+            // that its L2 / HBM round trip overlaps the T-plane exchange instead of standing exposed at the end of a
+            // workgroup that lives only ~9 us
+            constexpr bool ONE_TASK = COUT == 32 && MB == 1 && NG == 1;
+            float4 pre[2][2];
+            if constexpr (ONE_TASK) {
+                if (p.res1 && !(p.flags & SBC_EPI_POOL)) {
+                    const int t = gtid >> 3, c4 = gtid & 7;
+                    const int tr = P2 ? t >> (p.wsh - 1) : t / Wt, tc = t - tr * Wt;
+                    const int grow = r0 + 2 * tr;
+                    if (grow < p.B * H) {
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int b = 0; b < 2; ++b)
+                                pre[a][b] = ld_stream(p.res1 + ((size_t)(grow + a) * W + 2 * tc + b) * COUT + c4 * 4);
+                    }
+                }
+            }
             __syncthreads();
             // finish: one (tile, channel quad) per thread and round
             float4 yk[4];                                                 // this thread's four outputs (SBC_EPI_MOMENTS_OUT)
@@ -297,7 +324,10 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
 #pragma unroll
                     for (int a = 0; a < 2; ++a)
 #pragma unroll
-                        for (int b = 0; b < 2; ++b) rr[a][b] = ld_stream(p.res1 + o[a][b]);
+                        for (int b = 0; b < 2; ++b) {
+                            if constexpr (ONE_TASK) rr[a][b] = pre[a][b];
+                            else rr[a][b] = ld_stream(p.res1 + o[a][b]);
+                        }
                     if (p.flags & SBC_EPI_RES1_ELU) {
 #pragma unroll
                         for (int a = 0; a < 2; ++a)

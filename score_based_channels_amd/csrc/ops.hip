@@ -355,6 +355,12 @@ __global__ __launch_bounds__(256) void end_conv_kernel(const float* __restrict__
         stats_from_moments_to_lds<CIN>(st, stats + (size_t)n * NT * CIN * 2, agb, NT, 128.f, H * W, tid);
         __syncthreads();
         stage_commit<CIN, 256, 9, false>(lds, pf, in, st, SBC_PRO_NORM | SBC_PRO_ELU, g, d, tid, 0);
+    } else if (!g.multi) {
+        // one sample per tile: the thread's (mu, scale, shift) in registers instead of three loads per staged chunk
+        float4 pf[9];
+        stage_issue<CIN, 256, 9>(pf, in, g, W, tid);
+        const RegStats rs = load_reg_stats<CIN, 256>(stats, g, tid);
+        stage_commit_reg<CIN, 256, 9>(lds, pf, in, rs, SBC_PRO_NORM | SBC_PRO_ELU, g, W, tid);
     } else {
         stage_tile<CIN, 256, 9, false>(lds, in, stats, SBC_PRO_NORM | SBC_PRO_ELU, g, d, tid);
     }

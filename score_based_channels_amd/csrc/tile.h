@@ -150,6 +150,42 @@ __device__ __forceinline__ void stage_commit(float* lds, const float4 (&pf)[NPF]
     for (int i = tid; i < S; i += NTHREADS) lds[g.nps * S + i] = 0.f;
 }
 
+// Statistics in registers: when a tile lies inside ONE sample (TM <= H*W) and NTHREADS is a multiple of CIN / 4, every
+// 16-byte chunk a thread stages belongs to the same channel quad of the same sample, so its (mu, scale, shift) are three
+// float4 loads per THREAD -- issued together with the tile loads -- and the copy of the statistics through LDS with its
+// workgroup barrier disappears from the prologue.
+struct RegStats { float4 mu, sc, sh; };
+template <int CIN, int NTHREADS>
+__device__ __forceinline__ RegStats load_reg_stats(const float* __restrict__ stats, const TileGeom& g, int tid) {
+    static_assert(NTHREADS % (CIN / 4) == 0, "a thread must keep its channel quad over all its chunks");
+    const float* st = stats + (size_t)g.n_first * 3 * CIN + (tid % (CIN / 4)) * 4;
+    RegStats r;
+    r.mu = *reinterpret_cast<const float4*>(st);
+    r.sc = *reinterpret_cast<const float4*>(st + CIN);
+    r.sh = *reinterpret_cast<const float4*>(st + 2 * CIN);
+    return r;
+}
+template <int CIN, int NTHREADS, int NPF>
+__device__ __forceinline__ void stage_commit_reg(float* lds, const float4 (&pf)[NPF], const float* __restrict__ in,
+                                                 const RegStats& rs, int flags, const TileGeom& g, int W, int tid) {
+    constexpr int S = CIN + 4, C4 = CIN / 4;
+    const int total = g.nps * C4;
+    auto put = [&](float4 x, int idx) {
+        x.x = (x.x - rs.mu.x) * rs.sc.x + rs.sh.x; x.y = (x.y - rs.mu.y) * rs.sc.y + rs.sh.y;
+        x.z = (x.z - rs.mu.z) * rs.sc.z + rs.sh.z; x.w = (x.w - rs.mu.w) * rs.sc.w + rs.sh.w;
+        if (flags & SBC_PRO_ELU) x = elu4(x);
+        *reinterpret_cast<float4*>(lds + (idx / C4) * S + (idx % C4) * 4) = x;
+    };
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) {
+        const int idx = u * NTHREADS + tid;
+        if (idx < total) put(pf[u], idx);
+    }
+    const float* src = in + (size_t)g.rs0 * W * CIN;
+    for (int idx = NPF * NTHREADS + tid; idx < total; idx += NTHREADS) put(ld_stream(src + (size_t)idx * 4), idx);
+    for (int i = tid; i < S; i += NTHREADS) lds[g.nps * S + i] = 0.f;
+}
+
 template <int CIN, int NTHREADS, int NPF, bool P2>
 __device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__ in, const float* __restrict__ stats,
                                            int flags, const TileGeom& g, const Dims<P2>& d, int tid) {
