@@ -235,25 +235,6 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) e[((r & 3) + 8 * (r >> 2)) * TS] = tv[r];
                 }
-            // One task per thread (32 output channels, 128 pixels): the residual operand is requested BEFORE the barrier, so
-            // that its L2 / HBM round trip overlaps the T-plane exchange instead of standing exposed at the end of a
-            // workgroup that lives only ~9 us
-            constexpr bool ONE_TASK = COUT == 32 && MB == 1 && NG == 1;
-            float4 pre[2][2];
-            if constexpr (ONE_TASK) {
-                if (p.res1 && !(p.flags & SBC_EPI_POOL)) {
-                    const int t = gtid >> 3, c4 = gtid & 7;
-                    const int tr = P2 ? t >> (p.wsh - 1) : t / Wt, tc = t - tr * Wt;
-                    const int grow = r0 + 2 * tr;
-                    if (grow < p.B * H) {
-#pragma unroll
-                        for (int a = 0; a < 2; ++a)
-#pragma unroll
-                            for (int b = 0; b < 2; ++b)
-                                pre[a][b] = ld_stream(p.res1 + ((size_t)(grow + a) * W + 2 * tc + b) * COUT + c4 * 4);
-                    }
-                }
-            }
             __syncthreads();
             // finish: one (tile, channel quad) per thread and round
             float4 yk[4];                                                 // this thread's four outputs (SBC_EPI_MOMENTS_OUT)
@@ -324,10 +305,7 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
 #pragma unroll
                     for (int a = 0; a < 2; ++a)
 #pragma unroll
-                        for (int b = 0; b < 2; ++b) {
-                            if constexpr (ONE_TASK) rr[a][b] = pre[a][b];
-                            else rr[a][b] = ld_stream(p.res1 + o[a][b]);
-                        }
+                        for (int b = 0; b < 2; ++b) rr[a][b] = ld_stream(p.res1 + o[a][b]);
                     if (p.flags & SBC_EPI_RES1_ELU) {
 #pragma unroll
                         for (int a = 0; a < 2; ++a)
