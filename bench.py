@@ -124,7 +124,7 @@ def parse_args():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--force-dist', action='store_true',
                     help='with --gpus 1: still create a one-rank RCCL process group and route the barrier / max / gather through it')
-    ap.add_argument('--conv-mode', default=None, choices=['bf16x3', 'f32', 'f16w'],
+    ap.add_argument('--conv-mode', default=None, choices=['bf16x3', 'f32', 'f16w', 'f16x2'],
                     help='convolution multiplier (scorenet.CONV_MODES); default bf16x3, f16w for --workload big')
     ap.add_argument('--overlap', type=int, default=None,
                     help='1: independent low-resolution branches of the network on the plan side stream, 0: strictly '
@@ -373,6 +373,7 @@ def main():
         value = world * T / (STEPS_PER_CHANNEL * dt / K)
         flops_fwd = P.count_conv_flops(net.score_plan(nt, nr)) * T          # conv FLOPs of one step on this GPU
         dtype = {'f32': 'f32', 'bf16x3': 'f32 (products as exact 3-term bf16 splits on the bf16 matrix cores, fp32 accumulate)',
+                 'f16x2': 'f32 (operands as two fp16 terms of a power-of-two-scaled value, hh + hl + lh on the fp16 matrix cores, fp32 accumulate)',
                  'f16w': 'f16 weights x f16-rounded activations on the fp16 matrix cores, fp32 accumulate, fp32 tensors in HBM'}
         out = {
             'metric': 'channels/s full ALD inference, %s Nt%dxNr%d' % ('CDL-C' if not big else 'ULA', nt, nr),
@@ -423,10 +424,10 @@ def main():
                 if tj.get('trajectories_per_launch') == T0 and tj.get('conv_mode') == conv_mode:
                     traffic, tsrc = tj.get('hbm_bytes_per_launch'), 'profiles/' + os.path.basename(tfile)
             alg_bytes = px * 32 * 4 * 3.0                                    # input + residual + output, fp32 NHWC
-            if conv_mode == 'bf16x3':
-                # Winograd F(2x2,3x3) executes 16/36 of the direct products, each as six bf16 MFMAs (exact 3-term split):
-                # algorithmic FLOP/s at which the bf16 matrix pipe would be 100 % busy with this algorithm
-                exec_ratio = 6.0 * 16.0 / 36.0
+            if conv_mode in ('bf16x3', 'f16x2'):
+                # Winograd F(2x2,3x3) executes 16/36 of the direct products, each as six bf16 MFMAs (exact 3-term split) or
+                # three fp16 MFMAs (two-term split): algorithmic FLOP/s at which the matrix pipe would be 100 % busy
+                exec_ratio = (6.0 if conv_mode == 'bf16x3' else 3.0) * 16.0 / 36.0
                 peak = PEAK_BF16_MFMA_TFLOPS / exec_ratio
                 rf = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
                       'traffic': traffic,

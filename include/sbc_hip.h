@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SBC_ABI_VERSION 7
+#define SBC_ABI_VERSION 8
 
 typedef enum sbc_status {
     SBC_OK = 0,
@@ -101,6 +101,14 @@ typedef enum sbc_op_kind {
                                    fp16 term per weight (sbc_pack_conv_weight_f16 / _winograd_f16) instead of
                                    three bf16 terms; activations are rounded to fp16 as they enter the matrix
                                    cores (v_mfma_f32_32x32x16_f16), accumulation stays fp32                    */
+
+#define SBC_CONV_F16X2   0x10000 /* fp32-class arithmetic on the fp16 matrix cores: `weight_split` / `weight_wino_split` hold TWO
+                                   fp16 terms per (scaled) weight plus a 16-byte trailer with the scales
+                                   (sbc_pack_conv_weight_f16x2 / _winograd_f16x2); activations are scaled by a power of two and
+                                   split into two fp16 terms as they enter the matrix cores; three v_mfma_f32_32x32x16_f16
+                                   per product block (hh + hl + lh), fp32 accumulation.  Representation error <= 2^-22 per
+                                   operand.  A staged activation with |x| * act_scale >= 16000 raises the device's range
+                                   flag (sbc_range_flag) instead of overflowing silently                              */
 
 /* One fused launch.  Unused fields are 0 / NULL.  Tensor shapes per kind:
  *   BEGIN_CONV  in [B][H][W][2], weight [cout][2][3][3] (torch layout), bias [cout], out [B][H][W][cout]
@@ -332,6 +340,20 @@ void sbc_score_destroy(sbc_score* score);
  * Winograd form rounds U = G g G^T (double) once to fp16. */
 int sbc_pack_conv_weight_f16(const float* src, int32_t cout, int32_t cin, int32_t ksize, uint16_t* dst);
 int sbc_pack_conv_weight_winograd_f16(const float* src, int32_t cout, int32_t cin, uint16_t* dst);
+
+/* f16x2 weight forms for SBC_CONV_F16X2: every weight (or Winograd-transformed weight U = G g G^T, double -> float) is
+ * scaled by 2^s -- s chosen per layer so that the largest magnitude lies in [2^13, 2^14) -- and written as two fp16 terms
+ * h = fp16(w 2^s), l = fp16(w 2^s - h), in the layout of sbc_pack_conv_weight_split with 2 terms,
+ * [k*k | 16][cin/16][cout/32][2][64 lanes][8] uint16, followed by a 16-byte trailer of four float32: (act_scale =
+ * 2^SBC_F16X2_ACT_SHIFT, descale = 2^-(s + SBC_F16X2_ACT_SHIFT), 0, 0).  dst holds sbc_f16x2_elems(...) uint16. */
+#define SBC_F16X2_ACT_SHIFT 5
+#define sbc_f16x2_elems(taps, cin, cout) ((size_t)(taps) * (cin) * (cout) * 2 + 8)
+int sbc_pack_conv_weight_f16x2(const float* src, int32_t cout, int32_t cin, int32_t ksize, uint16_t* dst);
+int sbc_pack_conv_weight_winograd_f16x2(const float* src, int32_t cout, int32_t cin, uint16_t* dst);
+/* Range flag of the f16x2 kernels on the CURRENT device: *flag != 0 when, since the last reset, a convolution staged an
+ * activation with |x| * act_scale >= 16000 (results of that launch are not trustworthy: run the layer stack in split-bf16
+ * mode instead).  Synchronises with the device.  reset != 0 clears it. */
+int sbc_range_flag(int32_t* flag, int32_t reset);
 
 /* scratch floats SBC_OP_CONV_WGRAD / END_CONV_BWD / BEGIN_CONV_BWD need in `aux` for this shape */
 int64_t sbc_wgrad_scratch_floats(int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t ksize);

@@ -8,13 +8,14 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SBC_LIB_PATH') or os.path.join(_HERE, 'libsbc_hip.so')   # env override: A/B builds (tools/)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 EXPORTS = ('sbc_abi_version', 'sbc_last_error', 'sbc_device_count', 'sbc_op_launch', 'sbc_plan_create',
            'sbc_plan_run', 'sbc_plan_destroy', 'sbc_plan_profile', 'sbc_plan_profile_read',
            'sbc_pack_conv_weight', 'sbc_pack_conv_weight_winograd',
            'sbc_pack_conv_weight_split', 'sbc_pack_conv_weight_winograd_split',
            'sbc_pack_conv_weight_f16', 'sbc_pack_conv_weight_winograd_f16',
+           'sbc_pack_conv_weight_f16x2', 'sbc_pack_conv_weight_winograd_f16x2', 'sbc_range_flag',
            'sbc_score_create', 'sbc_score_buffers', 'sbc_score_ops', 'sbc_score_level_source', 'sbc_score_forward',
            'sbc_score_destroy', 'sbc_wgrad_scratch_floats')
 
@@ -97,6 +98,9 @@ def lib():
     h.sbc_pack_conv_weight_winograd_split.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     h.sbc_pack_conv_weight_f16.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     h.sbc_pack_conv_weight_winograd_f16.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    h.sbc_pack_conv_weight_f16x2.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    h.sbc_pack_conv_weight_winograd_f16x2.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    h.sbc_range_flag.argtypes = [C.POINTER(C.c_int32), C.c_int32]
     h.sbc_score_create.argtypes = [C.POINTER(sbc_score_desc), C.POINTER(sbc_tensor_ref), C.c_int32, C.POINTER(C.c_void_p)]
     h.sbc_score_buffers.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     h.sbc_score_ops.argtypes = [C.c_void_p, C.POINTER(C.POINTER(sbc_op)), C.POINTER(C.c_int32)]
@@ -115,6 +119,21 @@ def lib():
 def check(rc):
     if rc != 0:
         raise SbcError('libsbc_hip: %s (status %d)' % (lib().sbc_last_error().decode(), rc))
+
+
+def range_flag(reset=True):
+    """``sbc_range_flag``: non-zero when an f16x2 convolution on the current device staged an activation outside the fp16
+    range since the last reset (synchronises with the device)."""
+    v = C.c_int32()
+    check(lib().sbc_range_flag(C.byref(v), 1 if reset else 0))
+    return v.value
+
+
+def check_range(what='run'):
+    """Raise if the f16x2 kernels flagged an activation outside their range: the numbers of that run cannot be trusted."""
+    if range_flag(True):
+        raise SbcError('%s: an activation left the range of conv_mode f16x2 (|x| >= 500); results are invalid -- '
+                       'use conv_mode bf16x3 for this checkpoint' % what)
 
 
 class Plan:

@@ -1,5 +1,7 @@
 // C ABI of libsbc_hip.so (include/sbc_hip.h): error reporting, single-op launch, plans (eager or hipGraph
 // replay), per-tag kernel timing, host-side weight packing.
+#include <cmath>
+#include <math.h>
 #include <stdarg.h>
 #include <string.h>
 #include <map>
@@ -30,6 +32,23 @@ int ensure_dyn_lds(const void* kernel, size_t bytes) {
         SBC_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         cur = bytes;
     }
+    return SBC_OK;
+}
+
+// One 4-byte flag word per device for the f16x2 kernels (include/sbc_hip.h: sbc_range_flag).  Allocated outside any stream
+// capture: sbc_plan_create resolves every convolution once (dry run) before a plan can be captured.
+int range_flag_ptr(unsigned** out) {
+    static std::mutex mu;
+    static std::map<int, unsigned*> words;
+    int dev = 0;
+    SBC_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    unsigned*& w = words[dev];
+    if (!w) {
+        SBC_CHECK_HIP(hipMalloc((void**)&w, 16));
+        SBC_CHECK_HIP(hipMemset(w, 0, 16));
+    }
+    *out = w;
     return SBC_OK;
 }
 
@@ -186,6 +205,18 @@ int sbc_device_count(void) {
     int n = 0;
     SBC_CHECK_HIP(hipGetDeviceCount(&n));
     return n;
+}
+
+int sbc_range_flag(int32_t* flag, int32_t reset) {
+    SBC_REQUIRE(flag, "sbc_range_flag: flag is NULL");
+    unsigned* w = nullptr;
+    const int rc = range_flag_ptr(&w);
+    if (rc) return rc;
+    unsigned v = 0;
+    SBC_CHECK_HIP(hipMemcpy(&v, w, sizeof(v), hipMemcpyDeviceToHost));       // synchronises with the device
+    if (reset && v) SBC_CHECK_HIP(hipMemset(w, 0, sizeof(v)));
+    *flag = (int32_t)v;
+    return SBC_OK;
 }
 
 int sbc_op_launch(const sbc_op* op, void* stream) {
@@ -439,6 +470,83 @@ int sbc_pack_conv_weight_winograd_f16(const float* src, int32_t cout, int32_t ci
                     dst[((((size_t)(i * 4 + l) * KG + kg) * NB + nb) * 64 + lane) * 8 + j] = f16_rne((float)u);
                 }
         }
+    return SBC_OK;
+}
+
+// ---- f16x2 forms (SBC_CONV_F16X2): two fp16 terms of w * 2^s + the scale trailer --------------------------------------
+// s: the power of two that puts the largest |w| of the layer into [2^13, 2^14) (fp16 keeps 11 significant bits down to
+// 2^-14, so every weight above 2^-27 of the largest one keeps its 22 bits); activations are scaled by 2^SBC_F16X2_ACT_SHIFT.
+static int f16x2_shift(const float* w, size_t n) {
+    float m = 0.f;
+    for (size_t i = 0; i < n; ++i) { const float a = fabsf(w[i]); if (a > m) m = a; }
+    if (!(m > 0.f) || !std::isfinite(m)) return 0;
+    int e = 0;
+    (void)frexpf(m, &e);                       // m = f * 2^e, f in [0.5, 1)
+    int s = 14 - e;
+    return s < -100 ? -100 : s > 100 ? 100 : s;
+}
+static inline void f16x2_terms(float w, int s, uint16_t* h, uint16_t* l) {
+    const float a = ldexpf(w, s);
+    const _Float16 hh = (_Float16)a;
+    const _Float16 ll = (_Float16)(a - (float)hh);
+    memcpy(h, &hh, 2);
+    memcpy(l, &ll, 2);
+}
+static void f16x2_trailer_write(uint16_t* dst, size_t n16, int s) {
+    const float tr[4] = {ldexpf(1.f, SBC_F16X2_ACT_SHIFT), ldexpf(1.f, -(s + SBC_F16X2_ACT_SHIFT)), 0.f, 0.f};
+    memcpy(dst + n16, tr, sizeof(tr));
+}
+
+int sbc_pack_conv_weight_f16x2(const float* src, int32_t cout, int32_t cin, int32_t ksize, uint16_t* dst) {
+    SBC_REQUIRE(src && dst, "sbc_pack_conv_weight_f16x2: NULL pointer");
+    SBC_REQUIRE(cin % 16 == 0 && cout % 32 == 0 && (ksize == 1 || ksize == 3),
+                "sbc_pack_conv_weight_f16x2: cin %% 16, cout %% 32, ksize in {1,3} required (got %d, %d, %d)", cin, cout, ksize);
+    const int taps = ksize * ksize, KG = cin / 16, NB = cout / 32;
+    const int s = f16x2_shift(src, (size_t)cout * cin * taps);
+    for (int tap = 0; tap < taps; ++tap)
+        for (int g = 0; g < KG; ++g)
+            for (int nb = 0; nb < NB; ++nb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = nb * 32 + (lane & 31), ci = g * 16 + 8 * (lane >> 5) + j;
+                        const size_t base = (((size_t)tap * KG + g) * NB + nb) * 2;
+                        f16x2_terms(src[((size_t)co * cin + ci) * taps + tap], s, &dst[((base + 0) * 64 + lane) * 8 + j],
+                                    &dst[((base + 1) * 64 + lane) * 8 + j]);
+                    }
+    f16x2_trailer_write(dst, (size_t)taps * KG * NB * 2 * 512, s);
+    return SBC_OK;
+}
+
+int sbc_pack_conv_weight_winograd_f16x2(const float* src, int32_t cout, int32_t cin, uint16_t* dst) {
+    SBC_REQUIRE(src && dst, "sbc_pack_conv_weight_winograd_f16x2: NULL pointer");
+    SBC_REQUIRE(cin % 16 == 0 && cout % 32 == 0, "sbc_pack_conv_weight_winograd_f16x2: cin %% 16, cout %% 32 required (got %d, %d)",
+                cin, cout);
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    std::vector<float> u((size_t)cout * cin * 16);             // torch-like [cout][cin][4][4]
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+            const float* g = src + ((size_t)co * cin + ci) * 9;
+            for (int i = 0; i < 4; ++i)
+                for (int l = 0; l < 4; ++l) {
+                    double v = 0;
+                    for (int j = 0; j < 3; ++j)
+                        for (int k = 0; k < 3; ++k) v += G[i][j] * (double)g[j * 3 + k] * G[l][k];
+                    u[((size_t)co * cin + ci) * 16 + i * 4 + l] = (float)v;
+                }
+        }
+    const int KG = cin / 16, NB = cout / 32;
+    const int s = f16x2_shift(u.data(), u.size());
+    for (int tap = 0; tap < 16; ++tap)
+        for (int g = 0; g < KG; ++g)
+            for (int nb = 0; nb < NB; ++nb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = nb * 32 + (lane & 31), ci = g * 16 + 8 * (lane >> 5) + j;
+                        const size_t base = (((size_t)tap * KG + g) * NB + nb) * 2;
+                        f16x2_terms(u[((size_t)co * cin + ci) * 16 + tap], s, &dst[((base + 0) * 64 + lane) * 8 + j],
+                                    &dst[((base + 1) * 64 + lane) * 8 + j]);
+                    }
+    f16x2_trailer_write(dst, (size_t)16 * KG * NB * 2 * 512, s);
     return SBC_OK;
 }
 

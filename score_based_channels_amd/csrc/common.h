@@ -33,6 +33,9 @@ void set_error(const char* fmt, ...);
 // from several host threads (include/sbc_hip.h: threading).  Returns SBC_OK or SBC_ERR_HIP.
 int ensure_dyn_lds(const void* kernel, size_t bytes);
 
+// conv_mode f16x2: the current device's range-flag word (allocated and zeroed on first use; api.hip)
+int range_flag_ptr(unsigned** out);
+
 // per-kind launchers (each validates its op, then launches asynchronously on `stream`)
 // dry = true: validate, resolve the kernel variant and set its function attributes, but do not launch
 int launch_conv(const sbc_op& op, hipStream_t stream, bool dry = false);

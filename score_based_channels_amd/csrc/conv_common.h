@@ -24,7 +24,16 @@ struct ConvParams {
     // and needs the norm's alpha | gamma | beta; SBC_EPI_MOMENTS_OUT writes the output's tile moments
     const float* __restrict__ agb;
     float* __restrict__ pm_out;
+    // conv_mode f16x2: per-device word the kernels OR a 1 into when a staged activation leaves the fp16 range (tile.h)
+    unsigned* __restrict__ range_flag;
 };
+
+// Trailer of the f16x2 weight forms (sbc_pack_conv_weight_f16x2 / _winograd_f16x2): one 16-byte record behind the last
+// fragment, (act_scale, descale, 0, 0): activations are staged as x * act_scale, accumulators leave as acc * descale
+// (descale = 1 / (act_scale * weight_scale), all powers of two).
+__device__ __forceinline__ float4 f16x2_trailer(const float4* wpk, int n_frag16) {   // n_frag16: 16-byte fragments per lane slot
+    return wpk[(size_t)n_frag16 * 64];
+}
 
 
 // Winograd F(2x2,3x3) path (conv_wino.hip): returns SBC_OK after launching, or 1 when the shape is not eligible

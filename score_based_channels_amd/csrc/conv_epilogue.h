@@ -10,7 +10,7 @@ namespace sbc {
 // accumulators (32x32 MFMA map: column = lane & 31 = output channel, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) -> LDS
 template <int COUT, int MT, int NT>
 __device__ __forceinline__ void conv_acc_to_lds(float* lds, const f32x16 (&acc)[MT][NT], const float* __restrict__ bias,
-                                                int wm, int wn, int lane) {
+                                                int wm, int wn, int lane, float descale = 1.f) {
     constexpr int ES = COUT + 4;
     const int col = lane & 31, rhalf = 4 * (lane >> 5);
 #pragma unroll
@@ -19,10 +19,11 @@ __device__ __forceinline__ void conv_acc_to_lds(float* lds, const f32x16 (&acc)[
         for (int ni = 0; ni < NT; ++ni) {
             const int co = (wn * NT + ni) * 32 + col;
             float* e = lds + ((wm * MT + mi) * 32 + rhalf) * ES + co;
-            if (bias) {
-                const float bv = bias[co];
+            // (descale is an exact power of two: acc * descale + bias rounds once, like acc + bias)
+            const float bv = bias ? bias[co] : 0.f;
+            if (bias || descale != 1.f) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) e[((r & 3) + 8 * (r >> 2)) * ES] = acc[mi][ni][r] + bv;
+                for (int r = 0; r < 16; ++r) e[((r & 3) + 8 * (r >> 2)) * ES] = fmaf(acc[mi][ni][r], descale, bv);
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) e[((r & 3) + 8 * (r >> 2)) * ES] = acc[mi][ni][r];

@@ -247,6 +247,14 @@ int launch_conv(const sbc_op& op, hipStream_t stream, bool dry) {
     p.hsh = log2_exact(op.H); p.wsh = log2_exact(op.W);
     p.plane = 0; p.stats_off = 0; p.top = op.tag == 1;
     p.agb = (const float*)op.grad; p.pm_out = (float*)op.aux;
+    p.range_flag = nullptr;
+    if (op.flags & SBC_CONV_F16X2) {
+        SBC_REQUIRE(x3 && !(op.flags & SBC_CONV_F16W), "conv: SBC_CONV_F16X2 needs weight_split (sbc_pack_conv_weight_f16x2) and excludes SBC_CONV_F16W");
+        unsigned* word = nullptr;
+        const int rc = range_flag_ptr(&word);
+        if (rc) return rc;
+        p.range_flag = word;
+    }
     const bool moments = (op.flags & (SBC_PRO_NORM_MOMENTS | SBC_EPI_MOMENTS_OUT)) != 0;
     if (moments) {
         // statistics folded into the Winograd split-bf16 kernel only (tile.h): whole 128-pixel tiles inside one sample

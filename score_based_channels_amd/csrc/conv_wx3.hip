@@ -27,12 +27,19 @@ namespace sbc {
 // NG: wave groups of four waves (one per transform row).  With two groups the phases (output blocks) are dealt between
 // them, so a 128-output-channel layer on the 8x2 level -- a launch with fewer workgroups than CUs, i.e. pure
 // single-workgroup latency -- walks two phases per group instead of four, and twice the threads stage the tile.
-// F16 (conv_mode f16w, BASELINE config 5 "fp16 score-net weights"): the transformed filter is ONE fp16 term
+// MODE 1 (conv_mode f16w, BASELINE config 5 "fp16 score-net weights"): the transformed filter is ONE fp16 term
 // (sbc_pack_conv_weight_winograd_f16), the transformed input V is rounded to fp16 instead of split, and a transform column
 // is one v_mfma_f32_32x32x16_f16 per output block instead of six bf16 MFMAs; everything else is shared.
-template <int CIN, int COUT, int MB, bool P2, int WPE, bool TOP, int NBP, int NG, bool F16>
+// MODE 2 (conv_mode f16x2): fp32-class arithmetic with TWO fp16 terms per operand.  The tile is staged as x * act_scale (a
+// power of two, so V = B^T d B scales exactly), V is split in registers as h = fp16(V), l = fp16(V - h) -- three vector
+// instructions per pair of values where the exact bf16 split needs nine --, U = G g G^T was scaled and split on the host
+// (sbc_pack_conv_weight_winograd_f16x2), and a transform column is three v_mfma_f32_32x32x16_f16 per output block:
+// (l,h) (h,l) (h,h).  The finish multiplies by descale = 1 / (act_scale * weight_scale) in the fma that adds the bias.
+// MODE 0: the exact three-term bf16 split.
+template <int CIN, int COUT, int MB, bool P2, int WPE, bool TOP, int NBP, int NG, int MODE>
 __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
-    constexpr int NTERM = F16 ? 1 : 3;           // 16-bit terms per operand
+    constexpr bool F16 = MODE == 1;
+    constexpr int NTERM = MODE == 0 ? 3 : MODE;  // 16-bit terms per operand
     constexpr int TM = 128 * MB;                 // output pixels per workgroup
     constexpr int NTW = 32 * MB;                 // Winograd tiles (2x2 output blocks) per workgroup
     constexpr int S = CIN + 4;
@@ -58,7 +65,15 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
     const int col = lane & 31, rhalf = 4 * (lane >> 5);
 
     const TileGeom g = tile_geom(xcd_tile(blockIdx.x, gridDim.x), TM, p.B, dm, 1);
+    float descale = 1.f;
     {
+        StageScale ss{1.f, 0.f};
+        StageScale* const ssp = MODE == 2 ? &ss : nullptr;
+        if constexpr (MODE == 2) {
+            const float4 tr = f16x2_trailer(p.wpk, 16 * KG * NBLK * NTERM);
+            ss.scale = tr.x;
+            descale = tr.y;
+        }
         float4 pf[NPF];
         stage_issue<CIN, NTHREADS, NPF>(pf, p.in, g, W, tid);
         // InstanceNorm++ statistics of the tile's samples through LDS (behind the staged tile and the T planes)
@@ -74,14 +89,17 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
         } else if ((p.flags & SBC_PRO_NORM) && !g.multi) {
             // one sample per tile: statistics straight into registers, no LDS copy, no barrier (tile.h)
             const RegStats rs = load_reg_stats<CIN, NTHREADS>(p.stats, g, tid);
-            stage_commit_reg<CIN, NTHREADS, NPF>(lds, pf, p.in, rs, p.flags, g, W, tid);
+            stage_commit_reg<CIN, NTHREADS, NPF>(lds, pf, p.in, rs, p.flags, g, W, tid, ssp);
             direct = true;
 #endif
         } else if (p.flags & SBC_PRO_NORM) {
             stage_stats_to_lds<CIN, NTHREADS, P2>(st_lds, p.stats, g, dm, tid);
             __syncthreads();
         }
-        if (!direct) stage_commit<CIN, NTHREADS, NPF, P2>(lds, pf, p.in, st_lds, p.flags, g, dm, tid, 0);
+        if (!direct) stage_commit<CIN, NTHREADS, NPF, P2>(lds, pf, p.in, st_lds, p.flags, g, dm, tid, 0, ssp);
+        if constexpr (MODE == 2) {
+            if (ss.amax >= F16X2_LIMIT) atomicOr(p.range_flag, 1u);
+        }
     }
     // T planes [xi][b][tile][TS]: overlay the staged tile when there is a single output block, else live behind it
     float* const tl = (NBLK == 1 ? lds : lds + (size_t)(g.multi ? TM + 1 : TM + 2 * W + 1) * S) + (size_t)grp * 8 * NTW * 36;
@@ -183,6 +201,22 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
                     for (int q = 0; q < NBP; ++q)
                         acc[q][nu] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, __builtin_bit_cast(f16x8, uB[cur][q][0]),
                                                                             acc[q][nu], 0, 0, 0);
+                } else if constexpr (MODE == 2) {
+                    uint4 vhu, vlu;
+                    split_f16x2(v[0], v[1], vhu.x, vlu.x);
+                    split_f16x2(v[2], v[3], vhu.y, vlu.y);
+                    split_f16x2(v[4], v[5], vhu.z, vlu.z);
+                    split_f16x2(v[6], v[7], vhu.w, vlu.w);
+                    const f16x8 vh = __builtin_bit_cast(f16x8, vhu), vl = __builtin_bit_cast(f16x8, vlu);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < NBP; ++q) {
+                        const f16x8 uh = __builtin_bit_cast(f16x8, uB[cur][q][0]),
+                                    ul = __builtin_bit_cast(f16x8, uB[cur][q][NTERM > 1 ? 1 : 0]);
+                        acc[q][nu] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, uh, acc[q][nu], 0, 0, 0);
+                        acc[q][nu] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ul, acc[q][nu], 0, 0, 0);
+                        acc[q][nu] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, uh, acc[q][nu], 0, 0, 0);
+                    }
                 } else {
                     bf16x8 vh, vm, vl;
 #pragma unroll
@@ -259,7 +293,17 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
                 const int tr = P2 ? t >> (p.wsh - 1) : t / Wt, tc = t - tr * Wt;
                 const int grow = r0 + 2 * tr;
                 if (grow >= p.B * H) continue;
-                if (p.bias) {
+                if (MODE == 2) {
+                    // descale (an exact power of two) in the same rounding as the bias add
+                    const float4 bv = p.bias ? *reinterpret_cast<const float4*>(p.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            y[a][b].x = fmaf(y[a][b].x, descale, bv.x); y[a][b].y = fmaf(y[a][b].y, descale, bv.y);
+                            y[a][b].z = fmaf(y[a][b].z, descale, bv.z); y[a][b].w = fmaf(y[a][b].w, descale, bv.w);
+                        }
+                } else if (p.bias) {
                     const float4 bv = *reinterpret_cast<const float4*>(p.bias + co);
 #pragma unroll
                     for (int a = 0; a < 2; ++a)
@@ -388,7 +432,7 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------ dispatch
-template <int CIN, int COUT, int MB, bool F16>
+template <int CIN, int COUT, int MB, int F16>
 static int launch_wx3(const ConvParams& p, hipStream_t stream, bool dry) {
     SBC_REQUIRE(!(p.flags & SBC_EPI_MOMENTS_OUT) || (MB == 1 && COUT == 32),
                 "conv_wx3: tile moments are written by the 128-pixel, 32-output-channel variant only");
@@ -430,8 +474,9 @@ static int launch_wx3(const ConvParams& p, hipStream_t stream, bool dry) {
 
 template <int CIN, int COUT, int MB>
 static int launch_wx3_mode(const ConvParams& p, hipStream_t stream, bool dry) {
-    return (p.flags & SBC_CONV_F16W) ? launch_wx3<CIN, COUT, MB, true>(p, stream, dry)
-                                     : launch_wx3<CIN, COUT, MB, false>(p, stream, dry);
+    return (p.flags & SBC_CONV_F16W)    ? launch_wx3<CIN, COUT, MB, 1>(p, stream, dry)
+           : (p.flags & SBC_CONV_F16X2) ? launch_wx3<CIN, COUT, MB, 2>(p, stream, dry)
+                                        : launch_wx3<CIN, COUT, MB, 0>(p, stream, dry);
 }
 
 template <int CIN, int COUT>

@@ -49,7 +49,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_x3_kernel(ConvParams p) {
     const uint4* wp = reinterpret_cast<const uint4*>(p.wpk) + (size_t)(wn * NT) * TERMS * 64 + lane;
 
     const TileGeom g = tile_geom(blockIdx.x, TM, p.B, dm, KS == 3 ? p.dil : 0);
-    stage_tile_split<CIN, NTHREADS, NPF, P2, TERMS>(lds16, plane, p.in, p.stats, p.flags, g, dm, tid);
+    float descale = 1.f;
+    if constexpr (TERMS == 2) {
+        // conv_mode f16x2: scaled activations as two fp16 terms; the scales ride behind the packed weight (conv_common.h)
+        const float4 tr = f16x2_trailer(p.wpk, TAPS * KG * NBLK * TERMS);
+        StageScale ss{tr.x, 0.f};
+        descale = tr.y;
+        stage_tile_split<CIN, NTHREADS, NPF, P2, TERMS>(lds16, plane, p.in, p.stats, p.flags, g, dm, tid, &ss);
+        if (ss.amax >= F16X2_LIMIT) atomicOr(p.range_flag, 1u);
+    } else {
+        stage_tile_split<CIN, NTHREADS, NPF, P2, TERMS>(lds16, plane, p.in, p.stats, p.flags, g, dm, tid);
+    }
 
     // per 32-pixel block: this lane's LDS base offset and the 9-bit mask of taps inside the image (conv_mfma.hip)
     int abase[MT];
@@ -107,6 +117,19 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_x3_kernel(ConvParams p) {
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aS[cur][mi][0]),
                                                                          __builtin_bit_cast(f16x8, bS[cur][ni][0]),
                                                                          acc[mi][ni], 0, 0, 0);
+        } else if constexpr (TERMS == 2) {
+            // two fp16 terms per operand: (l,h) (h,l) (h,h); the dropped (l,l) is below 2^-22 of the product
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int ta = q == 0 ? 1 : 0, tb = q == 1 ? 1 : 0;
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NT; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            __builtin_bit_cast(f16x8, aS[cur][mi][ta]), __builtin_bit_cast(f16x8, bS[cur][ni][tb]),
+                            acc[mi][ni], 0, 0, 0);
+            }
         } else {
             // partial products, smallest first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
 #pragma unroll
@@ -212,7 +235,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_x3_kernel(ConvParams p) {
 
     // ---------------------------------------------------------------- epilogue (conv_epilogue.h)
     __syncthreads();   // every wave is done reading the staged planes
-    conv_acc_to_lds<COUT, MT, NT>(lds, acc, p.bias, wm, wn, lane);
+    conv_acc_to_lds<COUT, MT, NT>(lds, acc, p.bias, wm, wn, lane, descale);
     __syncthreads();
     conv_epilogue<COUT, TM, NTHREADS, P2>(lds, p, g, dm, tid);
 }
@@ -251,6 +274,10 @@ static int launch_variant(const ConvParams& p, hipStream_t stream, bool dry) {
         if (p2) return launch_kernel<CIN, COUT, KS, MT, NT, WM, WN, true, 1>(p, stream, dry);
         return launch_kernel<CIN, COUT, KS, MT, NT, WM, WN, false, 1>(p, stream, dry);
     }
+    if (p.flags & SBC_CONV_F16X2) {
+        if (p2) return launch_kernel<CIN, COUT, KS, MT, NT, WM, WN, true, 2>(p, stream, dry);
+        return launch_kernel<CIN, COUT, KS, MT, NT, WM, WN, false, 2>(p, stream, dry);
+    }
     if (p2) return launch_kernel<CIN, COUT, KS, MT, NT, WM, WN, true, 3>(p, stream, dry);
     return launch_kernel<CIN, COUT, KS, MT, NT, WM, WN, false, 3>(p, stream, dry);
 }
@@ -265,7 +292,7 @@ static int launch_sized(const ConvParams& p, hipStream_t stream, bool dry) {
     auto fits = [&](int tm) {
         return tm % p.W == 0 && (HW % tm == 0 || tm % HW == 0) && (!(p.flags & SBC_EPI_POOL) || tm % (2 * p.W) == 0);
     };
-    const int terms = (p.flags & SBC_CONV_F16W) ? 1 : 3;
+    const int terms = (p.flags & SBC_CONV_F16W) ? 1 : (p.flags & SBC_CONV_F16X2) ? 2 : 3;
     auto lds_of = [&](int tm) -> size_t {
         const int halo_px = (tm >= HW || KS == 1) ? 0 : 2 * p.dil * p.W;
         const size_t staged = (size_t)terms * (tm + halo_px + 1) * (CIN + 8) * 2, epi = (size_t)tm * (COUT + 4) * 4;

@@ -32,6 +32,19 @@ __device__ __forceinline__ void st_stream(float* p, float4 v) {
 #endif
 }
 
+// conv_mode f16x2 (SBC_CONV_F16X2): activations enter the matrix cores as x * scale (a power of two from the packed weight's
+// trailer, so the product is exact), split into two fp16 terms.  `amax` collects max |x * scale| of what a thread stages:
+// past F16X2_LIMIT the high term (or, in the Winograd kernel, a 4-term transform sum) could overflow fp16, and the kernel
+// raises the device range flag instead of returning silently wrong numbers.
+struct StageScale { float scale; float amax; };
+constexpr float F16X2_LIMIT = 16000.f;                   // 65504 / 4, rounded down
+__device__ __forceinline__ void scale_track(float4& x, StageScale* ss) {
+    if (!ss) return;
+    x.x *= ss->scale; x.y *= ss->scale; x.z *= ss->scale; x.w *= ss->scale;
+    ss->amax = __builtin_fmaxf(ss->amax, __builtin_fmaxf(__builtin_fabsf(x.x), __builtin_fabsf(x.y)));
+    ss->amax = __builtin_fmaxf(ss->amax, __builtin_fmaxf(__builtin_fabsf(x.z), __builtin_fabsf(x.w)));
+}
+
 // Image dimensions with the divisions the kernels need.  P2 = true: H and W are powers of two (every shape the
 // score network produces for Nt, Nr in {16, 64, 256}), so / and % are shifts and masks -- on gfx950 fp32 MFMA
 // shares the vector ALU with every other vector instruction, and a runtime integer division is ~25 of them.
@@ -103,7 +116,7 @@ __device__ __forceinline__ void stage_issue(float4 (&pf)[NPF], const float* __re
 // out of the staging loop.
 template <int CIN, bool P2>
 __device__ __forceinline__ void stage_put(float* lds, float4 x, int idx, const float* __restrict__ stats, int flags,
-                                          const TileGeom& g, const Dims<P2>& d, int n0 = -1) {
+                                          const TileGeom& g, const Dims<P2>& d, int n0 = -1, StageScale* ss = nullptr) {
     constexpr int S = CIN + 4;
     constexpr int C4 = CIN / 4;
     const int pix = idx / C4, c4 = idx % C4;
@@ -119,6 +132,7 @@ __device__ __forceinline__ void stage_put(float* lds, float4 x, int idx, const f
         x.w = (x.w - mu.w) * sc.w + sh.w;
     }
     if (flags & SBC_PRO_ELU) x = elu4(x);
+    scale_track(x, ss);
     *reinterpret_cast<float4*>(lds + pix * S + c4 * 4) = x;
 }
 
@@ -135,18 +149,18 @@ __device__ __forceinline__ void stage_stats_to_lds(float* st_lds, const float* _
 template <int CIN, int NTHREADS, int NPF, bool P2>
 __device__ __forceinline__ void stage_commit(float* lds, const float4 (&pf)[NPF], const float* __restrict__ in,
                                              const float* __restrict__ stats, int flags, const TileGeom& g,
-                                             const Dims<P2>& d, int tid, int n0 = -1) {
+                                             const Dims<P2>& d, int tid, int n0 = -1, StageScale* ss = nullptr) {
     constexpr int S = CIN + 4;
     const int W = d.W;
     const int total = g.nps * (CIN / 4);
 #pragma unroll
     for (int u = 0; u < NPF; ++u) {
         const int idx = u * NTHREADS + tid;
-        if (idx < total) stage_put<CIN, P2>(lds, pf[u], idx, stats, flags, g, d, n0);
+        if (idx < total) stage_put<CIN, P2>(lds, pf[u], idx, stats, flags, g, d, n0, ss);
     }
     const float* src = in + (size_t)g.rs0 * W * CIN;
     for (int idx = NPF * NTHREADS + tid; idx < total; idx += NTHREADS)
-        stage_put<CIN, P2>(lds, ld_stream(src + (size_t)idx * 4), idx, stats, flags, g, d, n0);
+        stage_put<CIN, P2>(lds, ld_stream(src + (size_t)idx * 4), idx, stats, flags, g, d, n0, ss);
     for (int i = tid; i < S; i += NTHREADS) lds[g.nps * S + i] = 0.f;
 }
 
@@ -167,13 +181,15 @@ __device__ __forceinline__ RegStats load_reg_stats(const float* __restrict__ sta
 }
 template <int CIN, int NTHREADS, int NPF>
 __device__ __forceinline__ void stage_commit_reg(float* lds, const float4 (&pf)[NPF], const float* __restrict__ in,
-                                                 const RegStats& rs, int flags, const TileGeom& g, int W, int tid) {
+                                                 const RegStats& rs, int flags, const TileGeom& g, int W, int tid,
+                                                 StageScale* ss = nullptr) {
     constexpr int S = CIN + 4, C4 = CIN / 4;
     const int total = g.nps * C4;
     auto put = [&](float4 x, int idx) {
         x.x = (x.x - rs.mu.x) * rs.sc.x + rs.sh.x; x.y = (x.y - rs.mu.y) * rs.sc.y + rs.sh.y;
         x.z = (x.z - rs.mu.z) * rs.sc.z + rs.sh.z; x.w = (x.w - rs.mu.w) * rs.sc.w + rs.sh.w;
         if (flags & SBC_PRO_ELU) x = elu4(x);
+        scale_track(x, ss);
         *reinterpret_cast<float4*>(lds + (idx / C4) * S + (idx % C4) * 4) = x;
     };
 #pragma unroll
@@ -215,11 +231,22 @@ __device__ __forceinline__ void split3(float4 x, bf16x4& h, bf16x4& m, bf16x4& l
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-// lds16: LDS viewed as 16-bit elements; `plane` = elements per plane; TERMS = 3 (exact bf16 split) or 1 (fp16)
+// Two-term fp16 split (conv_mode f16x2): a = h + l + O(2^-22 |a|), h = fp16(a) (round to nearest even), l = fp16(a - h); the
+// difference a - h is exact in fp32.  One v_cvt_pk_f16_f32 for the pair of high terms, one v_fma_mixlo/mixhi_f16 per low term
+// (fma(a, 1.0, -h) evaluated in fp32 from the fp16 half, rounded once to fp16).
+// h, l: the two values' terms packed low | high, as the matrix instructions take them.
+__device__ __forceinline__ void split_f16x2(float a, float b, unsigned& h, unsigned& l) {
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(a), "v"(b));
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[0,0,1] neg_lo:[0,0,1]" : "=v"(l) : "v"(a), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, %2 op_sel:[0,0,1] op_sel_hi:[0,0,1] neg_lo:[0,0,1]" : "+v"(l) : "v"(b), "v"(h));
+}
+
+// lds16: LDS viewed as 16-bit elements; `plane` = elements per plane; TERMS = 3 (exact bf16 split), 2 (fp16 pair of a scaled
+// value, conv_mode f16x2) or 1 (fp16)
 template <int CIN, bool P2, int TERMS = 3>
 __device__ __forceinline__ void stage_put_split(unsigned short* lds16, int plane, float4 x, int idx,
                                                 const float* __restrict__ stats, int flags, const TileGeom& g,
-                                                const Dims<P2>& d) {
+                                                const Dims<P2>& d, StageScale* ss = nullptr) {
     constexpr int SH = CIN + 8;
     constexpr int C4 = CIN / 4;
     const int pix = idx / C4, c4 = idx % C4;
@@ -240,6 +267,13 @@ __device__ __forceinline__ void stage_put_split(unsigned short* lds16, int plane
         f16x4 h;
         h[0] = (_Float16)x.x; h[1] = (_Float16)x.y; h[2] = (_Float16)x.z; h[3] = (_Float16)x.w;
         *reinterpret_cast<f16x4*>(dst) = h;
+    } else if constexpr (TERMS == 2) {
+        scale_track(x, ss);
+        uint2 h, l;
+        split_f16x2(x.x, x.y, h.x, l.x);
+        split_f16x2(x.z, x.w, h.y, l.y);
+        *reinterpret_cast<uint2*>(dst) = h;
+        *reinterpret_cast<uint2*>(dst + plane) = l;
     } else {
         bf16x4 h, m, l;
         split3(x, h, m, l);
@@ -252,7 +286,7 @@ __device__ __forceinline__ void stage_put_split(unsigned short* lds16, int plane
 template <int CIN, int NTHREADS, int NPF, bool P2, int TERMS = 3>
 __device__ __forceinline__ void stage_tile_split(unsigned short* lds16, int plane, const float* __restrict__ in,
                                                  const float* __restrict__ stats, int flags, const TileGeom& g,
-                                                 const Dims<P2>& d, int tid) {
+                                                 const Dims<P2>& d, int tid, StageScale* ss = nullptr) {
     constexpr int SH = CIN + 8;
     float4 pf[NPF];
     stage_issue<CIN, NTHREADS, NPF>(pf, in, g, d.W, tid);
@@ -260,11 +294,11 @@ __device__ __forceinline__ void stage_tile_split(unsigned short* lds16, int plan
 #pragma unroll
     for (int u = 0; u < NPF; ++u) {
         const int idx = u * NTHREADS + tid;
-        if (idx < total) stage_put_split<CIN, P2, TERMS>(lds16, plane, pf[u], idx, stats, flags, g, d);
+        if (idx < total) stage_put_split<CIN, P2, TERMS>(lds16, plane, pf[u], idx, stats, flags, g, d, ss);
     }
     const float* src = in + (size_t)g.rs0 * d.W * CIN;
     for (int idx = NPF * NTHREADS + tid; idx < total; idx += NTHREADS)
-        stage_put_split<CIN, P2, TERMS>(lds16, plane, ld_stream(src + (size_t)idx * 4), idx, stats, flags, g, d);
+        stage_put_split<CIN, P2, TERMS>(lds16, plane, ld_stream(src + (size_t)idx * 4), idx, stats, flags, g, d, ss);
     // the zero pixel of each plane (SH / 2 dwords each)
     for (int i = tid; i < TERMS * (SH / 2); i += NTHREADS)
         reinterpret_cast<unsigned*>(lds16 + (i / (SH / 2)) * plane + g.nps * SH)[i % (SH / 2)] = 0u;

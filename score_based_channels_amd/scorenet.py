@@ -14,8 +14,8 @@ import torch
 from . import _lib
 from . import plan as P
 from .weights import (check_state_dict, fp16_state_dict, get_sigmas, pack_conv_weight, pack_conv_weight_f16,
-                      pack_conv_weight_split, pack_conv_weight_winograd, pack_conv_weight_winograd_f16,
-                      pack_conv_weight_winograd_split)
+                      pack_conv_weight_f16x2, pack_conv_weight_split, pack_conv_weight_winograd,
+                      pack_conv_weight_winograd_f16, pack_conv_weight_winograd_f16x2, pack_conv_weight_winograd_split)
 
 
 def _ptr(t, offset_elems=0):
@@ -34,7 +34,7 @@ class BoundScore:
         self.keep = extra_keep
 
 
-CONV_MODES = ('bf16x3', 'f32', 'f16w')
+CONV_MODES = ('bf16x3', 'f32', 'f16w', 'f16x2')
 DEFAULT_OVERLAP = False
 DEFAULT_FOLD_STATS = False
 
@@ -146,6 +146,10 @@ class ScoreNet:
                     add(name + '#split', pack_conv_weight_split(w).view(np.float32))      # bf16 bit patterns
                     if w.shape[2:] == (3, 3):
                         add(name + '#winograd_split', pack_conv_weight_winograd_split(w).view(np.float32))
+                elif self.conv_mode == 'f16x2':
+                    add(name + '#split', pack_conv_weight_f16x2(w).view(np.float32))      # 2 fp16 terms + scale trailer
+                    if w.shape[2:] == (3, 3):
+                        add(name + '#winograd_split', pack_conv_weight_winograd_f16x2(w).view(np.float32))
                 else:
                     add(name + '#split', pack_conv_weight_f16(w).view(np.float32))        # fp16 bit patterns
                     if w.shape[2:] == (3, 3):
@@ -205,6 +209,8 @@ class ScoreNet:
                     o.weight_wino_split = _ptr(self._wdev, self._woff[op.weight + '#winograd_split'])
                 if self.conv_mode == 'f16w':
                     o.flags |= P.CONV_F16W
+                elif self.conv_mode == 'f16x2':
+                    o.flags |= P.CONV_F16X2
             if op.bias is not None:
                 o.bias = _ptr(self._wdev, self._woff[op.bias])
             if op.stats is not None:

@@ -236,3 +236,58 @@ def pack_conv_weight_winograd_f16(w):
         raise ValueError('Winograd F(2x2,3x3) needs a 3x3 kernel, got %s' % (w.shape,))
     u = np.einsum('ij,ocjk,lk->ocil', _WINO_G, w, _WINO_G)          # [O, C, 4, 4]
     return pack_conv_weight_f16(u.astype(np.float32))
+
+
+# ---- f16x2 forms (SBC_CONV_F16X2, conv_mode 'f16x2') -----------------------------------------------------------------
+F16X2_ACT_SHIFT = 5          # activations enter the matrix cores as x * 2^5 (include/sbc_hip.h: SBC_F16X2_ACT_SHIFT)
+
+
+def f16x2_shift(w):
+    """The power of two that puts the largest magnitude of ``w`` into ``[2^13, 2^14)``."""
+    m = float(np.max(np.abs(w))) if np.size(w) else 0.0
+    if not (m > 0.0) or not np.isfinite(m):
+        return 0
+    _, e = np.frexp(np.float32(m))                # m = f * 2^e, f in [0.5, 1)
+    return int(min(100, max(-100, 14 - int(e))))
+
+
+def split_f16x2(x):
+    """Two-term fp16 expansion ``x ~ h + l`` of float32 values (``h = fp16(x)``, ``l = fp16(x - h)``; both returned as
+    float16): the representation error is at most 2^-22 |x| while ``l`` is a normal fp16 number."""
+    x = np.asarray(x, np.float32)
+    h = x.astype(np.float16)
+    l = (x - h.astype(np.float32)).astype(np.float16)
+    return h, l
+
+
+def _pack_f16x2(w):
+    """``[O, C, T]`` float32 (T = taps or the 16 Winograd positions) -> ``[T, C/16, O/32, 2, 64, 8]`` uint16 + trailer."""
+    o, c, t = w.shape
+    if c % 16 or o % 32:
+        raise ValueError('f16x2 packing needs C %% 16 == 0 and O %% 32 == 0, got %s' % (w.shape,))
+    s = f16x2_shift(w)
+    terms = np.stack([v.view(np.uint16) for v in split_f16x2(np.ldexp(w, s).astype(np.float32))])   # [2, O, C, T]
+    a = terms.reshape(2, o // 32, 32, c // 16, 2, 8, t)              # [s, nb, l31, g, half, j, tap]
+    a = np.ascontiguousarray(a.transpose(6, 3, 1, 0, 4, 2, 5)).reshape(-1)   # [tap, g, nb, s, half, l31, j]
+    trailer = np.array([2.0 ** F16X2_ACT_SHIFT, 2.0 ** -(s + F16X2_ACT_SHIFT), 0, 0], np.float32).view(np.uint16)
+    return np.concatenate([a, trailer])
+
+
+def pack_conv_weight_f16x2(w):
+    """Two-term fp16 form of an ``[O, C, k, k]`` weight (``csrc/conv_x3.hip``, ``TERMS = 2``): the layer's weights scaled by
+    the power of two of ``f16x2_shift`` and split into ``h + l`` fp16 terms, in the fragment order of
+    ``pack_conv_weight_split`` with two terms, flat uint16, followed by the 16-byte trailer
+    ``(act_scale, descale, 0, 0)`` float32 the kernels read their scales from."""
+    w = np.asarray(w, np.float32)
+    o, c, kh, kw = w.shape
+    return _pack_f16x2(w.reshape(o, c, kh * kw))
+
+
+def pack_conv_weight_winograd_f16x2(w):
+    """Winograd F(2x2, 3x3) weights ``U = G g G^T`` (float64, rounded once to float32) in the ``pack_conv_weight_f16x2``
+    form with the 16 transform positions in place of the taps (``csrc/conv_wx3.hip``, ``MODE = 2``)."""
+    w = np.asarray(w, np.float64)
+    if w.shape[2:] != (3, 3):
+        raise ValueError('Winograd F(2x2,3x3) needs a 3x3 kernel, got %s' % (w.shape,))
+    u = np.einsum('ij,ocjk,lk->ocil', _WINO_G, w, _WINO_G).astype(np.float32)          # [O, C, 4, 4]
+    return _pack_f16x2(u.reshape(u.shape[0], u.shape[1], 16))

@@ -67,7 +67,8 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize('algo', ['direct', 'winograd', 'bf16x3', 'winograd_bf16x3', 'f16w', 'winograd_f16w'])
+@pytest.mark.parametrize('algo', ['direct', 'winograd', 'bf16x3', 'winograd_bf16x3', 'f16w', 'winograd_f16w', 'f16x2',
+                                  'winograd_f16x2'])
 @pytest.mark.parametrize('cin,cout,k,dil,B,H,W,mode', CONV_CASES)
 def test_conv_matches_oracle(gpu, cin, cout, k, dil, B, H, W, mode, algo):
     """The three multipliers behind SBC_OP_CONV: the fp32-MFMA direct implicit GEMM (weight); when the op also carries
@@ -75,8 +76,9 @@ def test_conv_matches_oracle(gpu, cin, cout, k, dil, B, H, W, mode, algo):
     when it carries weight_split, the split-bf16 kernel (three exact bf16 terms per fp32 operand, six bf16 MFMAs)."""
     torch, _lib = gpu
     from score_based_channels_amd import plan as P
-    from score_based_channels_amd.weights import (pack_conv_weight, pack_conv_weight_f16, pack_conv_weight_split,
-                                                  pack_conv_weight_winograd, pack_conv_weight_winograd_f16,
+    from score_based_channels_amd.weights import (pack_conv_weight, pack_conv_weight_f16, pack_conv_weight_f16x2,
+                                                  pack_conv_weight_split, pack_conv_weight_winograd,
+                                                  pack_conv_weight_winograd_f16, pack_conv_weight_winograd_f16x2,
                                                   pack_conv_weight_winograd_split, round_fp16)
     if algo.startswith('winograd') and (k != 3 or dil != 1):
         pytest.skip('Winograd F(2x2,3x3) applies to undilated 3x3 convolutions')
@@ -154,9 +156,19 @@ def test_conv_matches_oracle(gpu, cin, cout, k, dil, B, H, W, mode, algo):
         wf = _dev(torch, pack_conv_weight_f16(w).view(np.float32))
         wwf = _dev(torch, pack_conv_weight_winograd_f16(w).view(np.float32))
         op.weight_split, op.weight_wino_split, op.weight, op.flags = _p(wf), _p(wwf), None, flags | P.CONV_F16W
+    if algo == 'f16x2':
+        # two fp16 terms per (scaled) operand, three fp16 MFMAs per product: held to the fp32 tolerance of the other modes
+        wx = _dev(torch, pack_conv_weight_f16x2(w).view(np.float32))
+        op.weight_split, op.weight, op.flags = _p(wx), None, flags | P.CONV_F16X2
+    if algo == 'winograd_f16x2':
+        wx = _dev(torch, pack_conv_weight_f16x2(w).view(np.float32))
+        wwx = _dev(torch, pack_conv_weight_winograd_f16x2(w).view(np.float32))
+        op.weight_split, op.weight_wino_split, op.weight, op.flags = _p(wx), _p(wwx), None, flags | P.CONV_F16X2
     _launch(gpu, op)
     got = out.cpu().numpy()
     assert np.isfinite(got).all()
+    if algo.endswith('f16x2'):
+        assert _lib.range_flag() == 0
     assert rel_err(got, ref) < tol
     # and element by element for every output of at least 5 % of the largest magnitude: a 5x tighter statement than the
     # norm-wise bound implies for those elements
@@ -290,3 +302,37 @@ def test_end_conv_matches_oracle(gpu, B, H, W):
     v = O.elu((x - stats[:, None, None, 0]) * stats[:, None, None, 1] + stats[:, None, None, 2])
     ref = O.conv2d(v.transpose(0, 3, 1, 2), w, b).transpose(0, 2, 3, 1) / sigmas[labels][:, None, None, None]
     assert rel_err(out.cpu().numpy(), ref) < 1e-5
+
+
+@pytest.mark.parametrize('wino', [False, True])
+def test_f16x2_range_flag(gpu, wino):
+    """conv_mode f16x2 stages activations as two fp16 terms of x * 2^5: an activation beyond 16000 / 32 = 500 could overflow the
+    high term (or the Winograd transform's 4-term sums), so the kernels raise the device's range flag instead of returning
+    silently wrong numbers -- and stay quiet, and accurate, just below the limit."""
+    torch, _lib = gpu
+    from score_based_channels_amd import plan as P
+    from score_based_channels_amd.weights import pack_conv_weight_f16x2, pack_conv_weight_winograd_f16x2
+    rng = np.random.default_rng(5)
+    B, H, W, c = 2, 16, 16, 32
+    w = (rng.standard_normal((c, c, 3, 3)) / 17).astype(F32)
+    wx = _dev(torch, pack_conv_weight_f16x2(w).view(np.float32))
+    wwx = _dev(torch, pack_conv_weight_winograd_f16x2(w).view(np.float32))
+    _lib.range_flag()                                        # clear
+    for peak, expect in ((400.0, 0), (600.0, 1)):
+        x = rng.standard_normal((B, H, W, c)).astype(F32)
+        x[1, 7, 9, 3] = peak
+        out = torch.full((B, H, W, c), float('nan'), dtype=torch.float32, device='cuda')
+        dx = _dev(torch, x)
+        op = _lib.sbc_op(kind=P.CONV, flags=P.CONV_F16X2, B=B, H=H, W=W, cin=c, cout=c, ksize=3, dil=1, in_=_p(dx), out=_p(out),
+                         weight_split=_p(wx))
+        if wino:
+            op.weight_wino_split = _p(wwx)
+        _launch(gpu, op)
+        assert _lib.range_flag() == expect                   # reading resets
+        assert _lib.range_flag() == 0
+        if not expect:
+            ref = O.conv2d(x.transpose(0, 3, 1, 2), w, None, 1).transpose(0, 2, 3, 1)
+            assert rel_err(out.cpu().numpy(), ref) < TOL
+    with pytest.raises(_lib.SbcError):
+        op.flags |= P.CONV_F16W
+        _launch(gpu, op)

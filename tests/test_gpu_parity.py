@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 NMSE_RTOL = 1e-5      # BASELINE.json north_star: NMSE within 1e-5 relative of the reference
 
 
-@pytest.fixture(scope='module', params=['bf16x3', 'f32'])
+@pytest.fixture(scope='module', params=['bf16x3', 'f32', 'f16x2'])
 def net64(weights64, request):
     """Every parity case runs with both convolution multipliers (scorenet.CONV_MODES)."""
     import torch
@@ -60,6 +60,26 @@ def test_forward_matches_reference_golden(net64):
         assert tuple(out.shape) == (4, 2, 64, 16)
         assert rel_err(out.cpu().numpy(), g['out'][i]) < 2e-5, lv
         assert rel_err_elementwise(out.cpu().numpy(), g['out'][i], 0.02) < 1e-4, lv    # every element >= 2 % of the peak
+
+
+def test_f16x2_is_fp32_class(weights64):
+    """Acceptance gate of conv_mode f16x2 (two fp16 terms per operand on the fp16 matrix cores): its forward error against
+    the reference golden is no larger than that of true fp32 matrix arithmetic (conv_mode f32, v_mfma_f32_32x32x2_f32) on the
+    same inputs -- i.e. it is not a reduced-precision mode.  (Measured on MI355X: see DESIGN.md.)"""
+    import torch
+    from score_based_channels_amd import _lib
+    from score_based_channels_amd.scorenet import ScoreNet
+    cfg, sd = weights64
+    g = load_golden('forward_64x16.npz')
+    x = torch.from_numpy(g['x']).cuda()
+    err = {}
+    for mode in ('f32', 'f16x2', 'bf16x3'):
+        net = ScoreNet(cfg, conv_mode=mode).cuda().load_state_dict(sd).eval()
+        err[mode] = max(rel_err(net(x, torch.full((4,), int(lv), dtype=torch.long, device='cuda')).cpu().numpy(), g['out'][i])
+                        for i, lv in enumerate(g['levels']))
+    print('forward error vs reference golden:', err)
+    assert _lib.range_flag() == 0
+    assert err['f16x2'] <= 1.05 * err['f32'] + 1e-7, err
 
 
 def test_forward_accepts_reference_call_pattern(net64):

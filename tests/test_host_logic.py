@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     h = _lib.lib()
     for name in declared:
         assert hasattr(h, name), name
-    assert h.sbc_abi_version() == 7
+    assert h.sbc_abi_version() == 8
 
 
 def test_pack_conv_weight_c_matches_python():
@@ -288,6 +288,37 @@ def test_schedule_tables_keep_dc_boost_as_its_own_factor():
     a, _ = schedule_tables(sig, cfg.model.sigma_end, [0, 1000], 2, [3e-11], [0.01], [0.1], dc_boost=1.0)
     b, _ = schedule_tables(sig, cfg.model.sigma_end, [0, 1000], 2, [3e-11], [0.01], [0.1], dc_boost=2.5)
     assert np.array_equal(a[..., :3], b[..., :3]) and np.all(a[..., 3] == 1.0) and np.all(b[..., 3] == np.float32(2.5))
+
+
+def test_pack_conv_weight_f16x2_c_matches_python():
+    """conv_mode f16x2 weight forms: C packers == Python packers byte for byte (trailer included); h + l reproduces the scaled
+    weight to 2^-22, and the trailer carries act_scale = 2^5 and descale = 1 / (act_scale * weight scale)."""
+    from score_based_channels_amd import _lib
+    from score_based_channels_amd.weights import (F16X2_ACT_SHIFT, f16x2_shift, pack_conv_weight_f16x2,
+                                                  pack_conv_weight_winograd_f16x2)
+    rng = np.random.default_rng(11)
+    for (o, c, k) in [(32, 32, 3), (64, 32, 1), (128, 64, 3)]:
+        w = (rng.standard_normal((o, c, k, k)) * rng.choice([1e-3, 0.05, 3.0])).astype(np.float32)
+        ref = pack_conv_weight_f16x2(w)
+        dst = np.zeros_like(ref)
+        _lib.check(_lib.lib().sbc_pack_conv_weight_f16x2(w.ctypes.data, o, c, k, dst.ctypes.data))
+        assert np.array_equal(ref, dst)
+        s = f16x2_shift(w)
+        tr = ref[-8:].view(np.float32)
+        assert tr[0] == 2.0 ** F16X2_ACT_SHIFT and tr[1] == 2.0 ** -(s + F16X2_ACT_SHIFT) and tr[2] == tr[3] == 0
+        assert 2 ** 13 <= np.abs(w).max() * 2.0 ** s < 2 ** 14
+        terms = ref[:-8].view(np.float16).reshape(k * k, c // 16, o // 32, 2, 64, 8).astype(np.float64)
+        back = (terms[:, :, :, 0] + terms[:, :, :, 1]) * 2.0 ** -s            # [tap, g, nb, lane, j]
+        back = back.reshape(k * k, c // 16, o // 32, 2, 32, 8).transpose(2, 4, 1, 3, 5, 0).reshape(o, c, k, k)
+        assert np.max(np.abs(back - w)) <= 2.0 ** -22 * np.abs(w).max()
+        big = np.abs(w) >= np.abs(w).max() * 2.0 ** -10
+        assert np.max(np.abs(back[big] / w[big] - 1)) <= 2.0 ** -22
+        if k == 3:
+            refw = pack_conv_weight_winograd_f16x2(w)
+            dstw = np.zeros_like(refw)
+            _lib.check(_lib.lib().sbc_pack_conv_weight_winograd_f16x2(w.ctypes.data, o, c, dstw.ctypes.data))
+            assert np.array_equal(refw, dstw)
+    assert _lib.lib().sbc_pack_conv_weight_f16x2(w.ctypes.data, 32, 24, 3, dst.ctypes.data) == -1
 
 
 def test_library_contains_no_packed_fp32_instructions():

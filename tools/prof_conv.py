@@ -8,7 +8,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from score_based_channels_amd import _lib, plan as P
 from score_based_channels_amd.weights import (pack_conv_weight, pack_conv_weight_split, pack_conv_weight_winograd,
-                                              pack_conv_weight_winograd_split)
+                                              pack_conv_weight_winograd_split, pack_conv_weight_f16x2,
+                                              pack_conv_weight_winograd_f16x2, pack_conv_weight_f16, pack_conv_weight_winograd_f16)
 ap = argparse.ArgumentParser()
 ap.add_argument('shape', nargs='*', type=int, default=[32, 32, 3, 1, 1700, 64, 16])
 ap.add_argument('--mode', default='bf16x3')
@@ -33,6 +34,16 @@ if os.environ.get('SBC_LIB_PATH'):
     _lib.LIB_PATH = os.environ['SBC_LIB_PATH']
 if a.mode == 'wx3':
     keep.append(torch.from_numpy(pack_conv_weight_winograd_split(wn).view(np.float32)).cuda()); op.weight_wino_split = keep[-1].data_ptr()
+if a.mode in ('f16x2', 'wx2'):
+    keep.append(torch.from_numpy(pack_conv_weight_f16x2(wn).view(np.float32)).cuda()); op.weight_split = keep[-1].data_ptr()
+    op.flags |= P.CONV_F16X2
+    if a.mode == 'wx2':
+        keep.append(torch.from_numpy(pack_conv_weight_winograd_f16x2(wn).view(np.float32)).cuda()); op.weight_wino_split = keep[-1].data_ptr()
+if a.mode in ('f16w', 'wf16w'):
+    keep.append(torch.from_numpy(pack_conv_weight_f16(wn).view(np.float32)).cuda()); op.weight_split = keep[-1].data_ptr()
+    op.flags |= P.CONV_F16W
+    if a.mode == 'wf16w':
+        keep.append(torch.from_numpy(pack_conv_weight_winograd_f16(wn).view(np.float32)).cuda()); op.weight_wino_split = keep[-1].data_ptr()
 h = _lib.lib()
 for _ in range(3):
     _lib.check(h.sbc_op_launch(C.byref(op), None))
