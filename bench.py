@@ -132,6 +132,9 @@ def parse_args():
     ap.add_argument('--fold-stats', type=int, default=None,
                     help='1: full-resolution InstanceNorm++ statistics from tile moments (no statistics launches there), '
                          '0: a statistics launch per norm; default: scorenet.DEFAULT_FOLD_STATS')
+    ap.add_argument('--fuse-pairs', type=int, default=None,
+                    help='1: 32-channel RCU blocks as one launch each (csrc/conv_pair.hip), 0: two convolution launches; '
+                         'default: scorenet.DEFAULT_FUSE_PAIRS')
     ap.add_argument('--streams', type=int, default=1,
                     help='split the trajectories into this many concurrent sub-batch streams (DESIGN.md section 7)')
     return ap.parse_args()
@@ -245,7 +248,8 @@ def main():
     sd = seeded_state_dict(cfg, 2024)                     # random-init weights of the reference architecture
     net = ScoreNet(cfg, 'cuda:%d' % local, conv_mode=conv_mode,
                    overlap=None if args.overlap is None else bool(args.overlap),
-                   fold_stats=None if args.fold_stats is None else bool(args.fold_stats)).load_state_dict(sd)
+                   fold_stats=None if args.fold_stats is None else bool(args.fold_stats),
+                   fuse_pairs=None if args.fuse_pairs is None else bool(args.fuse_pairs)).load_state_dict(sd)
     use_graph = DEFAULT_USE_GRAPH if args.graph is None else bool(args.graph)
     snr = np.arange(-10, 32.5, 2.5)[:nsnr]
 

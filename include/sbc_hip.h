@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SBC_ABI_VERSION 8
+#define SBC_ABI_VERSION 9
 
 typedef enum sbc_status {
     SBC_OK = 0,
@@ -66,7 +66,9 @@ typedef enum sbc_op_kind {
     SBC_OP_PACK_WEIGHT = 17, /* torch-layout weight (device) -> split-bf16 fragments, optionally of the adjoint conv */
     SBC_OP_END_CONV_BWD = 18,/* backward of SBC_OP_END_CONV up to the ELU output  ncsnv2.py:291-298           */
     SBC_OP_BEGIN_CONV_BWD = 19, /* weight / bias gradient of SBC_OP_BEGIN_CONV    ncsnv2.py:270-275           */
-    SBC_OP_ADAM_EMA = 20     /* torch.optim.Adam step + EMAHelper.update          losses/__init__.py:3-7, ema.py:17-22 */
+    SBC_OP_ADAM_EMA = 20,    /* torch.optim.Adam step + EMAHelper.update          losses/__init__.py:3-7, ema.py:17-22 */
+    SBC_OP_CONV_PAIR = 21    /* one RCU block in one launch: out = x + conv2(ELU(conv1(ELU(x))))   layers.py:126-134;
+                                32 channels, 3x3, no bias; the intermediate stays in LDS (csrc/conv_pair.hip)            */
 } sbc_op_kind;
 
 /* sbc_op.flags for SBC_OP_CONV / SBC_OP_MAXPOOL5 */
@@ -122,6 +124,9 @@ typedef enum sbc_op_kind {
  *   END_CONV    in [B][H][W][cin], stats, weight [2][cin][3][3] (torch layout), bias [2], out [B][H][W][2];
  *               divides by sigmas[labels[b]] if labels != NULL else by sigma_of_step[*step]
  *   LANGEVIN    see sbc_langevin below (passed through `ext`)
+ *   CONV_PAIR   in / out [B][H][W][32] (distinct buffers), weight_split + weight2_split, flags = SBC_CONV_F16X2 or
+ *               SBC_CONV_F16W; W in {8, 16}, H % 8 == 0.  The same numbers as the two CONV records it replaces
+ *               (PRO_ELU; PRO_ELU + res1 = in) up to fp32 summation order.
  */
 typedef struct sbc_op {
     int32_t kind, flags;
@@ -161,6 +166,9 @@ typedef struct sbc_op {
     void* aux;                   /* kind-specific second output or scratch (see "Training operators") */
     void* wgrad;                 /* parameter-gradient output: conv weight in torch layout, or alpha|gamma|beta [3][cin] */
     void* bgrad;                 /* bias-gradient output [cout] or NULL */
+    /* --- ABI 9 --- */
+    const void* weight2_split;   /* CONV_PAIR: the second convolution's weight in the form `weight_split` holds the first one's
+                                    (sbc_pack_conv_weight_f16x2 with SBC_CONV_F16X2, sbc_pack_conv_weight_f16 with SBC_CONV_F16W) */
 } sbc_op;
 
 /* Training operators.  The reverse of a forward record `y = epi(conv(pro(x)))` is built by the host

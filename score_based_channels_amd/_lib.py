@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SBC_LIB_PATH') or os.path.join(_HERE, 'libsbc_hip.so')   # env override: A/B builds (tools/)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 EXPORTS = ('sbc_abi_version', 'sbc_last_error', 'sbc_device_count', 'sbc_op_launch', 'sbc_plan_create',
            'sbc_plan_run', 'sbc_plan_destroy', 'sbc_plan_profile', 'sbc_plan_profile_read',
@@ -34,7 +34,8 @@ class sbc_op(C.Structure):
                 ('ext', C.c_void_p), ('weight_wino', C.c_void_p), ('weight_split', C.c_void_p),
                 ('weight_wino_split', C.c_void_p),
                 # training operators (ABI 7)
-                ('grad', C.c_void_p), ('aux', C.c_void_p), ('wgrad', C.c_void_p), ('bgrad', C.c_void_p)]
+                ('grad', C.c_void_p), ('aux', C.c_void_p), ('wgrad', C.c_void_p), ('bgrad', C.c_void_p),
+                ('weight2_split', C.c_void_p)]
 
 
 class sbc_endconv(C.Structure):

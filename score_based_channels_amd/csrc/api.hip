@@ -96,6 +96,7 @@ static int dispatch(const sbc_op& op, const void* ext, hipStream_t s) {
         case SBC_OP_BEGIN_CONV: return launch_begin_conv(op, s);
         case SBC_OP_INORM_STATS: return launch_inorm_stats(op, s);
         case SBC_OP_CONV: return launch_conv(op, s);
+        case SBC_OP_CONV_PAIR: return launch_conv_pair(op, s);
         case SBC_OP_MAXPOOL5: return launch_maxpool5(op, s);
         case SBC_OP_END_CONV:
             SBC_REQUIRE(endc, "end_conv: ext (sbc_endconv) must be set");
@@ -240,6 +241,7 @@ int sbc_plan_create(const sbc_op* ops, int32_t n_ops, sbc_plan** out_plan) {
         // resolve kernel variants / set function attributes now, so a later hipGraph capture sees launches only
         int rc = SBC_OK;
         if (po.op.kind == SBC_OP_CONV) rc = launch_conv(po.op, nullptr, true);
+        else if (po.op.kind == SBC_OP_CONV_PAIR) rc = launch_conv_pair(po.op, nullptr, true);
         else if (po.op.kind == SBC_OP_END_CONV) rc = launch_end_conv(po.op, po.ext.endc, nullptr, true);
         else if (po.op.kind == SBC_OP_LANGEVIN) rc = launch_langevin(po.op, po.ext.lang, nullptr, true);
         if (rc) { delete plan; return rc; }

@@ -1,0 +1,340 @@
+// One RCU block of the score network in ONE launch (SBC_OP_CONV_PAIR):
+//       out = x + conv2(ELU(conv1(ELU(x))))        ncsnv2/models/layers.py:126-134 (n_stages = 2, 3x3, no bias)
+// for 32-channel NHWC fp32 tensors.  The unfused pair streams five tensors through HBM (x; t out, t in; x again, out) and
+// both launches sit at 0.6 of the achievable HBM rate; here the intermediate t = conv1(ELU(x)) never leaves the chip.
+//
+// Persistent workgroups (two per CU, 256 threads) walk tiles of R output rows of one sample:
+//   1. the tile's R + 4 input rows (one contiguous run of NHWC memory) arrive by LDS-DMA (global_load_lds_dwordx4) -- the
+//      request for tile k + 1 is issued as soon as tile k's raw copy has been converted, so it flies during both K loops;
+//   2. convert: raw fp32 -> ELU -> x act_scale -> two fp16 terms (conv_mode f16x2; one rounded term for f16w) -> operand
+//      planes [term][k-group of 8 channels][row][W + 2 pixels][8 halves]: zero columns left and right stand in for the
+//      padding, and 16 consecutive pixels of a row are 16 consecutive 16-byte slots (conflict-free ds_read_b128);
+//   3. conv1 as a direct implicit GEMM on v_mfma_f32_16x16x32_f16: D[16 couts][16 pixels] += W[16 couts][32 cin] X[32 cin][16
+//      pixels] per tap and term pair -- (h,l) (l,h) (h,h), the split-fp16 products of conv_x3.hip -- for the R + 2 rows conv2
+//      needs; ALL filter fragments of both convolutions (2 x 9 taps x 2 terms x 4 registers for this wave's 16 output
+//      channels) stay in registers for the life of the workgroup, so the K loop is LDS reads and matrix instructions only;
+//   4. the accumulators go x descale1 -> ELU -> x act_scale -> split -> a second set of planes (rows outside the sample: zeros);
+//   5. conv2 the same way on the R output rows; its epilogue adds the residual x (re-read from L2, fp32) and stores float4s.
+// A 16 x 16 unit is one image row (W = 16), two rows (W = 8) or part of a row (W >= 32); wave w owns output-channel half w & 1
+// and every second unit, so with R = 8 at W = 16 the four waves run 5 + 4 units each: no idle wave in either convolution.
+#include <stdlib.h>
+#include <type_traits>
+#include "conv_common.h"
+
+namespace sbc {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+struct PairParams {
+    const float* __restrict__ in;
+    float* __restrict__ out;
+    const uint4* __restrict__ w1;       // sbc_pack_conv_weight_f16x2 / _f16 layout of conv1 (32 -> 32, 3x3)
+    const uint4* __restrict__ w2;
+    unsigned* __restrict__ range_flag;
+    int B, H, ntiles, tiles_per_sample, wgs_per_xcd, tiles_per_xcd;
+    unsigned long long* dbg;            // SBC_PAIR_TIMING builds: per-phase cycle sums of wave 0 of every workgroup
+};
+
+#ifdef SBC_PAIR_TIMING
+#define PT_MARK(k) do { const unsigned long long _t = __builtin_readcyclecounter(); pt[k] += _t - pt_last; pt_last = _t; } while (0)
+#else
+#define PT_MARK(k) do { } while (0)
+#endif
+
+__device__ __forceinline__ void lds_barrier() {
+    // LDS traffic only: the tile in flight by LDS-DMA (vmcnt) must NOT be waited for here
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int W, int R, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_pair_kernel(PairParams p) {
+    constexpr int C = 32;
+    constexpr int NT = MODE == 2 ? 2 : 1;            // fp16 terms per operand
+    constexpr int RI = R + 4, RM = R + 2;             // staged input rows, intermediate rows
+    constexpr int WP = W + 2;                         // row of a plane: zero pixel, W pixels, zero pixel
+    constexpr int XPS = (RI * WP * 16 + 255) / 256 * 256;     // bytes of one k-group plane (multiple of the 256-byte bank row)
+    constexpr int MPS = (RM * WP * 16 + 255) / 256 * 256;
+    constexpr int RAW_BYTES = RI * W * C * 4;
+    constexpr int X_OFF = RAW_BYTES, M_OFF = X_OFF + NT * 4 * XPS;
+    constexpr int NQ = RI * W * 8;                    // 16-byte chunks of the raw tile
+    static_assert(NQ % 256 == 0, "raw tile must divide over 256 threads");
+    constexpr int CB = W >= 16 ? W / 16 : 1;          // units per image row (W >= 16)
+    constexpr int RPU = W >= 16 ? 1 : 16 / W;         // image rows per unit (W < 16)
+    constexpr int NU1T = RM * W / 16, NU2T = R * W / 16;       // units of 16 pixels per output-channel half
+    constexpr int NU1 = (NU1T + 1) / 2, NU2 = (NU2T + 1) / 2;  // per wave
+    static_assert(RM % RPU == 0 && R % RPU == 0, "units must not straddle the tile");
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hf = wave & 1, sub = wave >> 1;         // output-channel half, unit parity of this wave
+    const int kq = lane >> 4, c = lane & 15;          // k-group (8 input channels) / pixel of the unit
+    const int H = p.H;
+
+    // ---- filter fragments of both convolutions, resident for the whole launch (A operand: lane = cout l & 15, k-group l >> 4)
+    uint4 wf[2][9][NT];
+    {
+        const int lsrc = (16 * hf + c) + 32 * (kq & 1), g = kq >> 1;
+#pragma unroll
+        for (int cv = 0; cv < 2; ++cv) {
+            const uint4* w = cv == 0 ? p.w1 : p.w2;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) wf[cv][tap][t] = w[((tap * 2 + g) * NT + t) * 64 + lsrc];
+        }
+    }
+    float scale1 = 1.f, descale1 = 1.f, scale2 = 1.f, descale2 = 1.f;
+    if constexpr (MODE == 2) {
+        const float4 t1 = f16x2_trailer(reinterpret_cast<const float4*>(p.w1), 9 * 2 * NT);
+        const float4 t2 = f16x2_trailer(reinterpret_cast<const float4*>(p.w2), 9 * 2 * NT);
+        scale1 = t1.x; descale1 = t1.y; scale2 = t2.x; descale2 = t2.y;
+    }
+
+    // ---- zero the padding columns of every plane once (nothing writes them afterwards)
+    for (int i = tid; i < NT * 4 * RI * 2; i += 256) {
+        const int side = i & 1, row = (i >> 1) % RI, pl = (i >> 1) / RI;
+        *reinterpret_cast<uint4*>(smem + X_OFF + pl * XPS + (row * WP + side * (W + 1)) * 16) = make_uint4(0, 0, 0, 0);
+    }
+    for (int i = tid; i < NT * 4 * RM * 2; i += 256) {
+        const int side = i & 1, row = (i >> 1) % RM, pl = (i >> 1) / RM;
+        *reinterpret_cast<uint4*>(smem + M_OFF + pl * MPS + (row * WP + side * (W + 1)) * 16) = make_uint4(0, 0, 0, 0);
+    }
+
+    // ---- tile walk: XCD x (= blockIdx % 8) owns a contiguous run of tiles, its workgroups take consecutive tiles of it
+    const int xcd = blockIdx.x & 7, jw = blockIdx.x >> 3;
+    const int t_begin = xcd * p.tiles_per_xcd;
+    const int t_end = min(t_begin + p.tiles_per_xcd, p.ntiles);
+    auto issue_dma = [&](int tile) {
+        const int n = tile / p.tiles_per_sample, r0 = (tile - n * p.tiles_per_sample) * R;
+        const char* src = reinterpret_cast<const char*>(p.in) + ((size_t)(n * H + r0 - 2) * W * C) * 4;   // may point before the sample: masked
+#pragma unroll
+        for (int k = 0; k < NQ / 256; ++k) {
+            const int j = k * 4 + wave;                                   // wave-instruction: chunks j * 64 .. + 63
+            const int ri = (j * 64) / (W * 8);                            // its (single) tile row
+            const int grow = r0 - 2 + ri;
+            if (grow >= 0 && grow < H) {
+                // by hand: hipcc puts an s_waitcnt vmcnt(0) in front of every __builtin_amdgcn_global_load_lds of this loop
+                // (each piece would wait for the one before: six serialised HBM round trips per tile).  M0 = LDS byte address of
+                // the wave's 1 KiB piece; lane l lands at M0 + 16 l.  hipcc does not count these requests: the waits are explicit.
+                // (scalar base + 32-bit lane offset: per-lane 64-bit source pointers for six pieces would be hoisted and spilled)
+                const char* sbase = src + (size_t)j * 1024;
+                const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem + j * 1024;
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(lane * 16), "s"(dst), "s"(sbase) : "memory");
+            }
+        }
+    };
+    int tile = t_begin + jw;
+    if (tile < t_end) issue_dma(tile);
+    float amax = 0.f;
+#ifdef SBC_PAIR_TIMING
+    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_last = __builtin_readcyclecounter();
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // first tile (and the filter fragments) landed
+
+    for (; tile < t_end; tile += p.wgs_per_xcd) {
+        const int n = tile / p.tiles_per_sample, r0 = (tile - n * p.tiles_per_sample) * R;
+        // (1) raw tile landed, for every wave (each wave waited for its own pieces before its previous epilogue / the loop)
+        PT_MARK(0);
+        asm volatile("s_barrier" ::: "memory");
+        PT_MARK(1);
+        // (2) convert raw -> operand planes of conv1
+#pragma unroll
+        for (int k = 0; k < NQ / 256; ++k) {
+            const int q = k * 256 + tid;
+            const int px = q >> 3, c4 = q & 7;
+            const int ri = px / W, col = px - ri * W;
+            const int grow = r0 - 2 + ri;
+            float4 v = *reinterpret_cast<const float4*>(smem + q * 16);
+            if (grow < 0 || grow >= H) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            v = elu4(v);
+            unsigned char* dst = smem + X_OFF + (c4 >> 1) * XPS + (ri * WP + col + 1) * 16 + (c4 & 1) * 8;
+            if constexpr (MODE == 2) {
+                StageScale ss{scale1, amax};
+                scale_track(v, &ss);
+                amax = ss.amax;
+                uint2 h, l;
+                split_f16x2(v.x, v.y, h.x, l.x);
+                split_f16x2(v.z, v.w, h.y, l.y);
+                *reinterpret_cast<uint2*>(dst) = h;
+                *reinterpret_cast<uint2*>(dst + 4 * XPS) = l;
+            } else {
+                f16x4 h;
+                h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+                *reinterpret_cast<f16x4*>(dst) = h;
+            }
+        }
+        PT_MARK(2);
+        lds_barrier();
+        PT_MARK(3);
+        // the raw copy is consumed: request the next tile of this workgroup; it flies during both K loops
+        if (tile + p.wgs_per_xcd < t_end) issue_dma(tile + p.wgs_per_xcd);
+
+        // one convolution over units `sub`, `sub + 2`, ...: acc[i] = D[16 couts of this wave][16 pixels of unit i]
+        auto conv = [&](auto cvc, const int plane_off, const int PS, auto nuc, auto nutc, f32x4v* acc) {
+            constexpr int CV = decltype(cvc)::value, NU = decltype(nuc)::value, NUT = decltype(nutc)::value;
+            static_assert(W <= 16, "unit stride below assumes one unit per row (or several rows per unit)");
+            constexpr int DU = 2 * RPU * WP * 16;                          // bytes from unit u to unit u + 2
+            // source pixel of tap (0, 0) of unit `sub` = plane row prow (the row above the output row), slot column pcol (-1 + 1)
+            const int ub0 = plane_off + kq * PS + ((sub * RPU + (W >= 16 ? 0 : c / W)) * WP + (W >= 16 ? c : c % W)) * 16;
+#pragma unroll
+            for (int i = 0; i < NU; ++i) acc[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            // flat walk over (tap, unit) steps; the X fragments of a step are requested D - 1 steps ahead of its MFMAs through a
+            // ring of statically indexed registers (the scheduler would otherwise hoist every read of the loop and spill)
+            constexpr int NS = 9 * NU, D = NT == 2 ? 3 : 6;
+            f16x8 ring[D][NT];
+            auto ld = [&](int s) {                                          // s is a compile-time constant at every call
+                const int tap = s / NU, i = s % NU;
+                const int off = i * DU + ((tap / 3) * WP + (tap % 3)) * 16;
+                if (NUT % 2 == 0 || sub + 2 * i < NUT) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        ring[s % D][t] = *reinterpret_cast<const f16x8*>(smem + ub0 + (off + t * 4 * PS));
+                }
+            };
+#pragma unroll
+            for (int s = 0; s < D - 1; ++s) ld(s);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int tap = s / NU, i = s % NU;
+                if (s + D - 1 < NS) ld(s + D - 1);
+                if (NUT % 2 == 0 || sub + 2 * i < NUT) {
+                    const f16x8 xh = ring[s % D][0];
+                    const f16x8 wh = __builtin_bit_cast(f16x8, wf[CV][tap][0]);
+                    if constexpr (NT == 2) {
+                        const f16x8 xl = ring[s % D][NT - 1];
+                        const f16x8 wl = __builtin_bit_cast(f16x8, wf[CV][tap][NT - 1]);
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc[i], 0, 0, 0);
+                    }
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[i], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+
+        // (3) conv1 on the RM intermediate rows -> ELU -> split -> intermediate planes
+        {
+            f32x4v acc[NU1];
+            conv(std::integral_constant<int, 0>{}, X_OFF, XPS, std::integral_constant<int, NU1>{}, std::integral_constant<int, NU1T>{}, acc);
+            const int cq = 4 * hf + kq;                                    // channel quad of this lane's four outputs
+#pragma unroll
+            for (int i = 0; i < NU1; ++i) {
+                const int u = sub + 2 * i;
+                if (u < NU1T) {
+                    const int prow = (W >= 16 ? u / CB : u * RPU) + (W >= 16 ? 0 : c / W);
+                    const int pcol = (W >= 16 ? (u % CB) * 16 + c : c % W);
+                    const int grow = r0 - 1 + prow;
+                    float4 v = make_float4(acc[i][0] * descale1, acc[i][1] * descale1, acc[i][2] * descale1, acc[i][3] * descale1);
+                    v = elu4(v);
+                    if (grow < 0 || grow >= H) v = make_float4(0.f, 0.f, 0.f, 0.f);    // zero padding of conv2, not conv1 of padding
+                    unsigned char* dst = smem + M_OFF + (cq >> 1) * MPS + (prow * WP + pcol + 1) * 16 + (cq & 1) * 8;
+                    if constexpr (MODE == 2) {
+                        StageScale ss{scale2, amax};
+                        scale_track(v, &ss);
+                        amax = ss.amax;
+                        uint2 h, l;
+                        split_f16x2(v.x, v.y, h.x, l.x);
+                        split_f16x2(v.z, v.w, h.y, l.y);
+                        *reinterpret_cast<uint2*>(dst) = h;
+                        *reinterpret_cast<uint2*>(dst + 4 * MPS) = l;
+                    } else {
+                        f16x4 h;
+                        h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+                        *reinterpret_cast<f16x4*>(dst) = h;
+                    }
+                }
+            }
+        }
+        PT_MARK(4);
+        lds_barrier();
+        PT_MARK(5);
+        // (4) conv2 on the R output rows, + residual, store
+        {
+            f32x4v acc[NU2];
+            // the residual operand: requested before the K loop (an L2 hit: this workgroup's DMA fetched the same lines), used after it
+            const int cq = 4 * hf + kq;
+            float4 xr[NU2];
+            constexpr int DO = 2 * RPU * W * C;                             // elements from unit u to unit u + 2
+            const unsigned o0 = (unsigned)(((n * H + r0 + sub * RPU + (W >= 16 ? 0 : c / W)) * W + (W >= 16 ? c : c % W)) * C + cq * 4);
+#pragma unroll
+            for (int i = 0; i < NU2; ++i)
+                if (NU2T % 2 == 0 || sub + 2 * i < NU2T) xr[i] = *reinterpret_cast<const float4*>(p.in + o0 + i * DO);
+            conv(std::integral_constant<int, 1>{}, M_OFF, MPS, std::integral_constant<int, NU2>{}, std::integral_constant<int, NU2T>{}, acc);
+            PT_MARK(6);
+            // everything this wave has in flight -- the residual, its pieces of the next tile's DMA -- has landed; the stores below
+            // are never waited for explicitly (the same wait one iteration later covers them)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < NU2; ++i) {
+                if (NU2T % 2 == 0 || sub + 2 * i < NU2T) {
+                    float4 y;
+                    y.x = fmaf(acc[i][0], descale2, xr[i].x); y.y = fmaf(acc[i][1], descale2, xr[i].y);
+                    y.z = fmaf(acc[i][2], descale2, xr[i].z); y.w = fmaf(acc[i][3], descale2, xr[i].w);
+                    st_stream(p.out + o0 + i * DO, y);
+                }
+            }
+            PT_MARK(7);
+        }
+        // the next iteration's barrier (1) orders conv2's reads of the intermediate planes before anything rewrites them
+    }
+    if constexpr (MODE == 2) {
+        if (amax >= F16X2_LIMIT) atomicOr(p.range_flag, 1u);
+    }
+#ifdef SBC_PAIR_TIMING
+    if (tid == 0 && p.dbg)
+        for (int k = 0; k < 8; ++k) atomicAdd(p.dbg + k, pt[k]);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------ dispatch
+template <int W, int R, int MODE>
+static int launch_pair(const PairParams& p0, hipStream_t stream, bool dry) {
+    constexpr int NT = MODE == 2 ? 2 : 1;
+    constexpr int RI = R + 4, RM = R + 2, WP = W + 2;
+    constexpr int XPS = (RI * WP * 16 + 255) / 256 * 256, MPS = (RM * WP * 16 + 255) / 256 * 256;
+    constexpr size_t lds = (size_t)RI * W * 128 + (size_t)NT * 4 * (XPS + MPS);
+    static_assert(lds <= 80 * 1024, "two workgroups per CU");
+    auto kern = conv_pair_kernel<W, R, MODE>;
+    { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds); if (rc) return rc; }
+    if (dry) return SBC_OK;
+    PairParams p = p0;
+    p.tiles_per_sample = p.H / R;
+    p.ntiles = p.B * p.tiles_per_sample;
+    int dev = 0, cus = 256;
+    SBC_CHECK_HIP(hipGetDevice(&dev));
+    SBC_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    p.tiles_per_xcd = (p.ntiles + 7) / 8;
+    p.wgs_per_xcd = max(1, min(2 * cus / 8, p.tiles_per_xcd));
+    hipLaunchKernelGGL(kern, dim3(8 * p.wgs_per_xcd), dim3(256), lds, stream, p);
+    SBC_CHECK_HIP(hipGetLastError());
+    return SBC_OK;
+}
+
+int launch_conv_pair(const sbc_op& op, hipStream_t stream, bool dry) {
+    SBC_REQUIRE(op.in && op.out && op.weight_split && op.weight2_split, "conv_pair: in / out / weight_split / weight2_split must be set");
+    SBC_REQUIRE(op.cin == 32 && op.cout == 32 && op.ksize == 3 && op.dil == 1, "conv_pair: 32 -> 32 -> 32 channels, 3x3, undilated");
+    SBC_REQUIRE(op.B > 0 && op.H > 0 && op.W > 0, "conv_pair: bad shape B=%d H=%d W=%d", op.B, op.H, op.W);
+    const bool x2 = (op.flags & SBC_CONV_F16X2) != 0, f16w = (op.flags & SBC_CONV_F16W) != 0;
+    SBC_REQUIRE(x2 != f16w, "conv_pair: exactly one of SBC_CONV_F16X2 / SBC_CONV_F16W (the forms of weight_split it reads)");
+    SBC_REQUIRE((long)op.B * op.H * op.W * 32 <= 0x7fffffffL, "conv_pair: tensor exceeds the 32-bit element index");
+    PairParams p{};
+    p.in = (const float*)op.in; p.out = (float*)op.out;
+    p.w1 = (const uint4*)op.weight_split; p.w2 = (const uint4*)op.weight2_split;
+    p.B = op.B; p.H = op.H;
+    p.dbg = (unsigned long long*)op.aux;
+    if (x2) {
+        unsigned* word = nullptr;
+        const int rc = range_flag_ptr(&word);
+        if (rc) return rc;
+        p.range_flag = word;
+    }
+    if (op.W == 16 && op.H % 8 == 0) return x2 ? launch_pair<16, 8, 2>(p, stream, dry) : launch_pair<16, 8, 1>(p, stream, dry);
+    if (op.W == 8 && op.H % 8 == 0) return x2 ? launch_pair<8, 8, 2>(p, stream, dry) : launch_pair<8, 8, 1>(p, stream, dry);
+    set_error("conv_pair: no kernel for image %dx%d", op.H, op.W);
+    return SBC_ERR_UNSUPPORTED;
+}
+
+}  // namespace sbc

@@ -237,8 +237,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // h, l: the two values' terms packed low | high, as the matrix instructions take them.
 __device__ __forceinline__ void split_f16x2(float a, float b, unsigned& h, unsigned& l) {
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(a), "v"(b));
-    asm("v_fma_mixlo_f16 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[0,0,1] neg_lo:[0,0,1]" : "=v"(l) : "v"(a), "v"(h));
-    asm("v_fma_mixhi_f16 %0, %1, 1.0, %2 op_sel:[0,0,1] op_sel_hi:[0,0,1] neg_lo:[0,0,1]" : "+v"(l) : "v"(b), "v"(h));
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(b), "v"(h));
 }
 
 // lds16: LDS viewed as 16-bit elements; `plane` = elements per plane; TERMS = 3 (exact bf16 split), 2 (fp16 pair of a scaled

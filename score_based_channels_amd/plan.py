@@ -33,6 +33,7 @@ CONV_F16X2 = 0x10000
 # training operators
 (DSM_PERTURB, DSM_LOSS, GRAD_ADD, INORM_BWD, MAXPOOL5_BWD, UPSAMPLE_BWD, POOL_BWD, CONV_WGRAD, PACK_WEIGHT, END_CONV_BWD,
  BEGIN_CONV_BWD, ADAM_EMA) = range(9, 21)
+CONV_PAIR = 21
 BWD_ACCUM, PACK_ADJOINT, OP_SIDE, OP_JOIN, PACK_WINOGRAD = 0x200, 0x400, 0x800, 0x1000, 0x2000
 
 # profiling tag of the dominant kernel class: 3x3 convs ngf->ngf at full resolution
@@ -60,6 +61,7 @@ class Op:
     src: Optional[Tensor] = None
     dst: Optional[Tensor] = None
     weight: Optional[str] = None        # state_dict key of the conv weight / norm prefix
+    weight2: Optional[str] = None       # CONV_PAIR: state_dict key of the second convolution's weight
     bias: Optional[str] = None
     stats: Optional[Tensor] = None
     res1: Optional[Tensor] = None
@@ -91,8 +93,9 @@ class ScorePlan:
 
 
 class _Builder:
-    def __init__(self, ngf, nt, nr, overlap=False, fold_stats=False):
+    def __init__(self, ngf, nt, nr, overlap=False, fold_stats=False, fuse_pairs=False):
         self.ngf, self.nt, self.nr = ngf, nt, nr
+        self.fuse_pairs = fuse_pairs    # RCU blocks of ngf channels as one CONV_PAIR record (csrc/conv_pair.hip)
         self.ops, self.tensors = [], []
         self.fold_stats = fold_stats    # full-resolution InstanceNorm++ statistics from tile moments (no statistics launch)
         self.producer = {}              # id(tensor) -> the record that writes it
@@ -181,6 +184,14 @@ class _Builder:
     def rcu(self, p, x, n_blocks):
         """layers.py:126-134 (n_stages = 2, no bias)."""
         for i in range(1, n_blocks + 1):
+            if self.fuse_pairs and pair_fusable(x.h, x.w, x.c):
+                # x + conv2(ELU(conv1(ELU(x)))) in one launch, the intermediate tensor never exists in memory
+                dst = self.t(p + '%d_2_conv' % i, x.h, x.w, x.c)
+                self.ops.append(Op(CONV_PAIR, p + '%d_pair' % i, src=x, dst=dst, weight=p + '%d_1_conv.weight' % i,
+                                   weight2=p + '%d_2_conv.weight' % i, side=self.side_now))
+                self.producer[id(dst)] = self.ops[-1]
+                x = dst
+                continue
             t = self.conv(p + '%d_1_conv' % i, x, p + '%d_1_conv' % i, x.c, bias=False, flags=PRO_ELU)
             x = self.conv(p + '%d_2_conv' % i, t, p + '%d_2_conv' % i, x.c, bias=False, flags=PRO_ELU, res1=x)
         return x
@@ -211,13 +222,21 @@ class _Builder:
         return self.rcu(p + 'output_convs.', h, 3 if end else 1)
 
 
-def build_score_plan(ngf=32, nt=64, nr=16, channels=2, share_slots=True, overlap=False, fold_stats=False):
+PAIR_WIDTHS = (16,)            # image widths the plan fuses (csrc/conv_pair.hip also takes W = 8: measured slower than two launches there)
+
+
+def pair_fusable(h, w, c):
+    """Shapes SBC_OP_CONV_PAIR takes: 32 channels, widths of ``PAIR_WIDTHS``, heights that are multiples of its 8-row tile."""
+    return c == 32 and w in PAIR_WIDTHS and h % 8 == 0
+
+
+def build_score_plan(ngf=32, nt=64, nr=16, channels=2, share_slots=True, overlap=False, fold_stats=False, fuse_pairs=False):
     """Op list of one ``NCSNv2Deepest.forward`` for ``[B, 2, nt, nr]`` inputs (ncsnv2.py:269-300).
     ``share_slots=False`` gives every logical tensor its own storage (a training step reads every activation again on
     the way back, ``train.py``)."""
     if nt % 8 or nr % 8:
         raise ValueError('Nt and Nr must be multiples of 8 (three 2x mean-pools), got %dx%d' % (nt, nr))
-    b = _Builder(ngf, nt, nr, overlap, fold_stats)
+    b = _Builder(ngf, nt, nr, overlap, fold_stats, fuse_pairs)
     x = b.t('x', nt, nr, channels)
     h = b.t('begin_conv', nt, nr, ngf)
     b.ops.append(Op(BEGIN_CONV, 'begin_conv', src=x, dst=h, weight='begin_conv.weight', bias='begin_conv.bias'))
@@ -299,6 +318,8 @@ def count_conv_flops(plan):
     for op in plan.ops:
         if op.kind == CONV:
             total += 2 * op.src.h * op.src.w * op.src.c * op.dst.c * op.ksize * op.ksize
+        elif op.kind == CONV_PAIR:
+            total += 2 * 2 * op.src.h * op.src.w * op.src.c * op.dst.c * 9
         elif op.kind in (BEGIN_CONV, END_CONV):
             total += 2 * op.src.h * op.src.w * op.src.c * op.dst.c * 9
     return total

@@ -37,6 +37,7 @@ class BoundScore:
 CONV_MODES = ('bf16x3', 'f32', 'f16w', 'f16x2')
 DEFAULT_OVERLAP = False
 DEFAULT_FOLD_STATS = False
+DEFAULT_FUSE_PAIRS = False
 
 
 class ScoreNet:
@@ -57,7 +58,7 @@ class ScoreNet:
                             ``.half()``, layers.py:179); tolerance stated in tests/test_gpu_parity.py.
     """
 
-    def __init__(self, config, device=None, conv_mode='bf16x3', overlap=None, fold_stats=None):
+    def __init__(self, config, device=None, conv_mode='bf16x3', overlap=None, fold_stats=None, fuse_pairs=None):
         if conv_mode not in CONV_MODES:
             raise ValueError('conv_mode must be one of %s, got %r' % (CONV_MODES, conv_mode))
         self.conv_mode = conv_mode
@@ -69,6 +70,9 @@ class ScoreNet:
         # writes (plan.py `stats`): 7 of the 25 statistics launches -- each a full read of a [B][64][16][32] tensor --
         # disappear.  Needs the Winograd split-bf16 kernels (not conv_mode 'f32').
         self.fold_stats = (DEFAULT_FOLD_STATS if fold_stats is None else bool(fold_stats)) and conv_mode != 'f32'
+        # fuse_pairs: every RCU block of 32 channels (act -> conv -> act -> conv, + x; layers.py:126-134) is ONE launch that keeps
+        # the intermediate tensor in LDS (csrc/conv_pair.hip); the kernel reads the fp16 weight forms of 'f16x2' / 'f16w'
+        self.fuse_pairs = (DEFAULT_FUSE_PAIRS if fuse_pairs is None else bool(fuse_pairs)) and conv_mode in ('f16x2', 'f16w')
         self.config = config
         m, d = config.model, config.data
         if str(m.normalization) != 'InstanceNorm++' or str(m.nonlinearity).lower() != 'elu':
@@ -172,7 +176,8 @@ class ScoreNet:
         key = (nt, nr)
         if key not in self._plans:
             fold = self.fold_stats and not (nt & (nt - 1)) and not (nr & (nr - 1))     # conv_wx3 takes power-of-two images
-            self._plans[key] = P.build_score_plan(self.ngf, nt, nr, self.channels, overlap=self.overlap, fold_stats=fold)
+            self._plans[key] = P.build_score_plan(self.ngf, nt, nr, self.channels, overlap=self.overlap, fold_stats=fold,
+                                                  fuse_pairs=self.fuse_pairs)
         return self._plans[key]
 
     def bind(self, B, nt, nr, *, step=None, sigma_of_step=None, use_labels=True):
@@ -197,7 +202,12 @@ class ScoreNet:
             o.cin, o.cout, o.ksize, o.dil, o.tag = op.src.c, op.dst.c, op.ksize, op.dil, op.tag
             o.in_ = _ptr(slots[op.src.slot])
             o.out = _ptr(slots[op.dst.slot])
-            if op.weight is not None and op.kind != P.CONV:
+            if op.kind == P.CONV_PAIR:
+                o.ksize, o.dil = 3, 1
+                o.weight_split = _ptr(self._wdev, self._woff[op.weight + '#split'])
+                o.weight2_split = _ptr(self._wdev, self._woff[op.weight2 + '#split'])
+                o.flags |= P.CONV_F16W if self.conv_mode == 'f16w' else P.CONV_F16X2
+            elif op.weight is not None and op.kind != P.CONV:
                 o.weight = _ptr(self._wdev, self._woff[op.weight])
             elif op.weight is not None and self.conv_mode == 'f32':
                 o.weight = _ptr(self._wdev, self._woff[op.weight])

@@ -75,6 +75,9 @@ def exec_op(op, sd, get, labels):
             out = _nhwc(O.max_pool5(_nchw(src)))
             if op.flags & P.PRO_ELU:
                 out = O.elu(out)
+        elif op.kind == P.CONV_PAIR:             # one RCU block (layers.py:126-134)
+            t = O.conv2d(_nchw(O.elu(src)), sd[op.weight], None, 1)
+            out = src + _nhwc(O.conv2d(O.elu(t), sd[op.weight2], None, 1))
         elif op.kind in (P.CONV, P.END_CONV):
             v = src
             flags = op.flags | ((P.PRO_NORM | P.PRO_ELU) if op.kind == P.END_CONV else 0)

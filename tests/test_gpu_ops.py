@@ -336,3 +336,49 @@ def test_f16x2_range_flag(gpu, wino):
     with pytest.raises(_lib.SbcError):
         op.flags |= P.CONV_F16W
         _launch(gpu, op)
+
+
+PAIR_CASES = [(3, 64, 16), (130, 64, 16), (1, 8, 16), (5, 32, 8), (70, 32, 8), (2, 16, 16)]
+
+
+@pytest.mark.parametrize('mode', ['f16x2', 'f16w'])
+@pytest.mark.parametrize('B,H,W', PAIR_CASES)
+def test_conv_pair_matches_oracle(gpu, B, H, W, mode):
+    """SBC_OP_CONV_PAIR: one RCU block, out = x + conv2(ELU(conv1(ELU(x)))) (layers.py:126-134), with the intermediate kept in
+    LDS (csrc/conv_pair.hip) -- against the oracle's two convolutions, and against the two SBC_OP_CONV launches it replaces."""
+    torch, _lib = gpu
+    from score_based_channels_amd import plan as P
+    from score_based_channels_amd.weights import pack_conv_weight_f16, pack_conv_weight_f16x2, round_fp16
+    rng = np.random.default_rng(B * 1000 + H + W)
+    x = (rng.standard_normal((B, H, W, 32)) * 1.5 + 0.3).astype(F32)
+    w1 = (rng.standard_normal((32, 32, 3, 3)) / np.sqrt(288)).astype(F32)
+    w2 = (rng.standard_normal((32, 32, 3, 3)) / np.sqrt(288) * 0.05).astype(F32)      # a different weight scale per convolution
+    if mode == 'f16x2':
+        pack, flag, tol = pack_conv_weight_f16x2, P.CONV_F16X2, TOL
+        t = O.conv2d(O.elu(x).transpose(0, 3, 1, 2), w1, None, 1)
+        ref = x + O.conv2d(O.elu(t), w2, None, 1).transpose(0, 2, 3, 1)
+    else:
+        pack, flag, tol = pack_conv_weight_f16, P.CONV_F16W, 2e-4
+        t = O.conv2d(round_fp16(O.elu(x)).transpose(0, 3, 1, 2), round_fp16(w1), None, 1)
+        ref = x + O.conv2d(round_fp16(O.elu(t)), round_fp16(w2), None, 1).transpose(0, 2, 3, 1)
+    dx = _dev(torch, x)
+    d1, d2 = _dev(torch, pack(w1).view(np.float32)), _dev(torch, pack(w2).view(np.float32))
+    out = torch.full((B, H, W, 32), float('nan'), dtype=torch.float32, device='cuda')
+    op = _lib.sbc_op(kind=P.CONV_PAIR, flags=flag, B=B, H=H, W=W, cin=32, cout=32, ksize=3, dil=1, in_=_p(dx), out=_p(out),
+                     weight_split=_p(d1), weight2_split=_p(d2))
+    _launch(gpu, op)
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    conv_part, ref_part = got - x, ref - x                          # the residual must not mask the convolution's error
+    assert rel_err(conv_part, ref_part) < tol
+    assert _lib.range_flag() == 0
+    # the two launches it replaces
+    mid = torch.empty_like(out)
+    out2 = torch.empty_like(out)
+    a = _lib.sbc_op(kind=P.CONV, flags=flag | P.PRO_ELU, B=B, H=H, W=W, cin=32, cout=32, ksize=3, dil=1, in_=_p(dx), out=_p(mid),
+                    weight_split=_p(d1))
+    b = _lib.sbc_op(kind=P.CONV, flags=flag | P.PRO_ELU, B=B, H=H, W=W, cin=32, cout=32, ksize=3, dil=1, in_=_p(mid), out=_p(out2),
+                    weight_split=_p(d2), res1=_p(dx))
+    _launch(gpu, a)
+    _launch(gpu, b)
+    assert rel_err(got - x, out2.cpu().numpy() - x) < tol

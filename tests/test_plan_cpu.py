@@ -62,3 +62,22 @@ def test_folded_statistics_plan_matches_reference_forward(weights64):
     assert rel_err(out.transpose(0, 3, 1, 2), g['out'][1][:2]) < 2e-5
     # nothing changes for arrays the fold does not apply to (here: not requested)
     assert all(op.moments is None for op in P.build_score_plan(32, 64, 16).ops)
+
+
+def test_fused_pair_plan_matches_reference_forward(weights64):
+    """``build_score_plan(fuse_pairs=True)``: every 32-channel RCU block is ONE record (SBC_OP_CONV_PAIR) whose intermediate
+    tensor does not exist; interpreted on the CPU the plan still computes the reference forward."""
+    _, sd = weights64
+    g = load_golden('forward_64x16.npz')
+    pl = P.build_score_plan(32, 64, 16, fuse_pairs=True)
+    kinds = [op.kind for op in pl.ops]
+    # refine5: adapt_convs.0 (2 blocks) + output_convs (3 blocks) at 64x16
+    assert kinds.count(P.CONV_PAIR) == 5 and kinds.count(P.CONV) == 111 - 10 and len(pl.ops) == 150 - 5
+    assert P.count_conv_flops(pl) == 820772864
+    assert sorted((op.src.h, op.src.w) for op in pl.ops if op.kind == P.CONV_PAIR) == [(64, 16)] * 5
+    assert all(op.src.c == 32 and op.weight2 for op in pl.ops if op.kind == P.CONV_PAIR)
+    x = np.ascontiguousarray(g['x'][:2].transpose(0, 2, 3, 1))
+    out = run_plan(pl, sd, x, np.full((2,), 1155))
+    assert rel_err(out.transpose(0, 3, 1, 2), g['out'][1][:2]) < 2e-5
+    # wider arrays (config 5) keep the unfused records at the widths the kernel is not built for
+    assert all(op.src.w in P.PAIR_WIDTHS for op in P.build_score_plan(32, 256, 64, fuse_pairs=True).ops if op.kind == P.CONV_PAIR)
