@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(PairParams p) {
     if (tile < t_end) issue_dma(tile);
     float amax = 0.f;
 #ifdef SBC_PAIR_TIMING
-    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_last = __builtin_readcyclecounter();
+    unsigned long long pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt_last = __builtin_readcyclecounter();
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // first tile (and the filter fragments) landed
 
@@ -171,6 +171,7 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(PairParams p) {
         PT_MARK(3);
         // the raw copy is consumed: request the next tile of this workgroup; it flies during both K loops
         if (tile + p.wgs_per_xcd < t_end) issue_dma(tile + p.wgs_per_xcd);
+        PT_MARK(8);
 
         // one convolution over units `sub`, `sub + 2`, ...: acc[i] = D[16 couts of this wave][16 pixels of unit i]
         auto conv = [&](auto cvc, const int plane_off, const int PS, auto nuc, auto nutc, f32x4v* acc) {
@@ -219,6 +220,7 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(PairParams p) {
         {
             f32x4v acc[NU1];
             conv(std::integral_constant<int, 0>{}, X_OFF, XPS, std::integral_constant<int, NU1>{}, std::integral_constant<int, NU1T>{}, acc);
+            PT_MARK(9);
             const int cq = 4 * hf + kq;                                    // channel quad of this lane's four outputs
 #pragma unroll
             for (int i = 0; i < NU1; ++i) {
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(PairParams p) {
     }
 #ifdef SBC_PAIR_TIMING
     if (tid == 0 && p.dbg)
-        for (int k = 0; k < 8; ++k) atomicAdd(p.dbg + k, pt[k]);
+        for (int k = 0; k < 10; ++k) atomicAdd(p.dbg + k, pt[k]);
 #endif
 }
 

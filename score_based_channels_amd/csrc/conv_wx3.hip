@@ -457,7 +457,8 @@ static int launch_wx3(const ConvParams& p, hipStream_t stream, bool dry) {
     // 32 -> 32 with 128-pixel tiles: three waves per SIMD (168 registers), filter ring three columns deep.  (Four waves at 128
     // registers with a one-column ring measured 4 % faster per launch, but only with the packed-fp32 instructions the build
     // no longer allows -- see the Makefile; without them that variant spills.)
-    constexpr int WPE = (CIN == 32 && COUT == 32 && MB == 1) ? 3 : 2;
+    // (the two-term fp16 mode needs fewer registers -- no middle term, a two-set filter ring -- and fits four waves: 126 VGPRs)
+    constexpr int WPE = (CIN == 32 && COUT == 32 && MB == 1) ? (F16 == 2 ? 4 : 3) : 2;
     constexpr int NBP_BIG = NBLK == 2 ? 2 : 1;
     const bool top = (CIN == 32 && COUT == 32) && p.top;
     auto kern = ng == 2 ? conv_wx3_kernel<CIN, COUT, MB, true, 2, false, (NBLK == 4 ? 2 : 1), NGMAX, F16>

@@ -37,9 +37,9 @@ def timeit(ops):
     return e0.elapsed_time(e1) / a.iters * 1e3
 tp, tu = timeit([pair]), timeit([c1, c2])
 if 'pt' in os.environ.get('SBC_LIB_PATH', ''):
-    dbg = torch.zeros(8, dtype=torch.int64, device='cuda'); pair.aux = dbg.data_ptr()
+    dbg = torch.zeros(10, dtype=torch.int64, device='cuda'); pair.aux = dbg.data_ptr()
     run([pair], 1); torch.cuda.synchronize()
-    names = ['conv2 epilogue -> loop top', 'barrier 1', 'convert', 'barrier 2', 'dma issue + conv1 + mid write', 'barrier 3', 'residual issue + conv2', 'wait + store']
+    names = ['conv2 epilogue -> loop top', 'barrier 1', 'convert', 'barrier 2', 'mid write', 'barrier 3', 'residual issue + conv2', 'wait + store', 'dma issue', 'conv1']
     tot = dbg.sum().item()
     print('wave-0 cycles per phase (sum over %d workgroups): ' % 512 + ', '.join('%s %.1f%%' % (n, 100.0 * v / tot) for n, v in zip(names, dbg.tolist())), '| cycles per WG %.0f' % (tot / 512))
 err = float((out - out2).abs().max() / (out2 - x).abs().max())
