@@ -38,7 +38,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3       # v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2516.6     # v_mfma_f32_32x32x16_bf16 / _f16 dense ("~2.5 PF"), 16x the fp32 MFMA rate
 PEAK_HBM_TBS = 8.0                 # HBM3E spec (6.3 TB/s achievable by a float4 copy)
 STEPS_PER_CHANNEL = 2311 * 3
-PROFILE_ROUND = 'r02'
+PROFILE_ROUND = 'r03'
+REFERENCE_CPU_CHANNELS_PER_S = 0.046   # the reference's own test_score loop (torch, 8 cores of the build container)
 
 
 def _cpu_worker(job):
@@ -124,8 +125,8 @@ def parse_args():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--force-dist', action='store_true',
                     help='with --gpus 1: still create a one-rank RCCL process group and route the barrier / max / gather through it')
-    ap.add_argument('--conv-mode', default=None, choices=['bf16x3', 'f32', 'f16w', 'f16x2'],
-                    help='convolution multiplier (scorenet.CONV_MODES); default bf16x3, f16w for --workload big')
+    ap.add_argument('--conv-mode', default=None, choices=['f16x2', 'bf16x3', 'f32', 'f16w'],
+                    help='convolution multiplier (config.CONV_MODES); default: config.DEFAULT_CONV_MODE, f16w for --workload big')
     ap.add_argument('--overlap', type=int, default=None,
                     help='1: independent low-resolution branches of the network on the plan side stream, 0: strictly '
                          'sequential launches; default: scorenet.DEFAULT_OVERLAP')
@@ -135,8 +136,9 @@ def parse_args():
     ap.add_argument('--fuse-pairs', type=int, default=None,
                     help='1: 32-channel RCU blocks as one launch each (csrc/conv_pair.hip), 0: two convolution launches; '
                          'default: scorenet.DEFAULT_FUSE_PAIRS')
-    ap.add_argument('--streams', type=int, default=1,
-                    help='split the trajectories into this many concurrent sub-batch streams (DESIGN.md section 7)')
+    ap.add_argument('--streams', type=int, default=None,
+                    help='split the trajectories into this many concurrent sub-batch streams; default: what the CLIs default '
+                         'to (config.DEFAULT_STREAMS)')
     return ap.parse_args()
 
 
@@ -214,31 +216,42 @@ def main():
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     n_dev = max(1, torch.cuda.device_count())
-    local %= n_dev                                       # identity on a full node; lets 2 ranks share 1 GPU in a smoke test
+    explicit_gloo = os.environ.get('SBC_DIST_BACKEND') == 'gloo'
+    if local >= n_dev and not explicit_gloo:
+        # one process per GPU: more local ranks than devices is a launch error, not something to fold silently.  (A smoke run
+        # that shares one GPU between ranks has to say so: SBC_DIST_BACKEND=gloo -- RCCL refuses two ranks on one device.)
+        raise SystemExit('LOCAL_RANK %d but only %d visible device(s): launch one rank per GPU (or set SBC_DIST_BACKEND=gloo '
+                         'to share a device in a smoke test)' % (local, n_dev))
+    local %= n_dev
     torch.cuda.set_device(local)
     use_dist = world > 1 or args.force_dist
     backend = None
     if use_dist:
-        # 'nccl' is RCCL on ROCm.  RCCL refuses two ranks on one device ("Duplicate GPU detected"), so a smoke run with more
-        # ranks than GPUs (2 ranks on the 1-GPU dev box) falls back to gloo for the barrier / max / gather.
-        backend = os.environ.get('SBC_DIST_BACKEND', 'nccl' if world <= n_dev else 'gloo')
+        backend = os.environ.get('SBC_DIST_BACKEND', 'nccl')          # 'nccl' is RCCL on ROCm
         if world == 1:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29533')
             os.environ.setdefault('RANK', '0')
             os.environ.setdefault('WORLD_SIZE', '1')
+        import datetime
         kw = {'device_id': torch.device('cuda', local)} if backend == 'nccl' else {}
-        dist.init_process_group(backend, **kw)
+        # a rank that never arrives must end the job with an error, not hang it
+        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=int(os.environ.get('SBC_DIST_TIMEOUT_S', '300'))), **kw)
+        if dist.get_world_size() != world:
+            raise SystemExit('process group has %d ranks, WORLD_SIZE says %d' % (dist.get_world_size(), world))
 
     from score_based_channels_amd import plan as P, shard, synth
     from score_based_channels_amd.ald import AldBatch, snr_to_noise
     from score_based_channels_amd.config import default_config
+    from score_based_channels_amd import _lib
+    from score_based_channels_amd.config import DEFAULT_CONV_MODE, DEFAULT_STREAMS
     from score_based_channels_amd.driver import DEFAULT_USE_GRAPH, run_concurrently
     from score_based_channels_amd.scorenet import ScoreNet
     from score_based_channels_amd.weights import seeded_state_dict
 
     big = args.workload == 'big'
-    conv_mode = args.conv_mode or ('f16w' if big else 'bf16x3')
+    conv_mode = args.conv_mode or ('f16w' if big else DEFAULT_CONV_MODE)
+    n_streams = DEFAULT_STREAMS if args.streams is None else max(1, args.streams)
     nt, nr = (256, 64) if big else (64, 16)
     npil = int(np.floor(nt * 0.6))
     nch = args.channels or (64 if big else 100)
@@ -305,20 +318,11 @@ def main():
     init = torch.randn(nch, nt, nr, dtype=torch.complex64, device=net.device,
                        generator=torch.Generator(net.device).manual_seed(rank))   # one init shared by all SNR points (:115)
     alds, streams = make_batches(H, Pm, idx, idx, ln, np.full(T, 3e-11), np.full(T, 0.01), rank * T + np.arange(T), init,
-                                 args.streams)
-    ald = alds[0]
+                                 n_streams)
 
     K = STEPS_PER_CHANNEL - args.warmup if args.full_schedule else args.steps
-    # headline: the launch mode the CLIs default to.  Per-kernel hipEvent timing needs eager launches: it brackets the
-    # timed region itself when that is eager, otherwise it is taken in an extra eager segment right after it.
-    if not use_graph:
-        ald.plan.profile(P.TAG_CONV_TOP)
+    # headline: the launch mode and stream count the CLIs default to; nothing but the K steps inside the timed region
     dt = timed(alds, streams, K, use_graph, args.warmup)
-    if use_graph:
-        ald.plan.profile(P.TAG_CONV_TOP)
-        timed(alds, streams, min(K, 30), False, 1)
-    kern_ms, kern_n = ald.plan.profile_read()
-    ald.plan.profile(-1)
     other = None
     if not args.no_other_mode and not args.full_schedule:
         other = timed(alds, streams, K, not use_graph, args.warmup)
@@ -337,10 +341,45 @@ def main():
     torch.cuda.synchronize()
     gather_ms = (time.perf_counter() - t_g) * 1e3
     finite = bool(torch.isfinite(curves).all().item())
-    T0 = alds[0].T
     for a in alds:
         a.close()
-    del alds, ald
+    del alds
+
+    # ---------------------------------------------------------------- per-kernel roofline: AFTER the timed region
+    # One lock-step batch of all T trajectories on ONE stream with eager launches (a kernel then has the chip to itself, which
+    # is what a per-kernel roofline means and what `rocprofv3 --kernel-trace --stats` of a one-stream run reports); each tagged
+    # kernel class is bracketed by hipEvents on the launch stream (sbc_plan_profile) in its own short segment.
+    klass = {}
+    if rank == 0:
+        p_alds, p_streams = make_batches(H, Pm, idx, idx, ln, np.full(T, 3e-11), np.full(T, 0.01), rank * T + np.arange(T), init, 1)
+        pa = p_alds[0]
+        run_all(p_alds, p_streams, 2, False)
+        for tag in (P.TAG_CONV_TOP, P.TAG_PAIR_TOP, P.TAG_CONV_MID):
+            ops = [op for op in net.score_plan(nt, nr).ops if op.tag == tag]
+            if not ops:
+                continue
+            pa.rewind()
+            pa.plan.profile(tag)
+            run_all(p_alds, p_streams, 6, False)
+            torch.cuda.synchronize()
+            ms, n = pa.plan.profile_read()
+            pa.plan.profile(-1)
+            if n:
+                klass[tag] = {'ms_total': ms, 'launches': n, 'launches_per_step': len(ops), 'us_per_launch': ms / n * 1e3,
+                              'flops_per_step': float(sum((2 if op.kind == P.CONV_PAIR else 1) * 2.0 * T * op.src.h * op.src.w * 9
+                                                          * op.src.c * op.dst.c for op in ops)),
+                              'bytes_per_step': float(sum(4.0 * T * op.src.h * op.src.w * (op.src.c + op.dst.c * (1 + (op.res1 is not None)
+                                                                                                             + (op.res2 is not None)))
+                                                          for op in ops))}
+        pa.rewind()
+        t0 = time.perf_counter()
+        run_all(p_alds, p_streams, 10, False)
+        torch.cuda.synchronize()
+        one_stream_ms = (time.perf_counter() - t0) / 10 * 1e3
+        for a in p_alds:
+            a.close()
+        del p_alds, pa
+    range_flag = _lib.range_flag() if conv_mode == 'f16x2' else 0
 
     # ---------------------------------------------------------------- strong workload: the tuner grid, sharded
     strong = None
@@ -360,7 +399,7 @@ def main():
         lns = snr_to_noise(np.arange(-10, 32.5, 2.5), nt)[snr_of[sel]]
         init_s = torch.randn(nB, nt, nr, dtype=torch.complex64, device=net.device,
                              generator=torch.Generator(net.device).manual_seed(99))
-        s_alds, s_streams = make_batches(Hs, Ps, ch_of[sel], (cell_of * nB + ch_of)[sel], lns, a0, be, sel, init_s)
+        s_alds, s_streams = make_batches(Hs, Ps, ch_of[sel], (cell_of * nB + ch_of)[sel], lns, a0, be, sel, init_s, n_streams)
         Ks = max(5, min(K, 20))
         dts = timed(s_alds, s_streams, Ks, use_graph, 2)
         strong = {'scaling': 'strong', 'value': Ttot / (STEPS_PER_CHANNEL * dts / Ks), 'unit': 'channels/s',
@@ -376,7 +415,7 @@ def main():
         ms_per_step = dt / K * 1e3
         value = world * T / (STEPS_PER_CHANNEL * dt / K)
         flops_fwd = P.count_conv_flops(net.score_plan(nt, nr)) * T          # conv FLOPs of one step on this GPU
-        dtype = {'f32': 'f32', 'bf16x3': 'f32 (products as exact 3-term bf16 splits on the bf16 matrix cores, fp32 accumulate)',
+        dtype = {'f32': 'f32 (v_mfma_f32_32x32x2_f32)', 'bf16x3': 'f32 (products as exact 3-term bf16 splits on the bf16 matrix cores, fp32 accumulate)',
                  'f16x2': 'f32 (operands as two fp16 terms of a power-of-two-scaled value, hh + hl + lh on the fp16 matrix cores, fp32 accumulate)',
                  'f16w': 'f16 weights x f16-rounded activations on the fp16 matrix cores, fp32 accumulate, fp32 tensors in HBM'}
         out = {
@@ -396,7 +435,9 @@ def main():
                                           'trajectories; channels/s = trajectories / (6933 * s_per_step)',
                        'full_schedule_timed': bool(args.full_schedule), 'conv_mode': conv_mode,
                        'graph_replay': use_graph, 'launch_mode': 'hipGraph replay' if use_graph else 'eager launches',
-                       'launch_mode_is_cli_default': use_graph == DEFAULT_USE_GRAPH, 'streams': args.streams,
+                       'launch_mode_is_cli_default': use_graph == DEFAULT_USE_GRAPH, 'streams': n_streams,
+                       'streams_is_cli_default': n_streams == DEFAULT_STREAMS, 'fuse_pairs': bool(net.fuse_pairs),
+                       'world_size_seen_by_backend': dist.get_world_size() if use_dist else 1, 'dist_backend': backend,
                        'parallelism': 'independent trajectories sharded over %d rank(s) on %d device(s); one all_gather of '
                                       'NMSE curves at the end (%.2f ms, backend %s)'
                                       % (world, min(world, n_dev), gather_ms,
@@ -414,57 +455,69 @@ def main():
                                         'value': world * T / (STEPS_PER_CHANNEL * other / K)}
         if strong is not None:
             out['strong'] = strong
-        if kern_n:
-            t_k = kern_ms / kern_n * 1e-3                                   # seconds per launch
-            px = T0 * nt * nr
-            per_launch = 2.0 * px * 9 * 32 * 32                              # 3x3 conv 32->32, 2*MACs
-            ach = per_launch / t_k / 1e12
-            where = 'the timed region' if not use_graph else 'an eager segment after the (graph-replayed) timed region'
+        out['config']['one_stream_ms_per_step'] = one_stream_ms
+        if conv_mode == 'f16x2':
+            out['config']['f16x2_range_flag'] = int(range_flag)          # 0: every staged activation stayed inside the fp16 range
+        if klass:
+            # executed matrix-core FLOPs per algorithmic FLOP of each kernel class (conv_mode decides the terms per product):
+            #   Winograd F(2x2,3x3) kernels execute 16/36 of the direct products; the fused pair is a direct convolution whose
+            #   first stage also computes the 2 halo rows of its 8-row tile: (10 + 8) / (2 * 8)
+            terms = {'bf16x3': 6.0, 'f16x2': 3.0, 'f16w': 1.0}.get(conv_mode)
+            names = {P.TAG_CONV_TOP: 'conv_wx3_kernel<32, 32, 1, true, %s, true, 1, 1, %d>' % ({'bf16x3': '3', 'f16x2': '4', 'f16w': '3'}.get(conv_mode, '3'),
+                                                                                              {'bf16x3': 0, 'f16w': 1, 'f16x2': 2}.get(conv_mode, 0)),
+                     P.TAG_PAIR_TOP: 'conv_pair_kernel<%d, 8, %d>' % (nr, 2 if conv_mode == 'f16x2' else 1),
+                     P.TAG_CONV_MID: 'conv_wx3_kernel<64, 64, 1, true, 2, false, 2, 1, %d>' % {'bf16x3': 0, 'f16w': 1, 'f16x2': 2}.get(conv_mode, 0)}
+            what = {P.TAG_CONV_TOP: 'the unfused 3x3 32->32 convolutions at %dx%d (Winograd F(2x2,3x3))' % (nt, nr),
+                    P.TAG_PAIR_TOP: 'the fused RCU blocks at %dx%d: two direct 3x3 32->32 convolutions per launch, intermediate in LDS' % (nt, nr),
+                    P.TAG_CONV_MID: 'the undilated 3x3 64->64 convolutions of the %dx%d level (Winograd F(2x2,3x3))' % (nt // 2, nr // 2)}
+            entries = {}
+            for tag, kc in klass.items():
+                t_launch = kc['us_per_launch'] * 1e-6
+                fl = kc['flops_per_step'] / kc['launches_per_step']           # algorithmic FLOPs of an average launch of the class
+                by = kc['bytes_per_step'] / kc['launches_per_step']
+                ratio = (18.0 / 16.0 if tag == P.TAG_PAIR_TOP else 16.0 / 36.0) * (terms or 1.0)
+                ach = fl / t_launch / 1e12
+                e = {'kernel': names[tag], 'what': what[tag], 'launches_per_step': kc['launches_per_step'],
+                     'us_per_launch': kc['us_per_launch'], 'share_of_one_stream_step': kc['us_per_launch'] * kc['launches_per_step'] / 1e3 / one_stream_ms,
+                     'algorithmic_gflop_per_launch': fl / 1e9, 'algorithmic_tflops': ach,
+                     'algorithmic_hbm_bytes_per_launch': by, 'algorithmic_TBps': by / t_launch / 1e12}
+                if conv_mode == 'f32':
+                    e.update(executed_mfma_tflops=ach * 16.0 / 36.0, mfma_peak_tflops=PEAK_F32_MFMA_TFLOPS,
+                             mfma_busy=ach * 16.0 / 36.0 / PEAK_F32_MFMA_TFLOPS)
+                else:
+                    e.update(executed_mfma_tflops=ach * ratio, mfma_peak_tflops=PEAK_BF16_MFMA_TFLOPS,
+                             mfma_busy=ach * ratio / PEAK_BF16_MFMA_TFLOPS)
+                entries[tag] = e
+            dom = max(entries, key=lambda t: entries[t]['share_of_one_stream_step'])
+            d = entries[dom]
             tfile = os.path.join(ROOT, 'profiles', '%s_traffic_%s.json' % (PROFILE_ROUND, args.workload))
             traffic, tsrc = None, None
             if os.path.exists(tfile):
                 with open(tfile) as f:
                     tj = json.load(f)
-                if tj.get('trajectories_per_launch') == T0 and tj.get('conv_mode') == conv_mode:
+                if tj.get('trajectories_per_launch') == T and tj.get('conv_mode') == conv_mode and tj.get('kernel') == d['kernel']:
                     traffic, tsrc = tj.get('hbm_bytes_per_launch'), 'profiles/' + os.path.basename(tfile)
-            alg_bytes = px * 32 * 4 * 3.0                                    # input + residual + output, fp32 NHWC
-            if conv_mode in ('bf16x3', 'f16x2'):
-                # Winograd F(2x2,3x3) executes 16/36 of the direct products, each as six bf16 MFMAs (exact 3-term split) or
-                # three fp16 MFMAs (two-term split): algorithmic FLOP/s at which the matrix pipe would be 100 % busy
-                exec_ratio = (6.0 if conv_mode == 'bf16x3' else 3.0) * 16.0 / 36.0
-                peak = PEAK_BF16_MFMA_TFLOPS / exec_ratio
-                rf = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-                      'traffic': traffic,
-                      'executed_mfma_tflops': ach * exec_ratio, 'mfma_peak_tflops': PEAK_BF16_MFMA_TFLOPS,
-                      'frac_alternatives': {'vs_bf16_peak_over_6_no_winograd_credit': ach / (PEAK_BF16_MFMA_TFLOPS / 6),
-                                            'vs_fp32_mfma_peak': ach / PEAK_F32_MFMA_TFLOPS},
-                      'hbm': {'algorithmic_bytes_per_launch': alg_bytes, 'algorithmic_TBps': alg_bytes / t_k / 1e12,
-                              'frac_of_8TBps': alg_bytes / t_k / 1e12 / PEAK_HBM_TBS},
-                      'kernel': 'conv_wx3_kernel<32, 32, 1, true, 3, true, 1, 1, false>: the 18 3x3 32->32 convolutions at '
-                                '%dx%d of every step (%d tagged launches, avg %.1f us, hipEvents on the launch stream over %s).  '
-                                'achieved = direct-convolution FLOPs (2*9*32*32 per pixel) / time; peak = dense bf16 MFMA peak '
-                                '%.1f x 36/16 / 6: the kernel executes 16/36 of the products (Winograd F(2x2,3x3)), each as six '
-                                'bf16 MFMAs (fp32 operands as three exact bf16 terms), so frac IS the busy fraction of the '
-                                'bf16 matrix pipe' % (nt, nr, kern_n, t_k * 1e6, where, PEAK_BF16_MFMA_TFLOPS)}
-            elif conv_mode == 'f16w':
-                # one fp16 MFMA per executed product: the layer is bound by streaming its fp32 tensors through HBM
-                rf = {'bound': 'hbm', 'achieved': alg_bytes / t_k / 1e9, 'peak': PEAK_HBM_TBS * 1e3, 'unit': 'GB/s',
-                      'frac': alg_bytes / t_k / 1e12 / PEAK_HBM_TBS, 'traffic': traffic,
-                      'mfma': {'algorithmic_tflops': ach, 'executed_mfma_tflops': ach * 16.0 / 36.0,
-                               'frac_of_f16_peak': ach * 16.0 / 36.0 / PEAK_BF16_MFMA_TFLOPS},
-                      'kernel': 'conv_wx3_kernel<32, 32, 1, true, 3, true, 1, 1, true>: the 18 3x3 32->32 convolutions at '
-                                '%dx%d of every step (%d tagged launches, avg %.1f us, hipEvents over %s).  achieved = '
-                                'algorithmic bytes (fp32 input + residual + output = 3 x pixels x 32 x 4 B) / time against '
-                                'the 8 TB/s HBM3E peak (6.3 TB/s achievable); Winograd F(2x2,3x3) with one fp16 MFMA per '
-                                'product' % (nt, nr, kern_n, t_k * 1e6, where)}
+            hbm_bound = conv_mode == 'f16w'
+            note = ('dominant kernel = the tagged kernel class with the largest share of a one-stream step (%.0f %%): %s, %s.  '
+                    'Timed by hipEvents on the launch stream in a one-stream eager segment AFTER the timed region (%d launches, '
+                    'avg %.1f us); profiles/%s_kernel_stats_%s.csv is rocprofv3 --kernel-trace --stats of the same one-stream '
+                    'command.  ' % (100 * d['share_of_one_stream_step'], d['kernel'], d['what'], klass[dom]['launches'],
+                                    d['us_per_launch'], PROFILE_ROUND, args.workload))
+            if hbm_bound:
+                rf = {'bound': 'hbm', 'achieved': d['algorithmic_TBps'] * 1e3, 'peak': PEAK_HBM_TBS * 1e3, 'unit': 'GB/s',
+                      'frac': d['algorithmic_TBps'] / PEAK_HBM_TBS, 'traffic': traffic,
+                      'kernel': note + 'achieved = algorithmic bytes (fp32 input + output + residual operands) / time against the 8 TB/s '
+                                       'HBM3E peak (6.3 TB/s achievable)'}
             else:
-                rf = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS * 36 / 16, 'unit': 'TFLOP/s',
-                      'frac': ach * 16 / 36 / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
-                      'kernel': 'conv_wino_kernel<32, 32, 2, true>: the 18 3x3 32->32 convolutions at %dx%d of every step (%d '
-                                'launches, avg %.1f us); fp32 Winograd F(2x2,3x3) executes 16/36 of the algorithmic FLOPs '
-                                'on v_mfma_f32_32x32x2_f32' % (nt, nr, kern_n, t_k * 1e6)}
+                rf = {'bound': 'mfma', 'achieved': d['algorithmic_tflops'], 'peak': d['mfma_peak_tflops'] * d['algorithmic_tflops'] / d['executed_mfma_tflops'],
+                      'unit': 'TFLOP/s', 'frac': d['mfma_busy'], 'traffic': traffic,
+                      'kernel': note + 'achieved = algorithmic (direct-convolution) FLOPs / time; peak = the algorithmic rate at which the '
+                                       'matrix pipe would be 100 %% busy with this kernel\'s algorithm (dense f16/bf16 MFMA peak %.1f TFLOP/s / '
+                                       'executed-per-algorithmic FLOP ratio), so frac IS the busy fraction of the matrix cores'
+                                       % PEAK_BF16_MFMA_TFLOPS}
+            rf['kernels'] = {names[t]: {k: v for k, v in entries[t].items() if k != 'kernel'} for t in entries}
             if traffic is not None:
-                rf['traffic_source'] = tsrc + ' (rocprofv3 --pmc passes of this command: FETCH_SIZE x 2 + WRITE_SIZE per launch)'
+                rf['traffic_source'] = tsrc + ' (rocprofv3 --pmc passes of the one-stream command: FETCH_SIZE x 2 + WRITE_SIZE per launch)'
             out['roofline'] = rf
         if cpu_base is not None:
             out['cpu_baseline'] = cpu_base

@@ -109,8 +109,8 @@ typedef enum sbc_op_kind {
                                    (sbc_pack_conv_weight_f16x2 / _winograd_f16x2); activations are scaled by a power of two and
                                    split into two fp16 terms as they enter the matrix cores; three v_mfma_f32_32x32x16_f16
                                    per product block (hh + hl + lh), fp32 accumulation.  Representation error <= 2^-22 per
-                                   operand.  A staged activation with |x| * act_scale >= 16000 raises the device's range
-                                   flag (sbc_range_flag) instead of overflowing silently                              */
+                                   operand.  A staged activation with |x| * act_scale >= 16000 (act_scale = 1 as packed) raises
+                                   the device's range flag (sbc_range_flag) instead of overflowing silently                              */
 
 /* One fused launch.  Unused fields are 0 / NULL.  Tensor shapes per kind:
  *   BEGIN_CONV  in [B][H][W][2], weight [cout][2][3][3] (torch layout), bias [cout], out [B][H][W][cout]
@@ -240,9 +240,11 @@ typedef struct sbc_endconv {
  *   Htrue  [nH][Nt][Nr] ground truth, sample b uses Htrue[h_index[b]]  (:112-113,131)
  *   sched  [G][n_steps][4] float32 (alpha, dc_div, noise_scale, dc_boost) of group `group[b]` at step k,
  *          i.e. the float64 python scalars of :143-144,160,165 rounded to float32; dc_boost (1 for test_score,
- *          --dc_boost of test_mmse.py:231-233) multiplies the data-consistency gradient before the division
- *   noise  [n_steps][B][Nt][Nr] CN(0,1) draws or NULL -> in-kernel Philox4x32-10 keyed by
- *          (seed, traj_id[b], step, element)                            (:160-161)
+ *          --dc_boost of test_mmse.py:231-233) multiplies the data-consistency gradient before the division; 0 means
+ *          "not set" and is read as 1 (hosts written against the three-column table of ABI <= 4)
+ *   noise  [n_steps][B][Nt][Nr] CN(0,1) draws or NULL -> in-kernel Philox4x32-10: elements 2q, 2q+1 of a trajectory share
+ *          the block of counter (q, step, traj_id lo, traj_id hi), key = seed; words (x, y) / (z, w) feed one Box-Muller
+ *          each (csrc/philox.h; restated on the host by oracle/ald_oracle.py::device_complex_normal)      (:160-161)
  *   nmse   [n_steps][B] float32 log, row *step is written               (:168-170)
  * SBC_OP_MEASURE reads Htrue and P and writes Y; its `noise` is [B][Np][Nr] and `meas_scale[b]` =
  * float32(sqrt(local_noise)).
@@ -317,8 +319,8 @@ int sbc_pack_conv_weight_winograd_split(const float* src, int32_t cout, int32_t 
  * device memory.  sbc_score_create does all of that inside the library from the tensors of the reference checkpoint's
  * `model_state` (names as in NCSNv2Deepest.state_dict(): "res2.0.conv2.conv.weight", "normalizer.alpha", ...; HOST
  * pointers, float32, torch layouts).  The handle owns its device memory (weights, activation slots for `batch` samples,
- * labels).  conv_mode: 0 = split-bf16 (fp32-accurate, default of the Python host), 1 = fp32 MFMA, 2 = fp16 weights
- * (SBC_CONV_F16W; every parameter is rounded to fp16 first).
+ * labels).  conv_mode: 0 = split-bf16 (fp32-accurate), 1 = fp32 MFMA, 2 = fp16 weights (SBC_CONV_F16W; every parameter is
+ * rounded to fp16 first), 3 = f16x2 (SBC_CONV_F16X2: fp32-class on the fp16 matrix cores, default of the Python host).
  *   sbc_score_buffers      device pointers of the input x [batch][Nt][Nr][2], the output score (same shape) and the
  *                          int64 noise-level labels [batch] (ncsnv2.py:295-298); fill x / labels, then
  *   sbc_score_forward      one score evaluation, asynchronous on `stream`;
@@ -334,7 +336,10 @@ typedef struct sbc_score_desc {
     int32_t conv_mode;
     const float* sigmas;         /* HOST [num_classes] (models/__init__.py:4-8) */
     int32_t num_classes;
+    int32_t flags;               /* ABI 9: SBC_SCORE_* */
 } sbc_score_desc;
+#define SBC_SCORE_FUSE_PAIRS 0x1 /* every RCU block of 32 channels at a width of 16 as one SBC_OP_CONV_PAIR record (conv_mode 2 / 3);
+                                    what the Python host does by default in those modes (scorenet.DEFAULT_FUSE_PAIRS) */
 typedef struct sbc_score sbc_score;
 int sbc_score_create(const sbc_score_desc* desc, const sbc_tensor_ref* tensors, int32_t n_tensors, sbc_score** out);
 int sbc_score_buffers(sbc_score* score, float** x, float** out, int64_t** labels);
@@ -354,7 +359,7 @@ int sbc_pack_conv_weight_winograd_f16(const float* src, int32_t cout, int32_t ci
  * h = fp16(w 2^s), l = fp16(w 2^s - h), in the layout of sbc_pack_conv_weight_split with 2 terms,
  * [k*k | 16][cin/16][cout/32][2][64 lanes][8] uint16, followed by a 16-byte trailer of four float32: (act_scale =
  * 2^SBC_F16X2_ACT_SHIFT, descale = 2^-(s + SBC_F16X2_ACT_SHIFT), 0, 0).  dst holds sbc_f16x2_elems(...) uint16. */
-#define SBC_F16X2_ACT_SHIFT 5
+#define SBC_F16X2_ACT_SHIFT 0
 #define sbc_f16x2_elems(taps, cin, cout) ((size_t)(taps) * (cin) * (cout) * 2 + 8)
 int sbc_pack_conv_weight_f16x2(const float* src, int32_t cout, int32_t cin, int32_t ksize, uint16_t* dst);
 int sbc_pack_conv_weight_winograd_f16x2(const float* src, int32_t cout, int32_t cin, uint16_t* dst);
@@ -362,6 +367,14 @@ int sbc_pack_conv_weight_winograd_f16x2(const float* src, int32_t cout, int32_t 
  * activation with |x| * act_scale >= 16000 (results of that launch are not trustworthy: run the layer stack in split-bf16
  * mode instead).  Synchronises with the device.  reset != 0 clears it. */
 int sbc_range_flag(int32_t* flag, int32_t reset);
+
+/* Known-answer hooks of the in-kernel random numbers (tests; synchronous, current device):
+ *   sbc_debug_philox4x32     n blocks of Philox4x32-10 from host (c0, c1, c2, c3, k0, k1) records -> host (x, y, z, w) records:
+ *                            the Random123 known-answer vectors must come back;
+ *   sbc_debug_complex_normal the CN(0,1) draws (re, im interleaved) SBC_OP_LANGEVIN (step >= 0) / SBC_OP_MEASURE (step = -1) use
+ *                            for elements 0 .. n_elem-1 of trajectory `traj` at `step` under `seed`. */
+int sbc_debug_philox4x32(const uint32_t* counters_keys, int32_t n, uint32_t* out);
+int sbc_debug_complex_normal(uint64_t seed, int64_t traj, int32_t step, int32_t n_elem, float* out);
 
 /* scratch floats SBC_OP_CONV_WGRAD / END_CONV_BWD / BEGIN_CONV_BWD need in `aux` for this shape */
 int64_t sbc_wgrad_scratch_floats(int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t ksize);

@@ -180,3 +180,52 @@ def channels_item(channels, mean, std, pilots, idx):
     return {'H_herm': np.stack((np.real(H_herm_norm), np.imag(H_herm_norm)), 0).astype(F32),
             'H': np.stack((np.real(Hn), np.imag(Hn)), 0).astype(F32),
             'P': pilots[idx].astype(C64)}
+
+
+# ----------------------------------------------------------------------------- the production noise stream, restated
+# The product's default noise is drawn inside the Langevin / measurement kernels (csrc/philox.h): Philox4x32-10 (Salmon,
+# Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11; Random123 ships known-answer vectors, pinned in
+# tests/test_oracle_golden.py) + Box-Muller.  The reference draws torch.randn_like (test_score.py:115,124,160-161) from an
+# unseeded generator, so there is no reference stream to match -- this restatement lets a run with in-kernel noise be replayed
+# on the host and held to the oracle loop number for number.
+_PHILOX_M0, _PHILOX_M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+_PHILOX_W0, _PHILOX_W1 = np.uint32(0x9E3779B9), np.uint32(0xBB67AE85)
+
+
+def philox4x32(counter, key, rounds=10):
+    """Philox4x32-``rounds`` of uint32 counters ``[..., 4]`` under keys ``[..., 2]`` (broadcast): uint32 ``[..., 4]``."""
+    c = np.array(np.broadcast_to(np.asarray(counter, np.uint32), np.broadcast_shapes(np.shape(counter), np.shape(key)[:-1] + (4,))))
+    k = np.array(np.broadcast_to(np.asarray(key, np.uint32), c.shape[:-1] + (2,)))
+    c0, c1, c2, c3 = (c[..., i].copy() for i in range(4))
+    k0, k1 = k[..., 0].copy(), k[..., 1].copy()
+    mask = np.uint64(0xFFFFFFFF)
+    with np.errstate(over='ignore'):
+        for _ in range(rounds):
+            p0 = c0.astype(np.uint64) * _PHILOX_M0
+            p1 = c2.astype(np.uint64) * _PHILOX_M1
+            hi0, lo0 = (p0 >> np.uint64(32)).astype(np.uint32), (p0 & mask).astype(np.uint32)
+            hi1, lo1 = (p1 >> np.uint64(32)).astype(np.uint32), (p1 & mask).astype(np.uint32)
+            c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+            k0 = k0 + _PHILOX_W0
+            k1 = k1 + _PHILOX_W1
+    return np.stack((c0, c1, c2, c3), axis=-1)
+
+
+def device_complex_normal(seed, traj, step, n_elem):
+    """The CN(0,1) draws csrc/philox.h::complex_normal gives elements ``0..n_elem-1`` of trajectory ``traj`` at Langevin step
+    ``step`` (``-1``: the measurement noise of SBC_OP_MEASURE): elements 2q, 2q+1 share the block of counter
+    (q, step, traj_lo, traj_hi) under key (seed_lo, seed_hi); words (x, y) / (z, w) -> u = ((w >> 8) + 0.5) / 2^24 ->
+    sqrt(-ln u1) (cos 2 pi u2, sin 2 pi u2).  float32 arithmetic like the kernel (libm vs the GPU's math library: ~1e-6)."""
+    nq = (int(n_elem) + 1) // 2
+    traj, seed = int(traj) & (2 ** 64 - 1), int(seed) & (2 ** 64 - 1)
+    ctr = np.zeros((nq, 4), np.uint32)
+    ctr[:, 0] = np.arange(nq, dtype=np.uint32)
+    ctr[:, 1] = np.uint32(int(step) & 0xFFFFFFFF)
+    ctr[:, 2] = np.uint32(traj & 0xFFFFFFFF)
+    ctr[:, 3] = np.uint32(traj >> 32)
+    r = philox4x32(ctr, np.array([seed & 0xFFFFFFFF, seed >> 32], np.uint32)).reshape(-1, 2)      # [(q, half), (a, b)]
+    u = ((r >> np.uint32(8)).astype(F32) + F32(0.5)) * F32(1.0 / 16777216.0)
+    rad = np.sqrt(-np.log(u[:, 0], dtype=F32), dtype=F32)
+    ang = (F32(6.283185307179586) * u[:, 1]).astype(F32)
+    z = (rad * np.cos(ang, dtype=F32)).astype(F32) + 1j * (rad * np.sin(ang, dtype=F32)).astype(F32)
+    return z.astype(C64)[:n_elem]

@@ -15,7 +15,7 @@ EXPORTS = ('sbc_abi_version', 'sbc_last_error', 'sbc_device_count', 'sbc_op_laun
            'sbc_pack_conv_weight', 'sbc_pack_conv_weight_winograd',
            'sbc_pack_conv_weight_split', 'sbc_pack_conv_weight_winograd_split',
            'sbc_pack_conv_weight_f16', 'sbc_pack_conv_weight_winograd_f16',
-           'sbc_pack_conv_weight_f16x2', 'sbc_pack_conv_weight_winograd_f16x2', 'sbc_range_flag',
+           'sbc_pack_conv_weight_f16x2', 'sbc_pack_conv_weight_winograd_f16x2', 'sbc_range_flag', 'sbc_debug_philox4x32', 'sbc_debug_complex_normal',
            'sbc_score_create', 'sbc_score_buffers', 'sbc_score_ops', 'sbc_score_level_source', 'sbc_score_forward',
            'sbc_score_destroy', 'sbc_wgrad_scratch_floats')
 
@@ -68,7 +68,7 @@ class sbc_tensor_ref(C.Structure):
 
 class sbc_score_desc(C.Structure):
     _fields_ = [('ngf', C.c_int32), ('channels', C.c_int32), ('nt', C.c_int32), ('nr', C.c_int32), ('batch', C.c_int32),
-                ('conv_mode', C.c_int32), ('sigmas', C.c_void_p), ('num_classes', C.c_int32)]
+                ('conv_mode', C.c_int32), ('sigmas', C.c_void_p), ('num_classes', C.c_int32), ('flags', C.c_int32)]
 
 
 _lib = None
@@ -102,6 +102,8 @@ def lib():
     h.sbc_pack_conv_weight_f16x2.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     h.sbc_pack_conv_weight_winograd_f16x2.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     h.sbc_range_flag.argtypes = [C.POINTER(C.c_int32), C.c_int32]
+    h.sbc_debug_philox4x32.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    h.sbc_debug_complex_normal.argtypes = [C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
     h.sbc_score_create.argtypes = [C.POINTER(sbc_score_desc), C.POINTER(sbc_tensor_ref), C.c_int32, C.POINTER(C.c_void_p)]
     h.sbc_score_buffers.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     h.sbc_score_ops.argtypes = [C.c_void_p, C.POINTER(C.POINTER(sbc_op)), C.POINTER(C.c_int32)]
@@ -133,7 +135,7 @@ def range_flag(reset=True):
 def check_range(what='run'):
     """Raise if the f16x2 kernels flagged an activation outside their range: the numbers of that run cannot be trusted."""
     if range_flag(True):
-        raise SbcError('%s: an activation left the range of conv_mode f16x2 (|x| >= 500); results are invalid -- '
+        raise SbcError('%s: an activation left the range of conv_mode f16x2 (|x| >= 16000); results are invalid -- '
                        'use conv_mode bf16x3 for this checkpoint' % what)
 
 

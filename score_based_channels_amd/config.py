@@ -14,6 +14,11 @@ small attribute dictionary with the two behaviours the hot path relies on:
 """
 import copy
 
+# Product defaults shared by ScoreNet, the driver, the CLIs and bench.py (kept here: this module imports neither torch nor HIP).
+CONV_MODES = ('f16x2', 'bf16x3', 'f32', 'f16w')      # scorenet.ScoreNet(conv_mode=...)
+DEFAULT_CONV_MODE = 'f16x2'     # fastest fp32-class multiplier (tests/test_gpu_parity.py::test_f16x2_is_fp32_class)
+DEFAULT_STREAMS = 2             # concurrent sub-batch streams of a lock-step chunk (driver.run_concurrently): +5 %, bit-identical
+
 
 class Config(dict):
     """DotMap-compatible attribute dictionary (auto-vivifying, empty == False)."""

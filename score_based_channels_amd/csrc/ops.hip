@@ -429,18 +429,6 @@ __device__ __forceinline__ float2 cfma_conj(float2 a, float2 b, float2 c) {  // 
     return make_float2(fmaf(a.x, b.x, fmaf(a.y, b.y, c.x)), fmaf(a.x, b.y, fmaf(-a.y, b.x, c.y)));
 }
 
-// one CN(0,1) sample (re, im each N(0, 1/2)) per (trajectory, step, element): Box-Muller on two uniforms
-__device__ __forceinline__ float2 complex_normal(uint64_t seed, int64_t traj, int step, int elem) {
-    const uint4 r = philox4x32(make_uint4((uint32_t)elem, (uint32_t)step, (uint32_t)traj, (uint32_t)((uint64_t)traj >> 32)),
-                               make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
-    const float u1 = ((float)(r.x >> 8) + 0.5f) * (1.f / 16777216.f);   // (0, 1)
-    const float u2 = ((float)(r.y >> 8) + 0.5f) * (1.f / 16777216.f);
-    const float rad = sqrtf(-logf(u1));                                  // sqrt(-2 ln u1) * sqrt(1/2)
-    float s, c;
-    sincosf(6.283185307179586f * u2, &s, &c);
-    return make_float2(rad * c, rad * s);
-}
-
 // One workgroup per trajectory b:  R = P X - Y  [Np x Nr],  G = P^H R  [Nt x Nr]  (test_score.py:157-158),
 // X <- X + alpha (S - G / dc_div) + noise_scale * n  (:160-165),  nmse[step][b] = |X - H|^2 / |H|^2  (:168-170).
 // X and R live in LDS; P (per-sample pilots, L2 resident) is read through the vector cache: in both products the
@@ -480,23 +468,41 @@ __global__ __launch_bounds__(256) void langevin_kernel(sbc_langevin a, int B, in
     }
     __syncthreads();
     const float* sc = a.sched + ((size_t)(a.group ? a.group[b] : 0) * a.n_steps + step) * 4;
-    const float alpha = sc[0], dc_div = sc[1], nscale = sc[2], dcb = sc[3];     // dcb: dc_boost of test_mmse.py:231-233
+    const float alpha = sc[0], dc_div = sc[1], nscale = sc[2];
+    const float dcb = sc[3] != 0.f ? sc[3] : 1.f;            // dc_boost of test_mmse.py:231-233; 0 = not set (hosts of the 3-column era)
     const float2* ext = a.noise ? reinterpret_cast<const float2*>(a.noise) + ((size_t)step * B + b) * Nt * Nr : nullptr;
     const int64_t traj = a.traj_id ? a.traj_id[b] : b;
     float err = 0.f, den = 0.f;
-    for (int e = tid; e < Nt * Nr; e += 256) {
-        const int t = e / Nr, r = e - t * Nr;
-        float2 gacc = make_float2(0.f, 0.f);
-        for (int m = 0; m < Np; ++m) gacc = cfma_conj(P[(size_t)m * Nt + t], Rs[m * Nr + r], gacc);
-        const float2 s = Sc[e], x = Xs[e], h = Ht[e];
-        const float2 n = ext ? ext[e] : complex_normal(a.seed, traj, step, e);
-        float2 u;
-        u.x = x.x + alpha * (s.x - (dcb * gacc.x) / dc_div) + nscale * n.x;      // x * 1.0f is exact: test_score semantics
-        u.y = x.y + alpha * (s.y - (dcb * gacc.y) / dc_div) + nscale * n.y;
-        X[e] = u;
-        const float dx = u.x - h.x, dy = u.y - h.y;
+    // two adjacent elements (same row t; Nr is even) per thread and round: one Philox block feeds both, one pilot load too
+    for (int q = tid; q < Nt * Nr / 2; q += 256) {
+        const int e = 2 * q, t = e / Nr, r = e - t * Nr;
+        float2 g0 = make_float2(0.f, 0.f), g1 = make_float2(0.f, 0.f);
+        for (int m = 0; m < Np; ++m) {
+            const float2 pv = P[(size_t)m * Nt + t];
+            g0 = cfma_conj(pv, Rs[m * Nr + r], g0);
+            g1 = cfma_conj(pv, Rs[m * Nr + r + 1], g1);
+        }
+        const float4 s = reinterpret_cast<const float4*>(Sc)[q], x = reinterpret_cast<const float4*>(Xs)[q];
+        const float4 h = reinterpret_cast<const float4*>(Ht)[q];
+        float2 n0, n1;
+        if (ext) {
+            const float4 nn = reinterpret_cast<const float4*>(ext)[q];
+            n0 = make_float2(nn.x, nn.y); n1 = make_float2(nn.z, nn.w);
+        } else {
+            complex_normal_pair(a.seed, traj, step, q, n0, n1);
+        }
+        float4 u;
+        u.x = x.x + alpha * (s.x - (dcb * g0.x) / dc_div) + nscale * n0.x;     // x * 1.0f is exact: test_score semantics
+        u.y = x.y + alpha * (s.y - (dcb * g0.y) / dc_div) + nscale * n0.y;
+        u.z = x.z + alpha * (s.z - (dcb * g1.x) / dc_div) + nscale * n1.x;
+        u.w = x.w + alpha * (s.w - (dcb * g1.y) / dc_div) + nscale * n1.y;
+        reinterpret_cast<float4*>(X)[q] = u;
+        float dx = u.x - h.x, dy = u.y - h.y;
         err += dx * dx + dy * dy;
         den += h.x * h.x + h.y * h.y;
+        dx = u.z - h.z; dy = u.w - h.w;
+        err += dx * dx + dy * dy;
+        den += h.z * h.z + h.w * h.w;
     }
     for (int off = 32; off > 0; off >>= 1) {
         err += __shfl_down(err, off);
@@ -568,7 +574,8 @@ __global__ __launch_bounds__(512) void langevin_tiled_kernel(sbc_langevin a, int
     }
     // ---- G = P^H R: output rows t = g + G*j, K = Np; then the update and the NMSE terms of those elements
     const float* sc = a.sched + ((size_t)(a.group ? a.group[b] : 0) * a.n_steps + step) * 4;
-    const float alpha = sc[0], dc_div = sc[1], nscale = sc[2], dcb = sc[3];
+    const float alpha = sc[0], dc_div = sc[1], nscale = sc[2];
+    const float dcb = sc[3] != 0.f ? sc[3] : 1.f;            // 0 = not set, as in langevin_kernel
     const float2* ext = a.noise ? reinterpret_cast<const float2*>(a.noise) + ((size_t)step * B + b) * Nt * Nr : nullptr;
     const int64_t traj = a.traj_id ? a.traj_id[b] : b;
     float err = 0.f, den = 0.f;
@@ -702,3 +709,41 @@ int launch_step_inc(const sbc_op& op, hipStream_t stream) {
 }
 
 }  // namespace sbc
+
+// ---- known-answer hooks of the in-kernel random numbers (include/sbc_hip.h: sbc_debug_philox4x32, sbc_debug_complex_normal) ----
+namespace sbc {
+__global__ void debug_philox_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int n) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const uint4 r = philox4x32(make_uint4(in[i * 6], in[i * 6 + 1], in[i * 6 + 2], in[i * 6 + 3]), make_uint2(in[i * 6 + 4], in[i * 6 + 5]));
+    out[i * 4] = r.x; out[i * 4 + 1] = r.y; out[i * 4 + 2] = r.z; out[i * 4 + 3] = r.w;
+}
+__global__ void debug_normal_kernel(uint64_t seed, int64_t traj, int step, int n, float2* __restrict__ out) {
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e < n) out[e] = complex_normal(seed, traj, step, e);
+}
+}  // namespace sbc
+
+extern "C" int sbc_debug_philox4x32(const uint32_t* counters_keys, int32_t n, uint32_t* out) {
+    using namespace sbc;
+    SBC_REQUIRE(counters_keys && out && n > 0, "sbc_debug_philox4x32: bad arguments");
+    uint32_t *din = nullptr, *dout = nullptr;
+    SBC_CHECK_HIP(hipMalloc((void**)&din, (size_t)n * 6 * 4));
+    SBC_CHECK_HIP(hipMalloc((void**)&dout, (size_t)n * 4 * 4));
+    SBC_CHECK_HIP(hipMemcpy(din, counters_keys, (size_t)n * 6 * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(debug_philox_kernel, dim3((n + 63) / 64), dim3(64), 0, nullptr, din, dout, n);
+    SBC_CHECK_HIP(hipMemcpy(out, dout, (size_t)n * 4 * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(din); (void)hipFree(dout);
+    return SBC_OK;
+}
+
+extern "C" int sbc_debug_complex_normal(uint64_t seed, int64_t traj, int32_t step, int32_t n_elem, float* out) {
+    using namespace sbc;
+    SBC_REQUIRE(out && n_elem > 0, "sbc_debug_complex_normal: bad arguments");
+    float2* d = nullptr;
+    SBC_CHECK_HIP(hipMalloc((void**)&d, (size_t)n_elem * 8));
+    hipLaunchKernelGGL(debug_normal_kernel, dim3((n_elem + 63) / 64), dim3(64), 0, nullptr, seed, traj, step, n_elem, d);
+    SBC_CHECK_HIP(hipMemcpy(out, d, (size_t)n_elem * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return SBC_OK;
+}

@@ -22,12 +22,13 @@ struct Tn { std::string name; int h, w, c; int slot = -1; };
 struct POp {
     int kind = 0, flags = 0, ksize = 3, dil = 1, tag = 0;
     int src = -1, dst = -1, stats = -1, res1 = -1, res2 = -1, up = -1;       // tensor indices
-    std::string weight, bias;
+    std::string weight, bias, weight2;       // weight2: the second convolution of an SBC_OP_CONV_PAIR
 };
 
 // ---- wiring: a transcription of plan.py's _Builder (reference lines cited there) --------------------------------
 struct Builder {
     int ngf, nt, nr;
+    bool fuse_pairs = false;         // plan.py: fuse_pairs / pair_fusable
     std::vector<Tn> t;
     std::vector<POp> ops;
     int tensor(const std::string& n, int h, int w, int c) { t.push_back({n, h, w, c}); return (int)t.size() - 1; }
@@ -41,7 +42,8 @@ struct Builder {
         if (bias) o.bias = wkey + ".bias";
         o.stats = stats; o.res1 = res1; o.res2 = res2; o.up = up;
         o.flags = flags | (up >= 0 ? SBC_EPI_UP : 0); o.ksize = ksize; o.dil = dil;
-        o.tag = (ksize == 3 && sc == ngf && cout == ngf && sh == nt) ? 1 : 0;
+        o.tag = (ksize == 3 && sc == ngf && cout == ngf && sh == nt) ? 1 : 0;                 // plan.TAG_CONV_TOP
+        if (ksize == 3 && dil == 1 && sc == 2 * ngf && cout == 2 * ngf && !pool && 2 * sh == nt) o.tag = 3;   // plan.TAG_CONV_MID
         ops.push_back(o);
         return dst;
     }
@@ -75,6 +77,15 @@ struct Builder {
     int rcu(const std::string& p, int x, int n_blocks) {                                        // layers.py:126-134
         for (int i = 1; i <= n_blocks; ++i) {
             const std::string a = p + std::to_string(i) + "_1_conv", b = p + std::to_string(i) + "_2_conv";
+            if (fuse_pairs && t[x].c == 32 && t[x].w == 16 && t[x].h % 8 == 0) {          // plan.pair_fusable
+                const int dst = tensor(b, t[x].h, t[x].w, t[x].c);
+                POp o;
+                o.kind = SBC_OP_CONV_PAIR; o.src = x; o.dst = dst; o.weight = a + ".weight"; o.weight2 = b + ".weight";
+                o.tag = t[x].h == nt ? 2 : 0;                                               // plan.TAG_PAIR_TOP
+                ops.push_back(o);
+                x = dst;
+                continue;
+            }
             const int tt = conv(a, x, a, t[x].c, false, SBC_PRO_ELU);
             x = conv(b, tt, b, t[x].c, false, SBC_PRO_ELU, -1, x);
         }
@@ -165,8 +176,10 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
     SBC_REQUIRE(d->ngf == 32 && d->channels == 2, "sbc_score_create: kernels are instantiated for ngf = 32, 2 channels");
     SBC_REQUIRE(d->nt > 0 && d->nr > 0 && d->nt % 8 == 0 && d->nr % 8 == 0,
                 "sbc_score_create: Nt and Nr must be multiples of 8 (three 2x mean pools), got %dx%d", d->nt, d->nr);
-    SBC_REQUIRE(d->batch > 0 && d->conv_mode >= 0 && d->conv_mode <= 2 && d->sigmas && d->num_classes > 0,
-                "sbc_score_create: batch, conv_mode in {0 bf16x3, 1 f32, 2 f16w}, sigmas required");
+    SBC_REQUIRE(d->batch > 0 && d->conv_mode >= 0 && d->conv_mode <= 3 && d->sigmas && d->num_classes > 0,
+                "sbc_score_create: batch, conv_mode in {0 bf16x3, 1 f32, 2 f16w, 3 f16x2}, sigmas required");
+    SBC_REQUIRE(!(d->flags & SBC_SCORE_FUSE_PAIRS) || d->conv_mode >= 2,
+                "sbc_score_create: SBC_SCORE_FUSE_PAIRS needs the fp16 weight forms (conv_mode 2 or 3)");
     std::map<std::string, const sbc_tensor_ref*> sd;
     for (int i = 0; i < n_tensors; ++i) {
         SBC_REQUIRE(tensors[i].name && tensors[i].data, "sbc_score_create: tensor %d has no name / data", i);
@@ -177,6 +190,7 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
     const int ngf = d->ngf, nt = d->nt, nr = d->nr, B = d->batch;
     // ---- wiring (plan.build_score_plan)
     Builder b{ngf, nt, nr};
+    b.fuse_pairs = (d->flags & SBC_SCORE_FUSE_PAIRS) != 0;
     const int x = b.tensor("x", nt, nr, d->channels);
     int h = b.tensor("begin_conv", nt, nr, ngf);
     { POp o; o.kind = SBC_OP_BEGIN_CONV; o.src = x; o.dst = h; o.weight = "begin_conv.weight"; o.bias = "begin_conv.bias"; b.ops.push_back(o); }
@@ -202,7 +216,7 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
     assign_slots(*s);
 
     // ---- parameters: one flat host image (16-byte aligned entries), packed by the library's own packers
-    const bool f16w = d->conv_mode == 2;
+    const bool f16w = d->conv_mode == 2, f16x2 = d->conv_mode == 3;
     std::vector<float> host;
     std::map<std::string, size_t> off;
     auto reserve = [&](const std::string& key, size_t n) {
@@ -247,12 +261,19 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
         if (o.weight.empty()) continue;                  // max pooling has no parameters
         const int k = o.ksize, cin = src.c, cout = dst.c;
         const size_t wn = (size_t)cout * cin * k * k;
-        if (!off.count(o.weight) && !off.count(o.weight + "#split")) {
-            const float* w = find(o.weight, (int64_t)wn);
+        for (const std::string& wkey : {o.weight, o.weight2}) {
+        if (wkey.empty()) continue;
+        if (!off.count(wkey) && !off.count(wkey + "#split")) {
+            const float* w = find(wkey, (int64_t)wn);
             if (!w) return fail();
             w = rounded(w, wn);
             std::vector<float> wkeep(w, w + wn);          // `tmp` is reused below
-            if (o.kind != SBC_OP_CONV) {
+            const std::string& okey = wkey;
+            if (o.kind == SBC_OP_CONV_PAIR) {
+                // the fused pair reads the direct fp16 forms only
+                if (f16x2) sbc_pack_conv_weight_f16x2(wkeep.data(), cout, cin, k, (uint16_t*)reserve(okey + "#split", sbc_f16x2_elems(k * k, cin, cout) / 2));
+                else sbc_pack_conv_weight_f16(wkeep.data(), cout, cin, k, (uint16_t*)reserve(okey + "#split", (wn + 1) / 2));
+            } else if (o.kind != SBC_OP_CONV) {
                 memcpy(reserve(o.weight, wn), wkeep.data(), sizeof(float) * wn);
             } else if (d->conv_mode == 1) {
                 sbc_pack_conv_weight(wkeep.data(), cout, cin, k, reserve(o.weight, wn));
@@ -261,11 +282,16 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
                 sbc_pack_conv_weight_split(wkeep.data(), cout, cin, k, (uint16_t*)reserve(o.weight + "#split", wn * 3 / 2));
                 if (k == 3) sbc_pack_conv_weight_winograd_split(wkeep.data(), cout, cin,
                                                                (uint16_t*)reserve(o.weight + "#winograd_split", (size_t)cout * cin * 16 * 3 / 2));
+            } else if (f16x2) {
+                sbc_pack_conv_weight_f16x2(wkeep.data(), cout, cin, k, (uint16_t*)reserve(o.weight + "#split", sbc_f16x2_elems(k * k, cin, cout) / 2));
+                if (k == 3) sbc_pack_conv_weight_winograd_f16x2(wkeep.data(), cout, cin,
+                                                               (uint16_t*)reserve(o.weight + "#winograd_split", sbc_f16x2_elems(16, cin, cout) / 2));
             } else {
                 sbc_pack_conv_weight_f16(wkeep.data(), cout, cin, k, (uint16_t*)reserve(o.weight + "#split", (wn + 1) / 2));
                 if (k == 3) sbc_pack_conv_weight_winograd_f16(wkeep.data(), cout, cin,
                                                              (uint16_t*)reserve(o.weight + "#winograd_split", (size_t)cout * cin * 16 / 2));
             }
+        }
         }
         if (!o.bias.empty() && !off.count(o.bias)) {
             const float* bv = find(o.bias, cout);
@@ -302,7 +328,11 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
         r.cin = src.c; r.cout = dst.c; r.ksize = o.ksize; r.dil = o.dil; r.tag = o.tag;
         r.in = s->slots[src.slot]; r.out = s->slots[dst.slot];
         auto wp = [&](const std::string& key) -> const void* { return off.count(key) ? s->wdev + off[key] : nullptr; };
-        if (o.kind != SBC_OP_CONV) {
+        if (o.kind == SBC_OP_CONV_PAIR) {
+            r.weight_split = wp(o.weight + "#split");
+            r.weight2_split = wp(o.weight2 + "#split");
+            r.flags |= f16w ? SBC_CONV_F16W : SBC_CONV_F16X2;
+        } else if (o.kind != SBC_OP_CONV) {
             r.weight = wp(o.weight);
         } else if (d->conv_mode == 1) {
             r.weight = wp(o.weight);
@@ -311,6 +341,7 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
             r.weight_split = wp(o.weight + "#split");
             if (o.ksize == 3 && o.dil == 1) r.weight_wino_split = wp(o.weight + "#winograd_split");
             if (f16w) r.flags |= SBC_CONV_F16W;
+            if (f16x2) r.flags |= SBC_CONV_F16X2;
         }
         if (!o.bias.empty()) r.bias = wp(o.bias);
         if (o.stats >= 0) r.stats = s->slots[s->tensors[o.stats].slot];

@@ -9,6 +9,7 @@ import torch
 
 from . import shard
 from .ald import AldBatch
+from .config import DEFAULT_STREAMS        # two concurrent sub-batch streams fill the gaps of the low-resolution launches
 
 
 # Launch mode of a Langevin step the CLIs and bench.py default to: False = eager launches, True = hipGraph replay of the
@@ -101,7 +102,7 @@ def host_noise_streams(seed, combo, shape, n_snr, n_steps, meas_shape):
 
 
 def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, beta_noise, levels, steps_each,
-                     seed, init, traj_base=0, max_batch=4096, use_graph=True, rank=0, world=1, n_streams=1,
+                     seed, init, traj_base=0, max_batch=4096, use_graph=None, rank=0, world=1, n_streams=None,
                      return_final=False, n_steps=None, dc_boost=1.0, init_index=None, Y=None, y_index=None,
                      step_noise=None, meas_noise=None):
     """Run ``T = len(h_index)`` trajectories, sharded over ``world`` ranks; returns the full NMSE log
@@ -118,6 +119,9 @@ def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, b
 
     ``step_noise`` ``[n_steps, T, Nt, Nr]`` / ``meas_noise`` ``[T, Np, Nr]`` complex64 (host arrays) replay externally
     drawn CN(0,1) noise instead of the in-kernel Philox streams (``--noise host`` parity runs against the reference)."""
+    from . import _lib
+    use_graph = DEFAULT_USE_GRAPH if use_graph is None else bool(use_graph)
+    n_streams = DEFAULT_STREAMS if n_streams is None else int(n_streams)
     h_index = np.asarray(h_index, np.int64)
     T = len(h_index)
     bc = lambda a: np.broadcast_to(np.asarray(a), (T,))            # noqa: E731
@@ -161,6 +165,8 @@ def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, b
             ald.close()
         del running
     torch.cuda.synchronize(net.device)
+    if getattr(net, 'conv_mode', None) == 'f16x2':
+        _lib.check_range('annealed-Langevin run')       # an activation outside the fp16 range of conv_mode f16x2: fail loudly
     full = shard.gather_trajectory_logs(local, T, rank, world)
     if not return_final:
         return full.cpu().numpy()

@@ -36,8 +36,10 @@ CONV_F16X2 = 0x10000
 CONV_PAIR = 21
 BWD_ACCUM, PACK_ADJOINT, OP_SIDE, OP_JOIN, PACK_WINOGRAD = 0x200, 0x400, 0x800, 0x1000, 0x2000
 
-# profiling tag of the dominant kernel class: 3x3 convs ngf->ngf at full resolution
-TAG_CONV_TOP = 1
+# profiling tags (sbc_op.tag; bench.py times each class by hipEvents in a single-stream segment after its timed region):
+TAG_CONV_TOP = 1        # 3x3 convs ngf -> ngf at full resolution (also their own kernel symbol in csrc/conv_wx3.hip)
+TAG_PAIR_TOP = 2        # fused RCU blocks (CONV_PAIR) at full resolution
+TAG_CONV_MID = 3        # undilated 3x3 convs 2 ngf -> 2 ngf at half resolution (the 32x8 level of a 64x16 array)
 
 
 @dataclass
@@ -113,6 +115,9 @@ class _Builder:
         pool = bool(flags & EPI_POOL)
         dst = self.t(name, src.h // 2 if pool else src.h, src.w // 2 if pool else src.w, cout)
         tag = TAG_CONV_TOP if (ksize == 3 and src.c == self.ngf and cout == self.ngf and src.h == self.nt) else 0
+        if (ksize == 3 and dil == 1 and src.c == 2 * self.ngf and cout == 2 * self.ngf and not flags & EPI_POOL
+                and 2 * src.h == self.nt):
+            tag = TAG_CONV_MID
         norm = None
         if stats is not None and id(stats) in self.moment_norm:       # statistics folded: `stats` are the input's tile moments
             assert ksize == 3 and dil == 1, name
@@ -188,7 +193,8 @@ class _Builder:
                 # x + conv2(ELU(conv1(ELU(x)))) in one launch, the intermediate tensor never exists in memory
                 dst = self.t(p + '%d_2_conv' % i, x.h, x.w, x.c)
                 self.ops.append(Op(CONV_PAIR, p + '%d_pair' % i, src=x, dst=dst, weight=p + '%d_1_conv.weight' % i,
-                                   weight2=p + '%d_2_conv.weight' % i, side=self.side_now))
+                                   weight2=p + '%d_2_conv.weight' % i, side=self.side_now,
+                                   tag=TAG_PAIR_TOP if x.h == self.nt else 0))
                 self.producer[id(dst)] = self.ops[-1]
                 x = dst
                 continue

@@ -13,6 +13,7 @@ import torch
 
 from . import _lib
 from . import plan as P
+from .config import CONV_MODES, DEFAULT_CONV_MODE
 from .weights import (check_state_dict, fp16_state_dict, get_sigmas, pack_conv_weight, pack_conv_weight_f16,
                       pack_conv_weight_f16x2, pack_conv_weight_split, pack_conv_weight_winograd,
                       pack_conv_weight_winograd_f16, pack_conv_weight_winograd_f16x2, pack_conv_weight_winograd_split)
@@ -34,16 +35,22 @@ class BoundScore:
         self.keep = extra_keep
 
 
-CONV_MODES = ('bf16x3', 'f32', 'f16w', 'f16x2')
 DEFAULT_OVERLAP = False
 DEFAULT_FOLD_STATS = False
-DEFAULT_FUSE_PAIRS = False
+DEFAULT_FUSE_PAIRS = True       # applies to the fp16-form modes only ('f16x2', 'f16w')
 
 
 class ScoreNet:
     """``conv_mode`` selects how the 32/64/128-channel convolutions multiply:
 
-    ``'bf16x3'`` (default)  fp32 operands split exactly into three bf16 terms (8 + 8 + 8 significand bits), six bf16 MFMAs
+    ``'f16x2'`` (default)   fp32-class arithmetic on the fp16 matrix cores: every operand is scaled by a power of two (weights per
+                            layer on the host) and split into two fp16 terms ``h + l`` (22-23 significant
+                            bits), a product is the three fp16 MFMAs ``hl + lh + hh`` with fp32 accumulation.  Forward error
+                            vs the reference 0.85e-6 (true fp32 MFMA: 0.98e-6); half the matrix instructions and a third of
+                            the split arithmetic of ``'bf16x3'``.  Activations beyond |x| = 16000 would leave the fp16 range:
+                            the kernels raise a device flag and the host raises ``SbcError`` (``_lib.check_range``) instead
+                            of returning wrong numbers -- use ``'bf16x3'`` for such a checkpoint.
+    ``'bf16x3'``            fp32 operands split exactly into three bf16 terms (8 + 8 + 8 significand bits), six bf16 MFMAs
                             per product block, fp32 accumulation: fp32-level accuracy (forward error vs the reference
                             0.8e-6, the fp32 kernels 1.0e-6) on the bf16 matrix cores -- Winograd F(2x2,3x3) for the
                             undilated 3x3 layers (``csrc/conv_wx3.hip``), direct for the rest (``csrc/conv_x3.hip``);
@@ -58,7 +65,8 @@ class ScoreNet:
                             ``.half()``, layers.py:179); tolerance stated in tests/test_gpu_parity.py.
     """
 
-    def __init__(self, config, device=None, conv_mode='bf16x3', overlap=None, fold_stats=None, fuse_pairs=None):
+    def __init__(self, config, device=None, conv_mode=None, overlap=None, fold_stats=None, fuse_pairs=None):
+        conv_mode = DEFAULT_CONV_MODE if conv_mode is None else conv_mode
         if conv_mode not in CONV_MODES:
             raise ValueError('conv_mode must be one of %s, got %r' % (CONV_MODES, conv_mode))
         self.conv_mode = conv_mode
@@ -258,6 +266,9 @@ class ScoreNet:
         bound.x.copy_(x.to(self.device, torch.float32).permute(0, 2, 3, 1))
         bound.labels.copy_(labels.to(self.device).long())
         plan.run(torch.cuda.current_stream(self.device).cuda_stream)
-        return bound.out.permute(0, 3, 1, 2).clone()
+        out = bound.out.permute(0, 3, 1, 2).clone()
+        if self.conv_mode == 'f16x2':
+            _lib.check_range('ScoreNet forward')          # synchronises; the module-call path is not the hot loop
+        return out
 
     forward = __call__

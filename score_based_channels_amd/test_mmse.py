@@ -16,6 +16,8 @@ import itertools
 import os
 
 import numpy as np
+
+from .config import CONV_MODES, DEFAULT_CONV_MODE, DEFAULT_STREAMS
 import torch
 
 from .ald import AldBatch
@@ -68,12 +70,12 @@ def parse_args(argv=None):
                    help='[added] tuned per-SNR hyper-parameters (default ./our_hyperparams_<model>.pt, test_mmse.py:123)')
     p.add_argument('--synthetic', action='store_true', help='[added] generated CDL-like channels instead of ./data')
     p.add_argument('--synthetic_weights', type=int, default=None, metavar='SEED', help='[added] seed-derived weights')
-    p.add_argument('--conv_mode', type=str, default='bf16x3', choices=['bf16x3', 'f32', 'f16w'], help='[added]')
+    p.add_argument('--conv_mode', type=str, default=DEFAULT_CONV_MODE, choices=list(CONV_MODES), help='[added]')
     p.add_argument('--noise', type=str, default='device', choices=['device', 'host'],
                    help='[added] in-kernel Philox noise, or the keyed host streams of noise.HostNoise (parity runs)')
     p.add_argument('--no_graph', action='store_true', help='[added] eager launches instead of hipGraph replay')
     p.add_argument('--graph', action='store_true', help='[added] replay each Langevin step as a hipGraph (default: driver.DEFAULT_USE_GRAPH)')
-    p.add_argument('--streams', type=int, default=1,
+    p.add_argument('--streams', type=int, default=DEFAULT_STREAMS,
                    help='[added] run each lock-step batch as this many concurrent sub-batches on their own HIP streams '
                         '(bit-identical results; +7 %% at 2 on MI355X for 1700 trajectories)')
     p.add_argument('--result_dir', type=str, default=None, help='[added] default TWC_rebuttal_MMSE_aug6_seed4321')
@@ -95,8 +97,8 @@ def start_points(kind, P_herm, Y, n_chains, nt, nr, seed, key):
 
 
 def posterior_chains(diffuser, val_H, val_P, local_noise, step, noise_boost, n_run, levels, steps_each, navg,
-                     start_point='Noise', seed=0, key=0, dc_boost=1.0, use_graph=True, rank=0, world=1, host_noise=None,
-                     n_streams=1):
+                     start_point='Noise', seed=0, key=0, dc_boost=1.0, use_graph=None, rank=0, world=1, host_noise=None,
+                     n_streams=None):
     """All chains of ONE SNR point (test_mmse.py:170-262): one measurement per kept sample shared by its ``navg`` chains
     (:176-193), start points (:196-203), ``n_run`` Langevin steps with that SNR's (step, noise) pair and ``dc_boost``
     (:216-233), early stop (:246-250).  ``val_H`` ``[kept, Nt, Nr]``, ``val_P`` ``[kept, Np, Nt]`` complex64 numpy.

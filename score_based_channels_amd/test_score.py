@@ -19,6 +19,8 @@ import os
 
 import numpy as np
 
+from .config import CONV_MODES, DEFAULT_CONV_MODE, DEFAULT_STREAMS
+
 
 def parse_args(argv=None):
     p = argparse.ArgumentParser()
@@ -41,12 +43,12 @@ def parse_args(argv=None):
                         "the keyed host streams of noise.HostNoise replayed from memory [host] -- the streams the "
                         "reference goldens were generated with (parity runs; needs n_steps x T x Nt x Nr x 8 bytes)")
     p.add_argument('--no_plot', action='store_true')
-    p.add_argument('--conv_mode', type=str, default='bf16x3', choices=['bf16x3', 'f32', 'f16w'],
-                   help='convolution multiplier: split-bf16 matrix cores (fp32-accurate, default), fp32 MFMA, or fp16 '
-                        'weights on the fp16 matrix cores (BASELINE config 5; looser tolerance)')
+    p.add_argument('--conv_mode', type=str, default=DEFAULT_CONV_MODE, choices=list(CONV_MODES),
+                   help='convolution multiplier (scorenet.ScoreNet): f16x2 [default] and bf16x3 are fp32-class on the fp16 / bf16 '
+                        'matrix cores, f32 is fp32 MFMA, f16w rounds the parameters to fp16 (BASELINE config 5; looser tolerance)')
     p.add_argument('--no_graph', action='store_true', help='launch kernels eagerly instead of hipGraph replay')
     p.add_argument('--graph', action='store_true', help='[added] replay each Langevin step as a hipGraph (default: driver.DEFAULT_USE_GRAPH)')
-    p.add_argument('--streams', type=int, default=1,
+    p.add_argument('--streams', type=int, default=DEFAULT_STREAMS,
                    help='[added] run each lock-step batch as this many concurrent sub-batches on their own HIP streams '
                         '(bit-identical results; +7 %% at 2 on MI355X for 1700 trajectories)')
     return p.parse_args(argv)

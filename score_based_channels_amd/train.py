@@ -97,6 +97,7 @@ class TrainNet:
         self.grads = torch.zeros(self.n_params, **f32)
         self.state = torch.zeros(3, self.n_params, **f32)            # exp_avg | exp_avg_sq | EMA shadow
         self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.eval_count = torch.zeros(1, dtype=torch.int32, device=dev)     # forward-only (validation) calls made so far
         self.sigmas = torch.from_numpy(get_sigmas(self.config)).to(dev)
         pl = self.plan
         self.slots = [torch.zeros(B * e, **f32) for e in pl.slot_elems]
@@ -140,6 +141,9 @@ class TrainNet:
         self.state.zero_()
         self.state[2].copy_(self.params)                               # EMAHelper.register: shadow = param.clone()
         self.step_count.zero_()
+        # these copies ran on the caller's current stream: the next _run (possibly on another stream) must wait for them
+        if self.params.is_cuda:                                        # (a CPU-resident TrainNet only exists in host-logic tests)
+            self._last_stream = torch.cuda.current_stream(self.device)
         return self
 
     def _export(self, flat):
@@ -370,8 +374,14 @@ class TrainNet:
         keep = []
         base = self.state[2] if mode == 'loss_ema' else self.params
         pl = self.plan
+        # Philox counter word 1 of the perturbation noise: the optimiser step for the training plans; forward-only (validation)
+        # plans draw from a stream of their own -- offset 2^30 + the number of forward-only calls so far -- so that every
+        # loss() call sees fresh noise (the reference draws a fresh randn per call, dsm.py:14) that no training step reuses
+        forward_only = mode in ('loss', 'loss_ema')
+        counter = self.eval_count if forward_only else self.step_count
         common = dict(sigmas=_ptr(self.sigmas), labels=_ptr(self.labels), sample_id=_ptr(self.sample_id), seed=self.seed,
-                      offset=0, anneal_power=self.anneal_power, step=_ptr(self.step_count), grad_scale=1.0 / self.world)
+                      offset=(1 << 30) if forward_only else 0, anneal_power=self.anneal_power, step=_ptr(counter),
+                      grad_scale=1.0 / self.world)
         dsm = _lib.sbc_dsm(noise=None, **common)
         dsm_replay = _lib.sbc_dsm(noise=_ptr(self.replay), **common)
         keep += [dsm, dsm_replay]
@@ -399,6 +409,8 @@ class TrainNet:
                 ops.append(_lib.sbc_op(kind=P.ADAM_EMA, flags=P.OP_JOIN, in_=_ptr(self.grads), out=_ptr(self.params), aux=_ptr(self.state),
                                        ext=C.cast(C.pointer(adam), C.c_void_p)))
                 ops.append(_lib.sbc_op(kind=P.STEP_INC, out=C.c_void_p(self.step_count.data_ptr())))
+            if forward_only:
+                ops.append(_lib.sbc_op(kind=P.STEP_INC, out=C.c_void_p(self.eval_count.data_ptr())))
             # profiling tags (sbc_plan_profile): 100 + kind for the packing / forward part, 200 + kind for the rest
             for i, o in enumerate(ops):
                 o.tag = (100 if i < n_fwd else 200) + o.kind

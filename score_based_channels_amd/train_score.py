@@ -7,7 +7,9 @@ with the whole optimiser step (perturbation, forward, loss, backward, Adam, EMA)
 Same arguments (``--gpu``, ``--train``, train_score.py:20-23), configuration (:34-67,98-115), data files
 (``./data/<profile>_Nt64_Nr16_ULA0.50_seed{1234,4321}.mat``), loop (:145-207: running loss, validation loss of the EMA copy
 every 100 steps) and output file ``./models/score/<train>/final_model.pt`` with the keys ``model_state, optim_state,
-config, train_loss, val_loss`` (:211-216; readable by ``test_score`` here and by the reference).  Additions, all optional:
+config, train_loss, val_loss`` (:211-216; read by ``test_score`` here; ``model_state`` and ``optim_state`` load into the
+reference's ``NCSNv2Deepest`` / ``torch.optim.Adam`` unchanged, ``config`` is a ``dotmap.DotMap`` only where dotmap is installed -- a
+plain dict otherwise, which the reference's scripts would have to wrap).  Additions, all optional:
 ``--seed`` (the reference never seeds), ``--n_epochs / --max_steps / --batch_size / --val_every`` (short runs),
 ``--synthetic`` (stand-in for the undistributed data), ``--init`` (start from a checkpoint), ``--graph`` (replay the step
 as a hipGraph).
@@ -150,8 +152,10 @@ def main(argv=None):
         return float(t.item()) / (per.numel() * world)
 
     def val_loss_ema():
-        """train_score.py:172-185: DSM loss of the EMA copy on the validation channels (fresh labels and noise), here in
-        chunks of the training batch size; the mean over all samples."""
+        """train_score.py:172-185: DSM loss of the EMA copy on the validation channels with fresh labels and fresh noise
+        (``TrainNet.loss`` draws from its own Philox stream, advanced per call).  The reference evaluates ONE fixed first
+        validation batch (``val_sample``, :120-121,172); here every full chunk of the validation set is evaluated and the
+        mean over all of them is logged: the same estimator with less variance, not the same number."""
         tot, cnt = 0.0, 0
         for s in range(0, len(val_x) - Bg + 1, Bg):
             labels = torch.randint(0, L, (Bg,), generator=gen)[rank * B:(rank + 1) * B]
@@ -197,7 +201,15 @@ def main(argv=None):
     os.makedirs(out_dir, exist_ok=True)
     config.log_path = out_dir
     to_t = lambda sd: {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}     # noqa: E731
-    torch.save({'model_state': to_t(net.state_dict()), 'optim_state': torch_optim_state(net), 'config': config.toDict(),
+    # `config`: the reference pickles its dotmap.DotMap and reads it back with attribute access (test_score.py:56,59).  With
+    # dotmap installed the same object type is written; without it (this image) a plain nested dict, which this package's
+    # loader re-wraps (checkpoint.load_checkpoint) and the reference's scripts would have to wrap in DotMap(...) themselves.
+    try:
+        from dotmap import DotMap
+        cfg_obj = DotMap(config.toDict())
+    except ImportError:
+        cfg_obj = config.toDict()
+    torch.save({'model_state': to_t(net.state_dict()), 'optim_state': torch_optim_state(net), 'config': cfg_obj,
                 'train_loss': train_loss, 'val_loss': val_loss,
                 'ema_state': to_t(net.ema_state_dict()), 'seed': seed},           # two additions of this build
                os.path.join(out_dir, 'final_model.pt'))

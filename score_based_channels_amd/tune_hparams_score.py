@@ -18,6 +18,8 @@ import os
 
 import numpy as np
 
+from .config import CONV_MODES, DEFAULT_CONV_MODE, DEFAULT_STREAMS
+
 
 def parse_args(argv=None):
     p = argparse.ArgumentParser()
@@ -37,14 +39,14 @@ def parse_args(argv=None):
     p.add_argument('--synthetic', action='store_true')
     p.add_argument('--synthetic_weights', type=int, default=None, metavar='SEED')
     p.add_argument('--no_plot', action='store_true')
-    p.add_argument('--conv_mode', type=str, default='bf16x3', choices=['bf16x3', 'f32', 'f16w'],
+    p.add_argument('--conv_mode', type=str, default=DEFAULT_CONV_MODE, choices=list(CONV_MODES),
                    help='convolution multiplier: split-bf16 matrix cores (fp32-accurate, default), fp32 MFMA, or fp16 '
                         'weights on the fp16 matrix cores (looser tolerance)')
     p.add_argument('--noise', type=str, default='device', choices=['device', 'host'],
                    help='in-kernel Philox noise [device] or the keyed host streams of noise.HostNoise [host, parity runs]')
     p.add_argument('--no_graph', action='store_true')
     p.add_argument('--graph', action='store_true', help='[added] replay each Langevin step as a hipGraph (default: driver.DEFAULT_USE_GRAPH)')
-    p.add_argument('--streams', type=int, default=1,
+    p.add_argument('--streams', type=int, default=DEFAULT_STREAMS,
                    help='[added] run each lock-step batch as this many concurrent sub-batches on their own HIP streams '
                         '(bit-identical results; +7 %% at 2 on MI355X for 1700 trajectories)')
     return p.parse_args(argv)

@@ -239,7 +239,7 @@ def pack_conv_weight_winograd_f16(w):
 
 
 # ---- f16x2 forms (SBC_CONV_F16X2, conv_mode 'f16x2') -----------------------------------------------------------------
-F16X2_ACT_SHIFT = 5          # activations enter the matrix cores as x * 2^5 (include/sbc_hip.h: SBC_F16X2_ACT_SHIFT)
+F16X2_ACT_SHIFT = 0          # activations enter the matrix cores unscaled (include/sbc_hip.h: SBC_F16X2_ACT_SHIFT): range 16000
 
 
 def f16x2_shift(w):

@@ -323,6 +323,10 @@ def reference_mmse(net, config, H, P, snr_db, levels, seed, best_step, best_nois
             current = torch.from_numpy(noise.init(tuple(global_H.shape)))
         elif start_point == 'Adjoint':
             current = torch.matmul(torch.conj(torch.transpose(global_P, -1, -2)), global_Y)
+        elif start_point == 'LS':
+            # test_mmse.py:200-202 as it is meant (the script calls .cuda() on lstsq's result tuple): the minimum-norm
+            # least-squares solution of P x = Y per chain, LAPACK gelsd
+            current = torch.linalg.lstsq(global_P, global_Y, driver='gelsd').solution
         y, forward, forward_h, oracle = global_Y, global_P, torch.conj(torch.transpose(global_P, -1, -2)), global_H
         draw = noise.step_stream(0, tuple(global_H.shape))
         trailing_idx, mark_break = 0, False
@@ -370,6 +374,54 @@ def gen_mmse():
     np.savez_compressed(os.path.join(GOLD, 'mmse.npz'), H=H, P=P, snr_db=np.array(snr), levels=np.array(levels), seed=108,
                         best_step=np.array(best_step), best_noise=np.array(best_noise), best_stop=np.array(best_stop),
                         mmse_avg=3, dc_boost=2.0, weight_seed=WEIGHT_SEED, **out)
+
+
+def gen_mmse_ls():
+    """F2, the third start point (test_mmse.py:200-202, ``--start_point LS``): same case as ``gen_mmse``, own file so that the
+    pinned ``mmse.npz`` stays byte for byte what it was."""
+    cfg = default_config()
+    net = reference_net(cfg, seeded_state_dict(cfg, WEIGHT_SEED))
+    H, P = case_inputs(108, 2, 64, 16, 0.6)
+    snr, levels = [-10.0, 10.0], [0, 1000, 2000]
+    best_step, best_noise, best_stop = [3e-11, 6e-11], [0.01, 0.1], [3, 4]
+    Y, log, saved = reference_mmse(net, cfg, H, P, snr, levels, 108, best_step, best_noise, best_stop, 3, 2.0, 'LS')
+    print('mmse LS: log at stop', log[0, 3].ravel()[:3], log[1, 4].ravel()[:3])
+    np.savez_compressed(os.path.join(GOLD, 'mmse_ls.npz'), H=H, P=P, snr_db=np.array(snr), levels=np.array(levels), seed=108,
+                        best_step=np.array(best_step), best_noise=np.array(best_noise), best_stop=np.array(best_stop),
+                        mmse_avg=3, dc_boost=2.0, weight_seed=WEIGHT_SEED, Y=Y, oracle_log_LS=log, saved_H_LS=saved)
+
+
+def gen_cross_b():
+    """BASELINE config 4, a second foreign profile: ``--train CDL-C --test CDL-B`` (as ``gen_cross``; seed 6, 3 noise levels)."""
+    seed, B = 6, 4
+    cfg, dataset, make_val, DataLoader = _reference_datasets('CDL-C', 'CDL-B', seed, 38)
+    H, P = _first_batch(make_val(), DataLoader, B)
+    net = reference_net(cfg, seeded_state_dict(cfg, WEIGHT_SEED))
+    snr = np.arange(-10, 32.5, 2.5)
+    Y, X, log = reference_ald(net, cfg, H, P, snr, [0, 1, 2], seed)
+    np.savez_compressed(os.path.join(GOLD, 'cli_cross_cdlc_cdlb.npz'), H=H, P=P, nmse_log=log, X_final=X, snr_db=snr,
+                        train_std=np.float64(dataset.std), seed=seed, weight_seed=WEIGHT_SEED,
+                        argv=np.array('--train CDL-C --test CDL-B --synthetic --synthetic_weights 2024 --num_levels 3 '
+                                      '--num_channels 4 --seed 6 --noise host --no_plot'))
+    print('cli_cross_b: std(train)=%g |H| rms %g nmse[0,-1]=%s' % (dataset.std, np.sqrt(np.mean(np.abs(H) ** 2)), log[0, -1]))
+
+
+def gen_tunecli2():
+    """BASELINE config 3 end to end over several noise levels: the 2 x 2 grid of ``gen_tunecli`` walked over the first TWO
+    levels x 3 steps (the per-level scalars alpha / noise scale / dc divisor change between levels)."""
+    seed, B = 9, 3
+    alphas, betas = [3e-11, 1e-10], [0.01, 0.001]
+    cfg, dataset, make_val, DataLoader = _reference_datasets('CDL-C', 'CDL-C', seed, 38)
+    net = reference_net(cfg, seeded_state_dict(cfg, WEIGHT_SEED))
+    snr = np.arange(-10, 32.5, 2.5)
+    logs = np.zeros((2, 2, len(snr), 6, B), np.float32)
+    for meta_idx, (a, b) in enumerate([(a, b) for a in alphas for b in betas]):
+        H, P = _first_batch(make_val(), DataLoader, B)
+        _, _, log = reference_ald(net, cfg, H, P, snr, [0, 1], seed, alpha_step=a, beta_noise=b, combo=meta_idx)
+        logs[meta_idx // 2, meta_idx % 2] = log
+    np.savez_compressed(os.path.join(GOLD, 'cli_tune_grid_2levels.npz'), nmse_log=logs, snr_db=snr, alpha_step_range=alphas,
+                        beta_noise_range=betas, seed=seed, weight_seed=WEIGHT_SEED, num_levels=2)
+    print('cli_tune2: nmse[...,0,-1,0] =', logs[..., 0, -1, 0])
 
 
 def gen_loader():

@@ -31,18 +31,28 @@ def test_bench_line_contract_single_gpu():
     assert 'workload' in d['config'] and 'model' not in d['config'] and d['config']['nmse_finite']
     r = d['roofline']
     assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+    assert len(r['kernels']) == 3 and d['config']['streams_is_cli_default'] and d['config']['f16x2_range_flag'] == 0
     assert d['sustained_steps'] == 6 and d['sustained_ms_per_step'] > 0 and 'other_launch_mode' in d
     assert d['strong']['scaling'] == 'strong' and d['strong']['trajectories_total'] == 20400
 
 
 def test_bench_self_launches_its_ranks():
-    """``python bench.py --gpus 2`` with no torchrun environment: the parent starts the ranks as children (gloo here: RCCL
-    refuses two ranks on the one GPU of this box) and rank 0 prints the line with the aggregate over both."""
-    env_clean = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    """``python bench.py --gpus 2`` with no torchrun environment: the parent starts the ranks as children and rank 0 prints the
+    line with the aggregate over both.  On this one-GPU box two ranks must share the device, which bench.py only accepts when it
+    is asked for explicitly (SBC_DIST_BACKEND=gloo; RCCL refuses two ranks on one device) -- without it, a local rank beyond the
+    visible devices is a launch error, not something to fold silently."""
+    import torch
+    env_clean = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'SBC_DIST_BACKEND')}
+    if torch.cuda.device_count() < 2:
+        bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0',
+                              '--channels', '4', '--snr-points', '1', '--sustained', '0', '--no-strong', '--no-other-mode'],
+                             capture_output=True, text=True, timeout=900, env=env_clean)
+        assert bad.returncode != 0 and 'one rank per GPU' in (bad.stderr + bad.stdout)
+        env_clean['SBC_DIST_BACKEND'] = 'gloo'
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
                         '--channels', '8', '--snr-points', '4', '--sustained', '0', '--no-strong', '--no-other-mode'],
                        capture_output=True, text=True, timeout=900, env=env_clean)
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')][-1])
-    assert d['n_gpus'] == 2 and d['config']['trajectories_per_gpu'] == 32
+    assert d['n_gpus'] == 2 and d['config']['trajectories_per_gpu'] == 32 and d['config']['world_size_seen_by_backend'] == 2
     assert abs(d['value'] - 2 * 32 / (6933 * d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']

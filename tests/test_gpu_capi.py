@@ -10,23 +10,23 @@ from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
 
-MODES = {'bf16x3': 0, 'f32': 1, 'f16w': 2}
+MODES = {'bf16x3': 0, 'f32': 1, 'f16w': 2, 'f16x2': 3}
 
 
-def _create(sd, cfg, B, nt, nr, mode):
+def _create(sd, cfg, B, nt, nr, mode, pairs=False):
     from score_based_channels_amd import _lib
     keep = {k: np.ascontiguousarray(v, np.float32) for k, v in sd.items() if k != 'sigmas'}
     refs = (_lib.sbc_tensor_ref * len(keep))(*[
         _lib.sbc_tensor_ref(name=k.encode(), data=v.ctypes.data, numel=v.size) for k, v in keep.items()])
     sig = np.ascontiguousarray(sd['sigmas'], np.float32)
     desc = _lib.sbc_score_desc(ngf=32, channels=2, nt=nt, nr=nr, batch=B, conv_mode=MODES[mode], sigmas=sig.ctypes.data,
-                               num_classes=sig.size)
+                               num_classes=sig.size, flags=1 if pairs else 0)
     h = C.c_void_p()
     _lib.check(_lib.lib().sbc_score_create(C.byref(desc), refs, len(keep), C.byref(h)))
     return h
 
 
-@pytest.mark.parametrize('mode', ['bf16x3', 'f32', 'f16w'])
+@pytest.mark.parametrize('mode', ['bf16x3', 'f32', 'f16w', 'f16x2', 'f16x2+pairs', 'f16w+pairs'])
 def test_c_built_score_network_equals_python_host(weights64, mode):
     import torch
     from score_based_channels_amd import _lib
@@ -34,11 +34,12 @@ def test_c_built_score_network_equals_python_host(weights64, mode):
     cfg, sd = weights64
     L = _lib.lib()
     B, nt, nr = 3, 64, 16
-    h = _create(sd, cfg, B, nt, nr, mode)
+    mode, _, pairs = mode.partition('+')
+    h = _create(sd, cfg, B, nt, nr, mode, bool(pairs))
     try:
         ops_p, n = C.POINTER(_lib.sbc_op)(), C.c_int32()
         _lib.check(L.sbc_score_ops(h, C.byref(ops_p), C.byref(n)))
-        net = ScoreNet(cfg, conv_mode=mode).cuda().load_state_dict(sd)
+        net = ScoreNet(cfg, conv_mode=mode, fuse_pairs=bool(pairs)).cuda().load_state_dict(sd)
         bound = net.bind(B, nt, nr)
         assert n.value == len(bound.ops)
         # identical records: every scalar field, and the same storage-sharing pattern (pointers renamed by first use)
@@ -52,7 +53,7 @@ def test_c_built_score_network_equals_python_host(weights64, mode):
                 assert (a is None) == (b is None), (i, f)
                 if a is not None:
                     assert ids_c.setdefault(a, len(ids_c)) == ids_p.setdefault(b, len(ids_p)), (i, f)
-            for f in ('weight', 'bias', 'weight_wino', 'weight_split', 'weight_wino_split'):
+            for f in ('weight', 'bias', 'weight_wino', 'weight_split', 'weight_wino_split', 'weight2_split'):
                 assert (getattr(got, f) is None) == (getattr(ref, f) is None), (i, f)
         # bit-identical forward
         g = load_golden('forward_64x16.npz')
@@ -95,7 +96,7 @@ def test_langevin_plan_composed_from_c_records(weights64):
     ln = float(snr_to_noise(g['snr_db'], nt)[0])
     steps = noise.step_block(0, H.shape, n_steps)
     # reference run through the Python host
-    net = ScoreNet(cfg).cuda().load_state_dict(sd)
+    net = ScoreNet(cfg, conv_mode='bf16x3').cuda().load_state_dict(sd)
     ald = AldBatch(net, H, Pm, np.arange(B), np.arange(B), ln, levels=levels, step_noise=torch.from_numpy(steps))
     ald.set_init(torch.from_numpy(noise.init(H.shape)))
     Y = ald.synthesize_measurements(torch.from_numpy(noise.measurement(0, (B, npil, nr)))).clone()

@@ -110,13 +110,26 @@ def test_step_with_device_noise_and_graph_replay(trainer, golden):
     l2 = trainer.step(x, labels).clone()
     assert torch.isfinite(l1).all() and not torch.equal(l1, l2)          # fresh noise (and new weights) every step
     p_eager = trainer.params.clone()
-    trainer.load_state_dict(sd)
-    torch.cuda.synchronize()                                             # side streams do not wait for the default stream
+    trainer.load_state_dict(sd)                # its copies run on the default stream; the next call waits for them itself
     with torch.cuda.stream(torch.cuda.Stream()):
         g1 = trainer.step(x, labels, use_graph=True).clone()
         g2 = trainer.step(x, labels, use_graph=True).clone()
         torch.cuda.synchronize()
     assert torch.equal(g1, l1) and torch.equal(g2, l2) and torch.equal(trainer.params, p_eager)
+
+
+def test_validation_loss_draws_fresh_noise_per_call(trainer, golden):
+    """Forward-only plans have their own Philox stream (offset 2^30 + calls so far): two ``loss()`` calls on the same samples
+    and labels perturb them with different noise, and none of it is the noise a training step uses."""
+    import torch
+    x, labels = golden['x'], golden['labels']
+    a = trainer.loss(x, labels).clone()
+    b = trainer.loss(x, labels, ema=True).clone()
+    c = trainer.loss(x, labels).clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(a).all() and not torch.equal(a, c) and not torch.equal(a, b)
+    z = torch.from_numpy(np.random.default_rng(1).standard_normal(golden['x'].shape).astype(np.float32))
+    assert torch.equal(trainer.loss(x, labels, noise=z).clone(), trainer.loss(x, labels, noise=z).clone())   # replay: the same
 
 
 def test_cli_train_score_writes_a_checkpoint_the_estimator_loads(tmp_path, monkeypatch):

@@ -101,12 +101,12 @@ def test_fp16_weight_goldens_match_oracle_with_rounded_parameters(weights64):
     assert rel_err(out, gb['out']) < 2e-5
 
 
-@pytest.mark.parametrize('start', ['Noise', 'Adjoint'])
+@pytest.mark.parametrize('start', ['Noise', 'Adjoint', 'LS'])
 def test_posterior_mean_loop_matches_reference(weights64, start):
     """F2: ``ald_oracle.mmse_run`` against the transcription of test_mmse.py:166-277 run around the reference network
     (2 samples x 3 chains sharing a measurement, per-SNR (step, noise, stop), dc_boost 2, both start points)."""
     cfg, sd = weights64
-    g = load_golden('mmse.npz')
+    g = load_golden('mmse_ls.npz' if start == 'LS' else 'mmse.npz')        # LS (test_mmse.py:200-202) has its own file
     H, P, navg = g['H'], g['P'], int(g['mmse_avg'])
     levels = [int(v) for v in g['levels']]
     for s, snr in enumerate(g['snr_db']):
@@ -116,6 +116,9 @@ def test_posterior_mean_loop_matches_reference(weights64, start):
         assert rel_err(Y, g['Y'][s]) < 1e-6
         if start == 'Noise':
             init = noise.init((H.shape[0] * navg,) + H.shape[1:])
+        elif start == 'LS':                                                # minimum-norm least squares per sample
+            init = np.repeat(np.stack([np.linalg.lstsq(P[b], Y[b], rcond=None)[0] for b in range(H.shape[0])]).astype(np.complex64),
+                             navg, axis=0)
         else:
             init = np.repeat(np.matmul(np.conj(np.transpose(P, (0, 2, 1))), Y), navg, axis=0)
         stop = int(g['best_stop'][s])
@@ -181,3 +184,41 @@ def test_adam_ema_restatement_matches_torch():
         shadow_t = (1. - 0.999) * pt.data + 0.999 * shadow_t
         p, m, v, sh = D.adam_ema_step(p, gk, m, v, sh, t)
     assert np.max(np.abs(p - pt.data.numpy())) < 5e-7 and np.max(np.abs(sh - shadow_t.numpy())) < 5e-7
+
+
+# Random123 (D. E. Shaw Research) known-answer vectors for philox4x32-10, examples/kat_vectors: counter, key -> output
+PHILOX_KAT = [((0x00000000, 0x00000000, 0x00000000, 0x00000000), (0x00000000, 0x00000000),
+               (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+              ((0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff), (0xffffffff, 0xffffffff),
+               (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+              ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+               (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+
+
+def test_philox4x32_known_answers():
+    """The host restatement of the in-kernel generator reproduces the published Random123 vectors (the same vectors are put
+    through the device code by tests/test_gpu_parity.py::test_device_philox_known_answers)."""
+    for ctr, key, out in PHILOX_KAT:
+        got = ald_oracle.philox4x32(np.array(ctr, np.uint32), np.array(key, np.uint32))
+        assert [int(v) for v in got] == list(out), (ctr, [hex(int(v)) for v in got])
+    # vectorised call = element-wise calls
+    ctrs = np.array([k[0] for k in PHILOX_KAT], np.uint32)
+    keys = np.array([k[1] for k in PHILOX_KAT], np.uint32)
+    assert np.array_equal(ald_oracle.philox4x32(ctrs, keys), np.array([k[2] for k in PHILOX_KAT], np.uint32))
+
+
+def test_device_noise_restatement_is_standard_complex_normal():
+    """``device_complex_normal``: CN(0,1) moments at N = 2^21 draws (tolerances = 5 standard errors), distinct streams per
+    (seed, trajectory, step), and a prefix property (element e does not depend on how many elements are drawn)."""
+    n = 1 << 21
+    z = ald_oracle.device_complex_normal(1234, 7, 3, n)
+    assert z.dtype == np.complex64 and z.shape == (n,)
+    se = 1.0 / np.sqrt(n)
+    assert abs(z.real.mean()) < 5 * se * np.sqrt(0.5) and abs(z.imag.mean()) < 5 * se * np.sqrt(0.5)
+    assert abs(z.real.var() - 0.5) < 5 * se * 0.5 * np.sqrt(2) and abs(z.imag.var() - 0.5) < 5 * se * 0.5 * np.sqrt(2)
+    assert abs(np.mean(z.real * z.imag)) < 5 * se * 0.5
+    assert abs(np.mean(np.abs(z) ** 4) - 2.0) < 5 * se * np.sqrt(20.0)          # E|z|^4 = 2, Var|z|^4 = 20 for CN(0,1)
+    assert abs(np.mean(z[:-1] * np.conj(z[1:]))) < 5 * se                      # neighbours (the two halves of a block) uncorrelated
+    assert np.array_equal(z[:1001], ald_oracle.device_complex_normal(1234, 7, 3, 1001))
+    for other in ((1235, 7, 3), (1234, 8, 3), (1234, 7, 4), (1234, 7 + 2 ** 32, 3)):
+        assert not np.array_equal(z[:64], ald_oracle.device_complex_normal(*other, 64))
