@@ -495,8 +495,8 @@ def main():
             if os.path.exists(tfile):
                 with open(tfile) as f:
                     tj = json.load(f)
-                if tj.get('trajectories_per_launch') == T and tj.get('conv_mode') == conv_mode and tj.get('kernel') == d['kernel']:
-                    traffic, tsrc = tj.get('hbm_bytes_per_launch'), 'profiles/' + os.path.basename(tfile)
+                if tj.get('trajectories_per_launch') == T and tj.get('conv_mode') == conv_mode and d['kernel'] in tj.get('kernels', {}):
+                    traffic, tsrc = tj['kernels'][d['kernel']]['hbm_bytes_per_launch'], 'profiles/' + os.path.basename(tfile)
             hbm_bound = conv_mode == 'f16w'
             note = ('dominant kernel = the tagged kernel class with the largest share of a one-stream step (%.0f %%): %s, %s.  '
                     'Timed by hipEvents on the launch stream in a one-stream eager segment AFTER the timed region (%d launches, '

@@ -64,6 +64,11 @@ CONV_CASES = [
     (64, 64, 3, 2, 5, 24, 8, 'up_same'),
     (32, 32, 3, 1, 900, 32, 8, 'crp2'),            # many tiles at 32x8: several residency rounds per CU
     (64, 64, 3, 1, 2500, 32, 8, 'norm_elu_res'),   # > 2^16 pixels x 64 channels: XCD-contiguous tile order active
+    # enough tiles for the persistent tile walk of conv_wx3 (fp16-form modes): every prologue / epilogue family at 64x16
+    (32, 32, 3, 1, 200, 64, 16, 'norm_elu_res'),
+    (32, 32, 3, 1, 210, 64, 16, 'crp2'),
+    (32, 32, 3, 1, 195, 64, 16, 'up_2x'),
+    (32, 64, 3, 1, 200, 64, 16, 'norm_elu_pool_res'),
 ]
 
 

@@ -24,8 +24,10 @@ def find(d, suffix):
 
 rows = list(csv.reader(open(find('stats', 'kernel_stats.csv'))))
 with open(P + '%s_kernel_stats_%s_steps10.csv' % (TAG, W), 'w', newline='') as f:
+    n_steps = max([int(r[1]) for r in rows[1:] if 'langevin' in r[0]] + [0])
     f.write('# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 10 %s '
-            '(13 steps incl. 3 warm-up), 1x MI355X, %s\n' % (CMD, DESC))
+            '(%d Langevin steps in all: 3 warm-up + 10 timed + the one-stream roofline segments of bench.py), 1x MI355X, %s\n'
+            % (CMD, n_steps, DESC))
     w = csv.writer(f, quoting=csv.QUOTE_ALL)
     for r in rows:
         w.writerow(r)
@@ -74,23 +76,20 @@ with open(P + '%s_pmc_hbm_traffic_%s.csv' % (TAG, W), 'w') as f:
         if key[0] not in tr or key[1] > tr[key[0]][3]:
             tr[key[0]] = (fs, ws, dur, key[1])
         f.write('"%s",%d,%d,%.1f,%.0f,%.0f,%.1f,%.1f,%.0f\n' % (key[0], key[1], n, dur / 1e3, fs, ws, rd, wr, (rd + wr) * 1e6 / dur))
-tot = {}
-for r in rows[1:]:
-    nm = r[0].replace('void sbc::', '').replace('sbc::', '').split('(')[0]
-    if nm in CANDIDATES:
-        tot[nm] = float(r[2])
-DOMINANT = max(tot, key=tot.get)
-fs, ws, dur, grid = tr[DOMINANT]
+kern = {}
+for name in CANDIDATES:
+    if name not in tr:
+        continue
+    fs, ws, dur, grid = tr[name]
+    kern[name] = {'grid_threads': grid, 'fetch_size_kb_raw': round(fs), 'write_size_kb': round(ws),
+                  'hbm_bytes_per_launch': int(round((2 * fs + ws) * 1024)), 'avg_dur_us_in_the_pmc_pass': round(dur / 1e3, 1)}
 json.dump({
-    'kernel': DOMINANT, 'grid_threads': grid,
     'trajectories_per_launch': T, 'conv_mode': 'f16w' if BIG else 'f16x2',
     'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), profiles/%s_pmc_hbm_traffic_%s.csv' % (TAG, W),
-    'fetch_size_kb_raw': round(fs), 'write_size_kb': round(ws),
     'correction': 'FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B for wide coalesced reads, '
                   'MI355X_MICROARCH.md); WRITE_SIZE as reported',
-    'hbm_bytes_per_launch': int(round((2 * fs + ws) * 1024)),
-    'note': 'largest-grid dispatches of the kernel (the same symbol also runs the lower-resolution level with a smaller grid)'},
-    open(P + '%s_traffic_%s.json' % (TAG, W), 'w'), indent=1)
+    'note': 'per kernel: its largest-grid dispatches (the 64 -> 64 symbol also runs the next level down with a smaller grid)',
+    'kernels': kern}, open(P + '%s_traffic_%s.json' % (TAG, W), 'w'), indent=1)
 for r in rows[1:6]:
     print(r[0][:70], r[1], '%.1f us' % (float(r[3]) / 1e3))
 print(open(P + '%s_traffic_%s.json' % (TAG, W)).read())
