@@ -125,7 +125,7 @@ typedef enum sbc_op_kind {
  *               divides by sigmas[labels[b]] if labels != NULL else by sigma_of_step[*step]
  *   LANGEVIN    see sbc_langevin below (passed through `ext`)
  *   CONV_PAIR   in / out [B][H][W][32] (distinct buffers), weight_split + weight2_split, flags = SBC_CONV_F16X2 or
- *               SBC_CONV_F16W; W in {8, 16}, H % 8 == 0.  The same numbers as the two CONV records it replaces
+ *               SBC_CONV_F16W; W in {8, 16} with H % 8 == 0, or (SBC_CONV_F16W only) W = 64 with H % 4 == 0.  The same numbers as the two CONV records it replaces
  *               (PRO_ELU; PRO_ELU + res1 = in) up to fp32 summation order.
  */
 typedef struct sbc_op {

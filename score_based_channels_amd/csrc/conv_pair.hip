@@ -46,9 +46,12 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int W, int R, int MODE>
-__global__ __launch_bounds__(256, 2) void conv_pair_kernel(PairParams p) {
+// NW waves per workgroup: 4 (two workgroups per CU) for images 8 / 16 pixels wide; 8 (one workgroup per CU, its LDS) for 64-pixel
+// rows, where wave pair `sub` owns column block `sub` of every row of the tile.
+template <int W, int R, int MODE, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void conv_pair_kernel(PairParams p) {
     constexpr int C = 32;
+    constexpr int NTH = 64 * NW, NSUB = NW / 2;
     constexpr int NT = MODE == 2 ? 2 : 1;            // fp16 terms per operand
     constexpr int RI = R + 4, RM = R + 2;             // staged input rows, intermediate rows
     constexpr int WP = W + 2;                         // row of a plane: zero pixel, W pixels, zero pixel
@@ -57,19 +60,27 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(PairParams p) {
     constexpr int RAW_BYTES = RI * W * C * 4;
     constexpr int X_OFF = RAW_BYTES, M_OFF = X_OFF + NT * 4 * XPS;
     constexpr int NQ = RI * W * 8;                    // 16-byte chunks of the raw tile
-    static_assert(NQ % 256 == 0, "raw tile must divide over 256 threads");
+    static_assert(NQ % NTH == 0, "raw tile must divide over the workgroup's threads");
     constexpr int CB = W >= 16 ? W / 16 : 1;          // units per image row (W >= 16)
     constexpr int RPU = W >= 16 ? 1 : 16 / W;         // image rows per unit (W < 16)
-    constexpr int NU1T = RM * W / 16, NU2T = R * W / 16;       // units of 16 pixels per output-channel half
-    constexpr int NU1 = (NU1T + 1) / 2, NU2 = (NU2T + 1) / 2;  // per wave
+    constexpr bool COLS = CB > 1;                     // wide rows: wave pair `sub` owns column block `sub`, unit i = row i
+    static_assert(!COLS || CB == NSUB, "one wave pair per column block");
+    constexpr int NU1T = COLS ? RM : RM * W / 16, NU2T = COLS ? R : R * W / 16;   // units per output-channel half (and column block)
+    constexpr int USTEP = COLS ? 1 : NSUB;            // unit index step between a wave's consecutive units
+    constexpr int NU1 = (NU1T + USTEP - 1) / USTEP, NU2 = (NU2T + USTEP - 1) / USTEP;  // per wave
     static_assert(RM % RPU == 0 && R % RPU == 0, "units must not straddle the tile");
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hf = wave & 1, sub = wave >> 1;         // output-channel half, unit parity of this wave
+    const int hf = wave & 1, sub = wave >> 1;         // output-channel half; unit parity / column block of this wave
     const int kq = lane >> 4, c = lane & 15;          // k-group (8 input channels) / pixel of the unit
     const int H = p.H;
+    // unit i of this wave: first plane row and slot column of its 16 pixels (this lane: pixel c), and the step to unit i + 1
+    const int u0 = COLS ? 0 : sub;
+    const int urow0 = u0 * RPU + (W >= 16 ? 0 : c / W);
+    const int ucol = COLS ? sub * 16 + c : (W >= 16 ? c : c % W);
+    constexpr int UROWS = USTEP * RPU;                 // image rows from a wave's unit i to its unit i + 1
 
     // ---- filter fragments of both convolutions, resident for the whole launch (A operand: lane = cout l & 15, k-group l >> 4)
     uint4 wf[2][9][NT];
@@ -92,11 +103,11 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(PairParams p) {
     }
 
     // ---- zero the padding columns of every plane once (nothing writes them afterwards)
-    for (int i = tid; i < NT * 4 * RI * 2; i += 256) {
+    for (int i = tid; i < NT * 4 * RI * 2; i += NTH) {
         const int side = i & 1, row = (i >> 1) % RI, pl = (i >> 1) / RI;
         *reinterpret_cast<uint4*>(smem + X_OFF + pl * XPS + (row * WP + side * (W + 1)) * 16) = make_uint4(0, 0, 0, 0);
     }
-    for (int i = tid; i < NT * 4 * RM * 2; i += 256) {
+    for (int i = tid; i < NT * 4 * RM * 2; i += NTH) {
         const int side = i & 1, row = (i >> 1) % RM, pl = (i >> 1) / RM;
         *reinterpret_cast<uint4*>(smem + M_OFF + pl * MPS + (row * WP + side * (W + 1)) * 16) = make_uint4(0, 0, 0, 0);
     }
@@ -109,8 +120,8 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(PairParams p) {
         const int n = tile / p.tiles_per_sample, r0 = (tile - n * p.tiles_per_sample) * R;
         const char* src = reinterpret_cast<const char*>(p.in) + ((size_t)(n * H + r0 - 2) * W * C) * 4;   // may point before the sample: masked
 #pragma unroll
-        for (int k = 0; k < NQ / 256; ++k) {
-            const int j = k * 4 + wave;                                   // wave-instruction: chunks j * 64 .. + 63
+        for (int k = 0; k < NQ / NTH; ++k) {
+            const int j = k * NW + wave;                                  // wave-instruction: chunks j * 64 .. + 63
             const int ri = (j * 64) / (W * 8);                            // its (single) tile row
             const int grow = r0 - 2 + ri;
             if (grow >= 0 && grow < H) {
@@ -142,8 +153,8 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(PairParams p) {
         PT_MARK(1);
         // (2) convert raw -> operand planes of conv1
 #pragma unroll
-        for (int k = 0; k < NQ / 256; ++k) {
-            const int q = k * 256 + tid;
+        for (int k = 0; k < NQ / NTH; ++k) {
+            const int q = k * NTH + tid;
             const int px = q >> 3, c4 = q & 7;
             const int ri = px / W, col = px - ri * W;
             const int grow = r0 - 2 + ri;
@@ -176,10 +187,9 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(PairParams p) {
         // one convolution over units `sub`, `sub + 2`, ...: acc[i] = D[16 couts of this wave][16 pixels of unit i]
         auto conv = [&](auto cvc, const int plane_off, const int PS, auto nuc, auto nutc, f32x4v* acc) {
             constexpr int CV = decltype(cvc)::value, NU = decltype(nuc)::value, NUT = decltype(nutc)::value;
-            static_assert(W <= 16, "unit stride below assumes one unit per row (or several rows per unit)");
-            constexpr int DU = 2 * RPU * WP * 16;                          // bytes from unit u to unit u + 2
-            // source pixel of tap (0, 0) of unit `sub` = plane row prow (the row above the output row), slot column pcol (-1 + 1)
-            const int ub0 = plane_off + kq * PS + ((sub * RPU + (W >= 16 ? 0 : c / W)) * WP + (W >= 16 ? c : c % W)) * 16;
+            constexpr int DU = UROWS * WP * 16;                            // bytes from a wave's unit i to its unit i + 1
+            // source pixel of tap (0, 0) of the wave's first unit = plane row urow0 (the row above the output row), slot column ucol (-1 + 1)
+            const int ub0 = plane_off + kq * PS + (urow0 * WP + ucol) * 16;
 #pragma unroll
             for (int i = 0; i < NU; ++i) acc[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
             // flat walk over (tap, unit) steps; the X fragments of a step are requested D - 1 steps ahead of its MFMAs through a
@@ -189,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(PairParams p) {
             auto ld = [&](int s) {                                          // s is a compile-time constant at every call
                 const int tap = s / NU, i = s % NU;
                 const int off = i * DU + ((tap / 3) * WP + (tap % 3)) * 16;
-                if (NUT % 2 == 0 || sub + 2 * i < NUT) {
+                if (NUT % USTEP == 0 || u0 + USTEP * i < NUT) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
                         ring[s % D][t] = *reinterpret_cast<const f16x8*>(smem + ub0 + (off + t * 4 * PS));
@@ -201,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(PairParams p) {
             for (int s = 0; s < NS; ++s) {
                 const int tap = s / NU, i = s % NU;
                 if (s + D - 1 < NS) ld(s + D - 1);
-                if (NUT % 2 == 0 || sub + 2 * i < NUT) {
+                if (NUT % USTEP == 0 || u0 + USTEP * i < NUT) {
                     const f16x8 xh = ring[s % D][0];
                     const f16x8 wh = __builtin_bit_cast(f16x8, wf[CV][tap][0]);
                     if constexpr (NT == 2) {
@@ -224,10 +234,8 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(PairParams p) {
             const int cq = 4 * hf + kq;                                    // channel quad of this lane's four outputs
 #pragma unroll
             for (int i = 0; i < NU1; ++i) {
-                const int u = sub + 2 * i;
-                if (u < NU1T) {
-                    const int prow = (W >= 16 ? u / CB : u * RPU) + (W >= 16 ? 0 : c / W);
-                    const int pcol = (W >= 16 ? (u % CB) * 16 + c : c % W);
+                if (u0 + USTEP * i < NU1T) {
+                    const int prow = urow0 + i * UROWS, pcol = ucol;
                     const int grow = r0 - 1 + prow;
                     float4 v = make_float4(acc[i][0] * descale1, acc[i][1] * descale1, acc[i][2] * descale1, acc[i][3] * descale1);
                     v = elu4(v);
@@ -259,11 +267,11 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(PairParams p) {
             // the residual operand: requested before the K loop (an L2 hit: this workgroup's DMA fetched the same lines), used after it
             const int cq = 4 * hf + kq;
             float4 xr[NU2];
-            constexpr int DO = 2 * RPU * W * C;                             // elements from unit u to unit u + 2
-            const unsigned o0 = (unsigned)(((n * H + r0 + sub * RPU + (W >= 16 ? 0 : c / W)) * W + (W >= 16 ? c : c % W)) * C + cq * 4);
+            constexpr int DO = UROWS * W * C;                               // elements from a wave's unit i to its unit i + 1
+            const unsigned o0 = (unsigned)(((n * H + r0 + urow0) * W + ucol) * C + cq * 4);
 #pragma unroll
             for (int i = 0; i < NU2; ++i)
-                if (NU2T % 2 == 0 || sub + 2 * i < NU2T) xr[i] = *reinterpret_cast<const float4*>(p.in + o0 + i * DO);
+                if (NU2T % USTEP == 0 || u0 + USTEP * i < NU2T) xr[i] = *reinterpret_cast<const float4*>(p.in + o0 + i * DO);
             conv(std::integral_constant<int, 1>{}, M_OFF, MPS, std::integral_constant<int, NU2>{}, std::integral_constant<int, NU2T>{}, acc);
             PT_MARK(6);
             // everything this wave has in flight -- the residual, its pieces of the next tile's DMA -- has landed; the stores below
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(PairParams p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int i = 0; i < NU2; ++i) {
-                if (NU2T % 2 == 0 || sub + 2 * i < NU2T) {
+                if (NU2T % USTEP == 0 || u0 + USTEP * i < NU2T) {
                     float4 y;
                     y.x = fmaf(acc[i][0], descale2, xr[i].x); y.y = fmaf(acc[i][1], descale2, xr[i].y);
                     y.z = fmaf(acc[i][2], descale2, xr[i].z); y.w = fmaf(acc[i][3], descale2, xr[i].w);
@@ -292,14 +300,15 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(PairParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------ dispatch
-template <int W, int R, int MODE>
+template <int W, int R, int MODE, int NW = 4>
 static int launch_pair(const PairParams& p0, hipStream_t stream, bool dry) {
     constexpr int NT = MODE == 2 ? 2 : 1;
     constexpr int RI = R + 4, RM = R + 2, WP = W + 2;
     constexpr int XPS = (RI * WP * 16 + 255) / 256 * 256, MPS = (RM * WP * 16 + 255) / 256 * 256;
     constexpr size_t lds = (size_t)RI * W * 128 + (size_t)NT * 4 * (XPS + MPS);
-    static_assert(lds <= 80 * 1024, "two workgroups per CU");
-    auto kern = conv_pair_kernel<W, R, MODE>;
+    constexpr int PER_CU = NW == 4 ? 2 : 1;                              // workgroups per CU (two waves per SIMD either way)
+    static_assert(lds <= 160 * 1024 / PER_CU, "LDS of the resident workgroups");
+    auto kern = conv_pair_kernel<W, R, MODE, NW>;
     { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds); if (rc) return rc; }
     if (dry) return SBC_OK;
     PairParams p = p0;
@@ -309,8 +318,8 @@ static int launch_pair(const PairParams& p0, hipStream_t stream, bool dry) {
     SBC_CHECK_HIP(hipGetDevice(&dev));
     SBC_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     p.tiles_per_xcd = (p.ntiles + 7) / 8;
-    p.wgs_per_xcd = max(1, min(2 * cus / 8, p.tiles_per_xcd));
-    hipLaunchKernelGGL(kern, dim3(8 * p.wgs_per_xcd), dim3(256), lds, stream, p);
+    p.wgs_per_xcd = max(1, min(PER_CU * cus / 8, p.tiles_per_xcd));
+    hipLaunchKernelGGL(kern, dim3(8 * p.wgs_per_xcd), dim3(64 * NW), lds, stream, p);
     SBC_CHECK_HIP(hipGetLastError());
     return SBC_OK;
 }
@@ -335,6 +344,9 @@ int launch_conv_pair(const sbc_op& op, hipStream_t stream, bool dry) {
     }
     if (op.W == 16 && op.H % 8 == 0) return x2 ? launch_pair<16, 8, 2>(p, stream, dry) : launch_pair<16, 8, 1>(p, stream, dry);
     if (op.W == 8 && op.H % 8 == 0) return x2 ? launch_pair<8, 8, 2>(p, stream, dry) : launch_pair<8, 8, 1>(p, stream, dry);
+    // 64-pixel rows (the full-resolution level of a 256 x 64 array, BASELINE config 5): one 8-wave workgroup per CU, tiles of
+    // 4 rows x 64 pixels; the fp16-weight mode only (two terms would not fit the LDS next to the 64 KB raw tile)
+    if (op.W == 64 && op.H % 4 == 0 && f16w) return launch_pair<64, 4, 1, 8>(p, stream, dry);
     set_error("conv_pair: no kernel for image %dx%d", op.H, op.W);
     return SBC_ERR_UNSUPPORTED;
 }

@@ -29,6 +29,7 @@ struct POp {
 struct Builder {
     int ngf, nt, nr;
     bool fuse_pairs = false;         // plan.py: fuse_pairs / pair_fusable
+    bool f16w = false;               // ... the fp16-weight mode also fuses 64-pixel rows (plan.PAIR_WIDTHS_F16W)
     std::vector<Tn> t;
     std::vector<POp> ops;
     int tensor(const std::string& n, int h, int w, int c) { t.push_back({n, h, w, c}); return (int)t.size() - 1; }
@@ -77,7 +78,7 @@ struct Builder {
     int rcu(const std::string& p, int x, int n_blocks) {                                        // layers.py:126-134
         for (int i = 1; i <= n_blocks; ++i) {
             const std::string a = p + std::to_string(i) + "_1_conv", b = p + std::to_string(i) + "_2_conv";
-            if (fuse_pairs && t[x].c == 32 && t[x].w == 16 && t[x].h % 8 == 0) {          // plan.pair_fusable
+            if (fuse_pairs && t[x].c == 32 && ((t[x].w == 16 && t[x].h % 8 == 0) || (f16w && t[x].w == 64 && t[x].h % 4 == 0))) {   // plan.pair_fusable
                 const int dst = tensor(b, t[x].h, t[x].w, t[x].c);
                 POp o;
                 o.kind = SBC_OP_CONV_PAIR; o.src = x; o.dst = dst; o.weight = a + ".weight"; o.weight2 = b + ".weight";
@@ -191,6 +192,7 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
     // ---- wiring (plan.build_score_plan)
     Builder b{ngf, nt, nr};
     b.fuse_pairs = (d->flags & SBC_SCORE_FUSE_PAIRS) != 0;
+    b.f16w = d->conv_mode == 2;
     const int x = b.tensor("x", nt, nr, d->channels);
     int h = b.tensor("begin_conv", nt, nr, ngf);
     { POp o; o.kind = SBC_OP_BEGIN_CONV; o.src = x; o.dst = h; o.weight = "begin_conv.weight"; o.bias = "begin_conv.bias"; b.ops.push_back(o); }

@@ -97,7 +97,7 @@ class ScorePlan:
 class _Builder:
     def __init__(self, ngf, nt, nr, overlap=False, fold_stats=False, fuse_pairs=False):
         self.ngf, self.nt, self.nr = ngf, nt, nr
-        self.fuse_pairs = fuse_pairs    # RCU blocks of ngf channels as one CONV_PAIR record (csrc/conv_pair.hip)
+        self.fuse_pairs = fuse_pairs    # RCU blocks of ngf channels as one CONV_PAIR record (csrc/conv_pair.hip): True / a tuple of widths
         self.ops, self.tensors = [], []
         self.fold_stats = fold_stats    # full-resolution InstanceNorm++ statistics from tile moments (no statistics launch)
         self.producer = {}              # id(tensor) -> the record that writes it
@@ -189,7 +189,7 @@ class _Builder:
     def rcu(self, p, x, n_blocks):
         """layers.py:126-134 (n_stages = 2, no bias)."""
         for i in range(1, n_blocks + 1):
-            if self.fuse_pairs and pair_fusable(x.h, x.w, x.c):
+            if self.fuse_pairs and pair_fusable(x.h, x.w, x.c, self.fuse_pairs if isinstance(self.fuse_pairs, tuple) else PAIR_WIDTHS):
                 # x + conv2(ELU(conv1(ELU(x)))) in one launch, the intermediate tensor never exists in memory
                 dst = self.t(p + '%d_2_conv' % i, x.h, x.w, x.c)
                 self.ops.append(Op(CONV_PAIR, p + '%d_pair' % i, src=x, dst=dst, weight=p + '%d_1_conv.weight' % i,
@@ -229,11 +229,13 @@ class _Builder:
 
 
 PAIR_WIDTHS = (16,)            # image widths the plan fuses (csrc/conv_pair.hip also takes W = 8: measured slower than two launches there)
+PAIR_WIDTHS_F16W = (16, 64)    # ... in the fp16-weight mode (BASELINE config 5: the 64-pixel rows of a 256 x 64 array, tiles of 4 rows)
 
 
-def pair_fusable(h, w, c):
-    """Shapes SBC_OP_CONV_PAIR takes: 32 channels, widths of ``PAIR_WIDTHS``, heights that are multiples of its 8-row tile."""
-    return c == 32 and w in PAIR_WIDTHS and h % 8 == 0
+def pair_fusable(h, w, c, widths=PAIR_WIDTHS):
+    """Shapes SBC_OP_CONV_PAIR takes: 32 channels, widths of ``widths``, heights that are multiples of its tile (8 rows; 4 rows
+    at a width of 64)."""
+    return c == 32 and w in widths and h % (4 if w == 64 else 8) == 0
 
 
 def build_score_plan(ngf=32, nt=64, nr=16, channels=2, share_slots=True, overlap=False, fold_stats=False, fuse_pairs=False):

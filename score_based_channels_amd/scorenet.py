@@ -185,7 +185,7 @@ class ScoreNet:
         if key not in self._plans:
             fold = self.fold_stats and not (nt & (nt - 1)) and not (nr & (nr - 1))     # conv_wx3 takes power-of-two images
             self._plans[key] = P.build_score_plan(self.ngf, nt, nr, self.channels, overlap=self.overlap, fold_stats=fold,
-                                                  fuse_pairs=self.fuse_pairs)
+                                                  fuse_pairs=(P.PAIR_WIDTHS_F16W if self.conv_mode == 'f16w' else P.PAIR_WIDTHS) if self.fuse_pairs else False)
         return self._plans[key]
 
     def bind(self, B, nt, nr, *, step=None, sigma_of_step=None, use_labels=True):
