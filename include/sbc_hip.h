@@ -92,13 +92,12 @@ typedef enum sbc_op_kind {
                                    end of the plan always joins                                                       */
 #define SBC_PACK_WINOGRAD 0x2000 /* SBC_OP_PACK_WEIGHT: the Winograd F(2x2,3x3) form (sbc_pack_conv_weight_winograd_split layout) of a
                                    3x3 weight; combines with SBC_PACK_ADJOINT                                          */
-#define SBC_PRO_NORM_MOMENTS 0x4000 /* with SBC_PRO_NORM (CONV, END_CONV; 32 channels, H*W % 128 == 0): `stats` holds the input's
-                                      TILE MOMENTS [B][H*W/128][cin][2] = (mean, sum (x - mean)^2) of each 128-pixel tile,
-                                      written by the launch that produced the input (SBC_EPI_MOMENTS_OUT), and `grad` the
-                                      norm's alpha|gamma|beta [3][cin]: the consumer forms InstanceNorm++'s (mu, scale,
-                                      shift) itself and no SBC_OP_INORM_STATS launch reads the tensor again               */
-#define SBC_EPI_MOMENTS_OUT 0x8000 /* CONV (Winograd split-bf16 kernel, 32 output channels, no pool) and BEGIN_CONV: also write
-                                      the tile moments of the output to `aux` [B][H*W/128][cout][2]                         */
+#define SBC_PRO_NORM_MOMENTS 0x4000 /* INORM_STATS: `in` holds the tensor's TILE MOMENTS [B][H*W/128][cin][2] = (mean, sum (x - mean)^2) of
+                                      each 128-pixel tile, written by the launch that produced the tensor (SBC_EPI_MOMENTS_OUT);
+                                      H, W, cin describe the tensor.  The statistics launch then reads a few KB per sample
+                                      instead of the tensor (32 channels)                                                  */
+#define SBC_EPI_MOMENTS_OUT 0x8000 /* CONV (Winograd split kernels, 32 output channels, whole 128-pixel tiles, no pool) and
+                                      BEGIN_CONV: also write the tile moments of the output to `aux` [B][H*W/128][cout][2]   */
 #define SBC_CONV_F16W    0x100  /* fp16 weights (BASELINE config 5): `weight_split` / `weight_wino_split` hold ONE
                                    fp16 term per weight (sbc_pack_conv_weight_f16 / _winograd_f16) instead of
                                    three bf16 terms; activations are rounded to fp16 as they enter the matrix
@@ -338,6 +337,8 @@ typedef struct sbc_score_desc {
     int32_t num_classes;
     int32_t flags;               /* ABI 9: SBC_SCORE_* */
 } sbc_score_desc;
+#define SBC_SCORE_FOLD_STATS 0x2 /* InstanceNorm++ statistics of the full-resolution tensors from the tile moments their producers write
+                                    (SBC_EPI_MOMENTS_OUT / SBC_PRO_NORM_MOMENTS; not conv_mode 1; scorenet.DEFAULT_FOLD_STATS) */
 #define SBC_SCORE_FUSE_PAIRS 0x1 /* every RCU block of 32 channels at a width of 16 as one SBC_OP_CONV_PAIR record (conv_mode 2 / 3);
                                     what the Python host does by default in those modes (scorenet.DEFAULT_FUSE_PAIRS) */
 typedef struct sbc_score sbc_score;

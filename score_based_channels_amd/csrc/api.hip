@@ -152,6 +152,7 @@ static int join_side(sbc_plan* plan, hipStream_t s) {
 
 static int run_eager(sbc_plan* plan, hipStream_t s) {
     bool side_busy = false;
+    bool main_moved = true;          // the run stream has had work queued since the side stream last forked from it
     for (auto& po : plan->ops) {
         hipStream_t os = s;                              // the stream this op runs on
         if (po.op.flags & SBC_OP_SIDE) {
@@ -160,14 +161,23 @@ static int run_eager(sbc_plan* plan, hipStream_t s) {
                 SBC_CHECK_HIP(hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming));
                 SBC_CHECK_HIP(hipEventCreateWithFlags(&plan->ev_join, hipEventDisableTiming));
             }
-            SBC_CHECK_HIP(hipEventRecord(plan->ev_fork, s));         // everything issued so far happens before the side op
-            SBC_CHECK_HIP(hipStreamWaitEvent(plan->side, plan->ev_fork, 0));
+            if (main_moved) {
+                // everything issued so far happens before the side op.  (Side ops keep their order among themselves, so a side op
+                // that directly follows another one -- a weight gradient and its reduction -- needs no second fork: two runtime
+                // calls less per such launch, on a path that is bound by how fast the host can issue it.)
+                SBC_CHECK_HIP(hipEventRecord(plan->ev_fork, s));
+                SBC_CHECK_HIP(hipStreamWaitEvent(plan->side, plan->ev_fork, 0));
+                main_moved = false;
+            }
             os = plan->side;
             side_busy = true;
-        } else if ((po.op.flags & SBC_OP_JOIN) && side_busy) {
-            const int rc = join_side(plan, s);
-            if (rc) return rc;
-            side_busy = false;
+        } else {
+            main_moved = true;
+            if ((po.op.flags & SBC_OP_JOIN) && side_busy) {
+                const int rc = join_side(plan, s);
+                if (rc) return rc;
+                side_busy = false;
+            }
         }
         const bool timed = plan->prof_tag >= 0 && po.op.tag == plan->prof_tag;
         if (timed) {

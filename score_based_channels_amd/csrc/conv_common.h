@@ -20,9 +20,7 @@ struct ConvParams {
     int plane;            // conv_x3: 16-bit elements per LDS plane
     int stats_off;        // conv_wx3: float offset of the statistics copy in LDS
     int top;              // op.tag == 1: a full-resolution ngf -> ngf layer (own kernel symbol for per-kernel profiles)
-    // statistics folded into the convolutions (tile.h): SBC_PRO_NORM_MOMENTS reads `stats` as tile moments [B][HW/128][CIN][2]
-    // and needs the norm's alpha | gamma | beta; SBC_EPI_MOMENTS_OUT writes the output's tile moments
-    const float* __restrict__ agb;
+    // SBC_EPI_MOMENTS_OUT (tile.h): the output's tile moments [B][HW/128][COUT][2], for SBC_OP_INORM_STATS + SBC_PRO_NORM_MOMENTS
     float* __restrict__ pm_out;
     // conv_mode f16x2: per-device word the kernels OR a 1 into when a staged activation leaves the fp16 range (tile.h)
     unsigned* __restrict__ range_flag;

@@ -246,7 +246,7 @@ int launch_conv(const sbc_op& op, hipStream_t stream, bool dry) {
     p.up_h = op.up_h; p.up_w = op.up_w; p.total_px = op.B * op.H * op.W;
     p.hsh = log2_exact(op.H); p.wsh = log2_exact(op.W);
     p.plane = 0; p.stats_off = 0; p.top = op.tag == 1;
-    p.agb = (const float*)op.grad; p.pm_out = (float*)op.aux;
+    p.pm_out = (float*)op.aux;
     p.range_flag = nullptr;
     if (op.flags & SBC_CONV_F16X2) {
         SBC_REQUIRE(x3 && !(op.flags & SBC_CONV_F16W), "conv: SBC_CONV_F16X2 needs weight_split (sbc_pack_conv_weight_f16x2) and excludes SBC_CONV_F16W");
@@ -255,15 +255,16 @@ int launch_conv(const sbc_op& op, hipStream_t stream, bool dry) {
         if (rc) return rc;
         p.range_flag = word;
     }
-    const bool moments = (op.flags & (SBC_PRO_NORM_MOMENTS | SBC_EPI_MOMENTS_OUT)) != 0;
+    const bool moments = (op.flags & SBC_EPI_MOMENTS_OUT) != 0;
     if (moments) {
-        // statistics folded into the Winograd split-bf16 kernel only (tile.h): whole 128-pixel tiles inside one sample
-        SBC_REQUIRE(op.weight_wino_split && op.ksize == 3 && op.dil == 1 && op.H * op.W == 1024 && !(op.flags & SBC_EPI_POOL && op.flags & SBC_EPI_MOMENTS_OUT),
-                    "conv: tile moments need the Winograd split-bf16 kernel, H*W == 1024 (8 tiles per sample) and an unpooled output");
-        SBC_REQUIRE(!(op.flags & SBC_PRO_NORM_MOMENTS) || ((op.flags & SBC_PRO_NORM) && op.stats && op.grad && op.cin == 32),
-                    "conv: PRO_NORM_MOMENTS needs PRO_NORM, stats = tile moments, grad = alpha|gamma|beta, 32 input channels");
-        SBC_REQUIRE(!(op.flags & SBC_EPI_MOMENTS_OUT) || (op.aux && op.cout == 32), "conv: EPI_MOMENTS_OUT needs aux and 32 output channels");
+        // tile moments of the output are written by the Winograd split kernels' 128-pixel, 32-output-channel variant (tile.h):
+        // whole 128-pixel tiles inside one sample, unpooled output
+        SBC_REQUIRE(op.weight_wino_split && op.ksize == 3 && op.dil == 1 && op.aux && op.cout == 32 && (op.H * op.W) % 128 == 0 &&
+                    128 % (2 * op.W) == 0 && !(op.flags & SBC_EPI_POOL),
+                    "conv: EPI_MOMENTS_OUT needs the Winograd split kernel (weight_wino_split), aux, 32 output channels, whole 128-pixel "
+                    "tiles per sample and an unpooled output");
     }
+    SBC_REQUIRE(!(op.flags & SBC_PRO_NORM_MOMENTS), "conv: SBC_PRO_NORM_MOMENTS belongs to SBC_OP_INORM_STATS (statistics from tile moments)");
     static const bool no_wx3 = getenv("SBC_NO_WX3") != nullptr;                    // A/B aid: direct split-bf16 kernel everywhere
     const bool direct_only = (op.flags & SBC_EPI_ELUGRAD) != 0;       // the fp32 Winograd kernel's epilogue does not know the flag
     if (op.weight_wino_split && !f32_only && !no_wx3 && op.ksize == 3 && op.dil == 1) {

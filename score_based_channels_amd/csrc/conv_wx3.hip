@@ -79,19 +79,11 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
         // InstanceNorm++ statistics of the tile's samples through LDS (behind the staged tile and the T planes)
         float* st_lds = lds + p.stats_off;
         bool direct = false;
-        if (p.flags & SBC_PRO_NORM_MOMENTS) {
-            // the producer left per-tile moments instead of statistics (one sample per workgroup: HW >= TM)
-            const int n = dm.div_hw(g.p0), NT = HW >> 7;
-            if constexpr (CIN == 32)
-                stats_from_moments_to_lds<CIN>(st_lds, p.stats + (size_t)n * NT * CIN * 2, p.agb, NT, 128.f, HW, tid);
-            __syncthreads();
-#ifndef SBC_LDS_STATS_ONLY                               // A/B aid (tools/build_variant.sh): the previous prologue
-        } else if ((p.flags & SBC_PRO_NORM) && !g.multi) {
+        if ((p.flags & SBC_PRO_NORM) && !g.multi) {
             // one sample per tile: statistics straight into registers, no LDS copy, no barrier (tile.h)
             const RegStats rs = load_reg_stats<CIN, NTHREADS>(p.stats, g, tid);
             stage_commit_reg<CIN, NTHREADS, NPF>(lds, pf, p.in, rs, p.flags, g, W, tid, ssp);
             direct = true;
-#endif
         } else if (p.flags & SBC_PRO_NORM) {
             stage_stats_to_lds<CIN, NTHREADS, P2>(st_lds, p.stats, g, dm, tid);
             __syncthreads();

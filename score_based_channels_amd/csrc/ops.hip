@@ -79,7 +79,7 @@ int launch_begin_conv(const sbc_op& op, hipStream_t stream) {
     SBC_REQUIRE(op.cin == 2 && op.cout == 32, "begin_conv: cin=%d cout=%d (kernel is built for 2 -> 32)", op.cin, op.cout);
     // rows per workgroup: ~256 pixels, a divisor of H (exactly 128 pixels when the tile moments are wanted)
     const bool moments = (op.flags & SBC_EPI_MOMENTS_OUT) != 0;
-    SBC_REQUIRE(!moments || (op.aux && 128 % op.W == 0 && op.H * op.W == 1024), "begin_conv: EPI_MOMENTS_OUT needs aux and H*W == 1024 in rows of 128 / W pixels");
+    SBC_REQUIRE(!moments || (op.aux && 128 % op.W == 0 && op.H % (128 / op.W) == 0), "begin_conv: EPI_MOMENTS_OUT needs aux and whole 128-pixel tiles (rows of 128 / W pixels)");
     int rows = (moments ? 128 : 256) / op.W > 0 ? (moments ? 128 : 256) / op.W : 1;
     if (rows > op.H) rows = op.H;
     while (op.H % rows) --rows;
@@ -186,8 +186,68 @@ __global__ __launch_bounds__(256) void inorm_stats_kernel(const float* __restric
     }
 }
 
+// SBC_PRO_NORM_MOMENTS: the same (mu, scale, shift) from the TILE MOMENTS a producing launch left (SBC_EPI_MOMENTS_OUT:
+// pm[B][NT][C][2] = (mean, M2) of each 128-pixel tile) instead of from the tensor itself -- a read of NT * C * 8 bytes per
+// sample where the statistics launch above reads H * W * C * 4.  Equal tile counts: mean = (1 / NT) sum mean_t and
+// M2 = sum M2_t + 128 sum (mean_t - mean)^2, both in a fixed order (8 partial sums per channel over interleaved tiles, combined
+// in ascending order): reproducible bit for bit and independent of what else is in the batch.
+template <int C>
+__global__ __launch_bounds__(256) void inorm_from_moments_kernel(const float* __restrict__ pm, const float* __restrict__ agb,
+                                                                  float* __restrict__ stats, int NT, int HW) {
+    static_assert(C == 32, "eight tile groups x 32 channels per workgroup");
+    __shared__ float part[8][C];
+    __shared__ float mean_s[C], var_s[C];
+    const int n = blockIdx.x, tid = threadIdx.x, c = tid & (C - 1), grp = tid / C;
+    const float2* src = reinterpret_cast<const float2*>(pm + (size_t)n * NT * C * 2) + c;
+    float sm = 0.f, sq = 0.f;
+    for (int t = grp; t < NT; t += 8) { const float2 v = src[(size_t)t * C]; sm += v.x; sq += v.y; }
+    part[grp][c] = sm;
+    __syncthreads();
+    float mean = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) mean += part[g][c];
+    mean *= 1.f / (float)NT;
+    __syncthreads();
+    float dd = 0.f;
+    for (int t = grp; t < NT; t += 8) { const float d = src[(size_t)t * C].x - mean; dd = fmaf(d, d, dd); }
+    part[grp][c] = fmaf(128.f, dd, sq);
+    __syncthreads();
+    if (grp == 0) {
+        float m2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) m2 += part[g][c];
+        mean_s[c] = mean;
+        var_s[c] = m2 * (1.f / (float)HW);
+    }
+    __syncthreads();
+    if (tid < C) {                                            // the "++" part, as in inorm_stats_kernel
+        float m = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < C; ++k) m += mean_s[k];
+        m *= 1.f / (float)C;
+        float v = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < C; ++k) { const float d = mean_s[k] - m; v = fmaf(d, d, v); }
+        v *= 1.f / (float)(C - 1);
+        const float mhat = (mean_s[tid] - m) / sqrtf(v + 1e-5f);
+        const float rstd = 1.f / sqrtf(fmaxf(var_s[tid], 0.f) + 1e-5f);
+        const float alpha = agb[tid], gamma = agb[C + tid], beta = agb[2 * C + tid];
+        float* o = stats + (size_t)n * 3 * C;
+        o[tid] = mean_s[tid];
+        o[C + tid] = gamma * rstd;
+        o[2 * C + tid] = fmaf(gamma, mhat * alpha, beta);
+    }
+}
+
 int launch_inorm_stats(const sbc_op& op, hipStream_t stream) {
     SBC_REQUIRE(op.in && op.out && op.weight, "inorm_stats: in/out/weight must be set");
+    if (op.flags & SBC_PRO_NORM_MOMENTS) {
+        SBC_REQUIRE(op.cin == 32 && (op.H * op.W) % 128 == 0, "inorm_stats: tile moments exist for 32 channels and whole 128-pixel tiles");
+        hipLaunchKernelGGL(inorm_from_moments_kernel<32>, dim3(op.B), dim3(256), 0, stream, (const float*)op.in,
+                           (const float*)op.weight, (float*)op.out, op.H * op.W / 128, op.H * op.W);
+        SBC_CHECK_HIP(hipGetLastError());
+        return SBC_OK;
+    }
     const int HW = op.H * op.W;
     const float* x = (const float*)op.in;
     const float* agb = (const float*)op.weight;
@@ -337,25 +397,14 @@ int launch_maxpool5(const sbc_op& op, hipStream_t stream) {
 template <int CIN>
 __global__ __launch_bounds__(256) void end_conv_kernel(const float* __restrict__ in, const float* __restrict__ stats,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
-                                                        float* __restrict__ out, sbc_endconv e, int B, int H, int W,
-                                                        const float* __restrict__ agb) {
+                                                        float* __restrict__ out, sbc_endconv e, int B, int H, int W) {
     constexpr int TM = 256, S = CIN + 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const Dims<false> d{H, W, H * W, 0, 0};
     const TileGeom g = tile_geom(blockIdx.x, TM, B, d, 1);
     float* wl = lds + (size_t)(g.nps + 1) * S;          // [9][CIN][2]
-    if (agb) {
-        // SBC_PRO_NORM_MOMENTS: `stats` are the tile moments the producer of `in` left; (mu, scale, shift) of this
-        // workgroup's sample are formed here, behind the weights in LDS (tile.h)
-        float* st = wl + 9 * CIN * 2;
-        const int n = g.p0 / (H * W), NT = (H * W) >> 7;
-        float4 pf[9];
-        stage_issue<CIN, 256, 9>(pf, in, g, W, tid);
-        stats_from_moments_to_lds<CIN>(st, stats + (size_t)n * NT * CIN * 2, agb, NT, 128.f, H * W, tid);
-        __syncthreads();
-        stage_commit<CIN, 256, 9, false>(lds, pf, in, st, SBC_PRO_NORM | SBC_PRO_ELU, g, d, tid, 0);
-    } else if (!g.multi) {
+    if (!g.multi) {
         // one sample per tile: the thread's (mu, scale, shift) in registers instead of three loads per staged chunk
         float4 pf[9];
         stage_issue<CIN, 256, 9>(pf, in, g, W, tid);
@@ -404,16 +453,14 @@ int launch_end_conv(const sbc_op& op, const sbc_endconv& e, hipStream_t stream, 
     SBC_REQUIRE(TM % op.W == 0 && (HW % TM == 0 || TM % HW == 0), "end_conv: image %dx%d does not tile", op.H, op.W);
     const int total = op.B * HW;
     const int halo_px = TM >= HW ? 0 : 2 * op.W;
-    const bool moments = (op.flags & SBC_PRO_NORM_MOMENTS) != 0;
-    SBC_REQUIRE(!moments || (op.grad && HW == 1024), "end_conv: PRO_NORM_MOMENTS needs grad = alpha|gamma|beta and H*W == 1024");
-    const size_t lds = ((size_t)(TM + halo_px + 1) * (op.cin + 4) + 9 * op.cin * 2 + (moments ? 3 * op.cin : 0)) * sizeof(float);
+    const size_t lds = ((size_t)(TM + halo_px + 1) * (op.cin + 4) + 9 * op.cin * 2) * sizeof(float);
     SBC_REQUIRE(lds <= 160 * 1024, "end_conv: tile needs %zu bytes of LDS", lds);
     SBC_REQUIRE(op.cin == 32, "end_conv: %d input channels (only ngf = 32)", op.cin);
     { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(end_conv_kernel<32>), lds); if (rc) return rc; }
     if (dry) return SBC_OK;
     hipLaunchKernelGGL(end_conv_kernel<32>, dim3((total + TM - 1) / TM), dim3(256), lds, stream, (const float*)op.in,
                        (const float*)op.stats, (const float*)op.weight, (const float*)op.bias, (float*)op.out, e, op.B,
-                       op.H, op.W, moments ? (const float*)op.grad : (const float*)nullptr);
+                       op.H, op.W);
     SBC_CHECK_HIP(hipGetLastError());
     return SBC_OK;
 }

@@ -22,6 +22,8 @@ struct Tn { std::string name; int h, w, c; int slot = -1; };
 struct POp {
     int kind = 0, flags = 0, ksize = 3, dil = 1, tag = 0;
     int src = -1, dst = -1, stats = -1, res1 = -1, res2 = -1, up = -1;       // tensor indices
+    int moments = -1;                // second output: tile moments of dst (SBC_EPI_MOMENTS_OUT)
+    int geom = -1;                   // INORM_STATS from tile moments: the tensor whose (H, W, C) the launch describes
     std::string weight, bias, weight2;       // weight2: the second convolution of an SBC_OP_CONV_PAIR
 };
 
@@ -30,6 +32,8 @@ struct Builder {
     int ngf, nt, nr;
     bool fuse_pairs = false;         // plan.py: fuse_pairs / pair_fusable
     bool f16w = false;               // ... the fp16-weight mode also fuses 64-pixel rows (plan.PAIR_WIDTHS_F16W)
+    bool fold_stats = false;         // plan.py: fold_stats (statistics of full-resolution tensors from their producers' tile moments)
+    std::map<int, int> producer;     // tensor -> index of the record that writes it
     std::vector<Tn> t;
     std::vector<POp> ops;
     int tensor(const std::string& n, int h, int w, int c) { t.push_back({n, h, w, c}); return (int)t.size() - 1; }
@@ -43,6 +47,7 @@ struct Builder {
         if (bias) o.bias = wkey + ".bias";
         o.stats = stats; o.res1 = res1; o.res2 = res2; o.up = up;
         o.flags = flags | (up >= 0 ? SBC_EPI_UP : 0); o.ksize = ksize; o.dil = dil;
+        producer[dst] = (int)ops.size();
         o.tag = (ksize == 3 && sc == ngf && cout == ngf && sh == nt) ? 1 : 0;                 // plan.TAG_CONV_TOP
         if (ksize == 3 && dil == 1 && sc == 2 * ngf && cout == 2 * ngf && !pool && 2 * sh == nt) o.tag = 3;   // plan.TAG_CONV_MID
         ops.push_back(o);
@@ -51,6 +56,19 @@ struct Builder {
     int stats(const std::string& name, int src, const std::string& nkey) {
         const int dst = tensor(name, 1, 3, t[src].c);
         POp o; o.kind = SBC_OP_INORM_STATS; o.src = src; o.dst = dst; o.weight = nkey;
+        const int hw = t[src].h * t[src].w, sw = t[src].w;
+        auto it = producer.find(src);
+        if (fold_stats && it != producer.end() && t[src].c == ngf && ngf == 32 && t[src].h == nt && hw % 128 == 0 && hw >= 256 &&
+            128 % (2 * sw) == 0 && t[src].h % (128 / sw > 0 ? 128 / sw : 1) == 0) {
+            POp& pr = ops[it->second];
+            if (pr.kind == SBC_OP_BEGIN_CONV || (pr.kind == SBC_OP_CONV && pr.ksize == 3 && pr.dil == 1 && !(pr.flags & SBC_EPI_POOL))) {
+                if (pr.moments < 0) {
+                    pr.moments = tensor(t[src].name + ".moments", hw / 128, t[src].c, 2);
+                    pr.flags |= SBC_EPI_MOMENTS_OUT;
+                }
+                o.src = ops[it->second].moments; o.flags = SBC_PRO_NORM_MOMENTS; o.geom = src;
+            }
+        }
         ops.push_back(o);
         return dst;
     }
@@ -151,12 +169,13 @@ void assign_slots(sbc_score& s) {       // plan.assign_slots: linear scan, outpu
     };
     alloc(s.x_t);
     for (int i = 0; i < n_ops; ++i) {
-        const int dst = s.pops[i].dst;
+        const int dst = s.pops[i].dst, mom = s.pops[i].moments;
         alloc(dst);
         live.push_back(dst);
+        if (mom >= 0) { alloc(mom); live.push_back(mom); }
         for (size_t k = 0; k < live.size();) {
             const int id = live[k];
-            if (!pinned(id) && id != dst && last_use[id] <= i) {
+            if (!pinned(id) && id != dst && id != mom && last_use[id] <= i) {
                 free_slots[elems(id)].push_back(s.tensors[id].slot);
                 live.erase(live.begin() + k);
             } else {
@@ -193,9 +212,10 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
     Builder b{ngf, nt, nr};
     b.fuse_pairs = (d->flags & SBC_SCORE_FUSE_PAIRS) != 0;
     b.f16w = d->conv_mode == 2;
+    b.fold_stats = (d->flags & SBC_SCORE_FOLD_STATS) != 0 && d->conv_mode != 1 && !(nt & (nt - 1)) && !(nr & (nr - 1));
     const int x = b.tensor("x", nt, nr, d->channels);
     int h = b.tensor("begin_conv", nt, nr, ngf);
-    { POp o; o.kind = SBC_OP_BEGIN_CONV; o.src = x; o.dst = h; o.weight = "begin_conv.weight"; o.bias = "begin_conv.bias"; b.ops.push_back(o); }
+    { POp o; o.kind = SBC_OP_BEGIN_CONV; o.src = x; o.dst = h; o.weight = "begin_conv.weight"; o.bias = "begin_conv.bias"; b.producer[h] = (int)b.ops.size(); b.ops.push_back(o); }
     struct Stage { const char* name; int cout; bool down; int dil; };
     const Stage stages[6] = {{"res1", ngf, false, 0}, {"res2", 2 * ngf, true, 0}, {"res3", 2 * ngf, true, 0},
                              {"res31", 2 * ngf, true, 0}, {"res4", 4 * ngf, true, 2}, {"res5", 4 * ngf, true, 4}};
@@ -246,7 +266,7 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
         return (const float*)tmp.data();
     };
     for (const POp& o : s->pops) {
-        const Tn& src = s->tensors[o.src];
+        const Tn& src = s->tensors[o.geom >= 0 ? o.geom : o.src];
         const Tn& dst = s->tensors[o.dst];
         if (o.kind == SBC_OP_INORM_STATS) {
             if (off.count(o.weight)) continue;
@@ -324,11 +344,12 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
     for (const POp& o : s->pops) {
         sbc_op r;
         memset(&r, 0, sizeof(r));
-        const Tn& src = s->tensors[o.src];
+        const Tn& src = s->tensors[o.geom >= 0 ? o.geom : o.src];     // (statistics from tile moments: the image's dims)
         const Tn& dst = s->tensors[o.dst];
         r.kind = o.kind; r.flags = o.flags; r.B = B; r.H = src.h; r.W = src.w;
         r.cin = src.c; r.cout = dst.c; r.ksize = o.ksize; r.dil = o.dil; r.tag = o.tag;
-        r.in = s->slots[src.slot]; r.out = s->slots[dst.slot];
+        r.in = s->slots[s->tensors[o.src].slot]; r.out = s->slots[dst.slot];
+        if (o.moments >= 0) r.aux = s->slots[s->tensors[o.moments].slot];
         auto wp = [&](const std::string& key) -> const void* { return off.count(key) ? s->wdev + off[key] : nullptr; };
         if (o.kind == SBC_OP_CONV_PAIR) {
             r.weight_split = wp(o.weight + "#split");

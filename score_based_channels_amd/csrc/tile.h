@@ -308,11 +308,13 @@ __device__ __forceinline__ void stage_tile_split(unsigned short* lds16, int plan
         reinterpret_cast<unsigned*>(lds16 + (i / (SH / 2)) * plane + g.nps * SH)[i % (SH / 2)] = 0u;
 }
 
-// ---- InstanceNorm++ statistics folded into the neighbouring convolutions (SBC_EPI_MOMENTS_OUT / SBC_PRO_NORM_MOMENTS) ---------
+// ---- InstanceNorm++ statistics from tile moments (SBC_EPI_MOMENTS_OUT -> SBC_OP_INORM_STATS + SBC_PRO_NORM_MOMENTS) --------------
 // Instead of a statistics launch that reads the whole tensor again, the PRODUCER of a tensor writes, per 128-pixel tile and
-// channel, the tile's (mean, M2 = sum (x - mean)^2), and the CONSUMER merges the tiles of its sample in ascending order
-// (Chan et al.) and forms (mu, scale, shift) in LDS -- the values inorm_stats_kernel would have written.  Everything has a
-// fixed order, so results stay independent of batch composition and reproducible bit for bit.
+// channel, the tile's (mean, M2 = sum (x - mean)^2); a small launch (ops.hip: inorm_from_moments_kernel, one workgroup per
+// sample) merges the tiles of a sample into the (mu, scale, shift) the statistics launch would have written, and consumers
+// read those as always.  (Round 2 merged the moments in every CONSUMER workgroup: that cost each of them a dependent chain of
+// loads before staging could start, and was limited to 8 tiles per sample.)  Everything has a fixed order, so results stay
+// independent of batch composition and reproducible bit for bit.
 __device__ __forceinline__ void chan_merge1(float& mean_a, float& m2_a, float na, float mean_b, float m2_b, float nb) {
     const float n = na + nb, d = mean_b - mean_a;
     mean_a += d * (nb / n);
@@ -371,55 +373,6 @@ __device__ __forceinline__ void tile_moments_out32(const float4 (&v)[4], float* 
 #pragma unroll
         for (int w = 0; w < 8; ++w) { const float d = mw[w] - mu; dd = fmaf(d, d, dd); }
         *reinterpret_cast<float2*>(pm_tile + tid * 2) = make_float2(mu, fmaf(16.f, dd, q));
-    }
-}
-
-// Consumer side: (mu, scale, shift) of one sample into LDS st[3][C] from its NT tile moments pm[NT][C][2] (n_tile pixels
-// each) and the norm's alpha | gamma | beta -- the arithmetic of inorm_stats_kernel's last stage.  Contains one workgroup
-// barrier; the caller puts another one before st is read.
-// sum over the 32 lanes of a half wave (all lanes get the result): xor 1, 2, 4 inside quads / rows by DPP, 8 by rotation,
-// 16 by swizzle -- no LDS traffic, no barrier
-__device__ __forceinline__ float sum32(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1 /* quad_perm 1,0,3,2 */, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e /* quad_perm 2,3,0,1 */, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x101f /* xor 4 */));
-    v += xor8(v);
-    v += xor16(v);
-    return v;
-}
-
-// Consumer side (32 channels): (mu, scale, shift) of one sample into LDS st[3][32] from its NT tile moments pm[NT][32][2]
-// (n_tile pixels each, equal counts) and the norm's alpha | gamma | beta -- the arithmetic of inorm_stats_kernel's last
-// stage, entirely in the registers of the first 32 lanes.  The caller puts a barrier before st is read.
-template <int C>
-__device__ __forceinline__ void stats_from_moments_to_lds(float* st, const float* __restrict__ pm, const float* __restrict__ agb,
-                                                          int NT, float n_tile, int HW, int tid) {
-    static_assert(C == 32, "one channel per lane of a half wave");
-    if (tid < 64) {                                    // the whole first wave executes the cross-lane steps
-        const int c = tid & 31;
-        constexpr int NTC = 8;                         // tiles per sample (the host folds 1024-pixel samples only)
-        float2 mq[NTC];
-#pragma unroll
-        for (int t = 0; t < NTC; ++t) mq[t] = *reinterpret_cast<const float2*>(pm + ((size_t)t * C + c) * 2);   // all in flight
-        float mu = 0.f, q = 0.f;
-#pragma unroll
-        for (int t = 0; t < NTC; ++t) { mu += mq[t].x; q += mq[t].y; }
-        mu *= 1.f / (float)NTC;
-        float dd = 0.f;
-#pragma unroll
-        for (int t = 0; t < NTC; ++t) { const float d = mq[t].x - mu; dd = fmaf(d, d, dd); }
-        const float var = fmaf(n_tile, dd, q) * (1.f / (float)HW);
-        const float m = sum32(mu) * (1.f / (float)C);
-        const float dc = mu - m;
-        const float v = sum32(dc * dc) * (1.f / (float)(C - 1));
-        const float mhat = dc / sqrtf(v + 1e-5f);
-        const float rstd = 1.f / sqrtf(fmaxf(var, 0.f) + 1e-5f);
-        const float alpha = agb[c], gamma = agb[C + c], beta = agb[2 * C + c];
-        if (tid < 32) {
-            st[c] = mu;
-            st[C + c] = gamma * rstd;
-            st[2 * C + c] = fmaf(gamma, mhat * alpha, beta);
-        }
     }
 }
 

@@ -204,7 +204,25 @@ __global__ __launch_bounds__(256) void inorm_bwd_reduce_kernel(const float* __re
 
 __global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                                const float* __restrict__ grad, const float* __restrict__ aux,
-                                                               float* __restrict__ out, long n4, int HW, int C, int flags) {
+                                                               float* __restrict__ out, long n4, int HW, int C, int flags,
+                                                               const float* __restrict__ agb, float* __restrict__ dagb, int B) {
+    if (blockIdx.x == gridDim.x - 1) {
+        // The last workgroup also sums the per-sample terms of d alpha | d gamma | d beta over the batch, in ascending order
+        // (a launch of its own until round 3: 25 launches per optimiser step on a host-launch-bound path).  It reads only `aux`,
+        // which the reduce launch finished before this one started.
+        for (int c = threadIdx.x; c < C; c += 256) {
+            const float alpha = agb[c], gamma = agb[C + c];
+            float da = 0.f, dg = 0.f, db = 0.f;
+            for (int b = 0; b < B; ++b) {
+                const float* o = aux + (size_t)b * 6 * C;
+                const float s1 = o[3 * C + c], s2h = o[4 * C + c], mhat = o[5 * C + c];
+                db += s1;
+                dg += fmaf(mhat * alpha, s1, s2h);
+                da = fmaf(gamma * mhat, s1, da);
+            }
+            dagb[c] = da; dagb[C + c] = dg; dagb[2 * C + c] = db;
+        }
+    }
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     const int C4 = C / 4;
@@ -230,22 +248,6 @@ __global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const float* __res
     st4(out + i * 4, v);
 }
 
-__global__ void inorm_param_grad_kernel(const float* __restrict__ aux, const float* __restrict__ agb,
-                                        float* __restrict__ dagb, int B, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float alpha = agb[c], gamma = agb[C + c];
-    float da = 0.f, dg = 0.f, db = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const float* o = aux + (size_t)b * 6 * C;
-        const float s1 = o[3 * C + c], s2h = o[4 * C + c], mhat = o[5 * C + c];
-        db += s1;
-        dg += fmaf(mhat * alpha, s1, s2h);
-        da = fmaf(gamma * mhat, s1, da);
-    }
-    dagb[c] = da; dagb[C + c] = dg; dagb[2 * C + c] = db;
-}
-
 int launch_inorm_bwd(const sbc_op& op, hipStream_t stream) {
     SBC_REQUIRE(op.in && op.stats && op.weight && op.grad && op.out && op.aux && op.wgrad,
                 "inorm_bwd: in/stats/weight/grad/out/aux/wgrad must be set");
@@ -264,10 +266,7 @@ int launch_inorm_bwd(const sbc_op& op, hipStream_t stream) {
     SBC_CHECK_HIP(hipGetLastError());
     const long n4 = (long)op.B * HW * C / 4;
     hipLaunchKernelGGL(inorm_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, st, g,
-                       (const float*)aux, (float*)op.out, n4, HW, C, op.flags);
-    SBC_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(inorm_param_grad_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, (const float*)aux, agb,
-                       (float*)op.wgrad, op.B, C);
+                       (const float*)aux, (float*)op.out, n4, HW, C, op.flags, agb, (float*)op.wgrad, op.B);
     SBC_CHECK_HIP(hipGetLastError());
     return SBC_OK;
 }

@@ -75,8 +75,8 @@ class Op:
     tag: int = 0
     side: bool = False        # may overlap the records that follow it, up to the next ``join`` record (SBC_OP_SIDE)
     join: bool = False        # waits for every side record issued before it (SBC_OP_JOIN)
-    moments: Optional[Tensor] = None    # second output: tile moments of dst (EPI_MOMENTS_OUT), [HW/128][2][C] per sample
-    norm: Optional[str] = None          # PRO_NORM_MOMENTS: state_dict prefix of the norm whose statistics this record forms
+    moments: Optional[Tensor] = None    # second output: tile moments of dst (EPI_MOMENTS_OUT), [HW/128][C][2] per sample
+    geom: Optional[Tensor] = None       # INORM_STATS from tile moments: the tensor whose (H, W, C) the launch describes
 
     def inputs(self):
         return [t for t in (self.src, self.stats, self.res1, self.res2, self.up) if t is not None]
@@ -101,7 +101,6 @@ class _Builder:
         self.ops, self.tensors = [], []
         self.fold_stats = fold_stats    # full-resolution InstanceNorm++ statistics from tile moments (no statistics launch)
         self.producer = {}              # id(tensor) -> the record that writes it
-        self.moment_norm = {}           # id(moments tensor) -> state_dict prefix of the norm it feeds
         self.overlap = overlap      # mark independent low-resolution branches as side records
         self.side_now = False       # records appended while set carry ``side``
 
@@ -118,15 +117,10 @@ class _Builder:
         if (ksize == 3 and dil == 1 and src.c == 2 * self.ngf and cout == 2 * self.ngf and not flags & EPI_POOL
                 and 2 * src.h == self.nt):
             tag = TAG_CONV_MID
-        norm = None
-        if stats is not None and id(stats) in self.moment_norm:       # statistics folded: `stats` are the input's tile moments
-            assert ksize == 3 and dil == 1, name
-            flags |= PRO_NORM_MOMENTS
-            norm = self.moment_norm[id(stats)]
         self.ops.append(Op(CONV, name, src=src, dst=dst, weight=wkey + '.weight',
                            bias=(wkey + '.bias') if bias else None, stats=stats, res1=res1, res2=res2, up=up,
                            flags=flags | (EPI_UP if up is not None else 0), ksize=ksize, dil=dil, tag=tag,
-                           side=self.side_now, norm=norm))
+                           side=self.side_now))
         self.producer[id(dst)] = self.ops[-1]
         return dst
 
@@ -137,19 +131,21 @@ class _Builder:
 
     def stats(self, name, src, nkey):
         """InstanceNorm++ statistics of ``src`` for the norm ``nkey``.  With ``fold_stats``, at full resolution and ngf
-        channels, when ``src`` comes out of the begin convolution or an unpooled undilated 3x3 convolution: no record at all
-        -- the producer also writes the moments of its 128-pixel tiles (EPI_MOMENTS_OUT) and the consumer forms (mu, scale,
-        shift) from them in its prologue (PRO_NORM_MOMENTS; include/sbc_hip.h)."""
+        channels, when ``src`` comes out of the begin convolution or an unpooled undilated 3x3 convolution: the producer also
+        writes the moments of its 128-pixel tiles (EPI_MOMENTS_OUT) and the statistics record reads THOSE (PRO_NORM_MOMENTS:
+        HW / 128 x C x 8 bytes per sample instead of the tensor); consumers see ordinary statistics either way."""
         prod = self.producer.get(id(src))
-        if (self.fold_stats and prod is not None and src.c == self.ngf == 32 and src.h == self.nt and src.h * src.w == 1024
+        dst = self.t(name, 1, 3, src.c)
+        hw = src.h * src.w
+        if (self.fold_stats and prod is not None and src.c == self.ngf == 32 and src.h == self.nt and hw % 128 == 0 and hw >= 256
+                and 128 % (2 * src.w) == 0 and src.h % max(1, 128 // src.w) == 0
                 and (prod.kind == BEGIN_CONV or (prod.kind == CONV and prod.ksize == 3 and prod.dil == 1
                                                  and not prod.flags & EPI_POOL))):
             if prod.moments is None:
-                prod.moments = self.t(src.name + '.moments', src.h * src.w // 128, 2, src.c)
+                prod.moments = self.t(src.name + '.moments', hw // 128, src.c, 2)     # [tile][channel][(mean, M2)]
                 prod.flags |= EPI_MOMENTS_OUT
-            self.moment_norm[id(prod.moments)] = nkey
-            return prod.moments
-        dst = self.t(name, 1, 3, src.c)
+            self.ops.append(Op(INORM_STATS, name, src=prod.moments, dst=dst, weight=nkey, flags=PRO_NORM_MOMENTS, geom=src))
+            return dst
         self.ops.append(Op(INORM_STATS, name, src=src, dst=dst, weight=nkey))
         return dst
 
@@ -265,9 +261,7 @@ def build_score_plan(ngf=32, nt=64, nr=16, channels=2, share_slots=True, overlap
     ref5 = b.refine('refine5.', [l1, ref4], ngf, end=True)
     sn = b.stats('normalizer', ref5, 'normalizer')
     out = b.t('score', nt, nr, channels)
-    folded = id(sn) in b.moment_norm
-    b.ops.append(Op(END_CONV, 'end_conv', src=ref5, dst=out, weight='end_conv.weight', bias='end_conv.bias',
-                    stats=sn, flags=PRO_NORM_MOMENTS if folded else 0, norm='normalizer' if folded else None))
+    b.ops.append(Op(END_CONV, 'end_conv', src=ref5, dst=out, weight='end_conv.weight', bias='end_conv.bias', stats=sn))
     plan = ScorePlan(b.ops, x, out, b.tensors)
     if share_slots:
         assign_slots(plan)

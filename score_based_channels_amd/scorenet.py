@@ -36,7 +36,7 @@ class BoundScore:
 
 
 DEFAULT_OVERLAP = False
-DEFAULT_FOLD_STATS = False
+DEFAULT_FOLD_STATS = True       # not conv_mode 'f32' (the tile moments are written by the Winograd split kernels); +2 %
 DEFAULT_FUSE_PAIRS = True       # applies to the fp16-form modes only ('f16x2', 'f16w')
 
 
@@ -75,8 +75,8 @@ class ScoreNet:
         # bit-identical results
         self.overlap = DEFAULT_OVERLAP if overlap is None else bool(overlap)
         # fold_stats: the full-resolution InstanceNorm++ statistics come from tile moments the producing convolution
-        # writes (plan.py `stats`): 7 of the 25 statistics launches -- each a full read of a [B][64][16][32] tensor --
-        # disappear.  Needs the Winograd split-bf16 kernels (not conv_mode 'f32').
+        # writes (plan.py `stats`): the statistics launches of those tensors read a few KB per sample instead of the tensor.
+        # Needs the Winograd split kernels (not conv_mode 'f32').
         self.fold_stats = (DEFAULT_FOLD_STATS if fold_stats is None else bool(fold_stats)) and conv_mode != 'f32'
         # fuse_pairs: every RCU block of 32 channels (act -> conv -> act -> conv, + x; layers.py:126-134) is ONE launch that keeps
         # the intermediate tensor in LDS (csrc/conv_pair.hip); the kernel reads the fp16 weight forms of 'f16x2' / 'f16w'
@@ -205,9 +205,10 @@ class ScoreNet:
         ops = []
         for op in pl.ops:
             o = _lib.sbc_op()
-            o.kind, o.flags, o.B, o.H, o.W = op.kind, op.flags, B, op.src.h, op.src.w
+            shape = op.geom if op.geom is not None else op.src              # (statistics from tile moments: the image's dims)
+            o.kind, o.flags, o.B, o.H, o.W = op.kind, op.flags, B, shape.h, shape.w
             o.flags |= (P.OP_SIDE if op.side else 0) | (P.OP_JOIN if op.join else 0)
-            o.cin, o.cout, o.ksize, o.dil, o.tag = op.src.c, op.dst.c, op.ksize, op.dil, op.tag
+            o.cin, o.cout, o.ksize, o.dil, o.tag = shape.c, op.dst.c, op.ksize, op.dil, op.tag
             o.in_ = _ptr(slots[op.src.slot])
             o.out = _ptr(slots[op.dst.slot])
             if op.kind == P.CONV_PAIR:
@@ -235,8 +236,6 @@ class ScoreNet:
                 o.stats = _ptr(slots[op.stats.slot])
             if op.moments is not None:
                 o.aux = _ptr(slots[op.moments.slot])
-            if op.norm is not None:
-                o.grad = _ptr(self._wdev, self._woff[op.norm])               # alpha | gamma | beta of the folded norm
             if op.res1 is not None:
                 o.res1 = _ptr(slots[op.res1.slot])
             if op.res2 is not None:

@@ -45,15 +45,15 @@ def run_plan(plan, sd, x_nhwc, labels):
         if op.moments is not None:               # EPI_MOMENTS_OUT: (mean, M2) of every 128-pixel tile of the output
             tiles = out.reshape(B, -1, 128, out.shape[-1]).astype(np.float64)
             mean = tiles.mean(axis=2)
-            slots[op.moments.slot] = np.stack((mean, ((tiles - mean[:, :, None]) ** 2).sum(axis=2)), axis=2).astype(F32)
+            slots[op.moments.slot] = np.stack((mean, ((tiles - mean[:, :, None]) ** 2).sum(axis=2)), axis=-1).astype(F32)   # [B,NT,C,2]
     return get(plan.out)
 
 
 def stats_from_moments(pm, alpha, gamma, beta, n_tile=128):
-    """(mu, scale, shift) [B,3,C] from tile moments [B,NT,2,C]: what a PRO_NORM_MOMENTS consumer forms in its prologue."""
+    """(mu, scale, shift) [B,3,C] from tile moments [B,NT,C,2]: what SBC_OP_INORM_STATS forms with SBC_PRO_NORM_MOMENTS."""
     pm = pm.astype(np.float64)
-    mu = pm[:, :, 0].mean(axis=1)
-    m2 = pm[:, :, 1].sum(axis=1) + n_tile * ((pm[:, :, 0] - mu[:, None]) ** 2).sum(axis=1)
+    mu = pm[..., 0].mean(axis=1)
+    m2 = pm[..., 1].sum(axis=1) + n_tile * ((pm[..., 0] - mu[:, None]) ** 2).sum(axis=1)
     var = m2 / (n_tile * pm.shape[1])
     m = mu.mean(axis=-1, keepdims=True)
     v = mu.var(axis=-1, keepdims=True, ddof=1)
@@ -68,6 +68,8 @@ def exec_op(op, sd, get, labels):
         src = get(op.src)
         if op.kind == P.BEGIN_CONV:
             out = _nhwc(O.conv2d(_nchw(F32(2) * src - F32(1)), sd[op.weight], sd[op.bias]))
+        elif op.kind == P.INORM_STATS and op.flags & P.PRO_NORM_MOMENTS:      # statistics from the producer's tile moments
+            out = stats_from_moments(src, sd[op.weight + '.alpha'], sd[op.weight + '.gamma'], sd[op.weight + '.beta'])[:, None]
         elif op.kind == P.INORM_STATS:
             out = inorm_stats(src, sd[op.weight + '.alpha'], sd[op.weight + '.gamma'],
                               sd[op.weight + '.beta'])[:, None]               # [B,1,3,C]
@@ -81,10 +83,7 @@ def exec_op(op, sd, get, labels):
         elif op.kind in (P.CONV, P.END_CONV):
             v = src
             flags = op.flags | ((P.PRO_NORM | P.PRO_ELU) if op.kind == P.END_CONV else 0)
-            if flags & P.PRO_NORM_MOMENTS:
-                st = stats_from_moments(get(op.stats), sd[op.norm + '.alpha'], sd[op.norm + '.gamma'], sd[op.norm + '.beta'])
-                v = (v - st[:, None, None, 0]) * st[:, None, None, 1] + st[:, None, None, 2]
-            elif flags & P.PRO_NORM:
+            if flags & P.PRO_NORM:
                 st = get(op.stats)[:, 0]
                 v = (v - st[:, None, None, 0]) * st[:, None, None, 1] + st[:, None, None, 2]
             if flags & P.PRO_ELU:

@@ -13,20 +13,20 @@ pytestmark = pytest.mark.gpu
 MODES = {'bf16x3': 0, 'f32': 1, 'f16w': 2, 'f16x2': 3}
 
 
-def _create(sd, cfg, B, nt, nr, mode, pairs=False):
+def _create(sd, cfg, B, nt, nr, mode, pairs=False, fold=False):
     from score_based_channels_amd import _lib
     keep = {k: np.ascontiguousarray(v, np.float32) for k, v in sd.items() if k != 'sigmas'}
     refs = (_lib.sbc_tensor_ref * len(keep))(*[
         _lib.sbc_tensor_ref(name=k.encode(), data=v.ctypes.data, numel=v.size) for k, v in keep.items()])
     sig = np.ascontiguousarray(sd['sigmas'], np.float32)
     desc = _lib.sbc_score_desc(ngf=32, channels=2, nt=nt, nr=nr, batch=B, conv_mode=MODES[mode], sigmas=sig.ctypes.data,
-                               num_classes=sig.size, flags=1 if pairs else 0)
+                               num_classes=sig.size, flags=(1 if pairs else 0) | (2 if fold else 0))
     h = C.c_void_p()
     _lib.check(_lib.lib().sbc_score_create(C.byref(desc), refs, len(keep), C.byref(h)))
     return h
 
 
-@pytest.mark.parametrize('mode', ['bf16x3', 'f32', 'f16w', 'f16x2', 'f16x2+pairs', 'f16w+pairs'])
+@pytest.mark.parametrize('mode', ['bf16x3', 'f32', 'f16w', 'f16x2', 'f16x2+pairs', 'f16w+pairs', 'f16x2+pairs+fold', 'bf16x3+fold'])
 def test_c_built_score_network_equals_python_host(weights64, mode):
     import torch
     from score_based_channels_amd import _lib
@@ -34,12 +34,13 @@ def test_c_built_score_network_equals_python_host(weights64, mode):
     cfg, sd = weights64
     L = _lib.lib()
     B, nt, nr = 3, 64, 16
-    mode, _, pairs = mode.partition('+')
-    h = _create(sd, cfg, B, nt, nr, mode, bool(pairs))
+    mode, *opts = mode.split('+')
+    pairs, fold = 'pairs' in opts, 'fold' in opts
+    h = _create(sd, cfg, B, nt, nr, mode, pairs, fold)
     try:
         ops_p, n = C.POINTER(_lib.sbc_op)(), C.c_int32()
         _lib.check(L.sbc_score_ops(h, C.byref(ops_p), C.byref(n)))
-        net = ScoreNet(cfg, conv_mode=mode, fuse_pairs=bool(pairs)).cuda().load_state_dict(sd)
+        net = ScoreNet(cfg, conv_mode=mode, fuse_pairs=pairs, fold_stats=fold).cuda().load_state_dict(sd)
         bound = net.bind(B, nt, nr)
         assert n.value == len(bound.ops)
         # identical records: every scalar field, and the same storage-sharing pattern (pointers renamed by first use)
@@ -48,7 +49,7 @@ def test_c_built_score_network_equals_python_host(weights64, mode):
             got = ops_p[i]
             for f in ('kind', 'flags', 'B', 'H', 'W', 'cin', 'cout', 'ksize', 'dil', 'up_h', 'up_w', 'tag'):
                 assert getattr(got, f) == getattr(ref, f), (i, f)
-            for f in ('in_', 'out', 'stats', 'res1', 'res2', 'up'):
+            for f in ('in_', 'out', 'stats', 'res1', 'res2', 'up', 'aux'):
                 a, b = getattr(got, f), getattr(ref, f)
                 assert (a is None) == (b is None), (i, f)
                 if a is not None:
@@ -96,7 +97,7 @@ def test_langevin_plan_composed_from_c_records(weights64):
     ln = float(snr_to_noise(g['snr_db'], nt)[0])
     steps = noise.step_block(0, H.shape, n_steps)
     # reference run through the Python host
-    net = ScoreNet(cfg, conv_mode='bf16x3').cuda().load_state_dict(sd)
+    net = ScoreNet(cfg, conv_mode='bf16x3', fold_stats=False).cuda().load_state_dict(sd)
     ald = AldBatch(net, H, Pm, np.arange(B), np.arange(B), ln, levels=levels, step_noise=torch.from_numpy(steps))
     ald.set_init(torch.from_numpy(noise.init(H.shape)))
     Y = ald.synthesize_measurements(torch.from_numpy(noise.measurement(0, (B, npil, nr)))).clone()

@@ -597,21 +597,23 @@ def test_overlapped_branches_do_not_change_results(weights64):
         assert torch.equal(ovl(x, labels), ref), rep
 
 
-def test_folded_statistics_match_the_statistics_launches(weights64):
-    """``ScoreNet(fold_stats=True)`` (optional): the seven full-resolution InstanceNorm++ statistics are formed from the tile
-    moments their producing convolutions write (SBC_EPI_MOMENTS_OUT / SBC_PRO_NORM_MOMENTS) instead of by statistics
-    launches.  Same mathematics in a different (fixed) summation order: golden-level agreement with the reference, and the
-    properties the default path has -- reproducible bit for bit, independent of what else is in the batch."""
+@pytest.mark.parametrize('mode', ['bf16x3', 'f16x2'])
+def test_folded_statistics_match_the_statistics_launches(weights64, mode):
+    """``ScoreNet(fold_stats=True)`` (optional): the full-resolution InstanceNorm++ statistics are formed from the tile moments
+    their producing launches write (SBC_EPI_MOMENTS_OUT) by statistics launches that read those moments instead of the tensors
+    (SBC_PRO_NORM_MOMENTS).  Same mathematics in a different (fixed) summation order: golden-level agreement with the
+    reference, and the properties the default path has -- reproducible bit for bit, independent of what else is in the batch."""
     import torch
     from score_based_channels_amd import plan as P
     from score_based_channels_amd.scorenet import ScoreNet
     cfg, sd = weights64
     g = load_golden('forward_64x16.npz')
     x = torch.from_numpy(g['x'])
-    fold = ScoreNet(cfg, conv_mode='bf16x3', fold_stats=True).cuda().load_state_dict(sd)
-    base = ScoreNet(cfg, conv_mode='bf16x3', fold_stats=False).cuda().load_state_dict(sd)
-    kinds = [op.kind for op in fold.score_plan(64, 16).ops]
-    assert kinds.count(P.INORM_STATS) == 18 and len(kinds) == 143
+    fold = ScoreNet(cfg, conv_mode=mode, fold_stats=True).cuda().load_state_dict(sd)
+    base = ScoreNet(cfg, conv_mode=mode, fold_stats=False).cuda().load_state_dict(sd)
+    ops = fold.score_plan(64, 16).ops
+    n_fold = sum(1 for op in ops if op.kind == P.INORM_STATS and op.flags & P.PRO_NORM_MOMENTS)
+    assert n_fold == (7 if mode == 'bf16x3' else 6)                      # f16x2: the last RCU block is a pair launch (no moments)
     for li, lev in enumerate([0, 1155, 2310]):
         labels = torch.full((x.shape[0],), lev)
         a = fold(x, labels)

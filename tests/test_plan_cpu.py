@@ -44,23 +44,31 @@ def test_plan_semantics_match_reference_forward(weights64):
 
 
 def test_folded_statistics_plan_matches_reference_forward(weights64):
-    """``build_score_plan(fold_stats=True)``: the seven full-resolution statistics records are gone; their producers carry
-    a tile-moments output, their consumers form the statistics from it.  Interpreted on the CPU the plan still computes the
-    reference forward, and the moments tensors take part in the storage sharing like any other tensor."""
+    """``build_score_plan(fold_stats=True)``: the full-resolution producers (begin convolution, unpooled 3x3 convolutions) carry
+    a tile-moments output and the statistics records of their tensors read those moments (PRO_NORM_MOMENTS) instead of the
+    tensors; consumers are untouched.  Interpreted on the CPU the plan still computes the reference forward, and the moments
+    tensors take part in the storage sharing like any other tensor."""
     _, sd = weights64
     g = load_golden('forward_64x16.npz')
     pl = P.build_score_plan(32, 64, 16, fold_stats=True)
     kinds = [op.kind for op in pl.ops]
-    assert kinds.count(P.INORM_STATS) == 18 and len(pl.ops) == 143
+    assert kinds.count(P.INORM_STATS) == 25 and len(pl.ops) == 150
     prod = [op for op in pl.ops if op.moments is not None]
-    cons = [op for op in pl.ops if op.flags & P.PRO_NORM_MOMENTS]
-    assert len(prod) == 7 == len(cons) and all(op.flags & P.EPI_MOMENTS_OUT for op in prod)
-    assert [c.stats for c in cons] == [q.moments for q in prod] and all(c.norm for c in cons)
+    fin = [op for op in pl.ops if op.kind == P.INORM_STATS and op.flags & P.PRO_NORM_MOMENTS]
+    assert len(prod) == 7 == len(fin) and all(op.flags & P.EPI_MOMENTS_OUT for op in prod)
+    assert [f.src for f in fin] == [q.moments for q in prod] and all(f.geom is q.dst for f, q in zip(fin, prod))
     assert all(m.elems == 8 * 2 * 32 for m in (q.moments for q in prod))
+    assert not any(op.flags & P.PRO_NORM_MOMENTS for op in pl.ops if op.kind != P.INORM_STATS)
     x = np.ascontiguousarray(g['x'][:2].transpose(0, 2, 3, 1))
     out = run_plan(pl, sd, x, np.full((2,), 1155))
     assert rel_err(out.transpose(0, 3, 1, 2), g['out'][1][:2]) < 2e-5
-    # nothing changes for arrays the fold does not apply to (here: not requested)
+    # with fused pairs the normalizer's input comes out of a pair launch (no moments there): six of the seven fold
+    plp = P.build_score_plan(32, 64, 16, fold_stats=True, fuse_pairs=True)
+    assert sum(1 for op in plp.ops if op.kind == P.INORM_STATS and op.flags & P.PRO_NORM_MOMENTS) == 6
+    # 256 x 64 arrays: 128 tiles per sample
+    big = P.build_score_plan(32, 256, 64, fold_stats=True)
+    assert sum(1 for op in big.ops if op.moments is not None) == 7 and all(op.moments.h == 128 for op in big.ops if op.moments is not None)
+    # nothing changes when the fold is not requested
     assert all(op.moments is None for op in P.build_score_plan(32, 64, 16).ops)
 
 
