@@ -488,33 +488,53 @@ def main():
                     e.update(executed_mfma_tflops=ach * ratio, mfma_peak_tflops=PEAK_BF16_MFMA_TFLOPS,
                              mfma_busy=ach * ratio / PEAK_BF16_MFMA_TFLOPS)
                 entries[tag] = e
-            dom = max(entries, key=lambda t: entries[t]['share_of_one_stream_step'])
-            d = entries[dom]
+            # Top-level entry: the LAYER CLASS that dominates the step, the 3x3 ngf -> ngf convolutions at full resolution (the
+            # class rounds 1-2 reported as one kernel).  Since round 3 two kernels run it -- the unfused Winograd launches and the
+            # fused RCU-pair launches (two convolutions each) -- so the entry aggregates both: algorithmic FLOPs (bytes) of the
+            # class per step / its time per step; executed matrix FLOPs summed kernel by kernel.
+            cls = [t for t in (P.TAG_CONV_TOP, P.TAG_PAIR_TOP) if t in entries]
+            t_cls = sum(entries[t]['us_per_launch'] * entries[t]['launches_per_step'] for t in cls) * 1e-6
+            n_launch = sum(entries[t]['launches_per_step'] for t in cls)
+            fl_cls = sum(klass[t]['flops_per_step'] for t in cls)
+            by_cls = sum(klass[t]['bytes_per_step'] for t in cls)
+            ex_cls = sum(entries[t]['executed_mfma_tflops'] * 1e12 * entries[t]['us_per_launch'] * 1e-6 * entries[t]['launches_per_step']
+                         for t in cls)
+            n_convs = sum((2 if t == P.TAG_PAIR_TOP else 1) * entries[t]['launches_per_step'] for t in cls)
             tfile = os.path.join(ROOT, 'profiles', '%s_traffic_%s.json' % (PROFILE_ROUND, args.workload))
             traffic, tsrc = None, None
             if os.path.exists(tfile):
                 with open(tfile) as f:
                     tj = json.load(f)
-                if tj.get('trajectories_per_launch') == T and tj.get('conv_mode') == conv_mode and d['kernel'] in tj.get('kernels', {}):
-                    traffic, tsrc = tj['kernels'][d['kernel']]['hbm_bytes_per_launch'], 'profiles/' + os.path.basename(tfile)
+                if (tj.get('trajectories_per_launch') == T and tj.get('conv_mode') == conv_mode
+                        and all(entries[t]['kernel'] in tj.get('kernels', {}) for t in cls)):
+                    traffic = sum(tj['kernels'][entries[t]['kernel']]['hbm_bytes_per_launch'] * entries[t]['launches_per_step']
+                                  for t in cls) / n_launch
+                    tsrc = 'profiles/' + os.path.basename(tfile)
             hbm_bound = conv_mode == 'f16w'
-            note = ('dominant kernel = the tagged kernel class with the largest share of a one-stream step (%.0f %%): %s, %s.  '
-                    'Timed by hipEvents on the launch stream in a one-stream eager segment AFTER the timed region (%d launches, '
-                    'avg %.1f us); profiles/%s_kernel_stats_%s.csv is rocprofv3 --kernel-trace --stats of the same one-stream '
-                    'command.  ' % (100 * d['share_of_one_stream_step'], d['kernel'], d['what'], klass[dom]['launches'],
-                                    d['us_per_launch'], PROFILE_ROUND, args.workload))
+            mpeak = PEAK_F32_MFMA_TFLOPS if conv_mode == 'f32' else PEAK_BF16_MFMA_TFLOPS
+            note = ('dominant layer class: the %d 3x3 32->32 convolutions at %dx%d of every step (%.0f %% of a one-stream step), run by '
+                    '%s.  Each kernel is timed by hipEvents on the launch stream in a one-stream eager segment AFTER the timed region; '
+                    'profiles/%s_kernel_stats_%s_steps10.csv is rocprofv3 --kernel-trace --stats of the same one-stream command.  '
+                    % (n_convs, nt, nr, 100 * t_cls * 1e3 / one_stream_ms,
+                       ' + '.join('%d launches of %s (avg %.1f us)' % (entries[t]['launches_per_step'], entries[t]['kernel'],
+                                                                       entries[t]['us_per_launch']) for t in cls),
+                       PROFILE_ROUND, args.workload))
             if hbm_bound:
-                rf = {'bound': 'hbm', 'achieved': d['algorithmic_TBps'] * 1e3, 'peak': PEAK_HBM_TBS * 1e3, 'unit': 'GB/s',
-                      'frac': d['algorithmic_TBps'] / PEAK_HBM_TBS, 'traffic': traffic,
-                      'kernel': note + 'achieved = algorithmic bytes (fp32 input + output + residual operands) / time against the 8 TB/s '
-                                       'HBM3E peak (6.3 TB/s achievable)'}
+                rf = {'bound': 'hbm', 'achieved': by_cls / t_cls / 1e9, 'peak': PEAK_HBM_TBS * 1e3, 'unit': 'GB/s',
+                      'frac': by_cls / t_cls / 1e12 / PEAK_HBM_TBS, 'traffic': traffic,
+                      'kernel': note + 'achieved = algorithmic bytes of the class per step (fp32 input + output + residual operands of every '
+                                       'launch; a fused pair moves its input and its output only) / its time per step, against the 8 TB/s '
+                                       'HBM3E peak (6.3 TB/s achievable); traffic = PMC bytes per launch averaged over the class'}
             else:
-                rf = {'bound': 'mfma', 'achieved': d['algorithmic_tflops'], 'peak': d['mfma_peak_tflops'] * d['algorithmic_tflops'] / d['executed_mfma_tflops'],
-                      'unit': 'TFLOP/s', 'frac': d['mfma_busy'], 'traffic': traffic,
-                      'kernel': note + 'achieved = algorithmic (direct-convolution) FLOPs / time; peak = the algorithmic rate at which the '
-                                       'matrix pipe would be 100 %% busy with this kernel\'s algorithm (dense f16/bf16 MFMA peak %.1f TFLOP/s / '
-                                       'executed-per-algorithmic FLOP ratio), so frac IS the busy fraction of the matrix cores'
-                                       % PEAK_BF16_MFMA_TFLOPS}
+                rf = {'bound': 'mfma', 'achieved': fl_cls / t_cls / 1e12, 'peak': mpeak * fl_cls / ex_cls, 'unit': 'TFLOP/s',
+                      'frac': ex_cls / t_cls / 1e12 / mpeak, 'traffic': traffic,
+                      'executed_mfma_tflops': ex_cls / t_cls / 1e12, 'mfma_peak_tflops': mpeak,
+                      'kernel': note + 'achieved = algorithmic (direct-convolution) FLOPs of the class per step / its time per step; peak = '
+                                       'the algorithmic rate at which the matrix pipe would be 100 %% busy with the algorithms the class runs '
+                                       '(dense f16 MFMA peak %.1f TFLOP/s x algorithmic / executed FLOPs: Winograd F(2x2,3x3) executes 16/36 of '
+                                       'the products, the direct fused pair all of them plus its halo rows, each as 3 fp16 MFMAs in f16x2), '
+                                       'so frac IS the busy fraction of the matrix cores over the class; traffic = PMC bytes per launch '
+                                       'averaged over the class' % mpeak}
             rf['kernels'] = {names[t]: {k: v for k, v in entries[t].items() if k != 'kernel'} for t in entries}
             if traffic is not None:
                 rf['traffic_source'] = tsrc + ' (rocprofv3 --pmc passes of the one-stream command: FETCH_SIZE x 2 + WRITE_SIZE per launch)'

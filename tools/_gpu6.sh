@@ -1,5 +1,6 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r3m
-timeout 3000 python -m pytest tests -q -m gpu 2>&1 | tail -30 > gpurun_out/r3m/gputests.txt
-python bench.py > gpurun_out/r3m/bench_default.txt 2>&1
-python bench.py --workload big > gpurun_out/r3m/bench_big.txt 2>&1
+mkdir -p gpurun_out/r3n
+timeout 900 python -m pytest tests/test_gpu_bench.py tests/test_gpu_train.py tests/test_gpu_train_ops.py -x -q -m gpu 2>&1 | tail -6 > gpurun_out/r3n/t.txt
+python bench.py --no-cpu-baseline --no-strong > gpurun_out/r3n/bench.txt 2>&1
+python bench.py --workload train > gpurun_out/r3n/train.txt 2>&1
+python bench.py --workload train --graph 1 > gpurun_out/r3n/train_graph.txt 2>&1
