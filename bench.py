@@ -186,13 +186,19 @@ def bench_train(args):
            'config': {'workload': 'DSM optimiser step: batch %d of Nt64xNr16 channels, 2311 noise levels, Adam lr 1e-4 eps 1e-3, '
                                   'EMA 0.999 (train_score.py:34-67); %s launches' % (B, 'hipGraph' if graph else 'eager')},
            'final_loss': loss,
-           'roofline': {'bound': 'launch latency at this batch size (about 720 launches per step)', 'achieved': flops / dt / 1e12,
-                        'peak': 157.3, 'unit': 'TFLOP/s', 'frac': flops / dt / 1e12 / 157.3, 'traffic': None,
-                        'note': 'algorithmic conv FLOPs of the step (3 x forward) against the fp32 MFMA peak',
+           'roofline': {'bound': 'the GPU-side chain of ~530 dependent small launches at this batch size (DESIGN.md section 10)',
+                        'achieved': flops / dt / 1e12, 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': flops / dt / 1e12 / 157.3, 'traffic': None,
+                        'note': 'algorithmic conv FLOPs of the step (3 x forward) against the fp32 MFMA peak, the pipe the weight '
+                                'gradients run on; forward and input-gradient convolutions run as exact 3-term bf16 splits on the '
+                                'bf16 pipe (peak / 6 x 36/16 Winograd = 943.7 TFLOP/s algorithmic), so this fraction is an upper bound '
+                                'on how busy either pipe is',
                         'ms_by_operator_class': classes},
-           'cpu_baseline': {'value': None, 'note': 'the reference step (autograd, Adam, EMA) was timed in the build container '
-                                                   'only: 0.26-0.33 s per step of 32 on 8 cores (DESIGN.md section 10); there '
-                                                   'is no CPU port of the backward pass to time on this host'}}
+           'cpu_baseline': {'value': None, 'unit': 'samples/s', 'cores': 0, 'kind': 'none',
+                            'reference_build_container': {'value': 32 / 0.295, 'unit': 'samples/s', 'cores': 8,
+                                                          'what': 'the reference step itself (NCSNv2Deepest + autograd + Adam + EMAHelper, '
+                                                                  'PyTorch CPU): 0.26-0.33 s per step of 32 in the build container'},
+                            'note': 'there is no CPU port of the backward pass to time on this host (the oracle restates loss and '
+                                    'optimiser only), so `value` is null'}}
     print(json.dumps(out))
 
 
