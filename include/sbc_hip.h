@@ -68,7 +68,8 @@ typedef enum sbc_op_kind {
     SBC_OP_BEGIN_CONV_BWD = 19, /* weight / bias gradient of SBC_OP_BEGIN_CONV    ncsnv2.py:270-275           */
     SBC_OP_ADAM_EMA = 20,    /* torch.optim.Adam step + EMAHelper.update          losses/__init__.py:3-7, ema.py:17-22 */
     SBC_OP_CONV_PAIR = 21    /* one RCU block in one launch: out = x + conv2(ELU(conv1(ELU(x))))   layers.py:126-134;
-                                32 channels, 3x3, no bias; the intermediate stays in LDS (csrc/conv_pair.hip)            */
+                                32 (or, fp16 weights, 64) channels, 3x3, no bias; the intermediate stays in LDS
+                                (csrc/conv_pair.hip)                                                                  */
 } sbc_op_kind;
 
 /* sbc_op.flags for SBC_OP_CONV / SBC_OP_MAXPOOL5 */
@@ -123,8 +124,9 @@ typedef enum sbc_op_kind {
  *   END_CONV    in [B][H][W][cin], stats, weight [2][cin][3][3] (torch layout), bias [2], out [B][H][W][2];
  *               divides by sigmas[labels[b]] if labels != NULL else by sigma_of_step[*step]
  *   LANGEVIN    see sbc_langevin below (passed through `ext`)
- *   CONV_PAIR   in / out [B][H][W][32] (distinct buffers), weight_split + weight2_split, flags = SBC_CONV_F16X2 or
- *               SBC_CONV_F16W; W in {8, 16} with H % 8 == 0, or (SBC_CONV_F16W only) W = 64 with H % 4 == 0.  The same numbers as the two CONV records it replaces
+ *   CONV_PAIR   in / out [B][H][W][C] (distinct buffers), weight_split + weight2_split, flags = SBC_CONV_F16X2 or
+ *               SBC_CONV_F16W; C = 32: W in {8, 16} with H % 8 == 0, or (SBC_CONV_F16W only) W in {32, 64} with H % 4 == 0;
+ *               C = 64 (SBC_CONV_F16W only): W = 16 with H % 8 == 0 or W = 32 with H % 4 == 0.  The same numbers as the two CONV records it replaces
  *               (PRO_ELU; PRO_ELU + res1 = in) up to fp32 summation order.
  */
 typedef struct sbc_op {

@@ -48,18 +48,22 @@ __device__ __forceinline__ void lds_barrier() {
 
 // NW waves per workgroup: 4 (two workgroups per CU) for images 8 / 16 pixels wide; 8 (one workgroup per CU, its LDS) for 64-pixel
 // rows, where wave pair `sub` owns column block `sub` of every row of the tile.
-template <int W, int R, int MODE, int NW = 4>
+// C channels (input = intermediate = output): 32, or 64 in the fp16-weight mode (one term: 2 x 9 taps x 2 k-halves x 4 registers
+// per wave -- the same 144 as 32 channels with two terms); a wave owns 16 output channels (C / 16 "quarters" hf) and NSUB = NW /
+// (C / 16) unit groups.
+template <int W, int R, int MODE, int NW = 4, int C = 32>
 __global__ __launch_bounds__(64 * NW, 2) void conv_pair_kernel(PairParams p) {
-    constexpr int C = 32;
-    constexpr int NTH = 64 * NW, NSUB = NW / 2;
+    constexpr int NTH = 64 * NW, NHF = C / 16, NSUB = NW / NHF;
+    constexpr int KGS = C / 8, KH = C / 32, C4 = C / 4;   // 8-channel plane groups, 32-channel halves of the contraction, channel quads
+    static_assert(C == 32 || (C == 64 && MODE == 1), "64 channels: fp16-weight mode only (filter fragments must fit in registers)");
     constexpr int NT = MODE == 2 ? 2 : 1;            // fp16 terms per operand
     constexpr int RI = R + 4, RM = R + 2;             // staged input rows, intermediate rows
     constexpr int WP = W + 2;                         // row of a plane: zero pixel, W pixels, zero pixel
     constexpr int XPS = (RI * WP * 16 + 255) / 256 * 256;     // bytes of one k-group plane (multiple of the 256-byte bank row)
     constexpr int MPS = (RM * WP * 16 + 255) / 256 * 256;
     constexpr int RAW_BYTES = RI * W * C * 4;
-    constexpr int X_OFF = RAW_BYTES, M_OFF = X_OFF + NT * 4 * XPS;
-    constexpr int NQ = RI * W * 8;                    // 16-byte chunks of the raw tile
+    constexpr int X_OFF = RAW_BYTES, M_OFF = X_OFF + NT * KGS * XPS;
+    constexpr int NQ = RI * W * C4;                   // 16-byte chunks of the raw tile
     static_assert(NQ % NTH == 0, "raw tile must divide over the workgroup's threads");
     constexpr int CB = W >= 16 ? W / 16 : 1;          // units per image row (W >= 16)
     constexpr int RPU = W >= 16 ? 1 : 16 / W;         // image rows per unit (W < 16)
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_pair_kernel(PairParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hf = wave & 1, sub = wave >> 1;         // output-channel half; unit parity / column block of this wave
+    const int hf = wave % NHF, sub = wave / NHF;      // 16-output-channel group; unit parity / column block of this wave
     const int kq = lane >> 4, c = lane & 15;          // k-group (8 input channels) / pixel of the unit
     const int H = p.H;
     // unit i of this wave: first plane row and slot column of its 16 pixels (this lane: pixel c), and the step to unit i + 1
@@ -83,31 +87,35 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_pair_kernel(PairParams p) {
     constexpr int UROWS = USTEP * RPU;                 // image rows from a wave's unit i to its unit i + 1
 
     // ---- filter fragments of both convolutions, resident for the whole launch (A operand: lane = cout l & 15, k-group l >> 4)
-    uint4 wf[2][9][NT];
+    // (packed layout [tap][C/16 input groups g][C/32 output blocks nb][terms][64 lanes]: lane l' = cout % 32 + 32 * (cin group half))
+    uint4 wf[2][9][KH][NT];
     {
-        const int lsrc = (16 * hf + c) + 32 * (kq & 1), g = kq >> 1;
+        const int lsrc = (16 * (hf & 1) + c) + 32 * (kq & 1), nb = hf >> 1;
 #pragma unroll
         for (int cv = 0; cv < 2; ++cv) {
             const uint4* w = cv == 0 ? p.w1 : p.w2;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) wf[cv][tap][t] = w[((tap * 2 + g) * NT + t) * 64 + lsrc];
+                for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        wf[cv][tap][kh][t] = w[(((tap * (C / 16) + 2 * kh + (kq >> 1)) * (C / 32) + nb) * NT + t) * 64 + lsrc];
         }
     }
     float scale1 = 1.f, descale1 = 1.f, scale2 = 1.f, descale2 = 1.f;
     if constexpr (MODE == 2) {
-        const float4 t1 = f16x2_trailer(reinterpret_cast<const float4*>(p.w1), 9 * 2 * NT);
-        const float4 t2 = f16x2_trailer(reinterpret_cast<const float4*>(p.w2), 9 * 2 * NT);
+        const float4 t1 = f16x2_trailer(reinterpret_cast<const float4*>(p.w1), 9 * (C / 16) * (C / 32) * NT);
+        const float4 t2 = f16x2_trailer(reinterpret_cast<const float4*>(p.w2), 9 * (C / 16) * (C / 32) * NT);
         scale1 = t1.x; descale1 = t1.y; scale2 = t2.x; descale2 = t2.y;
     }
 
     // ---- zero the padding columns of every plane once (nothing writes them afterwards)
-    for (int i = tid; i < NT * 4 * RI * 2; i += NTH) {
+    for (int i = tid; i < NT * KGS * RI * 2; i += NTH) {
         const int side = i & 1, row = (i >> 1) % RI, pl = (i >> 1) / RI;
         *reinterpret_cast<uint4*>(smem + X_OFF + pl * XPS + (row * WP + side * (W + 1)) * 16) = make_uint4(0, 0, 0, 0);
     }
-    for (int i = tid; i < NT * 4 * RM * 2; i += NTH) {
+    for (int i = tid; i < NT * KGS * RM * 2; i += NTH) {
         const int side = i & 1, row = (i >> 1) % RM, pl = (i >> 1) / RM;
         *reinterpret_cast<uint4*>(smem + M_OFF + pl * MPS + (row * WP + side * (W + 1)) * 16) = make_uint4(0, 0, 0, 0);
     }
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_pair_kernel(PairParams p) {
 #pragma unroll
         for (int k = 0; k < NQ / NTH; ++k) {
             const int j = k * NW + wave;                                  // wave-instruction: chunks j * 64 .. + 63
-            const int ri = (j * 64) / (W * 8);                            // its (single) tile row
+            const int ri = (j * 64) / (W * C4);                           // its (single) tile row
             const int grow = r0 - 2 + ri;
             if (grow >= 0 && grow < H) {
                 // by hand: hipcc puts an s_waitcnt vmcnt(0) in front of every __builtin_amdgcn_global_load_lds of this loop
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_pair_kernel(PairParams p) {
 #pragma unroll
         for (int k = 0; k < NQ / NTH; ++k) {
             const int q = k * NTH + tid;
-            const int px = q >> 3, c4 = q & 7;
+            const int px = q / C4, c4 = q % C4;
             const int ri = px / W, col = px - ri * W;
             const int grow = r0 - 2 + ri;
             float4 v = *reinterpret_cast<const float4*>(smem + q * 16);
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_pair_kernel(PairParams p) {
                 split_f16x2(v.x, v.y, h.x, l.x);
                 split_f16x2(v.z, v.w, h.y, l.y);
                 *reinterpret_cast<uint2*>(dst) = h;
-                *reinterpret_cast<uint2*>(dst + 4 * XPS) = l;
+                *reinterpret_cast<uint2*>(dst + KGS * XPS) = l;
             } else {
                 f16x4 h;
                 h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
@@ -194,29 +202,29 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_pair_kernel(PairParams p) {
             for (int i = 0; i < NU; ++i) acc[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
             // flat walk over (tap, unit) steps; the X fragments of a step are requested D - 1 steps ahead of its MFMAs through a
             // ring of statically indexed registers (the scheduler would otherwise hoist every read of the loop and spill)
-            constexpr int NS = 9 * NU, D = NT == 2 ? 3 : 6;
+            constexpr int NS = 9 * KH * NU, D = NT == 2 ? 3 : 6;             // steps: (tap, k-half, unit)
             f16x8 ring[D][NT];
             auto ld = [&](int s) {                                          // s is a compile-time constant at every call
-                const int tap = s / NU, i = s % NU;
-                const int off = i * DU + ((tap / 3) * WP + (tap % 3)) * 16;
+                const int tap = s / (KH * NU), kh = (s / NU) % KH, i = s % NU;
+                const int off = i * DU + ((tap / 3) * WP + (tap % 3)) * 16 + kh * 4 * PS;
                 if (NUT % USTEP == 0 || u0 + USTEP * i < NUT) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
-                        ring[s % D][t] = *reinterpret_cast<const f16x8*>(smem + ub0 + (off + t * 4 * PS));
+                        ring[s % D][t] = *reinterpret_cast<const f16x8*>(smem + ub0 + (off + t * KGS * PS));
                 }
             };
 #pragma unroll
             for (int s = 0; s < D - 1; ++s) ld(s);
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                const int tap = s / NU, i = s % NU;
+                const int tap = s / (KH * NU), kh = (s / NU) % KH, i = s % NU;
                 if (s + D - 1 < NS) ld(s + D - 1);
                 if (NUT % USTEP == 0 || u0 + USTEP * i < NUT) {
                     const f16x8 xh = ring[s % D][0];
-                    const f16x8 wh = __builtin_bit_cast(f16x8, wf[CV][tap][0]);
+                    const f16x8 wh = __builtin_bit_cast(f16x8, wf[CV][tap][kh][0]);
                     if constexpr (NT == 2) {
                         const f16x8 xl = ring[s % D][NT - 1];
-                        const f16x8 wl = __builtin_bit_cast(f16x8, wf[CV][tap][NT - 1]);
+                        const f16x8 wl = __builtin_bit_cast(f16x8, wf[CV][tap][kh][NT - 1]);
                         acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc[i], 0, 0, 0);
                         acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc[i], 0, 0, 0);
                     }
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_pair_kernel(PairParams p) {
                         split_f16x2(v.x, v.y, h.x, l.x);
                         split_f16x2(v.z, v.w, h.y, l.y);
                         *reinterpret_cast<uint2*>(dst) = h;
-                        *reinterpret_cast<uint2*>(dst + 4 * MPS) = l;
+                        *reinterpret_cast<uint2*>(dst + KGS * MPS) = l;
                     } else {
                         f16x4 h;
                         h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
@@ -300,15 +308,15 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_pair_kernel(PairParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------ dispatch
-template <int W, int R, int MODE, int NW = 4>
+template <int W, int R, int MODE, int NW = 4, int C = 32>
 static int launch_pair(const PairParams& p0, hipStream_t stream, bool dry) {
     constexpr int NT = MODE == 2 ? 2 : 1;
     constexpr int RI = R + 4, RM = R + 2, WP = W + 2;
     constexpr int XPS = (RI * WP * 16 + 255) / 256 * 256, MPS = (RM * WP * 16 + 255) / 256 * 256;
-    constexpr size_t lds = (size_t)RI * W * 128 + (size_t)NT * 4 * (XPS + MPS);
+    constexpr size_t lds = (size_t)RI * W * C * 4 + (size_t)NT * (C / 8) * (XPS + MPS);
     constexpr int PER_CU = NW == 4 ? 2 : 1;                              // workgroups per CU (two waves per SIMD either way)
     static_assert(lds <= 160 * 1024 / PER_CU, "LDS of the resident workgroups");
-    auto kern = conv_pair_kernel<W, R, MODE, NW>;
+    auto kern = conv_pair_kernel<W, R, MODE, NW, C>;
     { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds); if (rc) return rc; }
     if (dry) return SBC_OK;
     PairParams p = p0;
@@ -326,11 +334,12 @@ static int launch_pair(const PairParams& p0, hipStream_t stream, bool dry) {
 
 int launch_conv_pair(const sbc_op& op, hipStream_t stream, bool dry) {
     SBC_REQUIRE(op.in && op.out && op.weight_split && op.weight2_split, "conv_pair: in / out / weight_split / weight2_split must be set");
-    SBC_REQUIRE(op.cin == 32 && op.cout == 32 && op.ksize == 3 && op.dil == 1, "conv_pair: 32 -> 32 -> 32 channels, 3x3, undilated");
+    SBC_REQUIRE(op.cin == op.cout && (op.cin == 32 || op.cin == 64) && op.ksize == 3 && op.dil == 1,
+                "conv_pair: C -> C -> C channels with C = 32 (or 64 with SBC_CONV_F16W), 3x3, undilated");
     SBC_REQUIRE(op.B > 0 && op.H > 0 && op.W > 0, "conv_pair: bad shape B=%d H=%d W=%d", op.B, op.H, op.W);
     const bool x2 = (op.flags & SBC_CONV_F16X2) != 0, f16w = (op.flags & SBC_CONV_F16W) != 0;
     SBC_REQUIRE(x2 != f16w, "conv_pair: exactly one of SBC_CONV_F16X2 / SBC_CONV_F16W (the forms of weight_split it reads)");
-    SBC_REQUIRE((long)op.B * op.H * op.W * 32 <= 0x7fffffffL, "conv_pair: tensor exceeds the 32-bit element index");
+    SBC_REQUIRE((long)op.B * op.H * op.W * op.cin <= 0x7fffffffL, "conv_pair: tensor exceeds the 32-bit element index");
     PairParams p{};
     p.in = (const float*)op.in; p.out = (float*)op.out;
     p.w1 = (const uint4*)op.weight_split; p.w2 = (const uint4*)op.weight2_split;
@@ -342,7 +351,18 @@ int launch_conv_pair(const sbc_op& op, hipStream_t stream, bool dry) {
         if (rc) return rc;
         p.range_flag = word;
     }
+    if (op.cin == 64) {
+        // 64 channels (the half- and quarter-resolution levels of BASELINE config 5), fp16-weight mode: 8-wave workgroups, one
+        // per CU -- four 16-output-channel groups x two unit groups (rows of a 16-pixel image; column blocks of a 32-pixel one)
+        SBC_REQUIRE(f16w, "conv_pair: 64 channels need SBC_CONV_F16W (two-term filter fragments would not fit in registers)");
+        if (op.W == 16 && op.H % 8 == 0) return launch_pair<16, 8, 1, 8, 64>(p, stream, dry);
+        if (op.W == 32 && op.H % 4 == 0) return launch_pair<32, 4, 1, 8, 64>(p, stream, dry);
+        set_error("conv_pair: no 64-channel kernel for image %dx%d", op.H, op.W);
+        return SBC_ERR_UNSUPPORTED;
+    }
     if (op.W == 16 && op.H % 8 == 0) return x2 ? launch_pair<16, 8, 2>(p, stream, dry) : launch_pair<16, 8, 1>(p, stream, dry);
+    // 32-pixel rows (the half-resolution level of a 256 x 64 array): tiles of 4 rows, wave pair `sub` owns column block `sub`
+    if (op.W == 32 && op.H % 4 == 0 && f16w) return launch_pair<32, 4, 1, 4>(p, stream, dry);
     if (op.W == 8 && op.H % 8 == 0) return x2 ? launch_pair<8, 8, 2>(p, stream, dry) : launch_pair<8, 8, 1>(p, stream, dry);
     // 64-pixel rows (the full-resolution level of a 256 x 64 array, BASELINE config 5): one 8-wave workgroup per CU, tiles of
     // 4 rows x 64 pixels; the fp16-weight mode only (two terms would not fit the LDS next to the 64 KB raw tile)

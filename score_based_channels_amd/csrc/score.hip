@@ -96,7 +96,10 @@ struct Builder {
     int rcu(const std::string& p, int x, int n_blocks) {                                        // layers.py:126-134
         for (int i = 1; i <= n_blocks; ++i) {
             const std::string a = p + std::to_string(i) + "_1_conv", b = p + std::to_string(i) + "_2_conv";
-            if (fuse_pairs && t[x].c == 32 && ((t[x].w == 16 && t[x].h % 8 == 0) || (f16w && t[x].w == 64 && t[x].h % 4 == 0))) {   // plan.pair_fusable
+            const int pc = t[x].c, pw = t[x].w, ph = t[x].h;                                // plan.pair_fusable / PAIR_SHAPES*
+            if (fuse_pairs && ((pc == 32 && pw == 16 && ph % 8 == 0) ||
+                               (f16w && ((pc == 32 && (pw == 32 || pw == 64) && ph % 4 == 0) || (pc == 64 && pw == 16 && ph % 8 == 0) ||
+                                         (pc == 64 && pw == 32 && ph % 4 == 0))))) {
                 const int dst = tensor(b, t[x].h, t[x].w, t[x].c);
                 POp o;
                 o.kind = SBC_OP_CONV_PAIR; o.src = x; o.dst = dst; o.weight = a + ".weight"; o.weight2 = b + ".weight";

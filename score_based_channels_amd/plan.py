@@ -97,7 +97,7 @@ class ScorePlan:
 class _Builder:
     def __init__(self, ngf, nt, nr, overlap=False, fold_stats=False, fuse_pairs=False):
         self.ngf, self.nt, self.nr = ngf, nt, nr
-        self.fuse_pairs = fuse_pairs    # RCU blocks of ngf channels as one CONV_PAIR record (csrc/conv_pair.hip): True / a tuple of widths
+        self.fuse_pairs = fuse_pairs    # RCU blocks as one CONV_PAIR record (csrc/conv_pair.hip): True / a tuple of (channels, width)
         self.ops, self.tensors = [], []
         self.fold_stats = fold_stats    # full-resolution InstanceNorm++ statistics from tile moments (no statistics launch)
         self.producer = {}              # id(tensor) -> the record that writes it
@@ -185,7 +185,7 @@ class _Builder:
     def rcu(self, p, x, n_blocks):
         """layers.py:126-134 (n_stages = 2, no bias)."""
         for i in range(1, n_blocks + 1):
-            if self.fuse_pairs and pair_fusable(x.h, x.w, x.c, self.fuse_pairs if isinstance(self.fuse_pairs, tuple) else PAIR_WIDTHS):
+            if self.fuse_pairs and pair_fusable(x.h, x.w, x.c, self.fuse_pairs if isinstance(self.fuse_pairs, tuple) else PAIR_SHAPES):
                 # x + conv2(ELU(conv1(ELU(x)))) in one launch, the intermediate tensor never exists in memory
                 dst = self.t(p + '%d_2_conv' % i, x.h, x.w, x.c)
                 self.ops.append(Op(CONV_PAIR, p + '%d_pair' % i, src=x, dst=dst, weight=p + '%d_1_conv.weight' % i,
@@ -224,14 +224,17 @@ class _Builder:
         return self.rcu(p + 'output_convs.', h, 3 if end else 1)
 
 
-PAIR_WIDTHS = (16,)            # image widths the plan fuses (csrc/conv_pair.hip also takes W = 8: measured slower than two launches there)
-PAIR_WIDTHS_F16W = (16, 64)    # ... in the fp16-weight mode (BASELINE config 5: the 64-pixel rows of a 256 x 64 array, tiles of 4 rows)
+# (channels, width) of the RCU blocks the plan fuses into SBC_OP_CONV_PAIR launches (csrc/conv_pair.hip; it also takes 32 channels
+# at a width of 8: measured slower than two launches there)
+PAIR_SHAPES = ((32, 16),)
+# ... in the fp16-weight mode (BASELINE config 5, a 256 x 64 array): also 32-pixel and 64-pixel rows, and the 64-channel levels
+PAIR_SHAPES_F16W = ((32, 16), (32, 32), (32, 64), (64, 16), (64, 32))
 
 
-def pair_fusable(h, w, c, widths=PAIR_WIDTHS):
-    """Shapes SBC_OP_CONV_PAIR takes: 32 channels, widths of ``widths``, heights that are multiples of its tile (8 rows; 4 rows
-    at a width of 64)."""
-    return c == 32 and w in widths and h % (4 if w == 64 else 8) == 0
+def pair_fusable(h, w, c, shapes=PAIR_SHAPES):
+    """Shapes SBC_OP_CONV_PAIR takes: (channels, width) in ``shapes``, heights that are multiples of its tile (8 rows at a width
+    of 16, 4 rows at 32 / 64)."""
+    return (c, w) in shapes and h % (8 if w == 16 else 4) == 0
 
 
 def build_score_plan(ngf=32, nt=64, nr=16, channels=2, share_slots=True, overlap=False, fold_stats=False, fuse_pairs=False):

@@ -78,7 +78,7 @@ class ScoreNet:
         # writes (plan.py `stats`): the statistics launches of those tensors read a few KB per sample instead of the tensor.
         # Needs the Winograd split kernels (not conv_mode 'f32').
         self.fold_stats = (DEFAULT_FOLD_STATS if fold_stats is None else bool(fold_stats)) and conv_mode != 'f32'
-        # fuse_pairs: every RCU block of 32 channels (act -> conv -> act -> conv, + x; layers.py:126-134) is ONE launch that keeps
+        # fuse_pairs: RCU blocks (act -> conv -> act -> conv, + x; layers.py:126-134; shapes: plan.PAIR_SHAPES*) are ONE launch that keeps
         # the intermediate tensor in LDS (csrc/conv_pair.hip); the kernel reads the fp16 weight forms of 'f16x2' / 'f16w'
         self.fuse_pairs = (DEFAULT_FUSE_PAIRS if fuse_pairs is None else bool(fuse_pairs)) and conv_mode in ('f16x2', 'f16w')
         self.config = config
@@ -185,7 +185,7 @@ class ScoreNet:
         if key not in self._plans:
             fold = self.fold_stats and not (nt & (nt - 1)) and not (nr & (nr - 1))     # conv_wx3 takes power-of-two images
             self._plans[key] = P.build_score_plan(self.ngf, nt, nr, self.channels, overlap=self.overlap, fold_stats=fold,
-                                                  fuse_pairs=(P.PAIR_WIDTHS_F16W if self.conv_mode == 'f16w' else P.PAIR_WIDTHS) if self.fuse_pairs else False)
+                                                  fuse_pairs=(P.PAIR_SHAPES_F16W if self.conv_mode == 'f16w' else P.PAIR_SHAPES) if self.fuse_pairs else False)
         return self._plans[key]
 
     def bind(self, B, nt, nr, *, step=None, sigma_of_step=None, use_labels=True):

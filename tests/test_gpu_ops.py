@@ -343,23 +343,26 @@ def test_f16x2_range_flag(gpu, wino):
         _launch(gpu, op)
 
 
-PAIR_CASES = [(3, 64, 16), (130, 64, 16), (1, 8, 16), (5, 32, 8), (70, 32, 8), (2, 16, 16), (1, 256, 64), (3, 12, 64), (40, 16, 64)]
+PAIR_CASES = [(3, 64, 16), (130, 64, 16), (1, 8, 16), (5, 32, 8), (70, 32, 8), (2, 16, 16), (1, 256, 64), (3, 12, 64), (40, 16, 64),
+              (2, 128, 32), (33, 8, 32), (2, 64, 16, 64), (35, 16, 16, 64), (2, 128, 32, 64), (17, 12, 32, 64)]     # (.., C = 64)
 
 
 @pytest.mark.parametrize('mode', ['f16x2', 'f16w'])
-@pytest.mark.parametrize('B,H,W', PAIR_CASES)
-def test_conv_pair_matches_oracle(gpu, B, H, W, mode):
+@pytest.mark.parametrize('case', PAIR_CASES)
+def test_conv_pair_matches_oracle(gpu, case, mode):
     """SBC_OP_CONV_PAIR: one RCU block, out = x + conv2(ELU(conv1(ELU(x)))) (layers.py:126-134), with the intermediate kept in
     LDS (csrc/conv_pair.hip) -- against the oracle's two convolutions, and against the two SBC_OP_CONV launches it replaces."""
     torch, _lib = gpu
     from score_based_channels_amd import plan as P
     from score_based_channels_amd.weights import pack_conv_weight_f16, pack_conv_weight_f16x2, round_fp16
-    if W == 64 and mode != 'f16w':
-        pytest.skip('64-pixel rows: the pair kernel exists in the fp16-weight mode only (BASELINE config 5)')
-    rng = np.random.default_rng(B * 1000 + H + W)
-    x = (rng.standard_normal((B, H, W, 32)) * 1.5 + 0.3).astype(F32)
-    w1 = (rng.standard_normal((32, 32, 3, 3)) / np.sqrt(288)).astype(F32)
-    w2 = (rng.standard_normal((32, 32, 3, 3)) / np.sqrt(288) * 0.05).astype(F32)      # a different weight scale per convolution
+    B, H, W = case[:3]
+    Cc = case[3] if len(case) > 3 else 32
+    if (W >= 32 or Cc == 64) and mode != 'f16w':
+        pytest.skip('32- / 64-pixel rows and 64 channels: the pair kernel exists in the fp16-weight mode only (BASELINE config 5)')
+    rng = np.random.default_rng(B * 1000 + H + W + Cc)
+    x = (rng.standard_normal((B, H, W, Cc)) * 1.5 + 0.3).astype(F32)
+    w1 = (rng.standard_normal((Cc, Cc, 3, 3)) / np.sqrt(9 * Cc)).astype(F32)
+    w2 = (rng.standard_normal((Cc, Cc, 3, 3)) / np.sqrt(9 * Cc) * 0.05).astype(F32)   # a different weight scale per convolution
     if mode == 'f16x2':
         pack, flag, tol = pack_conv_weight_f16x2, P.CONV_F16X2, TOL
         t = O.conv2d(O.elu(x).transpose(0, 3, 1, 2), w1, None, 1)
@@ -370,8 +373,8 @@ def test_conv_pair_matches_oracle(gpu, B, H, W, mode):
         ref = x + O.conv2d(round_fp16(O.elu(t)), round_fp16(w2), None, 1).transpose(0, 2, 3, 1)
     dx = _dev(torch, x)
     d1, d2 = _dev(torch, pack(w1).view(np.float32)), _dev(torch, pack(w2).view(np.float32))
-    out = torch.full((B, H, W, 32), float('nan'), dtype=torch.float32, device='cuda')
-    op = _lib.sbc_op(kind=P.CONV_PAIR, flags=flag, B=B, H=H, W=W, cin=32, cout=32, ksize=3, dil=1, in_=_p(dx), out=_p(out),
+    out = torch.full((B, H, W, Cc), float('nan'), dtype=torch.float32, device='cuda')
+    op = _lib.sbc_op(kind=P.CONV_PAIR, flags=flag, B=B, H=H, W=W, cin=Cc, cout=Cc, ksize=3, dil=1, in_=_p(dx), out=_p(out),
                      weight_split=_p(d1), weight2_split=_p(d2))
     _launch(gpu, op)
     got = out.cpu().numpy()
@@ -382,9 +385,9 @@ def test_conv_pair_matches_oracle(gpu, B, H, W, mode):
     # the two launches it replaces
     mid = torch.empty_like(out)
     out2 = torch.empty_like(out)
-    a = _lib.sbc_op(kind=P.CONV, flags=flag | P.PRO_ELU, B=B, H=H, W=W, cin=32, cout=32, ksize=3, dil=1, in_=_p(dx), out=_p(mid),
+    a = _lib.sbc_op(kind=P.CONV, flags=flag | P.PRO_ELU, B=B, H=H, W=W, cin=Cc, cout=Cc, ksize=3, dil=1, in_=_p(dx), out=_p(mid),
                     weight_split=_p(d1))
-    b = _lib.sbc_op(kind=P.CONV, flags=flag | P.PRO_ELU, B=B, H=H, W=W, cin=32, cout=32, ksize=3, dil=1, in_=_p(mid), out=_p(out2),
+    b = _lib.sbc_op(kind=P.CONV, flags=flag | P.PRO_ELU, B=B, H=H, W=W, cin=Cc, cout=Cc, ksize=3, dil=1, in_=_p(mid), out=_p(out2),
                     weight_split=_p(d2), res1=_p(dx))
     _launch(gpu, a)
     _launch(gpu, b)

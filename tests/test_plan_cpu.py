@@ -87,8 +87,12 @@ def test_fused_pair_plan_matches_reference_forward(weights64):
     x = np.ascontiguousarray(g['x'][:2].transpose(0, 2, 3, 1))
     out = run_plan(pl, sd, x, np.full((2,), 1155))
     assert rel_err(out.transpose(0, 3, 1, 2), g['out'][1][:2]) < 2e-5
-    # wider arrays (config 5): 64-pixel rows are fused in the fp16-weight mode only (scorenet passes plan.PAIR_WIDTHS_F16W)
+    # wider arrays (config 5): 32- / 64-pixel rows and the 64-channel levels are fused in the fp16-weight mode only (scorenet
+    # passes plan.PAIR_SHAPES_F16W)
     assert not any(op.kind == P.CONV_PAIR for op in P.build_score_plan(32, 256, 64, fuse_pairs=True).ops)
-    big = P.build_score_plan(32, 256, 64, fuse_pairs=P.PAIR_WIDTHS_F16W)
-    assert sorted((op.src.h, op.src.w) for op in big.ops if op.kind == P.CONV_PAIR) == [(256, 64)] * 5      # (the 128 x 32 level: no kernel for 32-pixel rows)
+    big = P.build_score_plan(32, 256, 64, fuse_pairs=P.PAIR_SHAPES_F16W)
+    shapes = sorted((op.src.c, op.src.h, op.src.w) for op in big.ops if op.kind == P.CONV_PAIR)
+    assert shapes == [(32, 128, 32)] * 3 + [(32, 256, 64)] * 5 + [(64, 64, 16)] * 5 + [(64, 128, 32)] * 2
     assert P.count_conv_flops(big) == 13132365824
+    small = P.build_score_plan(32, 64, 16, fuse_pairs=P.PAIR_SHAPES_F16W)                   # config 2 geometry in f16w mode
+    assert sorted((op.src.c, op.src.h, op.src.w) for op in small.ops if op.kind == P.CONV_PAIR) == [(32, 64, 16)] * 5 + [(64, 16, 4)] * 0
