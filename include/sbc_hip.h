@@ -360,8 +360,8 @@ int sbc_pack_conv_weight_winograd_f16(const float* src, int32_t cout, int32_t ci
 /* f16x2 weight forms for SBC_CONV_F16X2: every weight (or Winograd-transformed weight U = G g G^T, double -> float) is
  * scaled by 2^s -- s chosen per layer so that the largest magnitude lies in [2^13, 2^14) -- and written as two fp16 terms
  * h = fp16(w 2^s), l = fp16(w 2^s - h), in the layout of sbc_pack_conv_weight_split with 2 terms,
- * [k*k | 16][cin/16][cout/32][2][64 lanes][8] uint16, followed by a 16-byte trailer of four float32: (act_scale =
- * 2^SBC_F16X2_ACT_SHIFT, descale = 2^-(s + SBC_F16X2_ACT_SHIFT), 0, 0).  dst holds sbc_f16x2_elems(...) uint16. */
+ * [k*k | 16][cin/16][cout/32][2][64 lanes][8] uint16, followed by a 16-byte trailer of four float32: (1 [reserved: activations
+ * are not scaled], descale = 2^-s, 0, 0).  dst holds sbc_f16x2_elems(...) uint16. */
 #define SBC_F16X2_ACT_SHIFT 0
 #define sbc_f16x2_elems(taps, cin, cout) ((size_t)(taps) * (cin) * (cout) * 2 + 8)
 int sbc_pack_conv_weight_f16x2(const float* src, int32_t cout, int32_t cin, int32_t ksize, uint16_t* dst);

@@ -32,19 +32,15 @@ __device__ __forceinline__ void st_stream(float* p, float4 v) {
 #endif
 }
 
-// conv_mode f16x2 (SBC_CONV_F16X2): activations enter the matrix cores as x * scale (a power of two from the packed weight's
-// trailer, so the product is exact; the shipped packers write 1: |x| < 0.125 then keeps an absolute error of 2^-25 instead of a
-// relative 2^-22, far below the fp32 rounding of the O(1) values it is summed with, and the range reaches 16000), split into
-// two fp16 terms.  `amax` collects max |x * scale| of what a thread stages: past F16X2_LIMIT the high term (or, in the
-// Winograd kernel, a 4-term transform sum) could overflow fp16, and the kernel raises the device range flag instead of
-// returning silently wrong numbers.
-struct StageScale { float scale; float amax; };
+// conv_mode f16x2 (SBC_CONV_F16X2): activations enter the matrix cores UNSCALED, split into two fp16 terms (the first float of
+// the packed weight's trailer is reserved and written as 1: |x| < 0.125 keeps an absolute error of 2^-25 instead of a relative
+// 2^-22, far below the fp32 rounding of the O(1) values it is summed with, and the range reaches 16000).  `amax` collects max |x|
+// of what a thread stages: past F16X2_LIMIT the high term (or, in the Winograd kernel, a 4-term transform sum) could overflow
+// fp16, and the kernel raises the device range flag instead of returning silently wrong numbers.
+struct StageScale { float scale; float amax; };          // (scale: reserved, 1)
 constexpr float F16X2_LIMIT = 16000.f;                   // 65504 / 4, rounded down
-__device__ __forceinline__ void scale_track(float4& x, StageScale* ss) {
+__device__ __forceinline__ void scale_track(const float4& x, StageScale* ss) {
     if (!ss) return;
-    if (ss->scale != 1.f) {                              // wave-uniform; the shipped packers use act_scale = 1 (no multiplies)
-        x.x *= ss->scale; x.y *= ss->scale; x.z *= ss->scale; x.w *= ss->scale;
-    }
     ss->amax = __builtin_fmaxf(ss->amax, __builtin_fmaxf(__builtin_fabsf(x.x), __builtin_fabsf(x.y)));
     ss->amax = __builtin_fmaxf(ss->amax, __builtin_fmaxf(__builtin_fabsf(x.z), __builtin_fabsf(x.w)));
 }
