@@ -198,8 +198,6 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_pair_kernel(PairParams p) {
             constexpr int DU = UROWS * WP * 16;                            // bytes from a wave's unit i to its unit i + 1
             // source pixel of tap (0, 0) of the wave's first unit = plane row urow0 (the row above the output row), slot column ucol (-1 + 1)
             const int ub0 = plane_off + kq * PS + (urow0 * WP + ucol) * 16;
-#pragma unroll
-            for (int i = 0; i < NU; ++i) acc[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
             // flat walk over (tap, unit) steps; the X fragments of a step are requested D - 1 steps ahead of its MFMAs through a
             // ring of statically indexed registers (the scheduler would otherwise hoist every read of the loop and spill)
             constexpr int NS = 9 * KH * NU, D = NT == 2 ? 3 : 6;             // steps: (tap, k-half, unit)
@@ -222,13 +220,17 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_pair_kernel(PairParams p) {
                 if (NUT % USTEP == 0 || u0 + USTEP * i < NUT) {
                     const f16x8 xh = ring[s % D][0];
                     const f16x8 wh = __builtin_bit_cast(f16x8, wf[CV][tap][kh][0]);
+                    // the first matrix instruction of a unit takes a literal zero as its addend (no register zeroing per tile)
+                    const f32x4v c0 = (tap == 0 && kh == 0) ? f32x4v{0.f, 0.f, 0.f, 0.f} : acc[i];
                     if constexpr (NT == 2) {
                         const f16x8 xl = ring[s % D][NT - 1];
                         const f16x8 wl = __builtin_bit_cast(f16x8, wf[CV][tap][kh][NT - 1]);
-                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, c0, 0, 0, 0);
                         acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[i], 0, 0, 0);
+                    } else {
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, c0, 0, 0, 0);
                     }
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[i], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
