@@ -13,8 +13,20 @@
 // 32 channels) instead of the three bf16 planes of conv_x3.hip.
 #include <stdlib.h>
 #include "conv_common.h"
+#ifdef SBC_WITH_WSP   // tools/build_variant.sh wsp conv_wx3.hip -DSBC_WITH_WSP: the role-split experiment takes the layers it can
+namespace sbc { int launch_conv_wsp(const ConvParams& p, int cin, int cout, hipStream_t stream, bool dry); }
+#include "../../tools/experiments/conv_wsp.hip"
+#endif
 
 namespace sbc {
+
+constexpr int WX3_TS = 32;
+
+#ifdef SBC_WX3_TIMING   // tuning aid (tools/prof_conv.py WX3_TIMING=1): 100 MHz timestamps of wave 0 of every workgroup through p.up
+#define WT_MARK(k) do { if (tid == 0) wt[k] = wall_clock64(); } while (0)
+#else
+#define WT_MARK(k) do { } while (0)
+#endif
 
 // WPE: waves per SIMD the register allocation must allow (2 = 256 registers, 3 = 168).  A third resident workgroup per CU
 // is worth ~20 % where the kernel fits without spilling (32 -> 32 with 128-pixel tiles); the wider variants would spill.
@@ -49,7 +61,9 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
     // unrolled walk spills at two blocks and measures slower).
     constexpr int PH = NBLK / NBP;               // phases (K loops, then the outputs of NBP blocks)
     static_assert(MB == 1 || NBP == 1, "two tile blocks only with one output block per phase (registers)");
-    constexpr int TS = 36;                       // floats per (tile) row of a T plane: 32 channels + 4 pad
+    // floats per (tile) row of a T plane: the 32 channels, unpadded -- the finish's ds_read_b128 (thread = tile, channel quad) is
+    // then conflict-free in the instruction's four 16-lane groups; the 36 of conv_wino.hip's layout made two lanes of a group meet
+    constexpr int TS = WX3_TS;
     constexpr int NTHREADS = 256 * NG;           // staging; everything after it works per group of 256
     static_assert(NG == 1 || (COUT / 32 / NBP) % NG == 0, "phases must divide evenly between the wave groups");
     constexpr int NPF_FULL = ((TM + 32) * (CIN / 4) + NTHREADS - 1) / NTHREADS;
@@ -66,6 +80,10 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
 
     const TileGeom g = tile_geom(xcd_tile(blockIdx.x, gridDim.x), TM, p.B, dm, 1);
     float descale = 1.f;
+#ifdef SBC_WX3_TIMING
+    unsigned long long wt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    WT_MARK(0);
     {
         StageScale ss{1.f, 0.f};
         StageScale* const ssp = MODE == 2 ? &ss : nullptr;
@@ -76,6 +94,7 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
         }
         float4 pf[NPF];
         stage_issue<CIN, NTHREADS, NPF>(pf, p.in, g, W, tid);
+        WT_MARK(1);
         // InstanceNorm++ statistics of the tile's samples through LDS (behind the staged tile and the T planes)
         float* st_lds = lds + p.stats_off;
         bool direct = false;
@@ -93,8 +112,9 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
             if (ss.amax >= F16X2_LIMIT) atomicOr(p.range_flag, 1u);
         }
     }
+    WT_MARK(2);
     // T planes [xi][b][tile][TS]: overlay the staged tile when there is a single output block, else live behind it
-    float* const tl = (NBLK == 1 ? lds : lds + (size_t)(g.multi ? TM + 1 : TM + 2 * W + 1) * S) + (size_t)grp * 8 * NTW * 36;
+    float* const tl = (NBLK == 1 ? lds : lds + (size_t)(g.multi ? TM + 1 : TM + 2 * W + 1) * S) + (size_t)grp * 8 * NTW * TS;
 
     // B^T rows: xi=0: d0 - d2, xi=1: d1 + d2, xi=2: d2 - d1, xi=3: d1 - d3   ->  R = d[ia] + sgn * d[ib]
     const int ia = xi == 0 ? 0 : xi == 2 ? 2 : 1;
@@ -122,10 +142,14 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
             for (int j = 0; j < 4; ++j) {
                 const int ww = 2 * tc - 1 + j;
                 off[mb][k][j] = (rok && ww >= 0 && ww < W) ? ((grow - 1 + ii - g.rs0) * W + ww) * S + khalf : zoff;
+#ifdef SBC_WX3_NOCONF_HACK   // timing experiment only (wrong results): every lane of a half reads one address -> no bank conflicts
+                off[mb][k][j] = (k * 4 + j) * S + khalf;
+#endif
             }
         }
     }
     __syncthreads();                                                  // staged tile visible
+    WT_MARK(3);
 
     for (int ph = grp; ph < PH; ph += NG) {
         f32x16 T[MB][NBP][2];
@@ -137,6 +161,7 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
         // ring of SETS statically indexed register sets over the sequence g = step * 4 + nu), so their L2 latency hides
         // behind the MFMAs and splits in between: three columns ahead with one output block per phase, one column
         // ahead with two (twice the MFMAs per column; 48 registers either way).
+                // (round 3, f16x2: rings of 3 / 4 sets with two blocks, 4 / 6 with one at three waves per SIMD: within 1-3 % either way)
         constexpr int SETS = (NBP == 1 && WPE < 4) ? 4 : 2, D = SETS - 1, NSEQ = MB * KG * 4;
         uint4 uB[SETS][NBP][NTERM];                                   // 8 x 16-bit fragments (bf16 terms or fp16)
         auto u_load = [&](int gq) {                                   // gq is a compile-time constant at every call
@@ -247,6 +272,7 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
             }
         }
 
+        WT_MARK(4);
         if (NBLK == 1) __syncthreads();           // all waves are done with the staged tile (T planes overlay it)
 #pragma unroll
         for (int q = 0; q < NBP; ++q) {
@@ -262,6 +288,7 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
                     for (int r = 0; r < 16; ++r) e[((r & 3) + 8 * (r >> 2)) * TS] = tv[r];
                 }
             __syncthreads();
+            WT_MARK(5);
             // finish: one (tile, channel quad) per thread and round
             float4 yk[4];                                                 // this thread's four outputs (SBC_EPI_MOMENTS_OUT)
 #pragma unroll
@@ -421,6 +448,14 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
             if (q + 1 < NBP || ph + NG < PH) __syncthreads();
         }
     }
+#ifdef SBC_WX3_TIMING
+    WT_MARK(6);
+    if (tid == 0 && p.up && !(p.flags & SBC_EPI_UP)) {
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(const_cast<float*>(p.up)) + (size_t)blockIdx.x * 8;
+        for (int k = 0; k < 7; ++k) d[k] = wt[k];
+        d[7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ dispatch
@@ -439,7 +474,7 @@ static int launch_wx3(const ConvParams& p, hipStream_t stream, bool dry) {
     constexpr int NGMAX = ((NBLK == 4 || NBLK == 2) && MB == 1) ? 2 : 1;
     const int ntiles = (p.total_px + TM - 1) / TM;
     const int ng = (NGMAX == 2 && ntiles <= (NBLK == 4 ? 512 : 256)) ? 2 : 1;
-    const size_t tplanes = (size_t)8 * 32 * MB * 36 * sizeof(float) * ng;
+    const size_t tplanes = (size_t)8 * 32 * MB * WX3_TS * sizeof(float) * ng;
     const size_t lds = NBLK == 1 ? max(staged, tplanes) : staged + tplanes;
     // + the statistics of the samples of a tile: [samples][3][CIN] floats
     const size_t nsamp = multi ? TM / HW : 1;
@@ -450,7 +485,7 @@ static int launch_wx3(const ConvParams& p, hipStream_t stream, bool dry) {
     // registers with a one-column ring measured 4 % faster per launch, but only with the packed-fp32 instructions the build
     // no longer allows -- see the Makefile; without them that variant spills.)
     // (the two-term fp16 mode needs fewer registers -- no middle term, a two-set filter ring -- and fits four waves: 126 VGPRs)
-    constexpr int WPE = (CIN == 32 && COUT == 32 && MB == 1) ? (F16 == 2 ? 4 : 3) : 2;
+        constexpr int WPE = (CIN == 32 && COUT == 32 && MB == 1) ? (F16 == 2 ? 4 : 3) : 2;
     constexpr int NBP_BIG = NBLK == 2 ? 2 : 1;
     const bool top = (CIN == 32 && COUT == 32) && p.top;
     auto kern = ng == 2 ? conv_wx3_kernel<CIN, COUT, MB, true, 2, false, (NBLK == 4 ? 2 : 1), NGMAX, F16>
@@ -494,6 +529,9 @@ static int launch_wx3_sized(const ConvParams& p, hipStream_t stream, bool dry) {
 int launch_conv_wx3(const ConvParams& p, int cin, int cout, hipStream_t stream, bool dry) {
     // power-of-two images with even sides only (every level the score network produces for Nt, Nr in {16, 64, 256})
     if (p.dil != 1 || p.hsh < 1 || p.wsh < 1) return 1;
+#ifdef SBC_WITH_WSP
+    { const int rc = launch_conv_wsp(p, cin, cout, stream, dry); if (rc <= 0) return rc; }
+#endif
     const int key = cin * 1000 + cout;
     switch (key) {
         case 32 * 1000 + 32: return launch_wx3_sized<32, 32>(p, stream, dry);

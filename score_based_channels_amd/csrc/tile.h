@@ -336,8 +336,8 @@ __device__ __forceinline__ float4 xor16_4(float4 v) { return make_float4(xor16(v
 
 // Producer side, 256 threads, 32 channels: thread (tid >> 3, tid & 7) holds four pixels of channel quad tid & 7 (any four:
 // together the threads cover the tile's 128 pixels once).  `red`: LDS scratch of 8 * 8 * 8 floats that nobody else touches;
-// `pm_tile`: this tile's [32][2] output.  Contains one workgroup barrier.
-__device__ __forceinline__ void tile_moments_out32(const float4 (&v)[4], float* red, float* __restrict__ pm_tile, int tid) {
+// `pm_tile`: this tile's [32][2] output.  Contains one workgroup barrier (conv_wsp.hip calls the two halves around its own).
+__device__ __forceinline__ void tile_moments_partials32(const float4 (&v)[4], float* red, int tid) {
     float4 mean, m2;
     mean.x = ((v[0].x + v[1].x) + (v[2].x + v[3].x)) * 0.25f; mean.y = ((v[0].y + v[1].y) + (v[2].y + v[3].y)) * 0.25f;
     mean.z = ((v[0].z + v[1].z) + (v[2].z + v[3].z)) * 0.25f; mean.w = ((v[0].w + v[1].w) + (v[2].w + v[3].w)) * 0.25f;
@@ -357,19 +357,24 @@ __device__ __forceinline__ void tile_moments_out32(const float4 (&v)[4], float* 
         *reinterpret_cast<float4*>(red + (part * 8 + (lane & 7)) * 8) = mean;
         *reinterpret_cast<float4*>(red + (part * 8 + (lane & 7)) * 8 + 4) = m2;
     }
+}
+// second half, for tid < 32 (one channel each) after a barrier: the eight partials (16 pixels each) in order
+__device__ __forceinline__ void tile_moments_merge32(const float* red, float* __restrict__ pm_tile, int tid) {
+    const int c4 = tid >> 2, k = tid & 3;
+    // equal counts: mean of the means, and M2 = sum M2_w + 16 sum (mean_w - mean)^2 (fixed order, no dependent chain)
+    float mw[8], mu = 0.f, q = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { mw[w] = red[(w * 8 + c4) * 8 + k]; mu += mw[w]; q += red[(w * 8 + c4) * 8 + 4 + k]; }
+    mu *= 0.125f;
+    float dd = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { const float d = mw[w] - mu; dd = fmaf(d, d, dd); }
+    *reinterpret_cast<float2*>(pm_tile + tid * 2) = make_float2(mu, fmaf(16.f, dd, q));
+}
+__device__ __forceinline__ void tile_moments_out32(const float4 (&v)[4], float* red, float* __restrict__ pm_tile, int tid) {
+    tile_moments_partials32(v, red, tid);
     __syncthreads();
-    if (tid < 32) {                                   // one channel each: the eight partials (16 pixels each) in order
-        const int c4 = tid >> 2, k = tid & 3;
-        // equal counts: mean of the means, and M2 = sum M2_w + 16 sum (mean_w - mean)^2 (fixed order, no dependent chain)
-        float mw[8], mu = 0.f, q = 0.f;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) { mw[w] = red[(w * 8 + c4) * 8 + k]; mu += mw[w]; q += red[(w * 8 + c4) * 8 + 4 + k]; }
-        mu *= 0.125f;
-        float dd = 0.f;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) { const float d = mw[w] - mu; dd = fmaf(d, d, dd); }
-        *reinterpret_cast<float2*>(pm_tile + tid * 2) = make_float2(mu, fmaf(16.f, dd, q));
-    }
+    if (tid < 32) tile_moments_merge32(red, pm_tile, tid);
 }
 
 // host side: log2 of a power of two, or -1
