@@ -142,9 +142,6 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
             for (int j = 0; j < 4; ++j) {
                 const int ww = 2 * tc - 1 + j;
                 off[mb][k][j] = (rok && ww >= 0 && ww < W) ? ((grow - 1 + ii - g.rs0) * W + ww) * S + khalf : zoff;
-#ifdef SBC_WX3_NOCONF_HACK   // timing experiment only (wrong results): every lane of a half reads one address -> no bank conflicts
-                off[mb][k][j] = (k * 4 + j) * S + khalf;
-#endif
             }
         }
     }

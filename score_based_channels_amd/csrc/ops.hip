@@ -403,7 +403,6 @@ __global__ __launch_bounds__(256) void end_conv_kernel(const float* __restrict__
     const int tid = threadIdx.x;
     const Dims<false> d{H, W, H * W, 0, 0};
     const TileGeom g = tile_geom(blockIdx.x, TM, B, d, 1);
-    float* wl = lds + (size_t)(g.nps + 1) * S;          // [9][CIN][2]
     if (!g.multi) {
         // one sample per tile: the thread's (mu, scale, shift) in registers instead of three loads per staged chunk
         float4 pf[9];
@@ -413,28 +412,34 @@ __global__ __launch_bounds__(256) void end_conv_kernel(const float* __restrict__
     } else {
         stage_tile<CIN, 256, 9, false>(lds, in, stats, SBC_PRO_NORM | SBC_PRO_ELU, g, d, tid);
     }
-    for (int i = tid; i < 9 * CIN * 2; i += 256) {
-        const int o = i & 1, c = (i >> 1) % CIN, tap = i / (2 * CIN);
-        wl[i] = w[(o * CIN + c) * 9 + tap];             // torch [2][CIN][3][3]
-    }
     __syncthreads();
     const int px = g.p0 + tid;
     if (px >= B * H * W) return;
     const int row = px / W, wq = px - row * W, h = row % H;
-    float a0 = 0.f, a1 = 0.f;
-#pragma unroll 1
+    // LDS offsets of the nine taps of this pixel (the zero pixel for taps outside the image)
+    int toff[9];
+#pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int hh = h + tap / 3 - 1, ww = wq + tap % 3 - 1;
         const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
-        const float* a = lds + (ok ? (row + tap / 3 - 1 - g.rs0) * W + ww : g.nps) * S;
-        const float* wt = wl + tap * CIN * 2;
+        toff[tap] = (ok ? (row + tap / 3 - 1 - g.rs0) * W + ww : g.nps) * S;
+    }
+    // The weights never enter LDS or vector registers: every index below is uniform, so the 72 weights of a channel quad
+    // (torch [2][CIN][3][3]: the nine taps of a channel are contiguous) arrive by scalar loads and feed the FMAs as SGPR
+    // operands.  (Round 2 kept them in LDS as [tap][c][2]: 16 broadcast ds_read_b128 per tap beside the 8 that fetch the
+    // activations -- two thirds of the kernel's LDS instructions.)
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll 1
+    for (int cb = 0; cb < CIN; cb += 4) {
+        const float* w0 = w + cb * 9;                   // output 0, channels cb .. cb + 3
+        const float* w1 = w + (CIN + cb) * 9;           // output 1
 #pragma unroll
-        for (int c = 0; c < CIN; c += 4) {
-            const float4 v = *reinterpret_cast<const float4*>(a + c);
-            a0 = fmaf(v.x, wt[2 * c + 0], a0); a1 = fmaf(v.x, wt[2 * c + 1], a1);
-            a0 = fmaf(v.y, wt[2 * c + 2], a0); a1 = fmaf(v.y, wt[2 * c + 3], a1);
-            a0 = fmaf(v.z, wt[2 * c + 4], a0); a1 = fmaf(v.z, wt[2 * c + 5], a1);
-            a0 = fmaf(v.w, wt[2 * c + 6], a0); a1 = fmaf(v.w, wt[2 * c + 7], a1);
+        for (int tap = 0; tap < 9; ++tap) {
+            const float4 v = *reinterpret_cast<const float4*>(lds + toff[tap] + cb);
+            a0 = fmaf(v.x, w0[tap], a0);      a1 = fmaf(v.x, w1[tap], a1);
+            a0 = fmaf(v.y, w0[9 + tap], a0);  a1 = fmaf(v.y, w1[9 + tap], a1);
+            a0 = fmaf(v.z, w0[18 + tap], a0); a1 = fmaf(v.z, w1[18 + tap], a1);
+            a0 = fmaf(v.w, w0[27 + tap], a0); a1 = fmaf(v.w, w1[27 + tap], a1);
         }
     }
     const int n = px / (H * W);
@@ -453,7 +458,7 @@ int launch_end_conv(const sbc_op& op, const sbc_endconv& e, hipStream_t stream, 
     SBC_REQUIRE(TM % op.W == 0 && (HW % TM == 0 || TM % HW == 0), "end_conv: image %dx%d does not tile", op.H, op.W);
     const int total = op.B * HW;
     const int halo_px = TM >= HW ? 0 : 2 * op.W;
-    const size_t lds = ((size_t)(TM + halo_px + 1) * (op.cin + 4) + 9 * op.cin * 2) * sizeof(float);
+    const size_t lds = (size_t)(TM + halo_px + 1) * (op.cin + 4) * sizeof(float);
     SBC_REQUIRE(lds <= 160 * 1024, "end_conv: tile needs %zu bytes of LDS", lds);
     SBC_REQUIRE(op.cin == 32, "end_conv: %d input channels (only ngf = 32)", op.cin);
     { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(end_conv_kernel<32>), lds); if (rc) return rc; }

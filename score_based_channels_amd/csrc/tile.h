@@ -41,8 +41,9 @@ struct StageScale { float scale; float amax; };          // (scale: reserved, 1)
 constexpr float F16X2_LIMIT = 16000.f;                   // 65504 / 4, rounded down
 __device__ __forceinline__ void scale_track(const float4& x, StageScale* ss) {
     if (!ss) return;
-    ss->amax = __builtin_fmaxf(ss->amax, __builtin_fmaxf(__builtin_fabsf(x.x), __builtin_fabsf(x.y)));
-    ss->amax = __builtin_fmaxf(ss->amax, __builtin_fmaxf(__builtin_fabsf(x.z), __builtin_fabsf(x.w)));
+    // (max(max(a, |x|), |y|): the shape hipcc turns into one v_max3_f32 with |.| source modifiers)
+    ss->amax = __builtin_fmaxf(__builtin_fmaxf(ss->amax, __builtin_fabsf(x.x)), __builtin_fabsf(x.y));
+    ss->amax = __builtin_fmaxf(__builtin_fmaxf(ss->amax, __builtin_fabsf(x.z)), __builtin_fabsf(x.w));
 }
 
 // Image dimensions with the divisions the kernels need.  P2 = true: H and W are powers of two (every shape the

@@ -219,5 +219,7 @@ def test_data_parallel_training_is_the_same_optimisation(tmp_path):
     v1, v2 = np.array(runs[1]['val_loss']), np.array(runs[2]['val_loss'])
     assert np.max(np.abs(v2 / v1 - 1)) < 1e-4
     diff = torch.cat([(runs[1]['model_state'][k] - runs[2]['model_state'][k]).abs().flatten() for k in runs[1]['model_state']])
-    # 12 steps of at most lr = 1e-4 each; elements with |g| ~ eps amplify the rounding of the gradient sum by lr / eps
-    assert float(diff.max()) < 1e-4 and float(diff.median()) < 1e-7, (float(diff.max()), float(diff.median()))
+    # 12 steps of at most lr = 1e-4 each; elements with |g| ~ eps amplify the rounding of the gradient sum by lr / eps.  (The
+    # median moves with the seed and with any rounding-level change of a kernel: seeds 9-11 on two builds gave 0 ... 1.8e-7, and two
+    # single-rank runs of builds that differ in one summation order differ by 2.8e-8 / 2.3e-5 themselves.)
+    assert float(diff.max()) < 1e-4 and float(diff.median()) < 5e-7, (float(diff.max()), float(diff.median()))
