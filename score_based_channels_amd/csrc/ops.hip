@@ -33,13 +33,16 @@ __global__ __launch_bounds__(256) void begin_conv_kernel(const float* __restrict
         }
         hs[i] = v;
     }
-    float4 wr[18];                                               // [ci*9 + kh*3 + kw] for channels c4*4 .. c4*4+3
-#pragma unroll
-    for (int k = 0; k < 18; ++k)                                 // torch order [co][ci][kh][kw]
-        wr[k] = make_float4(w[(c4 * 4 + 0) * 18 + k], w[(c4 * 4 + 1) * 18 + k], w[(c4 * 4 + 2) * 18 + k],
-                            w[(c4 * 4 + 3) * 18 + k]);
+    // the 576 weights through LDS, transposed to [tap][co] (torch order [co][ci][kh][kw]): three coalesced loads per thread
+    // and 18 ds_read_b128 instead of 72 scattered global loads per thread -- with one 128-pixel tile per workgroup those
+    // loads, not the 223 MB the launch writes, set its time (82 us; the vector-memory address unit, 288 wave-loads per tile)
+    __shared__ __attribute__((aligned(16))) float wl[18 * COUT];
+    for (int i = tid; i < 18 * COUT; i += 256) wl[(i % 18) * COUT + i / 18] = w[i];
     const float4 b4 = *reinterpret_cast<const float4*>(bias + c4 * 4);
     __syncthreads();
+    float4 wr[18];                                               // [ci*9 + kh*3 + kw] for channels c4*4 .. c4*4+3
+#pragma unroll
+    for (int k = 0; k < 18; ++k) wr[k] = *reinterpret_cast<const float4*>(wl + k * COUT + c4 * 4);
     const int npx = rows_per_wg * W;
     float* obase = out + ((size_t)n * H + r0) * W * COUT + c4 * 4;
     auto pixel = [&](int lp) {
@@ -500,9 +503,16 @@ __global__ __launch_bounds__(256) void langevin_kernel(sbc_langevin a, int B, in
     const float2* Y = reinterpret_cast<const float2*>(a.Y) + (size_t)b * Np * Nr;
     const float2* Ht = reinterpret_cast<const float2*>(a.Htrue) + (size_t)(a.h_index ? a.h_index[b] : b) * Nt * Nr;
     const float2* Sc = reinterpret_cast<const float2*>(a.score) + (size_t)b * Nt * Nr;
+    // rows of P in LDS are Nt + 2 long: the first product reads pm[t] of four pilots m per wave, and Nt = 64 complex numbers are
+    // a whole number of bank rows (all four on one bank, a 4-way conflict on every read)
+    const int PS = p_in_lds ? Nt + 2 : Nt;
     if (p_in_lds) {
-        const float4* src = reinterpret_cast<const float4*>(P);          // Np*Nt is even: 16-byte copies
-        for (int e = tid; e < Np * Nt / 2; e += 256) reinterpret_cast<float4*>(Pl)[e] = src[e];
+        const float4* src = reinterpret_cast<const float4*>(P);          // Nt is even: 16-byte copies that stay inside a row
+        const int h = Nt / 2;
+        for (int e = tid; e < Np * h; e += 256) {
+            const int m = e / h, j = e - m * h;
+            reinterpret_cast<float4*>(Pl + (size_t)m * PS)[j] = src[e];
+        }
     }
     if (x_in_lds) {
         for (int e = tid; e < Nt * Nr; e += 256) Xl[e] = X[e];
@@ -510,13 +520,35 @@ __global__ __launch_bounds__(256) void langevin_kernel(sbc_langevin a, int B, in
     if (x_in_lds || p_in_lds) __syncthreads();
     const float2* Xs = x_in_lds ? Xl : X;
     if (p_in_lds) P = Pl;
-    for (int o = tid; o < Np * Nr; o += 256) {
-        const int m = o / Nr, r = o - m * Nr;
-        float2 acc = make_float2(0.f, 0.f);
-        const float2* pm = P + (size_t)m * Nt;
-        for (int t = 0; t < Nt; ++t) acc = cfma(pm[t], Xs[t * Nr + r], acc);
-        const float2 y = Y[o];
-        Rs[o] = make_float2(acc.x - y.x, acc.y - y.y);
+    if ((Nr & 3) == 0) {
+        // four adjacent receive antennas per thread: one pilot value and two 16-byte reads of X feed four independent chains
+        // (one output per thread was two 8-byte LDS reads per complex FMA and a single dependent chain of 4 Nt FMAs)
+        for (int o = tid * 4; o < Np * Nr; o += 1024) {
+            const int m = o / Nr, r = o - m * Nr;
+            float2 c0 = make_float2(0.f, 0.f), c1 = c0, c2 = c0, c3 = c0;
+            const float2* pm = P + (size_t)m * PS;
+            for (int t = 0; t < Nt; ++t) {
+                const float2 pv = pm[t];
+                const float4 xa = *reinterpret_cast<const float4*>(Xs + t * Nr + r);
+                const float4 xb = *reinterpret_cast<const float4*>(Xs + t * Nr + r + 2);
+                c0 = cfma(pv, make_float2(xa.x, xa.y), c0);
+                c1 = cfma(pv, make_float2(xa.z, xa.w), c1);
+                c2 = cfma(pv, make_float2(xb.x, xb.y), c2);
+                c3 = cfma(pv, make_float2(xb.z, xb.w), c3);
+            }
+            const float4 ya = *reinterpret_cast<const float4*>(Y + o), yb = *reinterpret_cast<const float4*>(Y + o + 2);
+            *reinterpret_cast<float4*>(Rs + o) = make_float4(c0.x - ya.x, c0.y - ya.y, c1.x - ya.z, c1.y - ya.w);
+            *reinterpret_cast<float4*>(Rs + o + 2) = make_float4(c2.x - yb.x, c2.y - yb.y, c3.x - yb.z, c3.y - yb.w);
+        }
+    } else {
+        for (int o = tid; o < Np * Nr; o += 256) {
+            const int m = o / Nr, r = o - m * Nr;
+            float2 acc = make_float2(0.f, 0.f);
+            const float2* pm = P + (size_t)m * PS;
+            for (int t = 0; t < Nt; ++t) acc = cfma(pm[t], Xs[t * Nr + r], acc);
+            const float2 y = Y[o];
+            Rs[o] = make_float2(acc.x - y.x, acc.y - y.y);
+        }
     }
     __syncthreads();
     const float* sc = a.sched + ((size_t)(a.group ? a.group[b] : 0) * a.n_steps + step) * 4;
@@ -530,9 +562,10 @@ __global__ __launch_bounds__(256) void langevin_kernel(sbc_langevin a, int B, in
         const int e = 2 * q, t = e / Nr, r = e - t * Nr;
         float2 g0 = make_float2(0.f, 0.f), g1 = make_float2(0.f, 0.f);
         for (int m = 0; m < Np; ++m) {
-            const float2 pv = P[(size_t)m * Nt + t];
-            g0 = cfma_conj(pv, Rs[m * Nr + r], g0);
-            g1 = cfma_conj(pv, Rs[m * Nr + r + 1], g1);
+            const float2 pv = P[(size_t)m * PS + t];
+            const float4 rr = *reinterpret_cast<const float4*>(Rs + m * Nr + r);      // (r even: 16-byte aligned)
+            g0 = cfma_conj(pv, make_float2(rr.x, rr.y), g0);
+            g1 = cfma_conj(pv, make_float2(rr.z, rr.w), g1);
         }
         const float4 s = reinterpret_cast<const float4*>(Sc)[q], x = reinterpret_cast<const float4*>(Xs)[q];
         const float4 h = reinterpret_cast<const float4*>(Ht)[q];
@@ -699,8 +732,8 @@ int launch_langevin(const sbc_op& op, const sbc_langevin& a, hipStream_t stream,
     if (rc) return rc;
     const size_t lds_all = (size_t)(a.Nt + a.Np) * a.Nr * sizeof(float2);
     const int x_in_lds = lds_all <= 64 * 1024;
-    const size_t lds_p = (size_t)a.Np * a.Nt * sizeof(float2);
-    const int p_in_lds = x_in_lds && (a.Np * a.Nt) % 2 == 0 && lds_all + lds_p <= 40 * 1024;   // keeps 4 workgroups per CU
+    const size_t lds_p = (size_t)a.Np * (a.Nt + 2) * sizeof(float2);                          // padded rows (langevin_kernel)
+    const int p_in_lds = x_in_lds && a.Nt % 2 == 0 && lds_all + lds_p <= 40 * 1024;            // keeps 4 workgroups per CU
     const size_t lds = (x_in_lds ? lds_all : (size_t)a.Np * a.Nr * sizeof(float2)) + (p_in_lds ? lds_p : 0);
     if (!x_in_lds && 512 % a.Nr == 0) {
         // large arrays: register-blocked, K-chunked products (langevin_tiled_kernel)
