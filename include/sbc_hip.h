@@ -75,6 +75,11 @@ typedef enum sbc_op_kind {
 /* sbc_op.flags for SBC_OP_CONV / SBC_OP_MAXPOOL5 */
 #define SBC_PRO_ELU      0x001  /* apply ELU to the input while staging it                                  */
 #define SBC_PRO_NORM     0x002  /* apply (x - mu) * scale + shift from `stats` first (InstanceNorm++)       */
+#define SBC_PRO_NORM_SELF 0x004 /* with SBC_PRO_NORM, 3x3 convolutions on the matrix-core kernels (weight_split set), images of at most 64
+                                   pixels (H*W a power of two): the launch computes the InstanceNorm++ statistics of its input
+                                   ITSELF -- a workgroup's tile holds whole samples there -- and `stats` points at the norm's
+                                   parameters [3][cin] = (alpha | gamma | beta) instead of at the output of an
+                                   SBC_OP_INORM_STATS launch, which then does not exist (normalization.py:163-176)          */
 #define SBC_EPI_RES1_ELU 0x010  /* ELU the res1 operand before adding (CRP: x = act(x))                    */
 #define SBC_EPI_POOL     0x020  /* 2x2 mean pool of (conv + bias), then + res1 (ConvMeanPool)               */
 #define SBC_EPI_UP       0x040  /* + bilinear(align_corners) resize of `up` [B][up_h][up_w][cout] (MSF)     */

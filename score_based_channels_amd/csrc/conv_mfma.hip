@@ -265,6 +265,13 @@ int launch_conv(const sbc_op& op, hipStream_t stream, bool dry) {
                     "tiles per sample and an unpooled output");
     }
     SBC_REQUIRE(!(op.flags & SBC_PRO_NORM_MOMENTS), "conv: SBC_PRO_NORM_MOMENTS belongs to SBC_OP_INORM_STATS (statistics from tile moments)");
+    if (op.flags & SBC_PRO_NORM_SELF) {
+        const int hw = op.H * op.W;
+        SBC_REQUIRE((op.flags & SBC_PRO_NORM) && (x3 || (op.weight_wino_split && !f32_only)) && op.ksize == 3 && hw <= 64 && !(hw & (hw - 1)) && p.hsh >= 0 && p.wsh >= 1 &&
+                    !(op.flags & SBC_EPI_ELUGRAD),
+                    "conv: SBC_PRO_NORM_SELF needs SBC_PRO_NORM, a matrix-core weight form (weight_split), a 3x3 kernel and a "
+                    "power-of-two image of at most 64 pixels (got %dx%d, ksize %d)", op.H, op.W, op.ksize);
+    }
     static const bool no_wx3 = getenv("SBC_NO_WX3") != nullptr;                    // A/B aid: direct split-bf16 kernel everywhere
     const bool direct_only = (op.flags & SBC_EPI_ELUGRAD) != 0;       // the fp32 Winograd kernel's epilogue does not know the flag
     if (op.weight_wino_split && !f32_only && !no_wx3 && op.ksize == 3 && op.dil == 1) {
@@ -282,6 +289,8 @@ int launch_conv(const sbc_op& op, hipStream_t stream, bool dry) {
         p.wpk = (const float4*)op.weight_split;
         return launch_conv_x3(p, op.cin, op.cout, op.ksize, stream, dry);
     }
+    SBC_REQUIRE(!(op.flags & SBC_PRO_NORM_SELF), "conv: SBC_PRO_NORM_SELF: no matrix-core kernel takes this layer (%dx%d, %d -> %d, dilation %d)",
+                op.H, op.W, op.cin, op.cout, op.dil);
     static const bool no_wino = getenv("SBC_NO_WINO") != nullptr;                  // A/B aid
     if (op.weight_wino && op.ksize == 3 && op.dil == 1 && !no_wino && !direct_only) {
         ConvParams pw = p;

@@ -103,6 +103,9 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
             const RegStats rs = load_reg_stats<CIN, NTHREADS>(p.stats, g, tid);
             stage_commit_reg<CIN, NTHREADS, NPF>(lds, pf, p.in, rs, p.flags, g, W, tid, ssp);
             direct = true;
+        } else if (p.flags & SBC_PRO_NORM_SELF) {
+            // whole samples per tile: the statistics are computed here, `stats` = the norm's parameters (tile.h; ends in a barrier)
+            self_stats_to_lds<CIN, NTHREADS, TM, P2>(st_lds, p.in, p.stats, g, dm, tid);
         } else if (p.flags & SBC_PRO_NORM) {
             stage_stats_to_lds<CIN, NTHREADS, P2>(st_lds, p.stats, g, dm, tid);
             __syncthreads();
@@ -476,7 +479,8 @@ static int launch_wx3(const ConvParams& p, hipStream_t stream, bool dry) {
     // + the statistics of the samples of a tile: [samples][3][CIN] floats
     const size_t nsamp = multi ? TM / HW : 1;
     const size_t stats_off = lds / sizeof(float);
-    const size_t lds_all = lds + ((p.flags & SBC_PRO_NORM) ? nsamp * 3 * CIN * sizeof(float) : 0);
+    SBC_REQUIRE(!(p.flags & SBC_PRO_NORM_SELF) || multi, "conv_wx3: SBC_PRO_NORM_SELF needs tiles of whole samples (H*W <= %d)", TM);
+    const size_t lds_all = lds + ((p.flags & SBC_PRO_NORM) ? nsamp * (3 * CIN + 2) * sizeof(float) : 0);
     if (lds_all > 160 * 1024) return 1;
     // 32 -> 32 with 128-pixel tiles: three waves per SIMD (168 registers), filter ring three columns deep.  (Four waves at 128
     // registers with a one-column ring measured 4 % faster per launch, but only with the packed-fp32 instructions the build

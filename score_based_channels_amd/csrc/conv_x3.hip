@@ -50,15 +50,24 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_x3_kernel(ConvParams p) {
 
     const TileGeom g = tile_geom(blockIdx.x, TM, p.B, dm, KS == 3 ? p.dil : 0);
     float descale = 1.f;
+    const float* stats = p.stats;
+    int n0 = -1;
+    if (p.flags & SBC_PRO_NORM_SELF) {
+        // whole samples per tile: the statistics are computed here, into LDS behind the planes / the epilogue tile (tile.h)
+        float* st = lds + p.stats_off;
+        self_stats_to_lds<CIN, NTHREADS, TM, P2>(st, p.in, p.stats, g, dm, tid);
+        stats = st;
+        n0 = 0;
+    }
     if constexpr (TERMS == 2) {
         // conv_mode f16x2: scaled activations as two fp16 terms; the scales ride behind the packed weight (conv_common.h)
         const float4 tr = f16x2_trailer(p.wpk, TAPS * KG * NBLK * TERMS);
         StageScale ss{tr.x, 0.f};
         descale = tr.y;
-        stage_tile_split<CIN, NTHREADS, NPF, P2, TERMS>(lds16, plane, p.in, p.stats, p.flags, g, dm, tid, &ss);
+        stage_tile_split<CIN, NTHREADS, NPF, P2, TERMS>(lds16, plane, p.in, stats, p.flags, g, dm, tid, &ss, n0);
         if (ss.amax >= F16X2_LIMIT) atomicOr(p.range_flag, 1u);
     } else {
-        stage_tile_split<CIN, NTHREADS, NPF, P2, TERMS>(lds16, plane, p.in, p.stats, p.flags, g, dm, tid);
+        stage_tile_split<CIN, NTHREADS, NPF, P2, TERMS>(lds16, plane, p.in, stats, p.flags, g, dm, tid, nullptr, n0);
     }
 
     // per 32-pixel block: this lane's LDS base offset and the 9-bit mask of taps inside the image (conv_mfma.hip)
@@ -256,7 +265,14 @@ static size_t x3_lds_bytes(const ConvParams& p, int* plane_out) {
 template <int CIN, int COUT, int KS, int MT, int NT, int WM, int WN, bool P2, int TERMS>
 static int launch_kernel(ConvParams p, hipStream_t stream, bool dry) {
     constexpr int TM = 32 * MT * WM;
-    const size_t lds = x3_lds_bytes<CIN, COUT, KS, MT, NT, WM, WN, TERMS>(p, &p.plane);
+    size_t lds = x3_lds_bytes<CIN, COUT, KS, MT, NT, WM, WN, TERMS>(p, &p.plane);
+    if (p.flags & SBC_PRO_NORM_SELF) {
+        const int HW = p.H * p.W;
+        SBC_REQUIRE(TM % HW == 0, "conv: SBC_PRO_NORM_SELF needs tiles of whole samples (H*W = %d, tile %d)", HW, TM);
+        lds = (lds + 15) / 16 * 16;
+        p.stats_off = (int)(lds / sizeof(float));
+        lds += (size_t)(TM / HW) * (3 * CIN + 2) * sizeof(float);
+    }
     SBC_REQUIRE(lds <= 160 * 1024, "conv tile needs %zu bytes of LDS (> 160 KiB)", lds);
     auto kern = conv_x3_kernel<CIN, COUT, KS, MT, NT, WM, WN, P2, TERMS>;
     { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds); if (rc) return rc; }

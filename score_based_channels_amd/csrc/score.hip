@@ -24,6 +24,7 @@ struct POp {
     int src = -1, dst = -1, stats = -1, res1 = -1, res2 = -1, up = -1;       // tensor indices
     int moments = -1;                // second output: tile moments of dst (SBC_EPI_MOMENTS_OUT)
     int geom = -1;                   // INORM_STATS from tile moments: the tensor whose (H, W, C) the launch describes
+    std::string norm_key;            // CONV with SBC_PRO_NORM_SELF: the norm whose (alpha | gamma | beta) `stats` points at (plan.py)
     std::string weight, bias, weight2;       // weight2: the second convolution of an SBC_OP_CONV_PAIR
 };
 
@@ -47,16 +48,23 @@ struct Builder {
         if (bias) o.bias = wkey + ".bias";
         o.stats = stats; o.res1 = res1; o.res2 = res2; o.up = up;
         o.flags = flags | (up >= 0 ? SBC_EPI_UP : 0); o.ksize = ksize; o.dil = dil;
+        if (stats == SELF_NORM) { o.stats = -1; o.norm_key = pending_norm; o.flags |= SBC_PRO_NORM_SELF; }   // plan.py: SelfNorm
         producer[dst] = (int)ops.size();
         o.tag = (ksize == 3 && sc == ngf && cout == ngf && sh == nt) ? 1 : 0;                 // plan.TAG_CONV_TOP
         if (ksize == 3 && dil == 1 && sc == 2 * ngf && cout == 2 * ngf && !pool && 2 * sh == nt) o.tag = 3;   // plan.TAG_CONV_MID
         ops.push_back(o);
         return dst;
     }
-    int stats(const std::string& name, int src, const std::string& nkey) {
+    static constexpr int SELF_NORM = -2;   // stats(): no statistics record, the consuming convolution computes them (plan.py: SelfNorm)
+    std::string pending_norm;
+    int stats(const std::string& name, int src, const std::string& nkey, bool consumer_is_conv = true) {
+        const int hw = t[src].h * t[src].w, sw = t[src].w;
+        if (fold_stats && consumer_is_conv && hw <= 64 && !(hw & (hw - 1)) && sw >= 2 && !(sw & (sw - 1))) {
+            pending_norm = nkey;
+            return SELF_NORM;
+        }
         const int dst = tensor(name, 1, 3, t[src].c);
         POp o; o.kind = SBC_OP_INORM_STATS; o.src = src; o.dst = dst; o.weight = nkey;
-        const int hw = t[src].h * t[src].w, sw = t[src].w;
         auto it = producer.find(src);
         if (fold_stats && it != producer.end() && t[src].c == ngf && ngf == 32 && t[src].h == nt && hw % 128 == 0 && hw >= 256 &&
             128 % (2 * sw) == 0 && t[src].h % (128 / sw > 0 ? 128 / sw : 1) == 0) {
@@ -234,7 +242,7 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
     const int ref3 = b.refine("refine3.", {layers[2], ref31}, 2 * ngf);
     const int ref4 = b.refine("refine4.", {layers[1], ref3}, ngf);
     const int ref5 = b.refine("refine5.", {layers[0], ref4}, ngf, true);
-    const int sn = b.stats("normalizer", ref5, "normalizer");
+    const int sn = b.stats("normalizer", ref5, "normalizer", false);
     const int o_t = b.tensor("score", nt, nr, d->channels);
     { POp o; o.kind = SBC_OP_END_CONV; o.src = ref5; o.dst = o_t; o.weight = "end_conv.weight"; o.bias = "end_conv.bias"; o.stats = sn; b.ops.push_back(o); }
     s->tensors = b.t; s->pops = b.ops; s->x_t = x; s->out_t = o_t;
@@ -271,18 +279,18 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
     for (const POp& o : s->pops) {
         const Tn& src = s->tensors[o.geom >= 0 ? o.geom : o.src];
         const Tn& dst = s->tensors[o.dst];
-        if (o.kind == SBC_OP_INORM_STATS) {
-            if (off.count(o.weight)) continue;
+        const std::string& nkey = o.kind == SBC_OP_INORM_STATS ? o.weight : o.norm_key;
+        if (!nkey.empty() && !off.count(nkey)) {             // a norm's (alpha | gamma | beta), [3][C]
             for (int k = 0; k < 3; ++k) {
                 const char* suffix[3] = {".alpha", ".gamma", ".beta"};
-                const float* v = find(o.weight + suffix[k], src.c);
+                const float* v = find(nkey + suffix[k], src.c);
                 if (!v) return fail();
-                if (k == 0) reserve(o.weight, 3 * (size_t)src.c);
+                if (k == 0) reserve(nkey, 3 * (size_t)src.c);
                 v = rounded(v, src.c);
-                memcpy(host.data() + off[o.weight] + (size_t)k * src.c, v, sizeof(float) * src.c);
+                memcpy(host.data() + off[nkey] + (size_t)k * src.c, v, sizeof(float) * src.c);
             }
-            continue;
         }
+        if (o.kind == SBC_OP_INORM_STATS) continue;
         if (o.weight.empty()) continue;                  // max pooling has no parameters
         const int k = o.ksize, cin = src.c, cout = dst.c;
         const size_t wn = (size_t)cout * cin * k * k;
@@ -371,6 +379,7 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
         }
         if (!o.bias.empty()) r.bias = wp(o.bias);
         if (o.stats >= 0) r.stats = s->slots[s->tensors[o.stats].slot];
+        if (!o.norm_key.empty()) r.stats = wp(o.norm_key);
         if (o.res1 >= 0) r.res1 = s->slots[s->tensors[o.res1].slot];
         if (o.res2 >= 0) r.res2 = s->slots[s->tensors[o.res2].slot];
         if (o.up >= 0) { r.up = s->slots[s->tensors[o.up].slot]; r.up_h = s->tensors[o.up].h; r.up_w = s->tensors[o.up].w; }

@@ -165,6 +165,90 @@ __device__ __forceinline__ void stage_commit(float* lds, const float4 (&pf)[NPF]
     for (int i = tid; i < S; i += NTHREADS) lds[g.nps * S + i] = 0.f;
 }
 
+// SBC_PRO_NORM_SELF: the InstanceNorm++ statistics of the tile's samples computed by the consumer itself, for tiles that hold
+// whole samples (the 16x4 and 8x2 levels of the score network: 64 / 16 pixels per sample).  A statistics launch there reads a
+// few MB and costs 9-13 us of pure launch latency on the critical path, 14 times per network evaluation; here the workgroup
+// reads its own samples once more (they are on their way to L2 anyway: stage_issue has requested them) and spends ~1 us.
+//   phase A: L adjacent lanes per (sample, channel quad) -- two passes over the sample's pixels (mean, then sum (x - mean)^2),
+//            lanes combined by shuffles;   phase B: one wave per sample: mean and unbiased variance of the channel means (the
+//            "++" term);   phase C: (mu, scale, shift) as ops.hip: inorm_stats_kernel defines them.
+// Every sum has a fixed order that depends only on (H*W, CIN, NTHREADS): results are independent of the batch and
+// reproducible.  st_lds: [samples][3][CIN] floats followed by 2 floats per sample of scratch.  All threads of the workgroup
+// call; three barriers, the last one behind the finished table.  `agb` = [3][CIN] (alpha | gamma | beta).
+template <int CIN, int NTHREADS, int TM, bool P2>
+__device__ __forceinline__ void self_stats_to_lds(float* st_lds, const float* __restrict__ in, const float* __restrict__ agb,
+                                                  const TileGeom& g, const Dims<P2>& d, int tid) {
+    constexpr int C4 = CIN / 4;
+    const int HW = d.HW;
+    const int ns = d.div_hw(g.nps);
+    const int pairs = ns * C4;
+    // lanes per (sample, quad): from the FULL tile's sample count, so that a sample is summed the same way in a ragged last tile
+    int L = 1;
+    while (L < 8 && d.div_hw(TM) * C4 * (2 * L) <= NTHREADS && 2 * L <= HW) L *= 2;
+    const int l = tid & (L - 1), pidx = tid / L;
+    const float* base = in + (size_t)g.rs0 * d.W * CIN;
+    const float inv_hw = 1.f / (float)HW;
+    float* tmp = st_lds + (size_t)ns * 3 * CIN;
+    for (int pr0 = 0; pr0 < pairs; pr0 += NTHREADS / L) {
+        const int pr = pr0 + pidx;
+        const bool act = pr < pairs;
+        const int s = act ? pr / C4 : 0, c4 = act ? pr % C4 : 0;
+        const float* q = base + ((size_t)s * HW + l) * CIN + c4 * 4;
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int px = l; px < HW; px += L) {
+            const float4 v = *reinterpret_cast<const float4*>(q + (size_t)(px - l) * CIN);
+            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        }
+        for (int m = 1; m < L; m <<= 1) {
+            sum.x += __shfl_xor(sum.x, m); sum.y += __shfl_xor(sum.y, m);
+            sum.z += __shfl_xor(sum.z, m); sum.w += __shfl_xor(sum.w, m);
+        }
+        const float4 mean = make_float4(sum.x * inv_hw, sum.y * inv_hw, sum.z * inv_hw, sum.w * inv_hw);
+        float4 m2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int px = l; px < HW; px += L) {
+            const float4 v = *reinterpret_cast<const float4*>(q + (size_t)(px - l) * CIN);
+            float t;
+            t = v.x - mean.x; m2.x = fmaf(t, t, m2.x); t = v.y - mean.y; m2.y = fmaf(t, t, m2.y);
+            t = v.z - mean.z; m2.z = fmaf(t, t, m2.z); t = v.w - mean.w; m2.w = fmaf(t, t, m2.w);
+        }
+        for (int m = 1; m < L; m <<= 1) {
+            m2.x += __shfl_xor(m2.x, m); m2.y += __shfl_xor(m2.y, m);
+            m2.z += __shfl_xor(m2.z, m); m2.w += __shfl_xor(m2.w, m);
+        }
+        if (act && l == 0) {
+            *reinterpret_cast<float4*>(st_lds + ((size_t)s * 3 + 0) * CIN + c4 * 4) = mean;
+            *reinterpret_cast<float4*>(st_lds + ((size_t)s * 3 + 1) * CIN + c4 * 4) =
+                make_float4(m2.x * inv_hw, m2.y * inv_hw, m2.z * inv_hw, m2.w * inv_hw);
+        }
+    }
+    __syncthreads();
+    {
+        const int lane = tid & 63;
+        for (int s = tid >> 6; s < ns; s += NTHREADS / 64) {
+            const float* mu = st_lds + (size_t)s * 3 * CIN;
+            float a = 0.f;
+            for (int c = lane; c < CIN; c += 64) a += mu[c];
+            for (int m = 1; m < 64; m <<= 1) a += __shfl_xor(a, m);
+            const float mm = a * (1.f / (float)CIN);
+            float b = 0.f;
+            for (int c = lane; c < CIN; c += 64) { const float t = mu[c] - mm; b = fmaf(t, t, b); }
+            for (int m = 1; m < 64; m <<= 1) b += __shfl_xor(b, m);
+            if (lane == 0) { tmp[2 * s] = mm; tmp[2 * s + 1] = b * (1.f / (float)(CIN - 1)); }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < ns * CIN; i += NTHREADS) {
+        const int s = i / CIN, c = i % CIN;
+        float* o = st_lds + (size_t)s * 3 * CIN;
+        const float mhat = (o[c] - tmp[2 * s]) / sqrtf(tmp[2 * s + 1] + 1e-5f);
+        const float rstd = 1.f / sqrtf(fmaxf(o[CIN + c], 0.f) + 1e-5f);
+        const float alpha = agb[c], gamma = agb[CIN + c], beta = agb[2 * CIN + c];
+        o[CIN + c] = gamma * rstd;
+        o[2 * CIN + c] = fmaf(gamma, mhat * alpha, beta);
+    }
+    __syncthreads();
+}
+
 // Statistics in registers: when a tile lies inside ONE sample (TM <= H*W) and NTHREADS is a multiple of CIN / 4, every
 // 16-byte chunk a thread stages belongs to the same channel quad of the same sample, so its (mu, scale, shift) are three
 // float4 loads per THREAD -- issued together with the tile loads -- and the copy of the statistics through LDS with its
@@ -247,12 +331,12 @@ __device__ __forceinline__ void split_f16x2(float a, float b, unsigned& h, unsig
 template <int CIN, bool P2, int TERMS = 3>
 __device__ __forceinline__ void stage_put_split(unsigned short* lds16, int plane, float4 x, int idx,
                                                 const float* __restrict__ stats, int flags, const TileGeom& g,
-                                                const Dims<P2>& d, StageScale* ss = nullptr) {
+                                                const Dims<P2>& d, StageScale* ss = nullptr, int n0 = -1) {
     constexpr int SH = CIN + 8;
     constexpr int C4 = CIN / 4;
     const int pix = idx / C4, c4 = idx % C4;
     if (flags & SBC_PRO_NORM) {
-        const int n = g.n_first + (g.multi ? d.div_hw(pix) : 0);
+        const int n = (n0 < 0 ? g.n_first : n0) + (g.multi ? d.div_hw(pix) : 0);   // n0 = 0: `stats` is the tile's own table
         const float* st = stats + (size_t)n * 3 * CIN + c4 * 4;
         const float4 mu = *reinterpret_cast<const float4*>(st);
         const float4 sc = *reinterpret_cast<const float4*>(st + CIN);
@@ -287,7 +371,7 @@ __device__ __forceinline__ void stage_put_split(unsigned short* lds16, int plane
 template <int CIN, int NTHREADS, int NPF, bool P2, int TERMS = 3>
 __device__ __forceinline__ void stage_tile_split(unsigned short* lds16, int plane, const float* __restrict__ in,
                                                  const float* __restrict__ stats, int flags, const TileGeom& g,
-                                                 const Dims<P2>& d, int tid, StageScale* ss = nullptr) {
+                                                 const Dims<P2>& d, int tid, StageScale* ss = nullptr, int n0 = -1) {
     constexpr int SH = CIN + 8;
     float4 pf[NPF];
     stage_issue<CIN, NTHREADS, NPF>(pf, in, g, d.W, tid);
@@ -295,11 +379,11 @@ __device__ __forceinline__ void stage_tile_split(unsigned short* lds16, int plan
 #pragma unroll
     for (int u = 0; u < NPF; ++u) {
         const int idx = u * NTHREADS + tid;
-        if (idx < total) stage_put_split<CIN, P2, TERMS>(lds16, plane, pf[u], idx, stats, flags, g, d, ss);
+        if (idx < total) stage_put_split<CIN, P2, TERMS>(lds16, plane, pf[u], idx, stats, flags, g, d, ss, n0);
     }
     const float* src = in + (size_t)g.rs0 * d.W * CIN;
     for (int idx = NPF * NTHREADS + tid; idx < total; idx += NTHREADS)
-        stage_put_split<CIN, P2, TERMS>(lds16, plane, ld_stream(src + (size_t)idx * 4), idx, stats, flags, g, d, ss);
+        stage_put_split<CIN, P2, TERMS>(lds16, plane, ld_stream(src + (size_t)idx * 4), idx, stats, flags, g, d, ss, n0);
     // the zero pixel of each plane (SH / 2 dwords each)
     for (int i = tid; i < TERMS * (SH / 2); i += NTHREADS)
         reinterpret_cast<unsigned*>(lds16 + (i / (SH / 2)) * plane + g.nps * SH)[i % (SH / 2)] = 0u;

@@ -25,7 +25,7 @@ from typing import List, Optional
 
 # op kinds / flags: numerically identical to include/sbc_hip.h
 BEGIN_CONV, INORM_STATS, CONV, MAXPOOL5, END_CONV, LANGEVIN, STEP_INC, MEASURE = 1, 2, 3, 4, 5, 6, 7, 8
-PRO_ELU, PRO_NORM = 0x001, 0x002
+PRO_ELU, PRO_NORM, PRO_NORM_SELF = 0x001, 0x002, 0x004
 PRO_NORM_MOMENTS, EPI_MOMENTS_OUT = 0x4000, 0x8000
 EPI_RES1_ELU, EPI_POOL, EPI_UP, EPI_ELUGRAD = 0x010, 0x020, 0x040, 0x080
 CONV_F16W = 0x100
@@ -40,6 +40,12 @@ BWD_ACCUM, PACK_ADJOINT, OP_SIDE, OP_JOIN, PACK_WINOGRAD = 0x200, 0x400, 0x800, 
 TAG_CONV_TOP = 1        # 3x3 convs ngf -> ngf at full resolution (also their own kernel symbol in csrc/conv_wx3.hip)
 TAG_PAIR_TOP = 2        # fused RCU blocks (CONV_PAIR) at full resolution
 TAG_CONV_MID = 3        # undilated 3x3 convs 2 ngf -> 2 ngf at half resolution (the 32x8 level of a 64x16 array)
+
+
+@dataclass
+class SelfNorm:
+    """What ``ScorePlan.stats`` returns instead of a statistics tensor when the consumer computes them itself (PRO_NORM_SELF)."""
+    key: str
 
 
 @dataclass
@@ -77,6 +83,7 @@ class Op:
     join: bool = False        # waits for every side record issued before it (SBC_OP_JOIN)
     moments: Optional[Tensor] = None    # second output: tile moments of dst (EPI_MOMENTS_OUT), [HW/128][C][2] per sample
     geom: Optional[Tensor] = None       # INORM_STATS from tile moments: the tensor whose (H, W, C) the launch describes
+    norm_key: Optional[str] = None      # CONV with PRO_NORM_SELF: state_dict prefix of the norm whose (alpha, gamma, beta) `stats` points at
 
     def inputs(self):
         return [t for t in (self.src, self.stats, self.res1, self.res2, self.up) if t is not None]
@@ -112,6 +119,9 @@ class _Builder:
     def conv(self, name, src, wkey, cout, *, bias=True, flags=0, stats=None, res1=None, res2=None, up=None,
              ksize=3, dil=1):
         pool = bool(flags & EPI_POOL)
+        norm_key = None
+        if isinstance(stats, SelfNorm):             # the launch computes the statistics of its input itself (PRO_NORM_SELF)
+            norm_key, stats, flags = stats.key, None, flags | PRO_NORM_SELF
         dst = self.t(name, src.h // 2 if pool else src.h, src.w // 2 if pool else src.w, cout)
         tag = TAG_CONV_TOP if (ksize == 3 and src.c == self.ngf and cout == self.ngf and src.h == self.nt) else 0
         if (ksize == 3 and dil == 1 and src.c == 2 * self.ngf and cout == 2 * self.ngf and not flags & EPI_POOL
@@ -120,7 +130,7 @@ class _Builder:
         self.ops.append(Op(CONV, name, src=src, dst=dst, weight=wkey + '.weight',
                            bias=(wkey + '.bias') if bias else None, stats=stats, res1=res1, res2=res2, up=up,
                            flags=flags | (EPI_UP if up is not None else 0), ksize=ksize, dil=dil, tag=tag,
-                           side=self.side_now))
+                           side=self.side_now, norm_key=norm_key))
         self.producer[id(dst)] = self.ops[-1]
         return dst
 
@@ -129,14 +139,19 @@ class _Builder:
         dominant kernel's per-launch time (the roofline entry of bench.py) stays the time it runs alone."""
         return self.overlap and t.h < self.nt
 
-    def stats(self, name, src, nkey):
-        """InstanceNorm++ statistics of ``src`` for the norm ``nkey``.  With ``fold_stats``, at full resolution and ngf
+    def stats(self, name, src, nkey, consumer_is_conv=True):
+        """InstanceNorm++ statistics of ``src`` for the norm ``nkey``.  With ``fold_stats``, for images of at most 64 pixels (the
+        16x4 and 8x2 levels of a 64x16 array) there is no statistics record at all: a workgroup of the consuming 3x3 convolution
+        holds whole samples and computes them itself (PRO_NORM_SELF; the return value is a ``SelfNorm`` marker that ``conv``
+        understands).  With ``fold_stats``, at full resolution and ngf
         channels, when ``src`` comes out of the begin convolution or an unpooled undilated 3x3 convolution: the producer also
         writes the moments of its 128-pixel tiles (EPI_MOMENTS_OUT) and the statistics record reads THOSE (PRO_NORM_MOMENTS:
         HW / 128 x C x 8 bytes per sample instead of the tensor); consumers see ordinary statistics either way."""
         prod = self.producer.get(id(src))
-        dst = self.t(name, 1, 3, src.c)
         hw = src.h * src.w
+        if self.fold_stats and consumer_is_conv and hw <= 64 and not hw & (hw - 1) and src.w >= 2 and not src.w & (src.w - 1):
+            return SelfNorm(nkey)
+        dst = self.t(name, 1, 3, src.c)
         if (self.fold_stats and prod is not None and src.c == self.ngf == 32 and src.h == self.nt and hw % 128 == 0 and hw >= 256
                 and 128 % (2 * src.w) == 0 and src.h % max(1, 128 // src.w) == 0
                 and (prod.kind == BEGIN_CONV or (prod.kind == CONV and prod.ksize == 3 and prod.dil == 1
@@ -262,7 +277,7 @@ def build_score_plan(ngf=32, nt=64, nr=16, channels=2, share_slots=True, overlap
     ref3 = b.refine('refine3.', [l3, ref31], 2 * ngf)
     ref4 = b.refine('refine4.', [l2, ref3], ngf)
     ref5 = b.refine('refine5.', [l1, ref4], ngf, end=True)
-    sn = b.stats('normalizer', ref5, 'normalizer')
+    sn = b.stats('normalizer', ref5, 'normalizer', consumer_is_conv=False)
     out = b.t('score', nt, nr, channels)
     b.ops.append(Op(END_CONV, 'end_conv', src=ref5, dst=out, weight='end_conv.weight', bias='end_conv.bias', stats=sn))
     plan = ScorePlan(b.ops, x, out, b.tensors)

@@ -234,6 +234,8 @@ class ScoreNet:
                 o.bias = _ptr(self._wdev, self._woff[op.bias])
             if op.stats is not None:
                 o.stats = _ptr(slots[op.stats.slot])
+            if op.norm_key is not None:                                 # PRO_NORM_SELF: the norm's (alpha | gamma | beta)
+                o.stats = _ptr(self._wdev, self._woff[op.norm_key])
             if op.moments is not None:
                 o.aux = _ptr(slots[op.moments.slot])
             if op.res1 is not None:

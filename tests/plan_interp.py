@@ -83,7 +83,11 @@ def exec_op(op, sd, get, labels):
         elif op.kind in (P.CONV, P.END_CONV):
             v = src
             flags = op.flags | ((P.PRO_NORM | P.PRO_ELU) if op.kind == P.END_CONV else 0)
-            if flags & P.PRO_NORM:
+            if flags & P.PRO_NORM_SELF:          # the consumer computes the statistics of its input itself
+                k = op.norm_key
+                st = inorm_stats(src, sd[k + '.alpha'], sd[k + '.gamma'], sd[k + '.beta'])
+                v = (v - st[:, None, None, 0]) * st[:, None, None, 1] + st[:, None, None, 2]
+            elif flags & P.PRO_NORM:
                 st = get(op.stats)[:, 0]
                 v = (v - st[:, None, None, 0]) * st[:, None, None, 1] + st[:, None, None, 2]
             if flags & P.PRO_ELU:

@@ -69,6 +69,18 @@ CONV_CASES = [
     (32, 32, 3, 1, 210, 64, 16, 'crp2'),
     (32, 32, 3, 1, 195, 64, 16, 'up_2x'),
     (32, 64, 3, 1, 200, 64, 16, 'norm_elu_pool_res'),
+    # SBC_PRO_NORM_SELF: the launch computes the InstanceNorm++ statistics of its own input (tiles of whole samples); `stats`
+    # carries the norm's parameters.  Winograd and direct kernels, one and two wave groups, pooled output, ragged last tile
+    (64, 64, 3, 1, 9, 16, 4, 'selfnorm_elu_res'),
+    (64, 64, 3, 1, 9, 16, 4, 'selfnorm_elu_pool_res'),
+    (64, 64, 3, 1, 21, 8, 2, 'selfnorm_elu_res'),
+    (64, 64, 3, 1, 5000, 8, 2, 'selfnorm_elu'),
+    (64, 64, 3, 2, 21, 8, 2, 'selfnorm_elu'),
+    (64, 128, 3, 2, 21, 8, 2, 'selfnorm_elu_res'),
+    (128, 128, 3, 4, 19, 8, 2, 'selfnorm_elu_res'),
+    (128, 128, 3, 1, 19, 8, 2, 'selfnorm_elu_res'),
+    (128, 128, 3, 2, 4100, 8, 2, 'selfnorm_elu'),
+    (32, 32, 3, 1, 37, 8, 8, 'selfnorm_elu_res'),
 ]
 
 
@@ -98,9 +110,15 @@ def test_conv_matches_oracle(gpu, cin, cout, k, dil, B, H, W, mode, algo):
     stats = None
     if 'norm' in mode:
         flags |= P.PRO_NORM
-        stats = inorm_stats(x, (1 + 0.1 * rng.standard_normal(cin)).astype(F32),
-                            (1 + 0.1 * rng.standard_normal(cin)).astype(F32), (0.1 * rng.standard_normal(cin)).astype(F32))
+        agb = [(1 + 0.1 * rng.standard_normal(cin)).astype(F32), (1 + 0.1 * rng.standard_normal(cin)).astype(F32),
+               (0.1 * rng.standard_normal(cin)).astype(F32)]
+        stats = inorm_stats(x, *agb)
         v = (v - stats[:, None, None, 0]) * stats[:, None, None, 1] + stats[:, None, None, 2]
+        if 'selfnorm' in mode:
+            if algo in ('direct', 'winograd'):
+                pytest.skip('SBC_PRO_NORM_SELF belongs to the matrix-core weight forms')
+            flags |= P.PRO_NORM_SELF
+            stats = np.concatenate(agb)              # what the launch is given: (alpha | gamma | beta)
     if 'elu' in mode:
         flags |= P.PRO_ELU
         v = O.elu(v)

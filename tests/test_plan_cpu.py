@@ -46,13 +46,20 @@ def test_plan_semantics_match_reference_forward(weights64):
 def test_folded_statistics_plan_matches_reference_forward(weights64):
     """``build_score_plan(fold_stats=True)``: the full-resolution producers (begin convolution, unpooled 3x3 convolutions) carry
     a tile-moments output and the statistics records of their tensors read those moments (PRO_NORM_MOMENTS) instead of the
-    tensors; consumers are untouched.  Interpreted on the CPU the plan still computes the reference forward, and the moments
-    tensors take part in the storage sharing like any other tensor."""
+    tensors.  Below 65 pixels per image (the 16x4 and 8x2 levels) there is no statistics record at all: the fourteen 3x3
+    convolutions that consume those norms compute the statistics of their own input (PRO_NORM_SELF, `stats` -> the norm's
+    parameters).  Interpreted on the CPU the plan still computes the reference forward, and the moments tensors take part in
+    the storage sharing like any other tensor."""
     _, sd = weights64
     g = load_golden('forward_64x16.npz')
     pl = P.build_score_plan(32, 64, 16, fold_stats=True)
     kinds = [op.kind for op in pl.ops]
-    assert kinds.count(P.INORM_STATS) == 25 and len(pl.ops) == 150
+    assert kinds.count(P.INORM_STATS) == 25 - 14 and len(pl.ops) == 150 - 14
+    selfn = [op for op in pl.ops if op.flags & P.PRO_NORM_SELF]
+    assert len(selfn) == 14 and all(op.kind == P.CONV and op.ksize == 3 and op.flags & P.PRO_NORM and op.stats is None
+                                    and op.norm_key == op.name.replace('conv', 'normalize') and op.src.h * op.src.w <= 64
+                                    for op in selfn)
+    assert not any(op.flags & P.PRO_NORM_SELF for op in P.build_score_plan(32, 64, 16).ops)
     prod = [op for op in pl.ops if op.moments is not None]
     fin = [op for op in pl.ops if op.kind == P.INORM_STATS and op.flags & P.PRO_NORM_MOMENTS]
     assert len(prod) == 7 == len(fin) and all(op.flags & P.EPI_MOMENTS_OUT for op in prod)
