@@ -257,11 +257,11 @@ int launch_conv(const sbc_op& op, hipStream_t stream, bool dry) {
     }
     const bool moments = (op.flags & SBC_EPI_MOMENTS_OUT) != 0;
     if (moments) {
-        // tile moments of the output are written by the Winograd split kernels' 128-pixel, 32-output-channel variant (tile.h):
+        // tile moments of the output are written by the Winograd split kernels' 128-pixel variants with 32 / 64 output channels (tile.h):
         // whole 128-pixel tiles inside one sample, unpooled output
-        SBC_REQUIRE(op.weight_wino_split && op.ksize == 3 && op.dil == 1 && op.aux && op.cout == 32 && (op.H * op.W) % 128 == 0 &&
+        SBC_REQUIRE(op.weight_wino_split && op.ksize == 3 && op.dil == 1 && op.aux && (op.cout == 32 || op.cout == 64) && (op.H * op.W) % 128 == 0 &&
                     128 % (2 * op.W) == 0 && !(op.flags & SBC_EPI_POOL),
-                    "conv: EPI_MOMENTS_OUT needs the Winograd split kernel (weight_wino_split), aux, 32 output channels, whole 128-pixel "
+                    "conv: EPI_MOMENTS_OUT needs the Winograd split kernel (weight_wino_split), aux, 32 / 64 output channels, whole 128-pixel "
                     "tiles per sample and an unpooled output");
     }
     SBC_REQUIRE(!(op.flags & SBC_PRO_NORM_MOMENTS), "conv: SBC_PRO_NORM_MOMENTS belongs to SBC_OP_INORM_STATS (statistics from tile moments)");

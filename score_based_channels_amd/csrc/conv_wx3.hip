@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
     // floats per (tile) row of a T plane: the 32 channels, unpadded -- the finish's ds_read_b128 (thread = tile, channel quad) is
     // then conflict-free in the instruction's four 16-lane groups; the 36 of conv_wino.hip's layout made two lanes of a group meet
     constexpr int TS = WX3_TS;
+    constexpr bool MOM = (COUT == 32 || COUT == 64) && MB == 1 && NG == 1;   // variants that can write tile moments (SBC_EPI_MOMENTS_OUT)
     constexpr int NTHREADS = 256 * NG;           // staging; everything after it works per group of 256
     static_assert(NG == 1 || (COUT / 32 / NBP) % NG == 0, "phases must divide evenly between the wave groups");
     constexpr int NPF_FULL = ((TM + 32) * (CIN / 4) + NTHREADS - 1) / NTHREADS;
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
                             y[a][b].w += lh0 * (lw0 * v00.w + lw1 * v01.w) + lh1 * (lw0 * v10.w + lw1 * v11.w);
                         }
                 }
-                if ((COUT == 32 && MB == 1 && NG == 1) && (p.flags & SBC_EPI_MOMENTS_OUT)) {
+                if ((MOM && (p.flags & SBC_EPI_MOMENTS_OUT))) {
                     // no statistics launch will read this tensor back in before its consumer does: store it cacheable, so
                     // that the consumer finds it in the last-level cache
 #pragma unroll
@@ -431,15 +432,15 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
 #pragma unroll
                         for (int b = 0; b < 2; ++b) st_stream(p.out + o[a][b], y[a][b]);
                 }
-                if constexpr (COUT == 32 && MB == 1 && NG == 1) {
+                if constexpr (MOM) {
                     yk[0] = y[0][0]; yk[1] = y[0][1]; yk[2] = y[1][0]; yk[3] = y[1][1];
                 }
             }
-            if constexpr (COUT == 32 && MB == 1 && NG == 1) {
+            if constexpr (MOM) {
                 if (p.flags & SBC_EPI_MOMENTS_OUT) {
                     // tile moments of the output for the InstanceNorm++ that reads it next (tile.h)
                     __shared__ __attribute__((aligned(16))) float red[8 * 8 * 8];
-                    tile_moments_out32(yk, red, p.pm_out + (size_t)(g.p0 >> 7) * 32 * 2, gtid);
+                    tile_moments_out32(yk, red, p.pm_out + ((size_t)(g.p0 >> 7) * COUT + nb * 32) * 2, gtid);      // [tile][COUT][2]
                 }
             }
             // The T planes of this GROUP are rewritten for its next block: every wave of the group must be done reading
@@ -461,8 +462,8 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
 // ------------------------------------------------------------------------------------------------ dispatch
 template <int CIN, int COUT, int MB, int F16>
 static int launch_wx3(const ConvParams& p, hipStream_t stream, bool dry) {
-    SBC_REQUIRE(!(p.flags & SBC_EPI_MOMENTS_OUT) || (MB == 1 && COUT == 32),
-                "conv_wx3: tile moments are written by the 128-pixel, 32-output-channel variant only");
+    SBC_REQUIRE(!(p.flags & SBC_EPI_MOMENTS_OUT) || (MB == 1 && (COUT == 32 || COUT == 64)),
+                "conv_wx3: tile moments are written by the 128-pixel variants with 32 / 64 output channels only");
     constexpr int TM = 128 * MB;
     constexpr int S = CIN + 4;
     constexpr int NBLK = COUT / 32;
@@ -473,7 +474,8 @@ static int launch_wx3(const ConvParams& p, hipStream_t stream, bool dry) {
     // then walks half of the blocks: one phase of two blocks for 128 output channels, one block for 64)
     constexpr int NGMAX = ((NBLK == 4 || NBLK == 2) && MB == 1) ? 2 : 1;
     const int ntiles = (p.total_px + TM - 1) / TM;
-    const int ng = (NGMAX == 2 && ntiles <= (NBLK == 4 ? 512 : 256)) ? 2 : 1;
+    // (tile moments come out of the one-group variants: a launch that writes them keeps one group even when it is small)
+    const int ng = (NGMAX == 2 && ntiles <= (NBLK == 4 ? 512 : 256) && !(p.flags & SBC_EPI_MOMENTS_OUT)) ? 2 : 1;
     const size_t tplanes = (size_t)8 * 32 * MB * WX3_TS * sizeof(float) * ng;
     const size_t lds = NBLK == 1 ? max(staged, tplanes) : staged + tplanes;
     // + the statistics of the samples of a tile: [samples][3][CIN] floats

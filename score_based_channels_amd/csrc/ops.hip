@@ -192,33 +192,34 @@ __global__ __launch_bounds__(256) void inorm_stats_kernel(const float* __restric
 // SBC_PRO_NORM_MOMENTS: the same (mu, scale, shift) from the TILE MOMENTS a producing launch left (SBC_EPI_MOMENTS_OUT:
 // pm[B][NT][C][2] = (mean, M2) of each 128-pixel tile) instead of from the tensor itself -- a read of NT * C * 8 bytes per
 // sample where the statistics launch above reads H * W * C * 4.  Equal tile counts: mean = (1 / NT) sum mean_t and
-// M2 = sum M2_t + 128 sum (mean_t - mean)^2, both in a fixed order (8 partial sums per channel over interleaved tiles, combined
+// M2 = sum M2_t + 128 sum (mean_t - mean)^2, both in a fixed order (256 / C partial sums per channel over interleaved tiles, combined
 // in ascending order): reproducible bit for bit and independent of what else is in the batch.
 template <int C>
 __global__ __launch_bounds__(256) void inorm_from_moments_kernel(const float* __restrict__ pm, const float* __restrict__ agb,
                                                                   float* __restrict__ stats, int NT, int HW) {
-    static_assert(C == 32, "eight tile groups x 32 channels per workgroup");
-    __shared__ float part[8][C];
+    static_assert(C == 32 || C == 64, "256 / C tile groups x C channels per workgroup");
+    constexpr int G = 256 / C;                                  // tile groups (8 at 32 channels, 4 at 64)
+    __shared__ float part[G][C];
     __shared__ float mean_s[C], var_s[C];
     const int n = blockIdx.x, tid = threadIdx.x, c = tid & (C - 1), grp = tid / C;
     const float2* src = reinterpret_cast<const float2*>(pm + (size_t)n * NT * C * 2) + c;
     float sm = 0.f, sq = 0.f;
-    for (int t = grp; t < NT; t += 8) { const float2 v = src[(size_t)t * C]; sm += v.x; sq += v.y; }
+    for (int t = grp; t < NT; t += G) { const float2 v = src[(size_t)t * C]; sm += v.x; sq += v.y; }
     part[grp][c] = sm;
     __syncthreads();
     float mean = 0.f;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) mean += part[g][c];
+    for (int g = 0; g < G; ++g) mean += part[g][c];
     mean *= 1.f / (float)NT;
     __syncthreads();
     float dd = 0.f;
-    for (int t = grp; t < NT; t += 8) { const float d = src[(size_t)t * C].x - mean; dd = fmaf(d, d, dd); }
+    for (int t = grp; t < NT; t += G) { const float d = src[(size_t)t * C].x - mean; dd = fmaf(d, d, dd); }
     part[grp][c] = fmaf(128.f, dd, sq);
     __syncthreads();
     if (grp == 0) {
         float m2 = 0.f;
 #pragma unroll
-        for (int g = 0; g < 8; ++g) m2 += part[g][c];
+        for (int g = 0; g < G; ++g) m2 += part[g][c];
         mean_s[c] = mean;
         var_s[c] = m2 * (1.f / (float)HW);
     }
@@ -245,9 +246,14 @@ __global__ __launch_bounds__(256) void inorm_from_moments_kernel(const float* __
 int launch_inorm_stats(const sbc_op& op, hipStream_t stream) {
     SBC_REQUIRE(op.in && op.out && op.weight, "inorm_stats: in/out/weight must be set");
     if (op.flags & SBC_PRO_NORM_MOMENTS) {
-        SBC_REQUIRE(op.cin == 32 && (op.H * op.W) % 128 == 0, "inorm_stats: tile moments exist for 32 channels and whole 128-pixel tiles");
-        hipLaunchKernelGGL(inorm_from_moments_kernel<32>, dim3(op.B), dim3(256), 0, stream, (const float*)op.in,
-                           (const float*)op.weight, (float*)op.out, op.H * op.W / 128, op.H * op.W);
+        SBC_REQUIRE((op.cin == 32 || op.cin == 64) && (op.H * op.W) % 128 == 0,
+                    "inorm_stats: tile moments exist for 32 / 64 channels and whole 128-pixel tiles");
+        if (op.cin == 32)
+            hipLaunchKernelGGL(inorm_from_moments_kernel<32>, dim3(op.B), dim3(256), 0, stream, (const float*)op.in,
+                               (const float*)op.weight, (float*)op.out, op.H * op.W / 128, op.H * op.W);
+        else
+            hipLaunchKernelGGL(inorm_from_moments_kernel<64>, dim3(op.B), dim3(256), 0, stream, (const float*)op.in,
+                               (const float*)op.weight, (float*)op.out, op.H * op.W / 128, op.H * op.W);
         SBC_CHECK_HIP(hipGetLastError());
         return SBC_OK;
     }

@@ -66,10 +66,11 @@ struct Builder {
         const int dst = tensor(name, 1, 3, t[src].c);
         POp o; o.kind = SBC_OP_INORM_STATS; o.src = src; o.dst = dst; o.weight = nkey;
         auto it = producer.find(src);
-        if (fold_stats && it != producer.end() && t[src].c == ngf && ngf == 32 && t[src].h == nt && hw % 128 == 0 && hw >= 256 &&
+        if (fold_stats && it != producer.end() && (t[src].c == 32 || t[src].c == 64) && hw % 128 == 0 && hw >= 256 &&
             128 % (2 * sw) == 0 && t[src].h % (128 / sw > 0 ? 128 / sw : 1) == 0) {
             POp& pr = ops[it->second];
-            if (pr.kind == SBC_OP_BEGIN_CONV || (pr.kind == SBC_OP_CONV && pr.ksize == 3 && pr.dil == 1 && !(pr.flags & SBC_EPI_POOL))) {
+            if ((pr.kind == SBC_OP_BEGIN_CONV && t[src].c == 32) ||
+                (pr.kind == SBC_OP_CONV && pr.ksize == 3 && pr.dil == 1 && !(pr.flags & SBC_EPI_POOL))) {
                 if (pr.moments < 0) {
                     pr.moments = tensor(t[src].name + ".moments", hw / 128, t[src].c, 2);
                     pr.flags |= SBC_EPI_MOMENTS_OUT;

@@ -143,8 +143,8 @@ class _Builder:
         """InstanceNorm++ statistics of ``src`` for the norm ``nkey``.  With ``fold_stats``, for images of at most 64 pixels (the
         16x4 and 8x2 levels of a 64x16 array) there is no statistics record at all: a workgroup of the consuming 3x3 convolution
         holds whole samples and computes them itself (PRO_NORM_SELF; the return value is a ``SelfNorm`` marker that ``conv``
-        understands).  With ``fold_stats``, at full resolution and ngf
-        channels, when ``src`` comes out of the begin convolution or an unpooled undilated 3x3 convolution: the producer also
+        understands).  With ``fold_stats``, for 32- and 64-channel tensors of whole 128-pixel tiles
+        that come out of the begin convolution or an unpooled undilated 3x3 convolution: the producer also
         writes the moments of its 128-pixel tiles (EPI_MOMENTS_OUT) and the statistics record reads THOSE (PRO_NORM_MOMENTS:
         HW / 128 x C x 8 bytes per sample instead of the tensor); consumers see ordinary statistics either way."""
         prod = self.producer.get(id(src))
@@ -152,10 +152,10 @@ class _Builder:
         if self.fold_stats and consumer_is_conv and hw <= 64 and not hw & (hw - 1) and src.w >= 2 and not src.w & (src.w - 1):
             return SelfNorm(nkey)
         dst = self.t(name, 1, 3, src.c)
-        if (self.fold_stats and prod is not None and src.c == self.ngf == 32 and src.h == self.nt and hw % 128 == 0 and hw >= 256
+        if (self.fold_stats and prod is not None and src.c in (32, 64) and hw % 128 == 0 and hw >= 256
                 and 128 % (2 * src.w) == 0 and src.h % max(1, 128 // src.w) == 0
-                and (prod.kind == BEGIN_CONV or (prod.kind == CONV and prod.ksize == 3 and prod.dil == 1
-                                                 and not prod.flags & EPI_POOL))):
+                and ((prod.kind == BEGIN_CONV and src.c == 32)
+                     or (prod.kind == CONV and prod.ksize == 3 and prod.dil == 1 and not prod.flags & EPI_POOL))):
             if prod.moments is None:
                 prod.moments = self.t(src.name + '.moments', hw // 128, src.c, 2)     # [tile][channel][(mean, M2)]
                 prod.flags |= EPI_MOMENTS_OUT

@@ -44,7 +44,7 @@ def test_plan_semantics_match_reference_forward(weights64):
 
 
 def test_folded_statistics_plan_matches_reference_forward(weights64):
-    """``build_score_plan(fold_stats=True)``: the full-resolution producers (begin convolution, unpooled 3x3 convolutions) carry
+    """``build_score_plan(fold_stats=True)``: the producers of 32- and 64-channel tensors of whole 128-pixel tiles (begin convolution, unpooled 3x3 convolutions) carry
     a tile-moments output and the statistics records of their tensors read those moments (PRO_NORM_MOMENTS) instead of the
     tensors.  Below 65 pixels per image (the 16x4 and 8x2 levels) there is no statistics record at all: the fourteen 3x3
     convolutions that consume those norms compute the statistics of their own input (PRO_NORM_SELF, `stats` -> the norm's
@@ -62,19 +62,22 @@ def test_folded_statistics_plan_matches_reference_forward(weights64):
     assert not any(op.flags & P.PRO_NORM_SELF for op in P.build_score_plan(32, 64, 16).ops)
     prod = [op for op in pl.ops if op.moments is not None]
     fin = [op for op in pl.ops if op.kind == P.INORM_STATS and op.flags & P.PRO_NORM_MOMENTS]
-    assert len(prod) == 7 == len(fin) and all(op.flags & P.EPI_MOMENTS_OUT for op in prod)
+    # seven tensors at full resolution (32 channels) and three at 32x8 (64 channels)
+    assert len(prod) == 10 == len(fin) and all(op.flags & P.EPI_MOMENTS_OUT for op in prod)
     assert [f.src for f in fin] == [q.moments for q in prod] and all(f.geom is q.dst for f, q in zip(fin, prod))
-    assert all(m.elems == 8 * 2 * 32 for m in (q.moments for q in prod))
+    assert [m.elems for m in (q.moments for q in prod)] == [8 * 2 * 32] * 6 + [2 * 2 * 64] * 3 + [8 * 2 * 32]
     assert not any(op.flags & P.PRO_NORM_MOMENTS for op in pl.ops if op.kind != P.INORM_STATS)
     x = np.ascontiguousarray(g['x'][:2].transpose(0, 2, 3, 1))
     out = run_plan(pl, sd, x, np.full((2,), 1155))
     assert rel_err(out.transpose(0, 3, 1, 2), g['out'][1][:2]) < 2e-5
     # with fused pairs the normalizer's input comes out of a pair launch (no moments there): six of the seven fold
     plp = P.build_score_plan(32, 64, 16, fold_stats=True, fuse_pairs=True)
-    assert sum(1 for op in plp.ops if op.kind == P.INORM_STATS and op.flags & P.PRO_NORM_MOMENTS) == 6
+    assert sum(1 for op in plp.ops if op.kind == P.INORM_STATS and op.flags & P.PRO_NORM_MOMENTS) == 9
     # 256 x 64 arrays: 128 tiles per sample
     big = P.build_score_plan(32, 256, 64, fold_stats=True)
-    assert sum(1 for op in big.ops if op.moments is not None) == 7 and all(op.moments.h == 128 for op in big.ops if op.moments is not None)
+    mom = [op.moments for op in big.ops if op.moments is not None]
+    assert len(mom) == 15
+    assert sorted({(m.h, m.w) for m in mom}) == [(2, 64), (8, 64), (32, 64), (128, 32)]
     # nothing changes when the fold is not requested
     assert all(op.moments is None for op in P.build_score_plan(32, 64, 16).ops)
 
