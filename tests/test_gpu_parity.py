@@ -623,3 +623,30 @@ def test_folded_statistics_match_the_statistics_launches(weights64, mode):
         assert rel_err(a.cpu().numpy(), base(x, labels).cpu().numpy()) < 3e-6
         assert torch.equal(fold(x, labels), a)
         assert torch.equal(fold(x[1:3], labels[1:3]), a[1:3])              # batch independence
+
+
+@pytest.mark.parametrize('nt,nr', [(16, 16), (32, 16), (16, 64), (64, 64), (128, 32)])
+@pytest.mark.parametrize('mode', ['f16x2', 'f16w'])
+def test_folded_statistics_at_other_array_sizes(weights64, mode, nt, nr):
+    """The folded statistics (tile moments from producers, statistics computed by the consumers of images of at most 64 pixels)
+    at array sizes other than the headline one: 8x8 / 4x4 / 2x2 levels (2, 8, 32 samples per 128-pixel tile), rows of 2 to 64
+    pixels, 64-channel moments at 64x16 and 32x8.  Same network, statistics
+    launches against folded statistics, batch of 5 (ragged last tiles at every level) and batch independence."""
+    import torch
+    from score_based_channels_amd import plan as P
+    from score_based_channels_amd.scorenet import ScoreNet
+    cfg, sd = weights64
+    fold = ScoreNet(cfg, conv_mode=mode, fold_stats=True).cuda().load_state_dict(sd)
+    base = ScoreNet(cfg, conv_mode=mode, fold_stats=False).cuda().load_state_dict(sd)
+    ops = fold.score_plan(nt, nr).ops
+    n_self = sum(1 for op in ops if op.flags & P.PRO_NORM_SELF)
+    n_mom = sum(1 for op in ops if op.kind == P.INORM_STATS and op.flags & P.PRO_NORM_MOMENTS)
+    assert n_self > 0 and (n_mom > 0 or nt * nr < 256)
+    x = torch.randn(5, 2, nt, nr, generator=torch.Generator().manual_seed(nt * 1000 + nr))
+    for lev in (0, 2310):
+        labels = torch.full((5,), lev)
+        a, b = fold(x, labels), base(x, labels)
+        assert torch.isfinite(a).all()
+        # (f16w rounds the transformed activations to fp16, 2^-11 each: a statistic one fp32 ulp off moves such roundings)
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < (3e-6 if mode == 'f16x2' else 4e-3)
+        assert torch.equal(fold(x[2:4], labels[2:4]), a[2:4])
