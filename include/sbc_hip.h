@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SBC_ABI_VERSION 9
+#define SBC_ABI_VERSION 10
 
 typedef enum sbc_status {
     SBC_OK = 0,
@@ -75,7 +75,7 @@ typedef enum sbc_op_kind {
 /* sbc_op.flags for SBC_OP_CONV / SBC_OP_MAXPOOL5 */
 #define SBC_PRO_ELU      0x001  /* apply ELU to the input while staging it                                  */
 #define SBC_PRO_NORM     0x002  /* apply (x - mu) * scale + shift from `stats` first (InstanceNorm++)       */
-#define SBC_PRO_NORM_SELF 0x004 /* with SBC_PRO_NORM, 3x3 convolutions on the matrix-core kernels (weight_split set), images of at most 64
+#define SBC_PRO_NORM_SELF 0x004 /* (ABI 10) with SBC_PRO_NORM, 3x3 convolutions on the matrix-core kernels (weight_split set), images of at most 64
                                    pixels (H*W a power of two): the launch computes the InstanceNorm++ statistics of its input
                                    ITSELF -- a workgroup's tile holds whole samples there -- and `stats` points at the norm's
                                    parameters [3][cin] = (alpha | gamma | beta) instead of at the output of an
@@ -101,9 +101,9 @@ typedef enum sbc_op_kind {
 #define SBC_PRO_NORM_MOMENTS 0x4000 /* INORM_STATS: `in` holds the tensor's TILE MOMENTS [B][H*W/128][cin][2] = (mean, sum (x - mean)^2) of
                                       each 128-pixel tile, written by the launch that produced the tensor (SBC_EPI_MOMENTS_OUT);
                                       H, W, cin describe the tensor.  The statistics launch then reads a few KB per sample
-                                      instead of the tensor (32 channels)                                                  */
-#define SBC_EPI_MOMENTS_OUT 0x8000 /* CONV (Winograd split kernels, 32 output channels, whole 128-pixel tiles, no pool) and
-                                      BEGIN_CONV: also write the tile moments of the output to `aux` [B][H*W/128][cout][2]   */
+                                      instead of the tensor (32 or, ABI 10, 64 channels)                                   */
+#define SBC_EPI_MOMENTS_OUT 0x8000 /* CONV (Winograd split kernels, 32 or -- ABI 10 -- 64 output channels, whole 128-pixel tiles, no
+                                      pool) and BEGIN_CONV: also write the tile moments of the output to `aux` [B][H*W/128][cout][2] */
 #define SBC_CONV_F16W    0x100  /* fp16 weights (BASELINE config 5): `weight_split` / `weight_wino_split` hold ONE
                                    fp16 term per weight (sbc_pack_conv_weight_f16 / _winograd_f16) instead of
                                    three bf16 terms; activations are rounded to fp16 as they enter the matrix

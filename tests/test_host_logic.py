@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     h = _lib.lib()
     for name in declared:
         assert hasattr(h, name), name
-    assert h.sbc_abi_version() == 9
+    assert h.sbc_abi_version() == 10
 
 
 def test_pack_conv_weight_c_matches_python():
