@@ -309,6 +309,281 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_pair_kernel(PairParams p) {
 #endif
 }
 
+// The same block as a three-stage pipeline over tiles (P3): one persistent workgroup per CU of 3 NW waves in three roles --
+//   role 2 (conversion): keeps one tile of LDS-DMA in flight and turns the raw copy of tile i into operand planes X[i & 1];
+//   role 0 (conv1):      K loop of conv1 on X[(i-1) & 1], ELU, split -> intermediate planes M[(i-1) & 1];
+//   role 1 (conv2):      K loop of conv2 on M[(i-2) & 1], + x, store.
+// Every buffer is double buffered, so one workgroup barrier per tile is all the synchronisation there is; each role keeps only its
+// own filter fragments (72 registers in f16x2), which is what lets three waves share a SIMD (168 registers each): two of them are
+// always inside a K loop while the third does the vector-ALU work.  Same arithmetic in the same order as conv_pair_kernel: the
+// outputs are identical bit for bit.  13 600 tiles: 180 us in the network against 203 (matrix pipe 0.57 busy against 0.51).
+// (Two roles -- four matrix waves that keep both convolutions' fragments, four conversion waves -- were slower than the
+// two-workgroup kernel above, 256 us against 244 back to back: ONE matrix wave per SIMD does not keep the matrix pipe fed.)
+template <int W, int R, int MODE, int NW = 4, int C = 32>
+__global__ __launch_bounds__(192 * NW, 3) void conv_pair_p3_kernel(PairParams p) {
+    constexpr int NTH = 64 * NW, NHF = C / 16, NSUB = NW / NHF;
+    constexpr int KGS = C / 8, KH = C / 32, C4 = C / 4;   // 8-channel plane groups, 32-channel halves of the contraction, channel quads
+    static_assert(C == 32 || (C == 64 && MODE == 1), "64 channels: fp16-weight mode only (filter fragments must fit in registers)");
+    constexpr int NT = MODE == 2 ? 2 : 1;            // fp16 terms per operand
+    constexpr int RI = R + 4, RM = R + 2;             // staged input rows, intermediate rows
+    constexpr int WP = W + 2;                         // row of a plane: zero pixel, W pixels, zero pixel
+    constexpr int XPS = (RI * WP * 16 + 255) / 256 * 256;     // bytes of one k-group plane (multiple of the 256-byte bank row)
+    constexpr int MPS = (RM * WP * 16 + 255) / 256 * 256;
+    constexpr int RAW_BYTES = RI * W * C * 4;
+    constexpr int XSZ = NT * KGS * XPS;                 // one set of input planes
+    constexpr int MSZ = NT * KGS * MPS;                 // one set of intermediate planes
+    constexpr int X_OFF = 2 * RAW_BYTES, M_OFF = X_OFF + 2 * XSZ;
+    constexpr int NQ = RI * W * C4;                   // 16-byte chunks of the raw tile
+    static_assert(NQ % NTH == 0, "raw tile must divide over the workgroup's threads");
+    constexpr int CB = W >= 16 ? W / 16 : 1;          // units per image row (W >= 16)
+    constexpr int RPU = W >= 16 ? 1 : 16 / W;         // image rows per unit (W < 16)
+    constexpr bool COLS = CB > 1;                     // wide rows: wave pair `sub` owns column block `sub`, unit i = row i
+    static_assert(!COLS || CB == NSUB, "one wave pair per column block");
+    constexpr int NU1T = COLS ? RM : RM * W / 16, NU2T = COLS ? R : R * W / 16;   // units per output-channel half (and column block)
+    constexpr int USTEP = COLS ? 1 : NSUB;            // unit index step between a wave's consecutive units
+    constexpr int NU1 = (NU1T + USTEP - 1) / USTEP, NU2 = (NU2T + USTEP - 1) / USTEP;  // per wave
+    static_assert(RM % RPU == 0 && R % RPU == 0, "units must not straddle the tile");
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+
+    const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x / NTH);      // 0: conv1 waves, 1: conv2 waves, 2: conversion waves
+    const int tid = threadIdx.x - role * NTH, lane = tid & 63;                   // (role-local)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hf = wave % NHF, sub = wave / NHF;      // 16-output-channel group; unit parity / column block of this wave
+    const int kq = lane >> 4, c = lane & 15;          // k-group (8 input channels) / pixel of the unit
+    const int H = p.H;
+    // unit i of this wave: first plane row and slot column of its 16 pixels (this lane: pixel c), and the step to unit i + 1
+    const int u0 = COLS ? 0 : sub;
+    const int urow0 = u0 * RPU + (W >= 16 ? 0 : c / W);
+    const int ucol = COLS ? sub * 16 + c : (W >= 16 ? c : c % W);
+    constexpr int UROWS = USTEP * RPU;                 // image rows from a wave's unit i to its unit i + 1
+
+    // ---- filter fragments of both convolutions, resident for the whole launch (A operand: lane = cout l & 15, k-group l >> 4)
+    // (packed layout [tap][C/16 input groups g][C/32 output blocks nb][terms][64 lanes]: lane l' = cout % 32 + 32 * (cin group half))
+    uint4 wf[9][KH][NT];
+    if (role < 2) {
+        const int lsrc = (16 * (hf & 1) + c) + 32 * (kq & 1), nb = hf >> 1;
+        const uint4* w = role == 0 ? p.w1 : p.w2;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    wf[tap][kh][t] = w[(((tap * (C / 16) + 2 * kh + (kq >> 1)) * (C / 32) + nb) * NT + t) * 64 + lsrc];
+    }
+    float scale1 = 1.f, descale1 = 1.f, scale2 = 1.f, descale2 = 1.f;
+    if constexpr (MODE == 2) {
+        const float4 t1 = f16x2_trailer(reinterpret_cast<const float4*>(p.w1), 9 * (C / 16) * (C / 32) * NT);
+        const float4 t2 = f16x2_trailer(reinterpret_cast<const float4*>(p.w2), 9 * (C / 16) * (C / 32) * NT);
+        scale1 = t1.x; descale1 = t1.y; scale2 = t2.x; descale2 = t2.y;
+    }
+
+    // ---- zero the padding columns of every plane once (nothing writes them afterwards)
+    for (int i = threadIdx.x; i < 2 * NT * KGS * RI * 2; i += 3 * NTH) {              // (the two sets are contiguous)
+        const int side = i & 1, row = (i >> 1) % RI, pl = (i >> 1) / RI;
+        *reinterpret_cast<uint4*>(smem + X_OFF + pl * XPS + (row * WP + side * (W + 1)) * 16) = make_uint4(0, 0, 0, 0);
+    }
+    for (int i = threadIdx.x; i < 2 * NT * KGS * RM * 2; i += 3 * NTH) {                      // (two contiguous sets)
+        const int side = i & 1, row = (i >> 1) % RM, pl = (i >> 1) / RM;
+        *reinterpret_cast<uint4*>(smem + M_OFF + pl * MPS + (row * WP + side * (W + 1)) * 16) = make_uint4(0, 0, 0, 0);
+    }
+
+    // ---- tile walk: XCD x (= blockIdx % 8) owns a contiguous run of tiles, its workgroups take consecutive tiles of it
+    const int xcd = blockIdx.x & 7, jw = blockIdx.x >> 3;
+    const int t_begin = xcd * p.tiles_per_xcd;
+    const int t_end = min(t_begin + p.tiles_per_xcd, p.ntiles);
+    auto issue_dma = [&](int tile, int buf) {
+        const int n = tile / p.tiles_per_sample, r0 = (tile - n * p.tiles_per_sample) * R;
+#pragma unroll
+        for (int k = 0; k < NQ / NTH; ++k) {
+            const int j = k * NW + wave;                                  // wave-instruction: chunks j * 64 .. + 63
+            const int ri = (j * 64) / (W * C4), within = j * 64 - ri * (W * C4);   // its (single) tile row, first chunk in the row
+            // rows outside the sample are requested from the nearest row inside it (the conversion writes zeros for them): every
+            // wave issues exactly NQ / NTH requests per tile, which is what its s_waitcnt vmcnt(NQ / NTH) counts on
+            const int grow = min(max(r0 - 2 + ri, 0), H - 1);
+            const char* sbase = reinterpret_cast<const char*>(p.in) + ((size_t)(n * H + grow) * W * C) * 4 + (size_t)within * 16;
+            const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem + buf * RAW_BYTES + j * 1024;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(lane * 16), "s"(dst), "s"(sbase) : "memory");
+        }
+    };
+    const int first = t_begin + jw;
+    const int n_my = first < t_end ? (t_end - first + p.wgs_per_xcd - 1) / p.wgs_per_xcd : 0;
+    if (n_my == 0) return;                                          // (whole workgroup)
+    auto tile_of = [&](int k) { return first + k * p.wgs_per_xcd; };
+    float amax = 0.f;
+    auto convert_tile = [&](int k, int rb, int xb) {                // raw[rb] -> input planes X[xb] of tile k
+        const int tile = tile_of(k);
+        const int n = tile / p.tiles_per_sample, r0 = (tile - n * p.tiles_per_sample) * R;
+        (void)n;
+        //  convert raw -> operand planes of conv1
+#pragma unroll
+        for (int k = 0; k < NQ / NTH; ++k) {
+            const int q = k * NTH + tid;
+            const int px = q / C4, c4 = q % C4;
+            const int ri = px / W, col = px - ri * W;
+            const int grow = r0 - 2 + ri;
+            float4 v = *reinterpret_cast<const float4*>(smem + rb * RAW_BYTES + q * 16);
+            if (grow < 0 || grow >= H) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            v = elu4(v);
+            unsigned char* dst = smem + X_OFF + xb * XSZ + (c4 >> 1) * XPS + (ri * WP + col + 1) * 16 + (c4 & 1) * 8;
+            if constexpr (MODE == 2) {
+                StageScale ss{scale1, amax};
+                scale_track(v, &ss);
+                amax = ss.amax;
+                uint2 h, l;
+                split_f16x2(v.x, v.y, h.x, l.x);
+                split_f16x2(v.z, v.w, h.y, l.y);
+                *reinterpret_cast<uint2*>(dst) = h;
+                *reinterpret_cast<uint2*>(dst + KGS * XPS) = l;
+            } else {
+                f16x4 h;
+                h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+                *reinterpret_cast<f16x4*>(dst) = h;
+            }
+        }
+    };
+    // the conversion waves request tile 0; the barrier that opens iteration 0 publishes it (and the padding zeros)
+    if (role == 2) {
+        issue_dma(tile_of(0), 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // filter fragments
+    }
+    // one convolution over units `sub`, `sub + 2`, ...: acc[i] = D[16 couts of this wave][16 pixels of unit i]
+    auto conv = [&](auto cvc, const int plane_off, const int PS, auto nuc, auto nutc, f32x4v* acc) {
+        constexpr int NU = decltype(nuc)::value, NUT = decltype(nutc)::value;   // (cvc: which convolution -- each role holds only its own fragments)
+        constexpr int DU = UROWS * WP * 16;                            // bytes from a wave's unit i to its unit i + 1
+        // source pixel of tap (0, 0) of the wave's first unit = plane row urow0 (the row above the output row), slot column ucol (-1 + 1)
+        const int ub0 = plane_off + kq * PS + (urow0 * WP + ucol) * 16;
+        // flat walk over (tap, unit) steps; the X fragments of a step are requested D - 1 steps ahead of its MFMAs through a
+        // ring of statically indexed registers (the scheduler would otherwise hoist every read of the loop and spill)
+        constexpr int NS = 9 * KH * NU, D = NT == 2 ? 3 : 6;             // steps: (tap, k-half, unit)
+        f16x8 ring[D][NT];
+        auto ld = [&](int s) {                                          // s is a compile-time constant at every call
+            const int tap = s / (KH * NU), kh = (s / NU) % KH, i = s % NU;
+            const int off = i * DU + ((tap / 3) * WP + (tap % 3)) * 16 + kh * 4 * PS;
+            if (NUT % USTEP == 0 || u0 + USTEP * i < NUT) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    ring[s % D][t] = *reinterpret_cast<const f16x8*>(smem + ub0 + (off + t * KGS * PS));
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < D - 1; ++s) ld(s);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int tap = s / (KH * NU), kh = (s / NU) % KH, i = s % NU;
+            if (s + D - 1 < NS) ld(s + D - 1);
+            if (NUT % USTEP == 0 || u0 + USTEP * i < NUT) {
+                const f16x8 xh = ring[s % D][0];
+                const f16x8 wh = __builtin_bit_cast(f16x8, wf[tap][kh][0]);
+                // the first matrix instruction of a unit takes a literal zero as its addend (no register zeroing per tile)
+                const f32x4v c0 = (tap == 0 && kh == 0) ? f32x4v{0.f, 0.f, 0.f, 0.f} : acc[i];
+                if constexpr (NT == 2) {
+                    const f16x8 xl = ring[s % D][NT - 1];
+                    const f16x8 wl = __builtin_bit_cast(f16x8, wf[tap][kh][NT - 1]);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, c0, 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[i], 0, 0, 0);
+                } else {
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, c0, 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+
+    for (int it = 0; it < n_my + 2; ++it) {
+        lds_barrier();
+        if (role == 2) {
+            // (two tiles in flight -- the conversion waves counting themselves in through LDS before they reuse a raw buffer --
+            // measured slower: the waiting waves take issue slots from the matrix waves)
+            if (it + 1 < n_my) issue_dma(tile_of(it + 1), (it + 1) & 1);  // raw[(it+1)&1]: tile it-1's copy, converted an iteration ago
+            if (it < n_my) convert_tile(it, it & 1, it & 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // tile it+1 has landed before the next barrier publishes it
+            continue;
+        }
+        if (role == 0) {
+            const int t1 = it - 1;
+            if (t1 < 0 || t1 >= n_my) continue;
+            const int tile = tile_of(t1);
+            const int n = tile / p.tiles_per_sample, r0 = (tile - n * p.tiles_per_sample) * R;
+            (void)n;
+            // (3) conv1 on the RM intermediate rows -> ELU -> split -> intermediate planes
+            {
+                f32x4v acc[NU1];
+                conv(std::integral_constant<int, 0>{}, X_OFF + (t1 & 1) * XSZ, XPS, std::integral_constant<int, NU1>{}, std::integral_constant<int, NU1T>{}, acc);
+                const int cq = 4 * hf + kq;                                    // channel quad of this lane's four outputs
+#pragma unroll
+                for (int i = 0; i < NU1; ++i) {
+                    if (u0 + USTEP * i < NU1T) {
+                        const int prow = urow0 + i * UROWS, pcol = ucol;
+                        const int grow = r0 - 1 + prow;
+                        float4 v = make_float4(acc[i][0] * descale1, acc[i][1] * descale1, acc[i][2] * descale1, acc[i][3] * descale1);
+                        v = elu4(v);
+                        if (grow < 0 || grow >= H) v = make_float4(0.f, 0.f, 0.f, 0.f);    // zero padding of conv2, not conv1 of padding
+                        unsigned char* dst = smem + M_OFF + (t1 & 1) * MSZ + (cq >> 1) * MPS + (prow * WP + pcol + 1) * 16 + (cq & 1) * 8;
+                        if constexpr (MODE == 2) {
+                            StageScale ss{scale2, amax};
+                            scale_track(v, &ss);
+                            amax = ss.amax;
+                            uint2 h, l;
+                            split_f16x2(v.x, v.y, h.x, l.x);
+                            split_f16x2(v.z, v.w, h.y, l.y);
+                            *reinterpret_cast<uint2*>(dst) = h;
+                            *reinterpret_cast<uint2*>(dst + KGS * MPS) = l;
+                        } else {
+                            f16x4 h;
+                            h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+                            *reinterpret_cast<f16x4*>(dst) = h;
+                        }
+                    }
+                }
+            }
+
+            continue;
+        }
+        const int t2 = it - 2;
+        if (t2 < 0 || t2 >= n_my) continue;
+        const int tile = tile_of(t2);
+        const int n = tile / p.tiles_per_sample, r0 = (tile - n * p.tiles_per_sample) * R;
+
+        // (4) conv2 on the R output rows, + residual, store
+        {
+            f32x4v acc[NU2];
+            // the residual operand: requested before the K loop (an L2 hit: this workgroup's DMA fetched the same lines), used after it
+            const int cq = 4 * hf + kq;
+            float4 xr[NU2];
+            constexpr int DO = UROWS * W * C;                               // elements from a wave's unit i to its unit i + 1
+            const unsigned o0 = (unsigned)(((n * H + r0 + urow0) * W + ucol) * C + cq * 4);
+#pragma unroll
+            for (int i = 0; i < NU2; ++i)
+                if (NU2T % USTEP == 0 || u0 + USTEP * i < NU2T) xr[i] = *reinterpret_cast<const float4*>(p.in + o0 + i * DO);
+            conv(std::integral_constant<int, 1>{}, M_OFF + (t2 & 1) * MSZ, MPS, std::integral_constant<int, NU2>{}, std::integral_constant<int, NU2T>{}, acc);
+            // everything this wave has in flight -- the residual, its pieces of the next tile's DMA -- has landed; the stores below
+            // are never waited for explicitly (the same wait one iteration later covers them)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < NU2; ++i) {
+                if (NU2T % USTEP == 0 || u0 + USTEP * i < NU2T) {
+                    float4 y;
+                    y.x = fmaf(acc[i][0], descale2, xr[i].x); y.y = fmaf(acc[i][1], descale2, xr[i].y);
+                    y.z = fmaf(acc[i][2], descale2, xr[i].z); y.w = fmaf(acc[i][3], descale2, xr[i].w);
+                    st_stream(p.out + o0 + i * DO, y);
+                }
+            }
+        }
+    }
+    if constexpr (MODE == 2) {
+        if (amax >= F16X2_LIMIT) atomicOr(p.range_flag, 1u);
+    }
+}
+
+
+
 // ------------------------------------------------------------------------------------------------ dispatch
 template <int W, int R, int MODE, int NW = 4, int C = 32>
 static int launch_pair(const PairParams& p0, hipStream_t stream, bool dry) {
@@ -330,6 +605,29 @@ static int launch_pair(const PairParams& p0, hipStream_t stream, bool dry) {
     p.tiles_per_xcd = (p.ntiles + 7) / 8;
     p.wgs_per_xcd = max(1, min(PER_CU * cus / 8, p.tiles_per_xcd));
     hipLaunchKernelGGL(kern, dim3(8 * p.wgs_per_xcd), dim3(64 * NW), lds, stream, p);
+    SBC_CHECK_HIP(hipGetLastError());
+    return SBC_OK;
+}
+
+template <int W, int R, int MODE, int NW = 4, int C = 32>
+static int launch_pair_p3(const PairParams& p0, hipStream_t stream, bool dry) {
+    constexpr int NT = MODE == 2 ? 2 : 1;
+    constexpr int RI = R + 4, RM = R + 2, WP = W + 2;
+    constexpr int XPS = (RI * WP * 16 + 255) / 256 * 256, MPS = (RM * WP * 16 + 255) / 256 * 256;
+    constexpr size_t lds = (size_t)2 * RI * W * C * 4 + (size_t)NT * (C / 8) * 2 * (XPS + MPS);
+    static_assert(lds <= 160 * 1024, "LDS of the one resident workgroup");
+    auto kern = conv_pair_p3_kernel<W, R, MODE, NW, C>;
+    { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds); if (rc) return rc; }
+    if (dry) return SBC_OK;
+    PairParams p = p0;
+    p.tiles_per_sample = p.H / R;
+    p.ntiles = p.B * p.tiles_per_sample;
+    int dev = 0, cus = 256;
+    SBC_CHECK_HIP(hipGetDevice(&dev));
+    SBC_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    p.tiles_per_xcd = (p.ntiles + 7) / 8;
+    p.wgs_per_xcd = max(1, min(cus / 8, p.tiles_per_xcd));
+    hipLaunchKernelGGL(kern, dim3(8 * p.wgs_per_xcd), dim3(192 * NW), lds, stream, p);
     SBC_CHECK_HIP(hipGetLastError());
     return SBC_OK;
 }
@@ -362,6 +660,11 @@ int launch_conv_pair(const sbc_op& op, hipStream_t stream, bool dry) {
         set_error("conv_pair: no 64-channel kernel for image %dx%d", op.H, op.W);
         return SBC_ERR_UNSUPPORTED;
     }
+    // many tiles per CU: the three-stage pipeline (identical results; below ~16 tiles per workgroup its fill and drain cost more
+    // than it gains: 1040 tiles 21.8 us against 21.3, 6800 tiles 112 against 122, 13600 tiles 230 against 242)
+    static const bool no_p3 = getenv("SBC_NO_PAIR_P3") != nullptr;           // A/B aid
+    if (!no_p3 && op.W == 16 && op.H % 8 == 0 && (long)op.B * (op.H / 8) >= 4096)
+        return x2 ? launch_pair_p3<16, 8, 2>(p, stream, dry) : launch_pair_p3<16, 8, 1>(p, stream, dry);
     if (op.W == 16 && op.H % 8 == 0) return x2 ? launch_pair<16, 8, 2>(p, stream, dry) : launch_pair<16, 8, 1>(p, stream, dry);
     // 32-pixel rows (the half-resolution level of a 256 x 64 array): tiles of 4 rows, wave pair `sub` owns column block `sub`
     if (op.W == 32 && op.H % 4 == 0 && f16w) return launch_pair<32, 4, 1, 4>(p, stream, dry);

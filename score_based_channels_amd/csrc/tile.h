@@ -172,19 +172,19 @@ __device__ __forceinline__ void stage_commit(float* lds, const float4 (&pf)[NPF]
 //   phase A: L adjacent lanes per (sample, channel quad) -- two passes over the sample's pixels (mean, then sum (x - mean)^2),
 //            lanes combined by shuffles;   phase B: one wave per sample: mean and unbiased variance of the channel means (the
 //            "++" term);   phase C: (mu, scale, shift) as ops.hip: inorm_stats_kernel defines them.
-// Every sum has a fixed order that depends only on (H*W, CIN, NTHREADS): results are independent of the batch and
-// reproducible.  st_lds: [samples][3][CIN] floats followed by 2 floats per sample of scratch.  All threads of the workgroup
+// Every sum has a fixed order that depends only on (H*W, CIN): results are independent of the batch, of the kernel variant a
+// batch size selects, and reproducible.  st_lds: [samples][3][CIN] floats followed by 2 floats per sample of scratch.  All threads of the workgroup
 // call; three barriers, the last one behind the finished table.  `agb` = [3][CIN] (alpha | gamma | beta).
-template <int CIN, int NTHREADS, int TM, bool P2>
+template <int CIN, int NTHREADS, int TM, bool P2>   // (TM: unused, kept for the call sites)
 __device__ __forceinline__ void self_stats_to_lds(float* st_lds, const float* __restrict__ in, const float* __restrict__ agb,
                                                   const TileGeom& g, const Dims<P2>& d, int tid) {
     constexpr int C4 = CIN / 4;
     const int HW = d.HW;
     const int ns = d.div_hw(g.nps);
     const int pairs = ns * C4;
-    // lanes per (sample, quad): from the FULL tile's sample count, so that a sample is summed the same way in a ragged last tile
-    int L = 1;
-    while (L < 8 && d.div_hw(TM) * C4 * (2 * L) <= NTHREADS && 2 * L <= HW) L *= 2;
+    // lanes per (sample, quad): a function of the image size ONLY -- the kernel variant (threads per workgroup, pixels per tile)
+    // depends on the batch size, and a sample's sums must not (two sub-batch streams against one: bit-identical results)
+    const int L = HW < 8 ? HW : 8;
     const int l = tid & (L - 1), pidx = tid / L;
     const float* base = in + (size_t)g.rs0 * d.W * CIN;
     const float inv_hw = 1.f / (float)HW;

@@ -410,3 +410,38 @@ def test_conv_pair_matches_oracle(gpu, case, mode):
     _launch(gpu, a)
     _launch(gpu, b)
     assert rel_err(got - x, out2.cpu().numpy() - x) < tol
+
+
+@pytest.mark.parametrize('mode', ['f16x2', 'bf16x3', 'f16w'])
+@pytest.mark.parametrize('cin,cout', [(32, 32), (32, 64), (64, 32), (64, 64), (64, 128), (128, 64), (128, 128)])
+def test_winograd_variants_are_accurate_and_batch_size_independent(gpu, cin, cout, mode):
+    """Which instantiation of the Winograd kernel runs (one or two wave groups, one or two output blocks per phase) depends on
+    the number of tiles in the launch, i.e. on the batch size.  Every one of them must (a) agree with a float64 convolution and
+    (b) return, for a sample, the same bits whatever the batch around it -- the sub-batch streams of a run rely on that.  (Round 3:
+    the two-block 128 -> 64 instantiation of the two-term fp16 mode, which only runs beyond 256 tiles, summed the last 16 input
+    channels wrongly; no test had a launch that large.)"""
+    torch, _lib = gpu
+    from score_based_channels_amd import plan as P
+    from score_based_channels_amd.weights import (pack_conv_weight_f16, pack_conv_weight_f16x2, pack_conv_weight_split,
+                                                  pack_conv_weight_winograd_f16, pack_conv_weight_winograd_f16x2,
+                                                  pack_conv_weight_winograd_split)
+    rng = np.random.default_rng(cin * 131 + cout)
+    w = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(9 * cin)).astype(F32)
+    pk, pkw, flag, tol = {'f16x2': (pack_conv_weight_f16x2, pack_conv_weight_winograd_f16x2, P.CONV_F16X2, 1e-5),
+                          'bf16x3': (pack_conv_weight_split, pack_conv_weight_winograd_split, 0, 1e-5),
+                          'f16w': (pack_conv_weight_f16, pack_conv_weight_winograd_f16, P.CONV_F16W, 1e-2)}[mode]
+    ws, ww = _dev(torch, pk(w).view(np.float32)), _dev(torch, pkw(w).view(np.float32))
+    wd = torch.from_numpy(w).cuda().double()
+    for H, W, sizes in ((8, 2, (2400, 1000, 100)), (16, 4, (600, 50)), (32, 8, (300, 10))):
+        x = torch.randn(sizes[0], H, W, cin, device='cuda', generator=torch.Generator('cuda').manual_seed(H)) * 1.5 + 0.3
+        ref = torch.nn.functional.conv2d(torch.nn.functional.elu(x).permute(0, 3, 1, 2).double(), wd, padding=1).permute(0, 2, 3, 1)
+        outs = []
+        for B in sizes:
+            out = torch.full((B, H, W, cout), float('nan'), dtype=torch.float32, device='cuda')
+            op = _lib.sbc_op(kind=P.CONV, flags=flag | P.PRO_ELU, B=B, H=H, W=W, cin=cin, cout=cout, ksize=3, dil=1, in_=_p(x), out=_p(out),
+                             weight_split=_p(ws), weight_wino_split=_p(ww))
+            _launch(gpu, op)
+            assert float((out.double() - ref[:B]).abs().max()) < tol, (H, W, B)
+            outs.append(out)
+        for out in outs[1:]:
+            assert torch.equal(out, outs[0][:out.shape[0]]), (H, W, out.shape[0])

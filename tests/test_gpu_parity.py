@@ -650,3 +650,20 @@ def test_folded_statistics_at_other_array_sizes(weights64, mode, nt, nr):
         # (f16w rounds the transformed activations to fp16, 2^-11 each: a statistic one fp32 ulp off moves such roundings)
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < (3e-6 if mode == 'f16x2' else 4e-3)
         assert torch.equal(fold(x[2:4], labels[2:4]), a[2:4])
+
+
+@pytest.mark.parametrize('mode', ['f16x2', 'f16w', 'bf16x3'])
+def test_forward_does_not_depend_on_the_batch_size(weights64, mode):
+    """A sample's score is the same bit pattern in a batch of 2400, 1200, 800 or 100: the kernel variants that large and small
+    launches select (wave groups, blocks per phase, tile sizes, the pipelined pair kernel) compute identical sums, and the
+    statistics folded into producers / consumers do not look at the batch.  Sub-batch streams rely on it."""
+    import torch
+    from score_based_channels_amd.scorenet import ScoreNet
+    cfg, sd = weights64
+    net = ScoreNet(cfg, conv_mode=mode).cuda().load_state_dict(sd)
+    x = torch.randn(2400, 2, 64, 16, generator=torch.Generator().manual_seed(5))
+    lab = torch.full((2400,), 1155)
+    a = net(x, lab)
+    assert torch.isfinite(a).all()
+    for n in (1200, 800, 100):
+        assert torch.equal(net(x[:n], lab[:n]), a[:n]), n

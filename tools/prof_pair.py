@@ -13,6 +13,7 @@ ap.add_argument('--mode', default='f16x2')
 ap.add_argument('--iters', type=int, default=30)
 a = ap.parse_args()
 B, H, W = a.shape
+torch.manual_seed(3); np.random.seed(3)
 x = torch.randn(B, H, W, 32, device='cuda')
 mid, out, out2 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
 w1, w2 = (np.random.randn(32, 32, 3, 3).astype(np.float32) / 17 for _ in range(2))
@@ -42,6 +43,8 @@ if 'pt' in os.environ.get('SBC_LIB_PATH', ''):
     names = ['conv2 epilogue -> loop top', 'barrier 1', 'convert', 'barrier 2', 'mid write', 'barrier 3', 'residual issue + conv2', 'wait + store', 'dma issue', 'conv1']
     tot = dbg.sum().item()
     print('wave-0 cycles per phase (sum over %d workgroups): ' % 512 + ', '.join('%s %.1f%%' % (n, 100.0 * v / tot) for n, v in zip(names, dbg.tolist())), '| cycles per WG %.0f' % (tot / 512))
+if os.environ.get('DUMP'):
+    np.save(os.environ['DUMP'], out.cpu().numpy())
 err = float((out - out2).abs().max() / (out2 - x).abs().max())
 by = 4.0 * B * H * W * 32
 print('%s %s: pair %.1f us (%.2f TB/s of 2 tensors), two launches %.1f us (%.2f TB/s of 5 tensors); max deviation %.2e of the conv part'
