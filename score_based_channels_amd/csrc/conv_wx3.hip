@@ -225,6 +225,7 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
                     split_f16x2(v[2], v[3], vhu.y, vlu.y);
                     split_f16x2(v[4], v[5], vhu.z, vlu.z);
                     split_f16x2(v[6], v[7], vhu.w, vlu.w);
+                    split_f16x2_settle(vhu, vlu);                  // wait states before the matrix instructions read the terms (tile.h)
                     const f16x8 vh = __builtin_bit_cast(f16x8, vhu), vl = __builtin_bit_cast(f16x8, vlu);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -489,10 +490,7 @@ static int launch_wx3(const ConvParams& p, hipStream_t stream, bool dry) {
     // no longer allows -- see the Makefile; without them that variant spills.)
     // (the two-term fp16 mode needs fewer registers -- no middle term, a two-set filter ring -- and fits four waves: 126 VGPRs)
         constexpr int WPE = (CIN == 32 && COUT == 32 && MB == 1) ? (F16 == 2 ? 4 : 3) : 2;
-    // (128 -> 64 in the two-term fp16 mode: one block per phase.  Its two-block instantiation returns wrong sums for the last 16
-    // input channels of the first output block -- found by a batch-independence probe at 2400 trajectories, the one-group variant
-    // only runs beyond 256 tiles; every other instantiation and mode agrees with an fp64 reference, see tests/test_gpu_ops.py)
-    constexpr int NBP_BIG = (NBLK == 2 && !(CIN == 128 && F16 == 2)) ? 2 : 1;
+    constexpr int NBP_BIG = NBLK == 2 ? 2 : 1;
     const bool top = (CIN == 32 && COUT == 32) && p.top;
     auto kern = ng == 2 ? conv_wx3_kernel<CIN, COUT, MB, true, 2, false, (NBLK == 4 ? 2 : 1), NGMAX, F16>
               : top     ? conv_wx3_kernel<CIN, COUT, MB, true, WPE, (CIN == 32 && COUT == 32), NBP_BIG, 1, F16>

@@ -320,6 +320,14 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // difference a - h is exact in fp32.  One v_cvt_pk_f16_f32 for the pair of high terms, one v_fma_mixlo/mixhi_f16 per low term
 // (fma(a, 1.0, -h) evaluated in fp32 from the fp16 half, rounded once to fp16).
 // h, l: the two values' terms packed low | high, as the matrix instructions take them.
+// HAZARD: hipcc does not look inside inline assembly, so it inserts none of the wait states a vector-ALU write needs before a
+// MATRIX instruction reads the register.  Where split terms feed v_mfma_* directly from registers (conv_wx3.hip) the caller puts
+// split_f16x2_settle() between the last split and the first matrix instruction: without it one instantiation (128 -> 64, two
+// output blocks per phase), in which nothing else happened to sit between the two, multiplied a stale high half -- results off
+// by 3e-4 ... 0.5, correct at -O1 and with the two wait states.  Terms that go through LDS first (conv_x3, conv_pair) are safe.
+__device__ __forceinline__ void split_f16x2_settle(uint4& h, uint4& l) {
+    asm volatile("s_nop 1" : "+v"(h.x), "+v"(h.y), "+v"(h.z), "+v"(h.w), "+v"(l.x), "+v"(l.y), "+v"(l.z), "+v"(l.w));
+}
 __device__ __forceinline__ void split_f16x2(float a, float b, unsigned& h, unsigned& l) {
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(a), "v"(b));
     asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a), "v"(h));

@@ -209,6 +209,7 @@ __global__ __launch_bounds__(512, 2) void conv_wsp_kernel(ConvParams p, WspWalk 
                             split_f16x2(v[2], v[3], vhu.y, vlu.y);
                             split_f16x2(v[4], v[5], vhu.z, vlu.z);
                             split_f16x2(v[6], v[7], vhu.w, vlu.w);
+                            split_f16x2_settle(vhu, vlu);                  // wait states before the matrix instructions read the terms (tile.h)
                             const f16x8 vh = __builtin_bit_cast(f16x8, vhu), vl = __builtin_bit_cast(f16x8, vlu);
                             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
