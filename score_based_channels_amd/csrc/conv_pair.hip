@@ -357,7 +357,7 @@ __global__ __launch_bounds__(192 * NW, 3) void conv_pair_p3_kernel(PairParams p)
     const int ucol = COLS ? sub * 16 + c : (W >= 16 ? c : c % W);
     constexpr int UROWS = USTEP * RPU;                 // image rows from a wave's unit i to its unit i + 1
 
-    // ---- filter fragments of both convolutions, resident for the whole launch (A operand: lane = cout l & 15, k-group l >> 4)
+    // ---- filter fragments of THIS ROLE's convolution, resident for the whole launch (A operand: lane = cout l & 15, k-group l >> 4)
     // (packed layout [tap][C/16 input groups g][C/32 output blocks nb][terms][64 lanes]: lane l' = cout % 32 + 32 * (cin group half))
     uint4 wf[9][KH][NT];
     if (role < 2) {
@@ -398,8 +398,8 @@ __global__ __launch_bounds__(192 * NW, 3) void conv_pair_p3_kernel(PairParams p)
         for (int k = 0; k < NQ / NTH; ++k) {
             const int j = k * NW + wave;                                  // wave-instruction: chunks j * 64 .. + 63
             const int ri = (j * 64) / (W * C4), within = j * 64 - ri * (W * C4);   // its (single) tile row, first chunk in the row
-            // rows outside the sample are requested from the nearest row inside it (the conversion writes zeros for them): every
-            // wave issues exactly NQ / NTH requests per tile, which is what its s_waitcnt vmcnt(NQ / NTH) counts on
+            // rows outside the sample are requested from the nearest row inside it (the conversion writes zeros for them): no
+            // branch around a request, every wave issues exactly NQ / NTH of them per tile
             const int grow = min(max(r0 - 2 + ri, 0), H - 1);
             const char* sbase = reinterpret_cast<const char*>(p.in) + ((size_t)(n * H + grow) * W * C) * 4 + (size_t)within * 16;
             const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem + buf * RAW_BYTES + j * 1024;
@@ -417,10 +417,9 @@ __global__ __launch_bounds__(192 * NW, 3) void conv_pair_p3_kernel(PairParams p)
         const int tile = tile_of(k);
         const int n = tile / p.tiles_per_sample, r0 = (tile - n * p.tiles_per_sample) * R;
         (void)n;
-        //  convert raw -> operand planes of conv1
 #pragma unroll
-        for (int k = 0; k < NQ / NTH; ++k) {
-            const int q = k * NTH + tid;
+        for (int kk = 0; kk < NQ / NTH; ++kk) {
+            const int q = kk * NTH + tid;
             const int px = q / C4, c4 = q % C4;
             const int ri = px / W, col = px - ri * W;
             const int grow = r0 - 2 + ri;
