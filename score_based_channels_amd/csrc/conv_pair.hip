@@ -318,7 +318,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_pair_kernel(PairParams p) {
 // always inside a K loop while the third does the vector-ALU work.  Same arithmetic in the same order as conv_pair_kernel: the
 // outputs are identical bit for bit.  13 600 tiles: 180 us in the network against 203 (matrix pipe 0.57 busy against 0.51).
 // (Two roles -- four matrix waves that keep both convolutions' fragments, four conversion waves -- were slower than the
-// two-workgroup kernel above, 256 us against 244 back to back: ONE matrix wave per SIMD does not keep the matrix pipe fed.)
+// two-workgroup kernel above, 256 us against 244 back to back: ONE matrix wave per SIMD does not keep the matrix pipe fed.  The same
+// holds inside the pipeline: matrix waves that own all 32 output channels of their units -- half the LDS reads, two waves per
+// matrix role -- run 279 us against 231.)
 template <int W, int R, int MODE, int NW = 4, int C = 32>
 __global__ __launch_bounds__(192 * NW, 3) void conv_pair_p3_kernel(PairParams p) {
     constexpr int NTH = 64 * NW, NHF = C / 16, NSUB = NW / NHF;
