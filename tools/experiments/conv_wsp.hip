@@ -1,7 +1,8 @@
 // EXPERIMENT (round 3), NOT part of the product build: Winograd F(2x2,3x3) with producer / consumer wave roles.
 // Result on MI355X (T = 1700, conv_mode f16x2, against conv_wx3.hip on the same box; bit-identical outputs for 32 -> 32):
-//   32 -> 32 at 64x16: 168 us against 167 us;  32 -> 32 at 32x8: 40.9 against 40.3;  64 -> 64 at 32x8: 130 against 121 (and the
-//   64 -> 64 path still has a mismatch in a quarter of its outputs -- not chased, since it was slower anyway).
+//   32 -> 32 at 64x16: 168 us against 167 us;  32 -> 32 at 32x8: 40.9 against 40.3;  64 -> 64 at 32x8: 130 against 121 with one group
+//   of matrix waves, 140 against 126 with two groups (one output block each, the form below).  (The 64 -> 64 path's mismatch in a
+//   quarter of its outputs was the inline-assembly hazard of DESIGN.md section 9: with split_f16x2_settle() it is bit-identical.)
 // Why it does not pay (PMC, tools/prof_conv.py): the 32 -> 32 kernel is bound by instruction issue, not by latency -- 700 vector
 // instructions per wave and tile (58 % of the SIMD cycles) plus 24 matrix instructions (14 %); splitting the work between roles
 // removes the waiting but not one instruction, and a SIMD's one matrix wave + one memory wave take the same 2.3 us per tile as
@@ -67,10 +68,12 @@ __device__ __forceinline__ void role_barrier() { asm volatile("s_waitcnt lgkmcnt
 // TBUF: T-plane buffers.  RES: the layer adds a residual (res1).  One workgroup per CU (512 threads, 256 VGPRs each).
 // TOP: instantiation tag (own kernel symbol for the full-resolution ngf -> ngf layers, as in conv_wx3.hip).
 template <int CIN, int COUT, int MODE, int TBUF, bool RES, bool TOP, int NPF>
-__global__ __launch_bounds__(512, 2) void conv_wsp_kernel(ConvParams p, WspWalk wk) {
+__global__ __launch_bounds__(256 * (COUT / 32 + 1), COUT / 32 + 1) void conv_wsp_kernel(ConvParams p, WspWalk wk) {
     constexpr int NTERM = MODE == 0 ? 3 : MODE;
     constexpr int TM = 128, NTW = 32, S = CIN + 4, KG = CIN / 16, NBLK = COUT / 32;
     static_assert(NBLK <= 2 && KG <= 4, "one phase of at most two output blocks");
+    // KGR groups of four matrix waves, one output block each (two waves of a SIMD inside K loops, as in conv_wx3 with two workgroups)
+    constexpr int KGR = NBLK, QN = NBLK / KGR;
     constexpr int TS = 36, TPL = 8 * NTW * TS;              // floats of one output block's T planes [xi][b][tile][TS]
     // filter fragments resident in registers: 4 nu x KG x NBLK x NTERM x 4 VGPRs
     constexpr bool WRES = (4 * KG * NBLK * NTERM * 4 <= 64);
@@ -96,9 +99,9 @@ __global__ __launch_bounds__(512, 2) void conv_wsp_kernel(ConvParams p, WspWalk 
     if constexpr (MODE == 2) descale = f16x2_trailer(p.wpk, 16 * KG * NBLK * NTERM).y;
     WS_INIT();
 
-    if (wave < 4) {
+    if (wave < 4 * KGR) {
         // ================================================================================ matrix role
-        const int xi = wave;
+        const int xi = wave & 3, q0 = (wave >> 2) * QN;               // B^T row; first output block of this wave group
         const int khalf = 8 * (lane >> 5), col = lane & 31, rhalf = 4 * (lane >> 5);
         // B^T rows: xi=0: d0 - d2, xi=1: d1 + d2, xi=2: d2 - d1, xi=3: d1 - d3   ->  R = d[ia] + sgn * d[ib]
         const int ia = xi == 0 ? 0 : xi == 2 ? 2 : 1;
@@ -138,19 +141,19 @@ __global__ __launch_bounds__(512, 2) void conv_wsp_kernel(ConvParams p, WspWalk 
                         off[kk][j] = (rok && ww >= 0 && ww < W) ? ((grow - 1 + ii - g.rs0) * W + ww) * S + khalf : zoff;
                     }
                 }
-                f32x16 T[NBLK][2];
-                f32x16 acc[NBLK][4];
-                auto u_frag = [&](int nu, int kg, int q, int tt) { return wp[((size_t)((nu * KG + kg) * NBLK + q) * NTERM + tt) * 64]; };
+                f32x16 T[QN][2];
+                f32x16 acc[QN][4];
+                auto u_frag = [&](int nu, int kg, int q, int tt) { return wp[((size_t)((nu * KG + kg) * NBLK + q0 + q) * NTERM + tt) * 64]; };
 #ifndef SBC_WSP_SETS
 #define SBC_WSP_SETS 2
 #endif
-                constexpr int SETS = NBLK == 1 ? 4 : SBC_WSP_SETS, D = SETS - 1, NSEQ = KG * 4;
-                uint4 uB[WRES ? 1 : SETS][NBLK][NTERM];
+                constexpr int SETS = QN == 1 ? 4 : SBC_WSP_SETS, D = SETS - 1, NSEQ = KG * 4;
+                uint4 uB[WRES ? 1 : SETS][QN][NTERM];
                 auto u_load = [&](int gq) {                       // gq is a compile-time constant at every call
                     if constexpr (!WRES) {
                         const int gg = gq % NSEQ, nu_g = gg & 3, kg_g = (gg >> 2) % KG;
 #pragma unroll
-                        for (int q = 0; q < NBLK; ++q)
+                        for (int q = 0; q < QN; ++q)
 #pragma unroll
                             for (int tt = 0; tt < NTERM; ++tt) uB[gq % SETS][q][tt] = u_frag(nu_g, kg_g, q, tt);
                     }
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(512, 2) void conv_wsp_kernel(ConvParams p, WspWalk 
 #pragma unroll
                 for (int gq = 0; gq < D; ++gq) u_load(gq);
 #pragma unroll
-                for (int q = 0; q < NBLK; ++q)
+                for (int q = 0; q < QN; ++q)
 #pragma unroll
                     for (int nu = 0; nu < 4; ++nu)
 #pragma unroll
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(512, 2) void conv_wsp_kernel(ConvParams p, WspWalk 
                             for (int c = 0; c < 8; ++c) vf[c] = (_Float16)v[c];
                             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                            for (int q = 0; q < NBLK; ++q)
+                            for (int q = 0; q < QN; ++q)
                                 acc[q][nu] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, __builtin_bit_cast(f16x8, u_get(gq, q, 0)),
                                                                                     acc[q][nu], 0, 0, 0);
                         } else if constexpr (MODE == 2) {
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(512, 2) void conv_wsp_kernel(ConvParams p, WspWalk 
                             const f16x8 vh = __builtin_bit_cast(f16x8, vhu), vl = __builtin_bit_cast(f16x8, vlu);
                             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                            for (int q = 0; q < NBLK; ++q) {
+                            for (int q = 0; q < QN; ++q) {
                                 const f16x8 uh = __builtin_bit_cast(f16x8, u_get(gq, q, 0)),
                                             ul = __builtin_bit_cast(f16x8, u_get(gq, q, NTERM > 1 ? 1 : 0));
                                 acc[q][nu] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, uh, acc[q][nu], 0, 0, 0);
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(512, 2) void conv_wsp_kernel(ConvParams p, WspWalk 
                             }
                             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                            for (int q = 0; q < NBLK; ++q) {
+                            for (int q = 0; q < QN; ++q) {
                                 const bf16x8 uh = __builtin_bit_cast(bf16x8, u_get(gq, q, 0)),
                                              um = __builtin_bit_cast(bf16x8, u_get(gq, q, NTERM > 1 ? 1 : 0)),
                                              ul = __builtin_bit_cast(bf16x8, u_get(gq, q, NTERM > 2 ? 2 : 0));
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void conv_wsp_kernel(ConvParams p, WspWalk 
                 }
                 // A^T = [[1, 1, 1, 0], [0, 1, -1, -1]] applied over nu
 #pragma unroll
-                for (int q = 0; q < NBLK; ++q)
+                for (int q = 0; q < QN; ++q)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         T[q][0][r] = (acc[q][0][r] + acc[q][1][r]) + acc[q][2][r];
@@ -260,10 +263,10 @@ __global__ __launch_bounds__(512, 2) void conv_wsp_kernel(ConvParams p, WspWalk 
                 WS_MARK(1);
                 float* const tl = tpl + (TBUF == 2 ? (k & 1) * NBLK * TPL : 0);
 #pragma unroll
-                for (int q = 0; q < NBLK; ++q)
+                for (int q = 0; q < QN; ++q)
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {
-                        float* e = tl + q * TPL + ((size_t)((xi * 2 + b) * NTW + rhalf)) * TS + col;
+                        float* e = tl + (q0 + q) * TPL + ((size_t)((xi * 2 + b) * NTW + rhalf)) * TS + col;
                         const f32x16 tv = T[q][b];
 #pragma unroll
                         for (int r = 0; r < 16; ++r) e[((r & 3) + 8 * (r >> 2)) * TS] = tv[r];
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void conv_wsp_kernel(ConvParams p, WspWalk 
     // (indices clamped instead of branches, the residual a template parameter, the bias held in registers): the compiler's
     // s_waitcnt placement then leaves the requests of the NEXT iteration in flight while this one's data is consumed.  With
     // conditional loads it falls back to vmcnt(0) in front of every load, and the role costs 2.6 us per tile instead of 0.9.
-    const int it = tid - 256;
+    const int it = tid - 256 * KGR;
     struct IoSet {
         float4 pf[NPF];
         RegStats rs;
@@ -503,7 +506,7 @@ static int launch_wsp(const ConvParams& p, hipStream_t stream, bool dry, unsigne
                        : (top ? conv_wsp_kernel<CIN, COUT, MODE, TBUF, false, TOPV, NPF> : conv_wsp_kernel<CIN, COUT, MODE, TBUF, false, false, NPF>);
     { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds_all); if (rc) return rc; }
     if (dry) return SBC_OK;
-    hipLaunchKernelGGL(kern, dim3(8 * wk.wgs_per_xcd), dim3(512), lds_all, stream, p, wk);
+    hipLaunchKernelGGL(kern, dim3(8 * wk.wgs_per_xcd), dim3(256 * (COUT / 32 + 1)), lds_all, stream, p, wk);
     SBC_CHECK_HIP(hipGetLastError());
     return SBC_OK;
 }
