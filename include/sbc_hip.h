@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SBC_ABI_VERSION 10
+#define SBC_ABI_VERSION 11
 
 typedef enum sbc_status {
     SBC_OK = 0,
@@ -80,6 +80,11 @@ typedef enum sbc_op_kind {
                                    ITSELF -- a workgroup's tile holds whole samples there -- and `stats` points at the norm's
                                    parameters [3][cin] = (alpha | gamma | beta) instead of at the output of an
                                    SBC_OP_INORM_STATS launch, which then does not exist (normalization.py:163-176)          */
+#define SBC_PRO_ELU_ACC  0x20000 /* (ABI 11) with SBC_PRO_ELU: evaluate ELU with fp32's relative accuracy for small negative inputs too (a
+                                   polynomial below |x| = 1/32 instead of exp(x) - 1, whose absolute error of 6e-8 is 6e-5 of an
+                                   activation of -1e-3): ten vector instructions per value instead of four.  The Python host sets
+                                   it in the exact modes (conv_mode 0 / 1); in conv_mode 3 the layer's weight trailer asks for it
+                                   when sbc_f16x2_calibrate finds the layer's input maximum below 0.5                       */
 #define SBC_EPI_RES1_ELU 0x010  /* ELU the res1 operand before adding (CRP: x = act(x))                    */
 #define SBC_EPI_POOL     0x020  /* 2x2 mean pool of (conv + bias), then + res1 (ConvMeanPool)               */
 #define SBC_EPI_UP       0x040  /* + bilinear(align_corners) resize of `up` [B][up_h][up_w][cout] (MSF)     */
@@ -111,11 +116,12 @@ typedef enum sbc_op_kind {
 
 #define SBC_CONV_F16X2   0x10000 /* fp32-class arithmetic on the fp16 matrix cores: `weight_split` / `weight_wino_split` hold TWO
                                    fp16 terms per (scaled) weight plus a 16-byte trailer with the scales
-                                   (sbc_pack_conv_weight_f16x2 / _winograd_f16x2); activations are scaled by a power of two and
-                                   split into two fp16 terms as they enter the matrix cores; three v_mfma_f32_32x32x16_f16
-                                   per product block (hh + hl + lh), fp32 accumulation.  Representation error <= 2^-22 per
-                                   operand.  A staged activation with |x| * act_scale >= 16000 (act_scale = 1 as packed) raises
-                                   the device's range flag (sbc_range_flag) instead of overflowing silently                              */
+                                   (sbc_pack_conv_weight_f16x2 / _winograd_f16x2); activations are scaled by the layer's
+                                   act_scale (a power of two; sbc_f16x2_calibrate) and split into two fp16 terms as they enter
+                                   the matrix cores; three fp16 MFMAs per product block (hh + hl + lh), fp32 accumulation.
+                                   Representation error <= 2^-22 per operand while 2^-3 <= |x| act_scale < 16000; outside that
+                                   window the device's range flag (sbc_range_flag) is raised instead of returning silently
+                                   degraded numbers                                                                       */
 
 /* One fused launch.  Unused fields are 0 / NULL.  Tensor shapes per kind:
  *   BEGIN_CONV  in [B][H][W][2], weight [cout][2][3][3] (torch layout), bias [cout], out [B][H][W][cout]
@@ -175,6 +181,9 @@ typedef struct sbc_op {
     /* --- ABI 9 --- */
     const void* weight2_split;   /* CONV_PAIR: the second convolution's weight in the form `weight_split` holds the first one's
                                     (sbc_pack_conv_weight_f16x2 with SBC_CONV_F16X2, sbc_pack_conv_weight_f16 with SBC_CONV_F16W) */
+    /* --- ABI 11 --- */
+    void* calib;                 /* NULL.  (Set by sbc_f16x2_calibrate on its private copies of the records: two device floats per
+                                    f16x2 convolution that collect max |x| of what the launch stages.) */
 } sbc_op;
 
 /* Training operators.  The reverse of a forward record `y = epi(conv(pro(x)))` is built by the host
@@ -254,6 +263,9 @@ typedef struct sbc_endconv {
  *   nmse   [n_steps][B] float32 log, row *step is written               (:168-170)
  * SBC_OP_MEASURE reads Htrue and P and writes Y; its `noise` is [B][Np][Nr] and `meas_scale[b]` =
  * float32(sqrt(local_noise)).
+ * Constraints of SBC_OP_LANGEVIN (checked, SBC_ERR_INVALID otherwise): Nr is EVEN -- the update takes the elements of a row in
+ * adjacent pairs (one Philox block, one pilot value, 16-byte accesses) -- and X, score, Y, Htrue and noise are 16-byte aligned
+ * (Nt * Nr even keeps every per-trajectory slice aligned too).  The score network itself needs Nt, Nr multiples of 8.
  */
 typedef struct sbc_langevin {
     float* X;
@@ -365,16 +377,38 @@ int sbc_pack_conv_weight_winograd_f16(const float* src, int32_t cout, int32_t ci
 /* f16x2 weight forms for SBC_CONV_F16X2: every weight (or Winograd-transformed weight U = G g G^T, double -> float) is
  * scaled by 2^s -- s chosen per layer so that the largest magnitude lies in [2^13, 2^14) -- and written as two fp16 terms
  * h = fp16(w 2^s), l = fp16(w 2^s - h), in the layout of sbc_pack_conv_weight_split with 2 terms,
- * [k*k | 16][cin/16][cout/32][2][64 lanes][8] uint16, followed by a 16-byte trailer of four float32: (1 [reserved: activations
- * are not scaled], descale = 2^-s, 0, 0).  dst holds sbc_f16x2_elems(...) uint16. */
+ * [k*k | 16][cin/16][cout/32][2][64 lanes][8] uint16, followed by a 16-byte trailer of four float32: (act_scale = 1, descale =
+ * 1 / (act_scale 2^s), 2^-s, 0); act_scale must be a power of two (sbc_f16x2_calibrate sets it per layer on the device copy; a
+ * host that knows its activations may write the first two words itself).  dst holds sbc_f16x2_elems(...) uint16. */
 #define SBC_F16X2_ACT_SHIFT 0
 #define sbc_f16x2_elems(taps, cin, cout) ((size_t)(taps) * (cin) * (cout) * 2 + 8)
 int sbc_pack_conv_weight_f16x2(const float* src, int32_t cout, int32_t cin, int32_t ksize, uint16_t* dst);
 int sbc_pack_conv_weight_winograd_f16x2(const float* src, int32_t cout, int32_t cin, uint16_t* dst);
-/* Range flag of the f16x2 kernels on the CURRENT device: *flag != 0 when, since the last reset, a convolution staged an
- * activation with |x| * act_scale >= 16000 (results of that launch are not trustworthy: run the layer stack in split-bf16
- * mode instead).  Synchronises with the device.  reset != 0 clears it. */
+/* Range flag of the f16x2 kernels on the CURRENT device, a bit set collected since the last reset:
+ *   bit 0 (SBC_RANGE_OVERFLOW)   a convolution staged an activation with |x| * act_scale >= 16000: its high fp16 term (or a
+ *                                Winograd transform sum of four) may have overflowed;
+ *   bit 1 (SBC_RANGE_UNDERFLOW)  a whole wavefront's share of an input tile (>= 8 pixels x every channel) was non-zero but below
+ *                                2^-6 after scaling: the low fp16 terms of that region are denormal, the products there carry a
+ *                                relative error above 2^-19 instead of 2^-22.
+ * Either way the results of that run are not fp32-class: run the batch again in split-bf16 mode (conv_mode 0), which has fp32's
+ * range -- the Python host does that by itself (driver.run_trajectories) and records it in the result file.  Synchronises with
+ * the whole device (every stream).  reset != 0 clears the word. */
+#define SBC_RANGE_OVERFLOW  1
+#define SBC_RANGE_UNDERFLOW 2
 int sbc_range_flag(int32_t* flag, int32_t reset);
+
+/* Per-layer activation scales of conv_mode f16x2 (ABI 11).  A two-term fp16 split x s = h + l is fp32-class only while l stays a
+ * normal fp16 number, i.e. for |x s| >= 2^-3; the packers write act_scale s = 1, which is right for O(1) activations only.
+ * sbc_f16x2_calibrate runs the records `ops` ONCE on the first sample of their buffers (B = 1; the caller has put
+ * sbc_f16x2_calibration_input there: a fixed CN(0,1)-like pattern, so the result depends on the checkpoint and the array size,
+ * never on the data or the batch), collects max |x| of what every SBC_CONV_F16X2 convolution stages, and rewrites the 16-byte
+ * trailers of their weight forms in DEVICE memory: act_scale = the power of two that puts that maximum into [2^8, 2^9) (31x
+ * head room below the overflow guard, two-term precision for everything down to 2^-11 of the maximum), descale accordingly.
+ * InstanceNorm++ makes the network's activations independent of the input's magnitude, so one calibration per checkpoint holds
+ * for every noise level; data that leaves the window anyway raises sbc_range_flag.  Synchronises `stream`; must not run while
+ * other launches use the same weights.  sbc_score_create (conv_mode 3) calls it; the Python host does on its first bind. */
+int sbc_f16x2_calibration_input(float* x_host, int64_t n);
+int sbc_f16x2_calibrate(const sbc_op* ops, int32_t n_ops, void* stream);
 
 /* Known-answer hooks of the in-kernel random numbers (tests; synchronous, current device):
  *   sbc_debug_philox4x32     n blocks of Philox4x32-10 from host (c0, c1, c2, c3, k0, k1) records -> host (x, y, z, w) records:

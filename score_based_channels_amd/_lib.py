@@ -8,14 +8,15 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SBC_LIB_PATH') or os.path.join(_HERE, 'libsbc_hip.so')   # env override: A/B builds (tools/)
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 EXPORTS = ('sbc_abi_version', 'sbc_last_error', 'sbc_device_count', 'sbc_op_launch', 'sbc_plan_create',
            'sbc_plan_run', 'sbc_plan_destroy', 'sbc_plan_profile', 'sbc_plan_profile_read',
            'sbc_pack_conv_weight', 'sbc_pack_conv_weight_winograd',
            'sbc_pack_conv_weight_split', 'sbc_pack_conv_weight_winograd_split',
            'sbc_pack_conv_weight_f16', 'sbc_pack_conv_weight_winograd_f16',
-           'sbc_pack_conv_weight_f16x2', 'sbc_pack_conv_weight_winograd_f16x2', 'sbc_range_flag', 'sbc_debug_philox4x32', 'sbc_debug_complex_normal',
+           'sbc_pack_conv_weight_f16x2', 'sbc_pack_conv_weight_winograd_f16x2', 'sbc_range_flag',
+           'sbc_f16x2_calibration_input', 'sbc_f16x2_calibrate', 'sbc_debug_philox4x32', 'sbc_debug_complex_normal',
            'sbc_score_create', 'sbc_score_buffers', 'sbc_score_ops', 'sbc_score_level_source', 'sbc_score_forward',
            'sbc_score_destroy', 'sbc_wgrad_scratch_floats')
 
@@ -35,7 +36,8 @@ class sbc_op(C.Structure):
                 ('weight_wino_split', C.c_void_p),
                 # training operators (ABI 7)
                 ('grad', C.c_void_p), ('aux', C.c_void_p), ('wgrad', C.c_void_p), ('bgrad', C.c_void_p),
-                ('weight2_split', C.c_void_p)]
+                ('weight2_split', C.c_void_p),
+                ('calib', C.c_void_p)]                # ABI 11: NULL (set by sbc_f16x2_calibrate on its own copies)
 
 
 class sbc_endconv(C.Structure):
@@ -102,6 +104,8 @@ def lib():
     h.sbc_pack_conv_weight_f16x2.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     h.sbc_pack_conv_weight_winograd_f16x2.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     h.sbc_range_flag.argtypes = [C.POINTER(C.c_int32), C.c_int32]
+    h.sbc_f16x2_calibration_input.argtypes = [C.c_void_p, C.c_int64]
+    h.sbc_f16x2_calibrate.argtypes = [C.POINTER(sbc_op), C.c_int32, C.c_void_p]
     h.sbc_debug_philox4x32.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     h.sbc_debug_complex_normal.argtypes = [C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
     h.sbc_score_create.argtypes = [C.POINTER(sbc_score_desc), C.POINTER(sbc_tensor_ref), C.c_int32, C.POINTER(C.c_void_p)]
@@ -124,19 +128,54 @@ def check(rc):
         raise SbcError('libsbc_hip: %s (status %d)' % (lib().sbc_last_error().decode(), rc))
 
 
-def range_flag(reset=True):
-    """``sbc_range_flag``: non-zero when an f16x2 convolution on the current device staged an activation outside the fp16
-    range since the last reset (synchronises with the device)."""
+RANGE_OVERFLOW, RANGE_UNDERFLOW = 1, 2
+
+
+def range_flag(reset=True, device=None):
+    """``sbc_range_flag`` of ``device`` (default: the current one): the bit set the f16x2 convolutions collected since the last
+    reset -- ``RANGE_OVERFLOW``: a staged activation left the fp16 range; ``RANGE_UNDERFLOW``: a region of an input was so far
+    below its layer's calibrated scale that the two-term split there is no longer fp32-class.  Waits for every stream of the
+    device."""
     v = C.c_int32()
-    check(lib().sbc_range_flag(C.byref(v), 1 if reset else 0))
+    if device is not None:
+        import torch
+        with torch.cuda.device(device):
+            check(lib().sbc_range_flag(C.byref(v), 1 if reset else 0))
+    else:
+        check(lib().sbc_range_flag(C.byref(v), 1 if reset else 0))
     return v.value
 
 
-def check_range(what='run'):
-    """Raise if the f16x2 kernels flagged an activation outside their range: the numbers of that run cannot be trusted."""
-    if range_flag(True):
-        raise SbcError('%s: an activation left the range of conv_mode f16x2 (|x| >= 16000); results are invalid -- '
-                       'use conv_mode bf16x3 for this checkpoint' % what)
+def describe_range(bits):
+    what = []
+    if bits & RANGE_OVERFLOW:
+        what.append('an activation left the fp16 range (|x| * act_scale >= 16000)')
+    if bits & RANGE_UNDERFLOW:
+        what.append('a region of an input stayed below 2^-6 of its layer\'s scale (denormal low terms)')
+    return '; '.join(what)
+
+
+def check_range(what='run', device=None):
+    """Raise if the f16x2 kernels flagged this run: its numbers are not fp32-class (``driver.run_trajectories`` re-runs such a
+    batch in ``bf16x3`` instead of raising)."""
+    bits = range_flag(True, device)
+    if bits:
+        raise SbcError('%s: %s in conv_mode f16x2; results are not fp32-class -- use conv_mode bf16x3 for this input'
+                       % (what, describe_range(bits)))
+
+
+def calibration_input(n):
+    """The library's fixed calibration pattern (``sbc_f16x2_calibration_input``) as a float32 numpy array of ``n`` values."""
+    import numpy as np
+    x = np.empty(int(n), np.float32)
+    check(lib().sbc_f16x2_calibration_input(x.ctypes.data_as(C.c_void_p), int(n)))
+    return x
+
+
+def calibrate_f16x2(ops, stream):
+    """``sbc_f16x2_calibrate`` over a list of bound ``sbc_op`` records (synchronises ``stream``)."""
+    arr = (sbc_op * len(ops))(*ops)
+    check(lib().sbc_f16x2_calibrate(arr, len(ops), C.c_void_p(stream)))
 
 
 class Plan:

@@ -224,9 +224,100 @@ int sbc_range_flag(int32_t* flag, int32_t reset) {
     const int rc = range_flag_ptr(&w);
     if (rc) return rc;
     unsigned v = 0;
-    SBC_CHECK_HIP(hipMemcpy(&v, w, sizeof(v), hipMemcpyDeviceToHost));       // synchronises with the device
+    // every stream of the device, non-blocking ones included (a blocking copy on the legacy stream alone does not wait for them:
+    // the flag of a run still in flight on a torch side stream would surface one call late)
+    SBC_CHECK_HIP(hipDeviceSynchronize());
+    SBC_CHECK_HIP(hipMemcpy(&v, w, sizeof(v), hipMemcpyDeviceToHost));
     if (reset && v) SBC_CHECK_HIP(hipMemset(w, 0, sizeof(v)));
     *flag = (int32_t)v;
+    return SBC_OK;
+}
+
+// ---- f16x2 activation scales (include/sbc_hip.h: sbc_f16x2_calibrate) ----------------------------------------------------
+// The fixed calibration input: CN(0, 1)-like values (re, im each of variance 1/2) from a counter-based hash, the same on every
+// host and for every batch, so that the scales are a function of the checkpoint and the array size only.
+static inline uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+int sbc_f16x2_calibration_input(float* x, int64_t n) {
+    SBC_REQUIRE(x && n >= 0, "sbc_f16x2_calibration_input: bad arguments");
+    for (int64_t i = 0; i < n; ++i) {
+        double sum = 0.0;                                   // Irwin-Hall: four uniforms, variance 1/3
+        for (uint32_t k = 1; k <= 4; ++k) sum += (double)(fmix32((uint32_t)i * 4u + k * 0x9E3779B9u) >> 8) * (1.0 / 16777216.0);
+        x[i] = (float)((sum - 2.0) * 1.224744871391589);    // sqrt(3) * sqrt(1/2)
+    }
+    return SBC_OK;
+}
+
+int sbc_f16x2_calibrate(const sbc_op* ops, int32_t n_ops, void* stream) {
+    SBC_REQUIRE(ops && n_ops > 0, "sbc_f16x2_calibrate: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<sbc_op> run(ops, ops + n_ops);
+    std::vector<int> slot_of(n_ops, -1);
+    int n_slots = 0;
+    for (int i = 0; i < n_ops; ++i) {
+        run[i].B = 1;                                       // the first sample of every buffer
+        run[i].flags &= ~(SBC_OP_SIDE | SBC_OP_JOIN);
+        if ((run[i].flags & SBC_CONV_F16X2) && (run[i].kind == SBC_OP_CONV || run[i].kind == SBC_OP_CONV_PAIR)) {
+            slot_of[i] = n_slots;
+            n_slots += 2;
+        }
+    }
+    if (n_slots == 0) return SBC_OK;                        // nothing to calibrate in this record list
+    float* dslots = nullptr;
+    SBC_CHECK_HIP(hipMalloc((void**)&dslots, n_slots * sizeof(float)));
+    auto fail = [&](int rc) { (void)hipFree(dslots); return rc; };
+    if (hipMemsetAsync(dslots, 0, n_slots * sizeof(float), s) != hipSuccess) { set_error("sbc_f16x2_calibrate: hipMemsetAsync failed"); return fail(SBC_ERR_HIP); }
+    for (int i = 0; i < n_ops; ++i) {
+        if (slot_of[i] >= 0) run[i].calib = dslots + slot_of[i];
+        const int rc = dispatch(run[i], run[i].ext, s);
+        if (rc) return fail(rc);
+    }
+    if (hipStreamSynchronize(s) != hipSuccess) { set_error("sbc_f16x2_calibrate: the calibration pass failed on the device"); return fail(SBC_ERR_HIP); }
+    std::vector<float> amax(n_slots);
+    if (hipMemcpy(amax.data(), dslots, n_slots * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { set_error("sbc_f16x2_calibrate: copy failed"); return fail(SBC_ERR_HIP); }
+    (void)hipFree(dslots);
+    // act_scale = the power of two that puts the layer's calibration maximum into [2^8, 2^9): 31x head room below the overflow
+    // guard, full two-term precision for everything within 2^-11 of that maximum
+    auto scale_for = [](float m) {
+        if (!(m > 0.f) || !std::isfinite(m)) return 1.f;
+        int e = 0;
+        (void)frexpf(m, &e);                                // m = f 2^e, f in [0.5, 1)  ->  m 2^(9 - e) in [2^8, 2^9)
+        int k = 9 - e;
+        k = k < -24 ? -24 : k > 40 ? 40 : k;
+        return ldexpf(1.f, k);
+    };
+    // (fourth word: the layer's inputs are small -- maximum below 0.5 -- so its ELU prologue must keep RELATIVE accuracy for small
+    // negative values: SBC_PRO_ELU_ACC, common.h)
+    auto set_trailer = [&](const void* w, int taps, int cin, int cout, float sc, float amax_in) -> int {
+        if (!w) return SBC_OK;
+        float* tr = (float*)((char*)const_cast<void*>(w) + (size_t)taps * cin * cout * 2 * sizeof(uint16_t));
+        float old[4];
+        SBC_CHECK_HIP(hipMemcpy(old, tr, sizeof(old), hipMemcpyDeviceToHost));
+        const float wd = old[2] != 0.f ? old[2] : old[1] * old[0];          // the weights' own descale 2^-s
+        const float upd[4] = {sc, wd / sc, wd, (amax_in > 0.f && amax_in < 0.5f) ? 1.f : 0.f};
+        SBC_CHECK_HIP(hipMemcpy(tr, upd, sizeof(upd), hipMemcpyHostToDevice));
+        return SBC_OK;
+    };
+    for (int i = 0; i < n_ops; ++i) {
+        if (slot_of[i] < 0) continue;
+        const sbc_op& o = ops[i];
+        const float s1 = scale_for(amax[slot_of[i]]), s2 = scale_for(amax[slot_of[i] + 1]);
+        int rc = SBC_OK;
+        if (o.kind == SBC_OP_CONV_PAIR) {
+            rc = set_trailer(o.weight_split, 9, o.cin, o.cout, s1, amax[slot_of[i]]);
+            if (!rc) rc = set_trailer(o.weight2_split, 9, o.cout, o.cout, s2, amax[slot_of[i] + 1]);
+        } else {
+            rc = set_trailer(o.weight_split, o.ksize * o.ksize, o.cin, o.cout, s1, amax[slot_of[i]]);
+            if (!rc && o.ksize == 3 && o.dil == 1) rc = set_trailer(o.weight_wino_split, 16, o.cin, o.cout, s1, amax[slot_of[i]]);
+        }
+        if (rc) return rc;
+    }
+    // whatever the pass itself flagged (it ran with the scales it is about to replace) is not a verdict on a real run
+    unsigned* w = nullptr;
+    { const int rc = range_flag_ptr(&w); if (rc) return rc; }
+    SBC_CHECK_HIP(hipMemset(w, 0, sizeof(unsigned)));
     return SBC_OK;
 }
 
@@ -505,7 +596,8 @@ static inline void f16x2_terms(float w, int s, uint16_t* h, uint16_t* l) {
     memcpy(l, &ll, 2);
 }
 static void f16x2_trailer_write(uint16_t* dst, size_t n16, int s) {
-    const float tr[4] = {ldexpf(1.f, SBC_F16X2_ACT_SHIFT), ldexpf(1.f, -(s + SBC_F16X2_ACT_SHIFT)), 0.f, 0.f};
+    // (act_scale, descale = 1 / (act_scale weight_scale), the weights' own descale 2^-s, 0): sbc_f16x2_calibrate rewrites the first two
+    const float tr[4] = {ldexpf(1.f, SBC_F16X2_ACT_SHIFT), ldexpf(1.f, -(s + SBC_F16X2_ACT_SHIFT)), ldexpf(1.f, -s), 0.f};
     memcpy(dst + n16, tr, sizeof(tr));
 }
 

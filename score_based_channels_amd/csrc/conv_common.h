@@ -24,6 +24,8 @@ struct ConvParams {
     float* __restrict__ pm_out;
     // conv_mode f16x2: per-device word the kernels OR a 1 into when a staged activation leaves the fp16 range (tile.h)
     unsigned* __restrict__ range_flag;
+    // sbc_f16x2_calibrate: the layer's amax slot (max |x| of everything staged), NULL in ordinary launches
+    float* __restrict__ calib;
 };
 
 // Trailer of the f16x2 weight forms (sbc_pack_conv_weight_f16x2 / _winograd_f16x2): one 16-byte record behind the last

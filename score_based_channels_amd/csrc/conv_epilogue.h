@@ -121,7 +121,7 @@ __device__ __forceinline__ void conv_epilogue(const float* lds, const ConvParams
                 if (ok[i]) rr[i] = ld_stream(p.res1 + o[i]);
             if (p.flags & SBC_EPI_RES1_ELU) {
 #pragma unroll
-                for (int i = 0; i < EC; ++i) rr[i] = elu4(rr[i]);
+                for (int i = 0; i < EC; ++i) rr[i] = elu4_acc(rr[i]);
             }
             if (p.res2 && !(p.flags & SBC_EPI_ELUGRAD)) {
                 float4 r2[EC];

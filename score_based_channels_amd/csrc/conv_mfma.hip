@@ -248,6 +248,7 @@ int launch_conv(const sbc_op& op, hipStream_t stream, bool dry) {
     p.plane = 0; p.stats_off = 0; p.top = op.tag == 1;
     p.pm_out = (float*)op.aux;
     p.range_flag = nullptr;
+    p.calib = (float*)op.calib;
     if (op.flags & SBC_CONV_F16X2) {
         SBC_REQUIRE(x3 && !(op.flags & SBC_CONV_F16W), "conv: SBC_CONV_F16X2 needs weight_split (sbc_pack_conv_weight_f16x2) and excludes SBC_CONV_F16W");
         unsigned* word = nullptr;

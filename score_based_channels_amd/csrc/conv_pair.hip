@@ -31,6 +31,7 @@ struct PairParams {
     const uint4* __restrict__ w1;       // sbc_pack_conv_weight_f16x2 / _f16 layout of conv1 (32 -> 32, 3x3)
     const uint4* __restrict__ w2;
     unsigned* __restrict__ range_flag;
+    float* __restrict__ calib;          // sbc_f16x2_calibrate: two amax slots (conv1's input, the intermediate), else NULL
     int B, H, ntiles, tiles_per_sample, wgs_per_xcd, tiles_per_xcd;
     unsigned long long* dbg;            // SBC_PAIR_TIMING builds: per-phase cycle sums of wave 0 of every workgroup
 };
@@ -40,6 +41,16 @@ struct PairParams {
 #else
 #define PT_MARK(k) do { } while (0)
 #endif
+
+// range tracking of one tile (tile.h): the wave's verdict on what it just converted goes into `rbits` (wave-uniform, raised once
+// at the end of the launch); calibration launches (calib != NULL) fold the wave's maximum into the record's slot right away
+__device__ __forceinline__ void pair_range_tile(float t, float scale, unsigned& rbits, float* __restrict__ calib_slot) {
+    rbits |= f16x2_range_bits(t, scale);
+    if (calib_slot) {
+        for (int o = 32; o > 0; o >>= 1) t = __builtin_fmaxf(t, __shfl_xor(t, o));
+        if ((threadIdx.x & 63) == 0 && t > 0.f) atomicMax(reinterpret_cast<unsigned*>(calib_slot), __float_as_uint(t));
+    }
+}
 
 __device__ __forceinline__ void lds_barrier() {
     // LDS traffic only: the tile in flight by LDS-DMA (vmcnt) must NOT be waited for here
@@ -104,10 +115,18 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_pair_kernel(PairParams p) {
         }
     }
     float scale1 = 1.f, descale1 = 1.f, scale2 = 1.f, descale2 = 1.f;
+    // range tracking (tile.h): per tile, max |x| of what this lane converts for conv1 (ta) / writes as the intermediate (tb); the
+    // wave-level verdicts accumulate in `rbits`
+    unsigned rbits = 0;
     if constexpr (MODE == 2) {
         const float4 t1 = f16x2_trailer(reinterpret_cast<const float4*>(p.w1), 9 * (C / 16) * (C / 32) * NT);
         const float4 t2 = f16x2_trailer(reinterpret_cast<const float4*>(p.w2), 9 * (C / 16) * (C / 32) * NT);
-        scale1 = t1.x; descale1 = t1.y; scale2 = t2.x; descale2 = t2.y;
+        scale1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t1.x)));
+        scale2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t2.x)));
+        descale1 = t1.y; descale2 = t2.y;
+        // the calibration found one of the two convolutions' inputs below 2^-4 (fourth trailer word): this kernel evaluates ELU as
+        // exp(x) - 1 only (it has no registers for the accurate form of common.h) -- say so, the host re-runs the batch in bf16x3
+        if (t1.w != 0.f || t2.w != 0.f) rbits |= 4u;
     }
 
     // ---- zero the padding columns of every plane once (nothing writes them afterwards)
@@ -147,7 +166,6 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_pair_kernel(PairParams p) {
     };
     int tile = t_begin + jw;
     if (tile < t_end) issue_dma(tile);
-    float amax = 0.f;
 #ifdef SBC_PAIR_TIMING
     unsigned long long pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt_last = __builtin_readcyclecounter();
 #endif
@@ -160,6 +178,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_pair_kernel(PairParams p) {
         asm volatile("s_barrier" ::: "memory");
         PT_MARK(1);
         // (2) convert raw -> operand planes of conv1
+        float ta = 0.f, tb = 0.f;
 #pragma unroll
         for (int k = 0; k < NQ / NTH; ++k) {
             const int q = k * NTH + tid;
@@ -171,12 +190,11 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_pair_kernel(PairParams p) {
             v = elu4(v);
             unsigned char* dst = smem + X_OFF + (c4 >> 1) * XPS + (ri * WP + col + 1) * 16 + (c4 & 1) * 8;
             if constexpr (MODE == 2) {
-                StageScale ss{scale1, amax};
+                StageScale ss{scale1, ta};
                 scale_track(v, &ss);
-                amax = ss.amax;
+                ta = ss.amax;
                 uint2 h, l;
-                split_f16x2(v.x, v.y, h.x, l.x);
-                split_f16x2(v.z, v.w, h.y, l.y);
+                split_f16x2(v, scale1, h, l);
                 *reinterpret_cast<uint2*>(dst) = h;
                 *reinterpret_cast<uint2*>(dst + KGS * XPS) = l;
             } else {
@@ -185,6 +203,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_pair_kernel(PairParams p) {
                 *reinterpret_cast<f16x4*>(dst) = h;
             }
         }
+        if constexpr (MODE == 2) pair_range_tile(ta, scale1, rbits, p.calib);
         PT_MARK(2);
         lds_barrier();
         PT_MARK(3);
@@ -252,12 +271,11 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_pair_kernel(PairParams p) {
                     if (grow < 0 || grow >= H) v = make_float4(0.f, 0.f, 0.f, 0.f);    // zero padding of conv2, not conv1 of padding
                     unsigned char* dst = smem + M_OFF + (cq >> 1) * MPS + (prow * WP + pcol + 1) * 16 + (cq & 1) * 8;
                     if constexpr (MODE == 2) {
-                        StageScale ss{scale2, amax};
+                        StageScale ss{scale2, tb};
                         scale_track(v, &ss);
-                        amax = ss.amax;
+                        tb = ss.amax;
                         uint2 h, l;
-                        split_f16x2(v.x, v.y, h.x, l.x);
-                        split_f16x2(v.z, v.w, h.y, l.y);
+                        split_f16x2(v, scale2, h, l);
                         *reinterpret_cast<uint2*>(dst) = h;
                         *reinterpret_cast<uint2*>(dst + KGS * MPS) = l;
                     } else {
@@ -268,6 +286,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_pair_kernel(PairParams p) {
                 }
             }
         }
+        if constexpr (MODE == 2) pair_range_tile(tb, scale2, rbits, p.calib ? p.calib + 1 : nullptr);
         PT_MARK(4);
         lds_barrier();
         PT_MARK(5);
@@ -301,7 +320,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_pair_kernel(PairParams p) {
         // the next iteration's barrier (1) orders conv2's reads of the intermediate planes before anything rewrites them
     }
     if constexpr (MODE == 2) {
-        if (amax >= F16X2_LIMIT) atomicOr(p.range_flag, 1u);
+        if (rbits && (threadIdx.x & 63) == 0) atomicOr(p.range_flag, rbits);
     }
 #ifdef SBC_PAIR_TIMING
     if (tid == 0 && p.dbg)
@@ -374,10 +393,18 @@ __global__ __launch_bounds__(192 * NW, 3) void conv_pair_p3_kernel(PairParams p)
                     wf[tap][kh][t] = w[(((tap * (C / 16) + 2 * kh + (kq >> 1)) * (C / 32) + nb) * NT + t) * 64 + lsrc];
     }
     float scale1 = 1.f, descale1 = 1.f, scale2 = 1.f, descale2 = 1.f;
+    // range tracking (tile.h): per tile, max |x| of what this lane converts for conv1 (ta) / writes as the intermediate (tb); the
+    // wave-level verdicts accumulate in `rbits`
+    unsigned rbits = 0;
     if constexpr (MODE == 2) {
         const float4 t1 = f16x2_trailer(reinterpret_cast<const float4*>(p.w1), 9 * (C / 16) * (C / 32) * NT);
         const float4 t2 = f16x2_trailer(reinterpret_cast<const float4*>(p.w2), 9 * (C / 16) * (C / 32) * NT);
-        scale1 = t1.x; descale1 = t1.y; scale2 = t2.x; descale2 = t2.y;
+        scale1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t1.x)));
+        scale2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t2.x)));
+        descale1 = t1.y; descale2 = t2.y;
+        // the calibration found one of the two convolutions' inputs below 2^-4 (fourth trailer word): this kernel evaluates ELU as
+        // exp(x) - 1 only (it has no registers for the accurate form of common.h) -- say so, the host re-runs the batch in bf16x3
+        if (t1.w != 0.f || t2.w != 0.f) rbits |= 4u;
     }
 
     // ---- zero the padding columns of every plane once (nothing writes them afterwards)
@@ -414,11 +441,11 @@ __global__ __launch_bounds__(192 * NW, 3) void conv_pair_p3_kernel(PairParams p)
     const int n_my = first < t_end ? (t_end - first + p.wgs_per_xcd - 1) / p.wgs_per_xcd : 0;
     if (n_my == 0) return;                                          // (whole workgroup)
     auto tile_of = [&](int k) { return first + k * p.wgs_per_xcd; };
-    float amax = 0.f;
     auto convert_tile = [&](int k, int rb, int xb) {                // raw[rb] -> input planes X[xb] of tile k
         const int tile = tile_of(k);
         const int n = tile / p.tiles_per_sample, r0 = (tile - n * p.tiles_per_sample) * R;
         (void)n;
+        float ta = 0.f;
 #pragma unroll
         for (int kk = 0; kk < NQ / NTH; ++kk) {
             const int q = kk * NTH + tid;
@@ -430,12 +457,11 @@ __global__ __launch_bounds__(192 * NW, 3) void conv_pair_p3_kernel(PairParams p)
             v = elu4(v);
             unsigned char* dst = smem + X_OFF + xb * XSZ + (c4 >> 1) * XPS + (ri * WP + col + 1) * 16 + (c4 & 1) * 8;
             if constexpr (MODE == 2) {
-                StageScale ss{scale1, amax};
+                StageScale ss{scale1, ta};
                 scale_track(v, &ss);
-                amax = ss.amax;
+                ta = ss.amax;
                 uint2 h, l;
-                split_f16x2(v.x, v.y, h.x, l.x);
-                split_f16x2(v.z, v.w, h.y, l.y);
+                split_f16x2(v, scale1, h, l);
                 *reinterpret_cast<uint2*>(dst) = h;
                 *reinterpret_cast<uint2*>(dst + KGS * XPS) = l;
             } else {
@@ -444,6 +470,7 @@ __global__ __launch_bounds__(192 * NW, 3) void conv_pair_p3_kernel(PairParams p)
                 *reinterpret_cast<f16x4*>(dst) = h;
             }
         }
+        if constexpr (MODE == 2) pair_range_tile(ta, scale1, rbits, p.calib);
     };
     // the conversion waves request tile 0; the barrier that opens iteration 0 publishes it (and the padding zeros)
     if (role == 2) {
@@ -518,6 +545,7 @@ __global__ __launch_bounds__(192 * NW, 3) void conv_pair_p3_kernel(PairParams p)
                 f32x4v acc[NU1];
                 conv(std::integral_constant<int, 0>{}, X_OFF + (t1 & 1) * XSZ, XPS, std::integral_constant<int, NU1>{}, std::integral_constant<int, NU1T>{}, acc);
                 const int cq = 4 * hf + kq;                                    // channel quad of this lane's four outputs
+                float tb = 0.f;
 #pragma unroll
                 for (int i = 0; i < NU1; ++i) {
                     if (u0 + USTEP * i < NU1T) {
@@ -528,12 +556,11 @@ __global__ __launch_bounds__(192 * NW, 3) void conv_pair_p3_kernel(PairParams p)
                         if (grow < 0 || grow >= H) v = make_float4(0.f, 0.f, 0.f, 0.f);    // zero padding of conv2, not conv1 of padding
                         unsigned char* dst = smem + M_OFF + (t1 & 1) * MSZ + (cq >> 1) * MPS + (prow * WP + pcol + 1) * 16 + (cq & 1) * 8;
                         if constexpr (MODE == 2) {
-                            StageScale ss{scale2, amax};
+                            StageScale ss{scale2, tb};
                             scale_track(v, &ss);
-                            amax = ss.amax;
+                            tb = ss.amax;
                             uint2 h, l;
-                            split_f16x2(v.x, v.y, h.x, l.x);
-                            split_f16x2(v.z, v.w, h.y, l.y);
+                            split_f16x2(v, scale2, h, l);
                             *reinterpret_cast<uint2*>(dst) = h;
                             *reinterpret_cast<uint2*>(dst + KGS * MPS) = l;
                         } else {
@@ -543,6 +570,7 @@ __global__ __launch_bounds__(192 * NW, 3) void conv_pair_p3_kernel(PairParams p)
                         }
                     }
                 }
+                if constexpr (MODE == 2) pair_range_tile(tb, scale2, rbits, p.calib ? p.calib + 1 : nullptr);
             }
 
             continue;
@@ -579,7 +607,7 @@ __global__ __launch_bounds__(192 * NW, 3) void conv_pair_p3_kernel(PairParams p)
         }
     }
     if constexpr (MODE == 2) {
-        if (amax >= F16X2_LIMIT) atomicOr(p.range_flag, 1u);
+        if (rbits && (threadIdx.x & 63) == 0) atomicOr(p.range_flag, rbits);
     }
 }
 
@@ -646,6 +674,7 @@ int launch_conv_pair(const sbc_op& op, hipStream_t stream, bool dry) {
     p.w1 = (const uint4*)op.weight_split; p.w2 = (const uint4*)op.weight2_split;
     p.B = op.B; p.H = op.H;
     p.dbg = (unsigned long long*)op.aux;
+    p.calib = (float*)op.calib;
     if (x2) {
         unsigned* word = nullptr;
         const int rc = range_flag_ptr(&word);

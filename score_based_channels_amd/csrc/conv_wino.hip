@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(ConvParams p) {
 #pragma unroll
                         for (int a = 0; a < 2; ++a)
 #pragma unroll
-                            for (int b = 0; b < 2; ++b) rr[a][b] = elu4(rr[a][b]);
+                            for (int b = 0; b < 2; ++b) rr[a][b] = elu4_acc(rr[a][b]);
                     }
                     if (p.res2) {
 #pragma unroll

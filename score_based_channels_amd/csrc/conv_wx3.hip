@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
     const int col = lane & 31, rhalf = 4 * (lane >> 5);
 
     const TileGeom g = tile_geom(xcd_tile(blockIdx.x, gridDim.x), TM, p.B, dm, 1);
-    float descale = 1.f;
+    float descale = 1.f, act_scale = 1.f;
 #ifdef SBC_WX3_TIMING
     unsigned long long wt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -88,10 +88,12 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
     {
         StageScale ss{1.f, 0.f};
         StageScale* const ssp = MODE == 2 ? &ss : nullptr;
+        int sflags = p.flags;                                             // prologue flags of the staging calls
         if constexpr (MODE == 2) {
             const float4 tr = f16x2_trailer(p.wpk, 16 * KG * NBLK * NTERM);
-            ss.scale = tr.x;
+            ss.scale = act_scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tr.x)));
             descale = tr.y;
+            if (__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tr.w)) != 0) sflags |= SBC_PRO_ELU_ACC;   // calibration: small inputs
         }
         float4 pf[NPF];
         stage_issue<CIN, NTHREADS, NPF>(pf, p.in, g, W, tid);
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
         if ((p.flags & SBC_PRO_NORM) && !g.multi) {
             // one sample per tile: statistics straight into registers, no LDS copy, no barrier (tile.h)
             const RegStats rs = load_reg_stats<CIN, NTHREADS>(p.stats, g, tid);
-            stage_commit_reg<CIN, NTHREADS, NPF>(lds, pf, p.in, rs, p.flags, g, W, tid, ssp);
+            stage_commit_reg<CIN, NTHREADS, NPF>(lds, pf, p.in, rs, sflags, g, W, tid, ssp);
             direct = true;
         } else if (p.flags & SBC_PRO_NORM_SELF) {
             // whole samples per tile: the statistics are computed here, `stats` = the norm's parameters (tile.h; ends in a barrier)
@@ -111,10 +113,8 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
             stage_stats_to_lds<CIN, NTHREADS, P2>(st_lds, p.stats, g, dm, tid);
             __syncthreads();
         }
-        if (!direct) stage_commit<CIN, NTHREADS, NPF, P2>(lds, pf, p.in, st_lds, p.flags, g, dm, tid, 0, ssp);
-        if constexpr (MODE == 2) {
-            if (ss.amax >= F16X2_LIMIT) atomicOr(p.range_flag, 1u);
-        }
+        if (!direct) stage_commit<CIN, NTHREADS, NPF, P2>(lds, pf, p.in, st_lds, sflags, g, dm, tid, 0, ssp);
+        if constexpr (MODE == 2) f16x2_range_report(ss.amax, act_scale, p.range_flag, p.calib);
     }
     WT_MARK(2);
     // T planes [xi][b][tile][TS]: overlay the staged tile when there is a single output block, else live behind it
@@ -221,10 +221,13 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
                                                                             acc[q][nu], 0, 0, 0);
                 } else if constexpr (MODE == 2) {
                     uint4 vhu, vlu;
-                    split_f16x2(v[0], v[1], vhu.x, vlu.x);
-                    split_f16x2(v[2], v[3], vhu.y, vlu.y);
-                    split_f16x2(v[4], v[5], vhu.z, vlu.z);
-                    split_f16x2(v[6], v[7], vhu.w, vlu.w);
+                    {
+                        uint2 ha, la, hb, lb;
+                        split_f16x2(make_float4(v[0], v[1], v[2], v[3]), act_scale, ha, la);
+                        split_f16x2(make_float4(v[4], v[5], v[6], v[7]), act_scale, hb, lb);
+                        vhu = make_uint4(ha.x, ha.y, hb.x, hb.y);
+                        vlu = make_uint4(la.x, la.y, lb.x, lb.y);
+                    }
                     split_f16x2_settle(vhu, vlu);                  // wait states before the matrix instructions read the terms (tile.h)
                     const f16x8 vh = __builtin_bit_cast(f16x8, vhu), vl = __builtin_bit_cast(f16x8, vlu);
                     __builtin_amdgcn_sched_barrier(0);
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
 #pragma unroll
                         for (int a = 0; a < 2; ++a)
 #pragma unroll
-                            for (int b = 0; b < 2; ++b) rr[a][b] = elu4(rr[a][b]);
+                            for (int b = 0; b < 2; ++b) rr[a][b] = elu4_acc(rr[a][b]);
                     }
                     if (p.res2 && !(p.flags & SBC_EPI_ELUGRAD)) {
 #pragma unroll

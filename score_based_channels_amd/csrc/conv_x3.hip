@@ -62,10 +62,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_x3_kernel(ConvParams p) {
     if constexpr (TERMS == 2) {
         // conv_mode f16x2: scaled activations as two fp16 terms; the scales ride behind the packed weight (conv_common.h)
         const float4 tr = f16x2_trailer(p.wpk, TAPS * KG * NBLK * TERMS);
-        StageScale ss{tr.x, 0.f};
+        StageScale ss{__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tr.x))), 0.f};
         descale = tr.y;
-        stage_tile_split<CIN, NTHREADS, NPF, P2, TERMS>(lds16, plane, p.in, stats, p.flags, g, dm, tid, &ss, n0);
-        if (ss.amax >= F16X2_LIMIT) atomicOr(p.range_flag, 1u);
+        const int sflags = p.flags | (__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tr.w)) != 0 ? SBC_PRO_ELU_ACC : 0);
+        stage_tile_split<CIN, NTHREADS, NPF, P2, TERMS>(lds16, plane, p.in, stats, sflags, g, dm, tid, &ss, n0);
+        f16x2_range_report(ss.amax, ss.scale, p.range_flag, p.calib);
     } else {
         stage_tile_split<CIN, NTHREADS, NPF, P2, TERMS>(lds16, plane, p.in, stats, p.flags, g, dm, tid, nullptr, n0);
     }

@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void maxpool5_kernel(const float* __restrict__
     float4 m0 = rowmax(h0 - 2), m1 = rowmax(h0 - 1), m2 = rowmax(h0), m3 = rowmax(h0 + 1), m4 = rowmax(h0 + 2);
     for (int h = h0; h < h1; ++h) {
         float4 m = max4(max4(max4(m0, m1), max4(m2, m3)), m4);
-        if (flags & SBC_PRO_ELU) m = elu4(m);
+        if (flags & SBC_PRO_ELU) m = elu4_acc(m);
         st_stream(obase + (size_t)h * row_stride, m);
         m0 = m1; m1 = m2; m2 = m3; m3 = m4;
         if (h + 1 < h1) m4 = rowmax(h + 3);
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void maxpool5_rows_kernel(const float* __restr
         for (int k = 0; k < 4; ++k) {
             const float4 m4 = col[(rr0 + 4 + k) * WT * C4];
             float4 m = max4(max4(max4(m0, m1), max4(m2, m3)), m4);
-            if (flags & SBC_PRO_ELU) m = elu4(m);
+            if (flags & SBC_PRO_ELU) m = elu4_acc(m);
             st_stream(obase + (size_t)(r0 + rr0 + k) * row_stride + ((size_t)(w0 + w) * C4 + c4) * 4, m);
             m0 = m1; m1 = m2; m2 = m3; m3 = m4;
         }
@@ -727,6 +727,11 @@ static int check_langevin(const sbc_op& op, const sbc_langevin& a, bool measure)
                     "langevin: X, score, sched, nmse, step must be set");
         const size_t lds = (size_t)a.Np * a.Nr * sizeof(float2);
         SBC_REQUIRE(lds <= 150 * 1024, "langevin: Nr=%d Np=%d needs %zu bytes of LDS", a.Nr, a.Np, lds);
+        // the update loop takes the elements of a row in adjacent PAIRS (one Philox block, one pilot value, 16-byte accesses):
+        // a pair must not straddle two rows, and every per-trajectory tensor must start on a 16-byte boundary
+        SBC_REQUIRE(a.Nr % 2 == 0, "langevin: Nr = %d must be even (elements are updated in adjacent pairs of a row)", a.Nr);
+        SBC_REQUIRE(!(((uintptr_t)a.X | (uintptr_t)a.score | (uintptr_t)a.Y | (uintptr_t)a.Htrue | (uintptr_t)a.noise) & 15),
+                    "langevin: X, score, Y, Htrue and noise must be 16-byte aligned");
     } else {
         SBC_REQUIRE(a.meas_scale, "measure: meas_scale must be set");
     }

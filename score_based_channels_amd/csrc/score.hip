@@ -378,6 +378,7 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
             if (f16w) r.flags |= SBC_CONV_F16W;
             if (f16x2) r.flags |= SBC_CONV_F16X2;
         }
+        if ((d->conv_mode == 0 || d->conv_mode == 1) && o.kind == SBC_OP_CONV && (o.flags & SBC_PRO_ELU)) r.flags |= SBC_PRO_ELU_ACC;   // scorenet.bind
         if (!o.bias.empty()) r.bias = wp(o.bias);
         if (o.stats >= 0) r.stats = s->slots[s->tensors[o.stats].slot];
         if (!o.norm_key.empty()) r.stats = wp(o.norm_key);
@@ -389,6 +390,19 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
     }
     const int rc = sbc_plan_create(s->ops.data(), (int32_t)s->ops.size(), &s->plan);
     if (rc) { sbc_score_destroy(s); return rc; }
+    if (f16x2) {
+        // per-layer activation scales (include/sbc_hip.h: sbc_f16x2_calibrate; scorenet.ScoreNet._ensure_calibrated): one pass over
+        // the fixed calibration input in the first sample of the x buffer
+        const size_t n = (size_t)nt * nr * d->channels;
+        std::vector<float> pat(n);
+        int rc2 = sbc_f16x2_calibration_input(pat.data(), (int64_t)n);
+        if (!rc2 && hipMemcpy(s->slots[s->tensors[s->x_t].slot], pat.data(), n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("sbc_score_create: upload of the calibration input failed");
+            rc2 = SBC_ERR_HIP;
+        }
+        if (!rc2) rc2 = sbc_f16x2_calibrate(s->ops.data(), (int32_t)s->ops.size(), nullptr);
+        if (rc2) { sbc_score_destroy(s); return rc2; }
+    }
     *out = s;
     return SBC_OK;
 }

@@ -32,18 +32,44 @@ __device__ __forceinline__ void st_stream(float* p, float4 v) {
 #endif
 }
 
-// conv_mode f16x2 (SBC_CONV_F16X2): activations enter the matrix cores UNSCALED, split into two fp16 terms (the first float of
-// the packed weight's trailer is reserved and written as 1: |x| < 0.125 keeps an absolute error of 2^-25 instead of a relative
-// 2^-22, far below the fp32 rounding of the O(1) values it is summed with, and the range reaches 16000).  `amax` collects max |x|
-// of what a thread stages: past F16X2_LIMIT the high term (or, in the Winograd kernel, a 4-term transform sum) could overflow
-// fp16, and the kernel raises the device range flag instead of returning silently wrong numbers.
-struct StageScale { float scale; float amax; };          // (scale: reserved, 1)
+// conv_mode f16x2 (SBC_CONV_F16X2): activations enter the matrix cores as x * act_scale split into two fp16 terms.  act_scale is a
+// power of two per LAYER, the first float of the packed weight's trailer: 1 as packed, set by sbc_f16x2_calibrate (api.hip) so that
+// the layer's calibration-time max |x| lands in [2^8, 2^9) -- fp16 then holds the low term l = fp16(x s - h) as a NORMAL number
+// for every |x s| >= 2^-3 (relative error 2^-22 over 12 binades below the calibrated maximum and 5 above it), where the unscaled
+// split of rounds 2-3 degraded to an absolute 2^-25 as soon as |x| < 0.125.  The multiplication rides in the split itself
+// (split_f16x2: fma(x, s, 0) / fma(x, s, -h) on the mixed-precision FMA), so it costs one instruction per PAIR of values.
+// `amax` collects max |x| (unscaled) of what a thread stages.  Both ends are guarded through the device's range-flag word
+// (sbc_range_flag): bit 0 when amax * act_scale >= F16X2_LIMIT (the high term or, in the Winograd kernel, a 4-term transform sum
+// could overflow fp16), bit 1 when a whole wave's share of a tile is non-zero but stays below F16X2_SMALL after scaling (the low
+// terms of that region are fp16 denormals: precision is no longer fp32-class).  The host re-runs such a batch in bf16x3.
+struct StageScale { float scale; float amax; };
 constexpr float F16X2_LIMIT = 16000.f;                   // 65504 / 4, rounded down
+constexpr float F16X2_SMALL = 0.015625f;                 // 2^-6: below it the relative error of the split exceeds 2^-19
 __device__ __forceinline__ void scale_track(const float4& x, StageScale* ss) {
     if (!ss) return;
     // (max(max(a, |x|), |y|): the shape hipcc turns into one v_max3_f32 with |.| source modifiers)
     ss->amax = __builtin_fmaxf(__builtin_fmaxf(ss->amax, __builtin_fabsf(x.x)), __builtin_fabsf(x.y));
     ss->amax = __builtin_fmaxf(__builtin_fmaxf(ss->amax, __builtin_fabsf(x.z)), __builtin_fabsf(x.w));
+}
+// range check of what this wave staged (all lanes call; `amax` = the lane's max |x|, unscaled): returns the bits to OR into the
+// device's range-flag word, 0 in the normal case
+__device__ __forceinline__ unsigned f16x2_range_bits(float amax, float scale) {
+    const float am = amax * scale;
+    unsigned bits = 0;
+    if (__builtin_amdgcn_ballot_w64(am >= F16X2_LIMIT)) bits |= 1u;
+    if (!__builtin_amdgcn_ballot_w64(am >= F16X2_SMALL) && __builtin_amdgcn_ballot_w64(amax > 0.f)) bits |= 2u;
+    return bits;
+}
+// ... and the store: one lane per wave raises the flag; in calibration launches (calib != NULL, sbc_f16x2_calibrate) the wave also
+// folds its max |x| into the layer's slot (non-negative floats order like their bit patterns)
+__device__ __forceinline__ void f16x2_range_report(float amax, float scale, unsigned* __restrict__ flag, float* __restrict__ calib) {
+    const unsigned bits = f16x2_range_bits(amax, scale);
+    if (bits && (threadIdx.x & 63) == 0) atomicOr(flag, bits);
+    if (calib) {
+        float m = amax;
+        for (int o = 32; o > 0; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o));
+        if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(calib), __float_as_uint(m));
+    }
 }
 
 // Image dimensions with the divisions the kernels need.  P2 = true: H and W are powers of two (every shape the
@@ -132,7 +158,7 @@ __device__ __forceinline__ void stage_put(float* lds, float4 x, int idx, const f
         x.z = (x.z - mu.z) * sc.z + sh.z;
         x.w = (x.w - mu.w) * sc.w + sh.w;
     }
-    if (flags & SBC_PRO_ELU) x = elu4(x);
+    if (flags & SBC_PRO_ELU) x = elu4(x, (flags & SBC_PRO_ELU_ACC) != 0);
     scale_track(x, ss);
     *reinterpret_cast<float4*>(lds + pix * S + c4 * 4) = x;
 }
@@ -273,7 +299,7 @@ __device__ __forceinline__ void stage_commit_reg(float* lds, const float4 (&pf)[
     auto put = [&](float4 x, int idx) {
         x.x = (x.x - rs.mu.x) * rs.sc.x + rs.sh.x; x.y = (x.y - rs.mu.y) * rs.sc.y + rs.sh.y;
         x.z = (x.z - rs.mu.z) * rs.sc.z + rs.sh.z; x.w = (x.w - rs.mu.w) * rs.sc.w + rs.sh.w;
-        if (flags & SBC_PRO_ELU) x = elu4(x);
+        if (flags & SBC_PRO_ELU) x = elu4(x, (flags & SBC_PRO_ELU_ACC) != 0);
         scale_track(x, ss);
         *reinterpret_cast<float4*>(lds + (idx / C4) * S + (idx % C4) * 4) = x;
     };
@@ -316,22 +342,42 @@ __device__ __forceinline__ void split3(float4 x, bf16x4& h, bf16x4& m, bf16x4& l
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-// Two-term fp16 split (conv_mode f16x2): a = h + l + O(2^-22 |a|), h = fp16(a) (round to nearest even), l = fp16(a - h); the
-// difference a - h is exact in fp32.  One v_cvt_pk_f16_f32 for the pair of high terms, one v_fma_mixlo/mixhi_f16 per low term
-// (fma(a, 1.0, -h) evaluated in fp32 from the fp16 half, rounded once to fp16).
+// Two-term fp16 split (conv_mode f16x2) of a * s (s = the layer's act_scale, a power of two): a s = h + l + O(2^-22 |a s|),
+// h = fp16(a s) (round to nearest even), l = fp16(a s - h); the product a s and the difference a s - h are exact in fp32, so each
+// term is ONE mixed-precision FMA rounded once to fp16: v_fma_mixlo/mixhi_f16 h = fma(a, s, 0), l = fma(a, s, -h) with the third
+// operand read from the fp16 half just written.  Four vector instructions per pair of values.
 // h, l: the two values' terms packed low | high, as the matrix instructions take them.
 // HAZARD: hipcc does not look inside inline assembly, so it inserts none of the wait states a vector-ALU write needs before a
-// MATRIX instruction reads the register.  Where split terms feed v_mfma_* directly from registers (conv_wx3.hip) the caller puts
-// split_f16x2_settle() between the last split and the first matrix instruction: without it one instantiation (128 -> 64, two
-// output blocks per phase), in which nothing else happened to sit between the two, multiplied a stale high half -- results off
-// by 3e-4 ... 0.5, correct at -O1 and with the two wait states.  Terms that go through LDS first (conv_x3, conv_pair) are safe.
+// MATRIX instruction reads the register.  Where split terms feed v_mfma_* directly from registers (conv_wx3.hip, conv_wp.hip) the
+// caller puts split_f16x2_settle() between the last split and the first matrix instruction: without it one instantiation (128 ->
+// 64, two output blocks per phase), in which nothing else happened to sit between the two, multiplied a stale high half -- results
+// off by 3e-4 ... 0.5, correct at -O1 and with the two wait states.  Terms that go through LDS first (conv_x3, conv_pair) are safe.
 __device__ __forceinline__ void split_f16x2_settle(uint4& h, uint4& l) {
     asm volatile("s_nop 1" : "+v"(h.x), "+v"(h.y), "+v"(h.z), "+v"(h.w), "+v"(l.x), "+v"(l.y), "+v"(l.z), "+v"(l.w));
 }
-__device__ __forceinline__ void split_f16x2(float a, float b, unsigned& h, unsigned& l) {
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(a), "v"(b));
-    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a), "v"(h));
-    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(b), "v"(h));
+// Four values at a time: the two high terms are complete before the first low term reads them, so no instruction reads a
+// register in the slot right behind a 16-bit (partial) write of it.
+__device__ __forceinline__ void split_f16x2(float4 x, float s, uint2& h, uint2& l) {
+#ifdef SBC_F16X2_UNSCALED   // timing aid (tools/): the three-instruction split of round 3, right only while every act_scale is 1
+    asm("v_cvt_pk_f16_f32 %0, %2, %3\n\tv_cvt_pk_f16_f32 %1, %4, %5" : "=&v"(h.x), "=&v"(h.y) : "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w));
+    asm("v_fma_mixlo_f16 %0, %2, 1.0, -%4 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %1, %3, 1.0, -%5 op_sel:[0,0,0] op_sel_hi:[0,0,1]"
+        : "=&v"(l.x), "=&v"(l.y) : "v"(x.x), "v"(x.z), "v"(h.x), "v"(h.y));
+    asm("v_fma_mixhi_f16 %0, %2, 1.0, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, 1.0, -%5 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "+v"(l.x), "+v"(l.y) : "v"(x.y), "v"(x.w), "v"(h.x), "v"(h.y));
+    (void)s;
+    return;
+#endif
+    asm("v_fma_mixlo_f16 %0, %4, %8, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixlo_f16 %1, %6, %8, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %5, %8, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %7, %8, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixlo_f16 %2, %4, %8, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %3, %6, %8, -%1 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %2, %5, %8, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %3, %7, %8, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(h.x), "=&v"(h.y), "=&v"(l.x), "=&v"(l.y) : "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w), "s"(s));
 }
 
 // lds16: LDS viewed as 16-bit elements; `plane` = elements per plane; TERMS = 3 (exact bf16 split), 2 (fp16 pair of a scaled
@@ -354,7 +400,7 @@ __device__ __forceinline__ void stage_put_split(unsigned short* lds16, int plane
         x.z = (x.z - mu.z) * sc.z + sh.z;
         x.w = (x.w - mu.w) * sc.w + sh.w;
     }
-    if (flags & SBC_PRO_ELU) x = elu4(x);
+    if (flags & SBC_PRO_ELU) x = elu4(x, (flags & SBC_PRO_ELU_ACC) != 0);
     unsigned short* dst = lds16 + pix * SH + c4 * 4;
     if constexpr (TERMS == 1) {
         f16x4 h;
@@ -363,8 +409,7 @@ __device__ __forceinline__ void stage_put_split(unsigned short* lds16, int plane
     } else if constexpr (TERMS == 2) {
         scale_track(x, ss);
         uint2 h, l;
-        split_f16x2(x.x, x.y, h.x, l.x);
-        split_f16x2(x.z, x.w, h.y, l.y);
+        split_f16x2(x, ss->scale, h, l);
         *reinterpret_cast<uint2*>(dst) = h;
         *reinterpret_cast<uint2*>(dst + plane) = l;
     } else {

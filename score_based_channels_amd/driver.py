@@ -104,7 +104,7 @@ def host_noise_streams(seed, combo, shape, n_snr, n_steps, meas_shape):
 def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, beta_noise, levels, steps_each,
                      seed, init, traj_base=0, max_batch=4096, use_graph=None, rank=0, world=1, n_streams=None,
                      return_final=False, n_steps=None, dc_boost=1.0, init_index=None, Y=None, y_index=None,
-                     step_noise=None, meas_noise=None):
+                     step_noise=None, meas_noise=None, info=None):
     """Run ``T = len(h_index)`` trajectories, sharded over ``world`` ranks; returns the full NMSE log
     ``[n_steps, T]`` (float32 numpy, identical on every rank).  ``init``: ``[nH, Nt, Nr]`` complex64 initial
     estimates indexed by ``h_index``.  Trajectory ``t`` draws its noise from Philox stream ``traj_base + t``.
@@ -118,7 +118,11 @@ def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, b
     after that many Langevin steps (early stop of ``test_mmse.py:246-250``).
 
     ``step_noise`` ``[n_steps, T, Nt, Nr]`` / ``meas_noise`` ``[T, Np, Nr]`` complex64 (host arrays) replay externally
-    drawn CN(0,1) noise instead of the in-kernel Philox streams (``--noise host`` parity runs against the reference)."""
+    drawn CN(0,1) noise instead of the in-kernel Philox streams (``--noise host`` parity runs against the reference).
+
+    ``conv_mode f16x2``: a chunk whose launches raised the device's range flag (an activation outside the window in which the
+    two-term fp16 split is fp32-class, ``sbc_range_flag``) is run again with ``net.fallback_net()`` (``bf16x3``) before its
+    results are used; ``info`` (a dict) receives one ``'f16x2_fallback'`` record per such chunk (rank-local)."""
     from . import _lib
     use_graph = DEFAULT_USE_GRAPH if use_graph is None else bool(use_graph)
     n_streams = DEFAULT_STREAMS if n_streams is None else int(n_streams)
@@ -136,8 +140,8 @@ def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, b
     cur = torch.cuda.current_stream(net.device)
     streams = [torch.cuda.Stream(net.device) for _ in range(max(1, int(n_streams)))]
     max_batch = batch_limit(net, nt, nr, max_batch)
-    for c0 in range(lo, hi, max_batch):
-        c1 = min(hi, c0 + max_batch)
+
+    def run_chunk(use_net, c0, c1):
         running = []
         for part, st in zip(np.array_split(np.arange(c0, c1), len(streams)), streams):
             if len(part) == 0:
@@ -145,7 +149,7 @@ def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, b
             st.wait_stream(cur)
             with torch.cuda.stream(st):                     # set-up on the sub-batch's stream; the walk itself below
                 sn = None if step_noise is None else torch.from_numpy(np.ascontiguousarray(step_noise[:n_steps, part]))
-                ald = AldBatch(net, Htrue, P, h_index[part], p_index[part], local_noise[part], alpha_step[part],
+                ald = AldBatch(use_net, Htrue, P, h_index[part], p_index[part], local_noise[part], alpha_step[part],
                                beta_noise[part], levels=levels, steps_each=steps_each, seed=seed,
                                traj_id=traj_base + part, dc_boost=dc_boost, step_noise=sn)
                 ald.set_init(init[torch.from_numpy(init_index[part])])
@@ -164,9 +168,24 @@ def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, b
         for _, ald, _ in running:
             ald.close()
         del running
+
+    f16x2 = getattr(net, 'conv_mode', None) == 'f16x2'
+    if f16x2:
+        _lib.range_flag(True, net.device)               # whatever an earlier, unrelated run left behind
+    for c0 in range(lo, hi, max_batch):
+        c1 = min(hi, c0 + max_batch)
+        run_chunk(net, c0, c1)
+        if f16x2:
+            bits = _lib.range_flag(True, net.device)
+            if bits:
+                # an activation of this chunk left the window in which the two-term fp16 split is fp32-class (sbc_range_flag):
+                # the same trajectories again in bf16x3 -- same noise keys, same measurements -- in this process
+                run_chunk(net.fallback_net(), c0, c1)
+                if info is not None:
+                    info.setdefault('f16x2_fallback', []).append(
+                        {'trajectories': [int(traj_base + c0), int(traj_base + c1)], 'range_flag': int(bits),
+                         'reason': _lib.describe_range(bits), 'rerun_in': 'bf16x3'})
     torch.cuda.synchronize(net.device)
-    if getattr(net, 'conv_mode', None) == 'f16x2':
-        _lib.check_range('annealed-Langevin run')       # an activation outside the fp16 range of conv_mode f16x2: fail loudly
     full = shard.gather_trajectory_logs(local, T, rank, world)
     if not return_final:
         return full.cpu().numpy()

@@ -30,6 +30,7 @@ PRO_NORM_MOMENTS, EPI_MOMENTS_OUT = 0x4000, 0x8000
 EPI_RES1_ELU, EPI_POOL, EPI_UP, EPI_ELUGRAD = 0x010, 0x020, 0x040, 0x080
 CONV_F16W = 0x100
 CONV_F16X2 = 0x10000
+PRO_ELU_ACC = 0x20000         # ELU with fp32's relative accuracy for small negative inputs (include/sbc_hip.h)
 # training operators
 (DSM_PERTURB, DSM_LOSS, GRAD_ADD, INORM_BWD, MAXPOOL5_BWD, UPSAMPLE_BWD, POOL_BWD, CONV_WGRAD, PACK_WEIGHT, END_CONV_BWD,
  BEGIN_CONV_BWD, ADAM_EMA) = range(9, 21)

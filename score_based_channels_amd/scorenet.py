@@ -7,6 +7,7 @@ Interface kept from the reference call sites (``test_score.py:59-63,137,151``):
 torch is used for device memory and streams only; no torch operator computes anything on this path.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -47,9 +48,11 @@ class ScoreNet:
                             layer on the host) and split into two fp16 terms ``h + l`` (22-23 significant
                             bits), a product is the three fp16 MFMAs ``hl + lh + hh`` with fp32 accumulation.  Forward error
                             vs the reference 0.85e-6 (true fp32 MFMA: 0.98e-6); half the matrix instructions and a third of
-                            the split arithmetic of ``'bf16x3'``.  Activations beyond |x| = 16000 would leave the fp16 range:
-                            the kernels raise a device flag and the host raises ``SbcError`` (``_lib.check_range``) instead
-                            of returning wrong numbers -- use ``'bf16x3'`` for such a checkpoint.
+                            the split arithmetic of ``'bf16x3'``.  Every layer's activations are scaled by a power of two
+                            chosen once per checkpoint (``_ensure_calibrated``) so that the low fp16 term stays a normal
+                            number over 17 binades; an input that leaves that window anyway (overflow, or a region too small
+                            for the split to be fp32-class) raises a device flag, and the host runs that call / batch again
+                            in ``'bf16x3'`` in the same process instead of returning degraded numbers.
     ``'bf16x3'``            fp32 operands split exactly into three bf16 terms (8 + 8 + 8 significand bits), six bf16 MFMAs
                             per product block, fp32 accumulation: fp32-level accuracy (forward error vs the reference
                             0.8e-6, the fp32 kernels 1.0e-6) on the bf16 matrix cores -- Winograd F(2x2,3x3) for the
@@ -100,6 +103,11 @@ class ScoreNet:
         self._sigmas = None
         self._call_cache = {}
         self._plans = {}
+        self._sd_host = None            # the loaded state dict (host arrays): what fallback_net() loads
+        self._calibrated = False        # conv_mode f16x2: per-layer activation scales set on the device copy of the weights
+        self._fallback = None
+        self.range_fallbacks = 0        # module calls answered by the bf16x3 fallback because the f16x2 range flag was raised
+        self.last_range_bits = 0
 
     # --- nn.Module look-alikes ------------------------------------------------------------------
     def cuda(self, device=None):
@@ -177,7 +185,33 @@ class ScoreNet:
         self._woff = off
         self._call_cache.clear()
         self._plans.clear()
+        self._sd_host = {k: v for k, v in state_dict.items()}
+        self._calibrated = False
+        self._fallback = None
         return self
+
+    def _ensure_calibrated(self, nt, nr):
+        """conv_mode f16x2: one pass over the library's fixed calibration input sets every layer's activation scale
+        (``sbc_f16x2_calibrate``, include/sbc_hip.h) -- once per loaded checkpoint, at the first array size that is bound, before
+        anything else uses the weights.  The input is fixed, so the scales (and with them every later result) depend on the
+        checkpoint only, never on the data or the batch."""
+        if self.conv_mode != 'f16x2' or self._calibrated or os.environ.get('SBC_NO_CALIB'):   # (env: A/B aid, scales stay 1)
+            return
+        self._calibrated = True                       # (bind below comes back here)
+        b = self.bind(1, nt, nr)
+        b.x.view(-1).copy_(torch.from_numpy(_lib.calibration_input(nt * nr * self.channels)))
+        with torch.cuda.device(self.device):
+            _lib.calibrate_f16x2(b.ops, torch.cuda.current_stream(self.device).cuda_stream)
+
+    def fallback_net(self):
+        """The same checkpoint in ``bf16x3`` (fp32's range and precision everywhere): what a batch that raised the f16x2 range
+        flag is run again with (``driver.run_trajectories``); built on first use."""
+        if self._fallback is None:
+            if self._sd_host is None:
+                raise RuntimeError('load_state_dict() must be called before fallback_net()')
+            self._fallback = ScoreNet(self.config, self.device, conv_mode='bf16x3', overlap=self.overlap,
+                                      fold_stats=self.fold_stats).load_state_dict(self._sd_host, strict=False)
+        return self._fallback
 
     # --- binding ----------------------------------------------------------------------------------
     def score_plan(self, nt, nr):
@@ -194,6 +228,7 @@ class ScoreNet:
         counter + ``sigma_of_step`` table (inside an ALD plan)."""
         if self._wdev is None:
             raise RuntimeError('load_state_dict() must be called before the network is used')
+        self._ensure_calibrated(nt, nr)
         pl = self.score_plan(nt, nr)
         dev = self.device
         slots = [torch.empty(B * e, dtype=torch.float32, device=dev) for e in pl.slot_elems]
@@ -230,6 +265,8 @@ class ScoreNet:
                     o.flags |= P.CONV_F16W
                 elif self.conv_mode == 'f16x2':
                     o.flags |= P.CONV_F16X2
+            if self.conv_mode in ('bf16x3', 'f32') and op.kind == P.CONV and op.flags & P.PRO_ELU:
+                o.flags |= P.PRO_ELU_ACC          # the exact modes: ELU keeps its relative accuracy for small inputs too
             if op.bias is not None:
                 o.bias = _ptr(self._wdev, self._woff[op.bias])
             if op.stats is not None:
@@ -269,7 +306,13 @@ class ScoreNet:
         plan.run(torch.cuda.current_stream(self.device).cuda_stream)
         out = bound.out.permute(0, 3, 1, 2).clone()
         if self.conv_mode == 'f16x2':
-            _lib.check_range('ScoreNet forward')          # synchronises; the module-call path is not the hot loop
+            # (waits for every stream of the device; the module-call path is not the hot loop)
+            bits = _lib.range_flag(True, self.device)
+            if bits:
+                # outside the window in which the two-term split is fp32-class: the same call in bf16x3, in this process
+                self.range_fallbacks += 1
+                self.last_range_bits = bits
+                return self.fallback_net()(x, labels)
         return out
 
     forward = __call__

@@ -136,10 +136,11 @@ def main(argv=None):
     ln = np.tile(np.repeat(noise_range, B), len(cells))
     a0 = np.asarray([c[0] for c in cells])[cell_of]
     be = np.asarray([c[1] for c in cells])[cell_of]
+    run_info = {}                                         # 'f16x2_fallback': chunks this rank re-ran in bf16x3 (driver.py)
     log = run_trajectories(diffuser, H_all, P_all, h_index, h_index, ln, a0, be, levels, steps_each, seed, init_all,
                            use_graph=resolve_launch_mode(args), rank=rank, world=world, n_streams=args.streams,
                            step_noise=step_noise,
-                           meas_noise=meas_noise)
+                           meas_noise=meas_noise, info=run_info)
     nmse_log = log.reshape(n_steps, len(alpha_step_range), len(beta_noise_range), S, B).transpose(1, 2, 3, 0, 4)
     nmse_log = nmse_log.astype(np.float64)
 
@@ -172,7 +173,8 @@ def main(argv=None):
         torch.save({'nmse_log': nmse_log, 'avg_nmse': avg_nmse, 'best_nmse': best_nmse,
                     'best_alpha_snr': best_alpha_snr, 'best_beta_snr': best_beta_snr, 'snr_range': snr_range,
                     'alpha_step_range': alpha_step_range, 'beta_noise_range': beta_noise_range, 'config': config,
-                    'args': args, 'seed': seed, 'levels': np.asarray(levels)},
+                    'args': args, 'seed': seed, 'levels': np.asarray(levels),
+                    'f16x2_fallback': run_info.get('f16x2_fallback', [])},
                    os.path.join(result_dir, '%s-hyperparameters.pt' % args.channel))
         print('best alpha per SNR:', best_alpha_snr)
         print('best beta  per SNR:', best_beta_snr)

@@ -239,7 +239,7 @@ def pack_conv_weight_winograd_f16(w):
 
 
 # ---- f16x2 forms (SBC_CONV_F16X2, conv_mode 'f16x2') -----------------------------------------------------------------
-F16X2_ACT_SHIFT = 0          # activations enter the matrix cores unscaled (include/sbc_hip.h: SBC_F16X2_ACT_SHIFT): range 16000
+F16X2_ACT_SHIFT = 0          # (include/sbc_hip.h: SBC_F16X2_ACT_SHIFT) the packers' own act_scale is 2^0; calibration sets the real one
 
 
 def f16x2_shift(w):
@@ -260,7 +260,17 @@ def split_f16x2(x):
     return h, l
 
 
-def _pack_f16x2(w):
+def f16x2_trailer(s, act_scale=1.0):
+    """The 16-byte record behind the fragments: (act_scale, descale = 1 / (act_scale 2^s), the weights' own descale 2^-s, 0).
+    ``act_scale`` must be a power of two (the library's calibration, ``sbc_f16x2_calibrate``, rewrites the first two words on
+    the device copy); the packers write 1."""
+    a = float(act_scale) * 2.0 ** F16X2_ACT_SHIFT
+    if a <= 0 or np.frexp(a)[0] != 0.5:
+        raise ValueError('act_scale must be a positive power of two, got %r' % (act_scale,))
+    return np.array([a, 2.0 ** -s / a, 2.0 ** -s, 0], np.float32).view(np.uint16)
+
+
+def _pack_f16x2(w, act_scale=1.0):
     """``[O, C, T]`` float32 (T = taps or the 16 Winograd positions) -> ``[T, C/16, O/32, 2, 64, 8]`` uint16 + trailer."""
     o, c, t = w.shape
     if c % 16 or o % 32:
@@ -269,25 +279,24 @@ def _pack_f16x2(w):
     terms = np.stack([v.view(np.uint16) for v in split_f16x2(np.ldexp(w, s).astype(np.float32))])   # [2, O, C, T]
     a = terms.reshape(2, o // 32, 32, c // 16, 2, 8, t)              # [s, nb, l31, g, half, j, tap]
     a = np.ascontiguousarray(a.transpose(6, 3, 1, 0, 4, 2, 5)).reshape(-1)   # [tap, g, nb, s, half, l31, j]
-    trailer = np.array([2.0 ** F16X2_ACT_SHIFT, 2.0 ** -(s + F16X2_ACT_SHIFT), 0, 0], np.float32).view(np.uint16)
-    return np.concatenate([a, trailer])
+    return np.concatenate([a, f16x2_trailer(s, act_scale)])
 
 
-def pack_conv_weight_f16x2(w):
+def pack_conv_weight_f16x2(w, act_scale=1.0):
     """Two-term fp16 form of an ``[O, C, k, k]`` weight (``csrc/conv_x3.hip``, ``TERMS = 2``): the layer's weights scaled by
     the power of two of ``f16x2_shift`` and split into ``h + l`` fp16 terms, in the fragment order of
     ``pack_conv_weight_split`` with two terms, flat uint16, followed by the 16-byte trailer
     ``(act_scale, descale, 0, 0)`` float32 the kernels read their scales from."""
     w = np.asarray(w, np.float32)
     o, c, kh, kw = w.shape
-    return _pack_f16x2(w.reshape(o, c, kh * kw))
+    return _pack_f16x2(w.reshape(o, c, kh * kw), act_scale)
 
 
-def pack_conv_weight_winograd_f16x2(w):
+def pack_conv_weight_winograd_f16x2(w, act_scale=1.0):
     """Winograd F(2x2, 3x3) weights ``U = G g G^T`` (float64, rounded once to float32) in the ``pack_conv_weight_f16x2``
     form with the 16 transform positions in place of the taps (``csrc/conv_wx3.hip``, ``MODE = 2``)."""
     w = np.asarray(w, np.float64)
     if w.shape[2:] != (3, 3):
         raise ValueError('Winograd F(2x2,3x3) needs a 3x3 kernel, got %s' % (w.shape,))
     u = np.einsum('ij,ocjk,lk->ocil', _WINO_G, w, _WINO_G).astype(np.float32)          # [O, C, 4, 4]
-    return _pack_f16x2(u.reshape(u.shape[0], u.shape[1], 16))
+    return _pack_f16x2(u.reshape(u.shape[0], u.shape[1], 16), act_scale)

@@ -450,3 +450,113 @@ def test_winograd_variants_are_accurate_and_batch_size_independent(gpu, cin, cou
             outs.append(out)
         for out in outs[1:]:
             assert torch.equal(out, outs[0][:out.shape[0]]), (H, W, out.shape[0])
+
+
+# ---- conv_mode f16x2 outside O(1) activations (round 4): scale, guard in both directions, library calibration -------------------
+def _f64_conv(torch, v, w, dil):
+    """float64 convolution of an NHWC float32 tensor ``v`` (already through the prologue) with a torch-layout weight."""
+    return torch.nn.functional.conv2d(v.permute(0, 3, 1, 2).double(), torch.from_numpy(w).cuda().double(), padding=dil,
+                                      dilation=dil).permute(0, 2, 3, 1)
+
+
+def _pow2_scale(amax):
+    """The act_scale ``sbc_f16x2_calibrate`` picks for a layer whose staged maximum is ``amax``: amax * s in [2^8, 2^9)."""
+    return 2.0 ** (9 - int(np.frexp(np.float32(amax))[1]))
+
+
+F16X2_SCALE_CASES = [(32, 32, 1, 6, 64, 16, True), (64, 64, 1, 9, 32, 8, True), (64, 64, 1, 30, 16, 4, False),
+                     (128, 128, 4, 19, 8, 2, False), (64, 128, 2, 21, 8, 2, True)]
+
+
+@pytest.mark.parametrize('wino', [False, True])
+@pytest.mark.parametrize('log2_scale', [15, 0, -4, -8, -12, -14])
+@pytest.mark.parametrize('cin,cout,dil,B,H,W,elu', F16X2_SCALE_CASES)
+def test_f16x2_is_fp32_class_at_every_input_scale(gpu, cin, cout, dil, B, H, W, elu, log2_scale, wino):
+    """The reference multiplies in IEEE fp32 (test_score.py:25-26), whose relative precision does not depend on the magnitude of
+    an activation.  The two-term fp16 split does: with act_scale = 1 (what the packers write) the low term of |x| < 2^-3 is an
+    fp16 denormal.  Hence (a) with the layer's act_scale set the way sbc_f16x2_calibrate sets it, the convolution holds the
+    tolerance of every other case at input scales 2^15 ... 2^-14 with the range flag clear; (b) with act_scale = 1 it is EITHER
+    within tolerance OR the device flag says why not (overflow / underflow bit) -- never silently degraded."""
+    torch, _lib = gpu
+    from score_based_channels_amd import plan as P
+    from score_based_channels_amd.weights import pack_conv_weight_f16x2, pack_conv_weight_winograd_f16x2
+    if wino and dil != 1:
+        pytest.skip('Winograd F(2x2,3x3) applies to undilated 3x3 convolutions')
+    rng = np.random.default_rng(cin * 7 + cout + H)
+    x = ((rng.standard_normal((B, H, W, cin)) * 1.5 + 0.3) * 2.0 ** log2_scale).astype(F32)
+    if elu:
+        # positive inputs: ELU is the identity there.  (For tiny NEGATIVE inputs any two fp32 evaluations of exp(x) - 1 differ by
+        # ~1e-7 absolute, i.e. by 1e-3 of the value at |x| = 1e-4: that is the ELU's conditioning, not the multiplier's.)
+        x = np.abs(x)
+    w = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(F32)
+    dx = _dev(torch, x)
+    v = dx
+    ref = _f64_conv(torch, v, w, dil)
+    amax = float(v.abs().max())
+    _lib.range_flag()
+    for act_scale in (_pow2_scale(amax), 1.0):
+        wx = _dev(torch, pack_conv_weight_f16x2(w, act_scale).view(np.float32))
+        out = torch.full((B, H, W, cout), float('nan'), dtype=torch.float32, device='cuda')
+        op = _lib.sbc_op(kind=P.CONV, flags=P.CONV_F16X2 | (P.PRO_ELU if elu else 0), B=B, H=H, W=W, cin=cin, cout=cout, ksize=3,
+                         dil=dil, in_=_p(dx), out=_p(out), weight_split=_p(wx))
+        if wino:
+            wwx = _dev(torch, pack_conv_weight_winograd_f16x2(w, act_scale).view(np.float32))
+            op.weight_wino_split = _p(wwx)
+        _launch(gpu, op)
+        flag = _lib.range_flag()
+        err = float((out.double() - ref).norm() / ref.norm())
+        if act_scale != 1.0 or log2_scale == 0:
+            assert flag == 0 and err < TOL, (act_scale, flag, err)
+        else:
+            assert err < TOL or flag != 0, (flag, err)
+            if log2_scale == 15:
+                assert flag & _lib.RANGE_OVERFLOW
+            if log2_scale <= -12:
+                assert flag & _lib.RANGE_UNDERFLOW and err > TOL / 4       # (the loss the guard exists for is real)
+
+
+@pytest.mark.parametrize('log2_scale', [12, 0, -6, -10, -14])
+def test_f16x2_library_calibration_sets_the_layer_scales(gpu, log2_scale):
+    """sbc_f16x2_calibrate on a record list (one CONV with both weight forms, one CONV_PAIR whose second convolution sees an
+    intermediate 2^-7 below its input): it runs the records on their first sample, and afterwards the trailers on the device hold
+    act_scale = 2^(9 - exponent of the staged maximum), descale to match -- and the launches are fp32-class with a clear flag."""
+    torch, _lib = gpu
+    from score_based_channels_amd import plan as P
+    from score_based_channels_amd.weights import pack_conv_weight_f16x2, pack_conv_weight_winograd_f16x2
+    rng = np.random.default_rng(100 + log2_scale)
+    B, H, W, c = 5, 64, 16, 32
+    x = np.abs((rng.standard_normal((B, H, W, c)) * 1.5 + 0.3) * 2.0 ** log2_scale).astype(F32)
+    w0 = (rng.standard_normal((c, c, 3, 3)) / 17).astype(F32)
+    w1 = np.abs(rng.standard_normal((c, c, 3, 3)) / 17 * 2.0 ** -7).astype(F32)   # positive: the intermediate stays where ELU is the identity
+    w2 = (rng.standard_normal((c, c, 3, 3)) / 17).astype(F32)
+    dx = _dev(torch, x)
+    dw0, dw0w = _dev(torch, pack_conv_weight_f16x2(w0).view(F32)), _dev(torch, pack_conv_weight_winograd_f16x2(w0).view(F32))
+    dw1, dw2 = _dev(torch, pack_conv_weight_f16x2(w1).view(F32)), _dev(torch, pack_conv_weight_f16x2(w2).view(F32))
+    o0 = torch.full((B, H, W, c), float('nan'), dtype=torch.float32, device='cuda')
+    o1 = torch.full((B, H, W, c), float('nan'), dtype=torch.float32, device='cuda')
+    ops = [_lib.sbc_op(kind=P.CONV, flags=P.CONV_F16X2 | P.PRO_ELU, B=B, H=H, W=W, cin=c, cout=c, ksize=3, dil=1, in_=_p(dx),
+                       out=_p(o0), weight_split=_p(dw0), weight_wino_split=_p(dw0w)),
+           _lib.sbc_op(kind=P.CONV_PAIR, flags=P.CONV_F16X2, B=B, H=H, W=W, cin=c, cout=c, ksize=3, dil=1, in_=_p(dx),
+                       out=_p(o1), weight_split=_p(dw1), weight2_split=_p(dw2))]
+    _lib.calibrate_f16x2(ops, torch.cuda.current_stream().cuda_stream)
+    assert _lib.range_flag() == 0                                     # the pass clears what it raised itself
+    v = dx                                                            # (positive inputs: ELU is the identity)
+    t = _f64_conv(torch, v, w1, 1).float()
+    te = torch.nn.functional.elu(t)
+    for dw, amax in ((dw0, v[0].abs().max()), (dw0w, v[0].abs().max()), (dw1, v[0].abs().max()), (dw2, te[0].abs().max())):
+        tr = dw[-4:].cpu().numpy()                                    # (the trailer: act_scale, descale, weight descale, 0)
+        assert tr[0] == _pow2_scale(float(amax)) and tr[1] == tr[2] / tr[0] and tr[2] > 0, (tr, float(amax))
+    for op in ops:
+        _launch(gpu, op)
+    assert _lib.range_flag() == 0
+    ref0 = _f64_conv(torch, v, w0, 1)
+    ref1 = _f64_conv(torch, te, w2, 1)
+    assert float((o0.double() - ref0).norm() / ref0.norm()) < TOL
+    assert float(((o1 - dx).double() - ref1).norm() / ref1.norm()) < 2 * TOL   # (two convolutions; the second on a rounded fp32 t)
+
+
+def test_f16x2_calibration_input_is_fixed():
+    """The calibration pattern is a pure function of the element index (same on every host, CN(0,1)-like)."""
+    from score_based_channels_amd import _lib
+    a, b = _lib.calibration_input(4096), _lib.calibration_input(8192)
+    assert np.array_equal(a, b[:4096]) and abs(float(b.mean())) < 0.03 and abs(float(b.var()) - 0.5) < 0.03

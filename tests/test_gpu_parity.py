@@ -542,10 +542,84 @@ def test_forward_other_geometries_match_oracle(nt, nr, weights64):
     x = np.random.default_rng(nt * 1000 + nr).standard_normal((3, 2, nt, nr)).astype(np.float32)
     labels = np.array([0, 1155, 2310])
     ref = ncsnv2_oracle.score_forward(sd, x, labels)
-    for mode in ('bf16x3', 'f32'):
-        net = ScoreNet(cfg, conv_mode=mode).cuda().load_state_dict(sd).eval()
+    for mode, pairs in (('bf16x3', False), ('f32', False), ('f16x2', False), ('f16x2', True)):   # (the last one: the shipped default)
+        net = ScoreNet(cfg, conv_mode=mode, fuse_pairs=pairs).cuda().load_state_dict(sd).eval()
         out = net(torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda())
-        assert rel_err(out.cpu().numpy(), ref) < 2e-5, (mode, nt, nr)
+        assert rel_err(out.cpu().numpy(), ref) < 2e-5, (mode, pairs, nt, nr)
+        assert net.range_fallbacks == 0
+
+
+def _scaled_refine_weights(sd, factor):
+    """The state dict with every RCU / CRP convolution of refine4 and refine5 (no normalisation between them: layers.py:76-83,
+    126-134) multiplied by ``factor``: the intermediates of those chains then sit ``factor`` (and ``factor``^2) below O(1)."""
+    out = dict(sd)
+    n = 0
+    for k, v in sd.items():
+        if k.startswith(('refine4.', 'refine5.')) and k.endswith('.weight') and ('adapt_convs' in k or 'crp' in k or 'output_convs' in k):
+            out[k] = (np.asarray(v, np.float32) * np.float32(factor)).astype(np.float32)
+            n += 1
+    assert n >= 30
+    return out
+
+
+@pytest.mark.parametrize('log2_factor', [-6, -10, 4])
+def test_f16x2_holds_the_tolerance_with_small_and_large_refine_activations(weights64, log2_factor):
+    """The reference computes in IEEE fp32 (test_score.py:25-26): its relative precision does not depend on how large a
+    checkpoint's un-normalised RCU / CRP activations are.  The shipped default (f16x2 + fused pairs + folded statistics) must not
+    either: with the refine4 / refine5 chain weights scaled by 2^-6, 2^-10 (intermediates down to 1e-6 of O(1)) or 2^4 the forward
+    still agrees with the oracle on the SAME scaled weights at the tolerance of the unscaled golden -- through the per-layer
+    activation scales of sbc_f16x2_calibrate, with the range flag clear and no fallback to bf16x3."""
+    import torch
+    from oracle import ncsnv2_oracle
+    from score_based_channels_amd.scorenet import ScoreNet
+    cfg, sd = weights64
+    sd2 = _scaled_refine_weights(sd, 2.0 ** log2_factor)
+    g = load_golden('forward_64x16.npz')
+    x, labels = g['x'][:3], np.array([0, 1155, 2310])
+    ref = ncsnv2_oracle.score_forward(sd2, x, labels)
+    net = ScoreNet(cfg).cuda().load_state_dict(sd2).eval()
+    assert net.conv_mode == 'f16x2' and net.fuse_pairs and net.fold_stats
+    out = net(torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda()).cpu().numpy()
+    assert net.range_fallbacks == 0
+    exact = ScoreNet(cfg, conv_mode='bf16x3').cuda().load_state_dict(sd2).eval()
+    out_exact = exact(torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda()).cpu().numpy()
+    assert rel_err(out_exact, ref) < 2e-5
+    assert rel_err(out, ref) < 2e-5 and rel_err(out, out_exact) < 5e-6, (rel_err(out, ref), rel_err(out, out_exact))
+
+
+def test_f16x2_guard_reruns_in_bf16x3_in_process(weights64, monkeypatch):
+    """Without the calibration (act_scale = 1 everywhere, what rounds 2-3 shipped) the same scaled checkpoint drives whole
+    regions of the refine chains below 2^-6: the kernels raise the underflow bit, and the host answers the call from the bf16x3
+    network in the same process (module call) / re-runs the chunk (driver.run_trajectories) -- never silently degraded numbers."""
+    import torch
+    from oracle import ncsnv2_oracle
+    from score_based_channels_amd import _lib, synth
+    from score_based_channels_amd.ald import snr_to_noise
+    from score_based_channels_amd.driver import run_trajectories
+    from score_based_channels_amd.scorenet import ScoreNet
+    cfg, sd = weights64
+    sd2 = _scaled_refine_weights(sd, 2.0 ** -10)
+    g = load_golden('forward_64x16.npz')
+    x, labels = g['x'][:3], np.array([0, 1155, 2310])
+    ref = ncsnv2_oracle.score_forward(sd2, x, labels)
+    monkeypatch.setenv('SBC_NO_CALIB', '1')
+    net = ScoreNet(cfg).cuda().load_state_dict(sd2).eval()
+    out = net(torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda()).cpu().numpy()
+    assert net.range_fallbacks == 1 and net.last_range_bits & _lib.RANGE_UNDERFLOW
+    assert rel_err(out, ref) < 2e-5
+    # the sampling loop: the chunk is run again, the result file entry says so, and the numbers are the bf16x3 run's
+    nch, nt, nr, npil = 3, 64, 16, 38
+    raw = synth.generate_channels('CDL-C', nch, nt, nr, 0.5, seed=2)
+    H = np.conj(np.transpose(raw / np.std(raw), (0, 2, 1))).astype(np.complex64)
+    Pm = np.conj(np.transpose(synth.qpsk_pilots(np.random.default_rng(3), nch, nt, npil), (0, 2, 1)))
+    ln = snr_to_noise(np.zeros(nch), nt)
+    init = torch.randn(nch, nt, nr, dtype=torch.complex64, generator=torch.Generator().manual_seed(1))
+    info = {}
+    log = run_trajectories(net, H, Pm, np.arange(nch), np.arange(nch), ln, 3e-11, 0.01, [0, 2310], 3, 5, init, info=info)
+    assert len(info['f16x2_fallback']) == 1 and info['f16x2_fallback'][0]['rerun_in'] == 'bf16x3'
+    exact = ScoreNet(cfg, conv_mode='bf16x3').cuda().load_state_dict(sd2).eval()
+    log_exact = run_trajectories(exact, H, Pm, np.arange(nch), np.arange(nch), ln, 3e-11, 0.01, [0, 2310], 3, 5, init)
+    assert np.array_equal(log, log_exact)
 
 
 def test_full_batch_is_the_sum_of_its_trajectories(net64):

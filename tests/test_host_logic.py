@@ -22,7 +22,23 @@ def test_library_exports_every_declared_symbol():
     h = _lib.lib()
     for name in declared:
         assert hasattr(h, name), name
-    assert h.sbc_abi_version() == 10
+    assert h.sbc_abi_version() == 11
+
+
+def test_f16x2_calibration_input_is_fixed_and_trailers_carry_the_scale():
+    """The calibration pattern of sbc_f16x2_calibrate is a pure function of the element index (same on every host), CN(0,1)-like;
+    the packers' trailer is (act_scale, descale = 2^-s / act_scale, 2^-s, 0) and refuses scales that are not powers of two."""
+    from score_based_channels_amd import _lib
+    from score_based_channels_amd.weights import f16x2_shift, pack_conv_weight_f16x2
+    a, b = _lib.calibration_input(4096), _lib.calibration_input(8192)
+    assert np.array_equal(a, b[:4096]) and abs(float(b.mean())) < 0.03 and abs(float(b.var()) - 0.5) < 0.03
+    w = np.random.default_rng(1).standard_normal((32, 32, 3, 3)).astype(np.float32)
+    s = f16x2_shift(w)
+    for sc in (1.0, 2.0 ** 7, 2.0 ** -5):
+        tr = pack_conv_weight_f16x2(w, sc)[-8:].view(np.float32)
+        assert tr[0] == sc and tr[1] == 2.0 ** -s / sc and tr[2] == 2.0 ** -s and tr[3] == 0
+    with pytest.raises(ValueError):
+        pack_conv_weight_f16x2(w, 3.0)
 
 
 def test_pack_conv_weight_c_matches_python():
@@ -305,7 +321,7 @@ def test_pack_conv_weight_f16x2_c_matches_python():
         assert np.array_equal(ref, dst)
         s = f16x2_shift(w)
         tr = ref[-8:].view(np.float32)
-        assert tr[0] == 2.0 ** F16X2_ACT_SHIFT and tr[1] == 2.0 ** -(s + F16X2_ACT_SHIFT) and tr[2] == tr[3] == 0
+        assert tr[0] == 2.0 ** F16X2_ACT_SHIFT and tr[1] == 2.0 ** -(s + F16X2_ACT_SHIFT) and tr[2] == 2.0 ** -s and tr[3] == 0
         assert 2 ** 13 <= np.abs(w).max() * 2.0 ** s < 2 ** 14
         terms = ref[:-8].view(np.float16).reshape(k * k, c // 16, o // 32, 2, 64, 8).astype(np.float64)
         back = (terms[:, :, :, 0] + terms[:, :, :, 1]) * 2.0 ** -s            # [tap, g, nb, lane, j]
