@@ -38,8 +38,20 @@ PEAK_F32_MFMA_TFLOPS = 157.3       # v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2516.6     # v_mfma_f32_32x32x16_bf16 / _f16 dense ("~2.5 PF"), 16x the fp32 MFMA rate
 PEAK_HBM_TBS = 8.0                 # HBM3E spec (6.3 TB/s achievable by a float4 copy)
 STEPS_PER_CHANNEL = 2311 * 3
-PROFILE_ROUND = 'r03'
-REFERENCE_CPU_CHANNELS_PER_S = 0.046   # the reference's own test_score loop (torch, 8 cores of the build container)
+PROFILE_ROUND = 'r04'
+REFERENCE_CPU_FILE = os.path.join(ROOT, 'profiles', PROFILE_ROUND + '_reference_cpu.json')   # written by tools/time_reference_cpu.py
+
+
+def reference_cpu_record():
+    """The reference's own test_score loop timed on the build container's cores (tools/time_reference_cpu.py: it needs
+    /root/reference, which does not exist on the GPU box, so the number travels as a committed record)."""
+    try:
+        with open(REFERENCE_CPU_FILE) as f:
+            rec = json.load(f)
+        rec['source'] = 'profiles/' + os.path.basename(REFERENCE_CPU_FILE)
+        return rec
+    except (OSError, ValueError):
+        return None
 
 
 def _cpu_worker(job):
@@ -123,6 +135,7 @@ def parse_args():
     ap.add_argument('--no-strong', action='store_true', help='skip the strong-scaling (tuner grid) measurement')
     ap.add_argument('--no-other-mode', action='store_true', help='skip timing the non-default launch mode')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-exact-mode', action='store_true', help='skip timing the same steps in conv_mode bf16x3')
     ap.add_argument('--force-dist', action='store_true',
                     help='with --gpus 1: still create a one-rank RCCL process group and route the barrier / max / gather through it')
     ap.add_argument('--conv-mode', default=None, choices=['f16x2', 'bf16x3', 'f32', 'f16w'],
@@ -302,6 +315,8 @@ def main():
 
     logged = [0]                 # rows of the NMSE log the most recent timed() call wrote
 
+    last_rank_times = [None]     # (wall seconds of this rank before the closing barrier, host CPU seconds) of the last timed() call
+
     def timed(alds, streams, n, graph, warm):
         """`warm` untimed steps, then exactly `n` steps between barrier + synchronize pairs; max over ranks (seconds)."""
         for a in alds:
@@ -309,10 +324,27 @@ def main():
         logged[0] = warm + n
         run_all(alds, streams, warm, graph)
         sync()
-        t0 = time.perf_counter()
+        t0, c0 = time.perf_counter(), time.process_time()
         run_all(alds, streams, n, graph)
+        torch.cuda.synchronize()
+        last_rank_times[0] = (time.perf_counter() - t0, time.process_time() - c0)
         sync()
         return max_over_ranks(time.perf_counter() - t0)
+
+    def per_rank(n):
+        """This rank's own time for the `n` steps of the last timed() call (before the closing barrier) and the CPU time its host
+        threads spent issuing them, gathered over the ranks: the spread says whether a slow step is one straggler or all of them."""
+        t = torch.tensor(last_rank_times[0], dtype=torch.float64, device=cdev)
+        allt = [torch.empty_like(t) for _ in range(world)] if use_dist else [t]
+        if use_dist:
+            dist.all_gather(allt, t)
+        a = torch.stack(allt).cpu().numpy() / n * 1e3
+        return {'ms_per_step_by_rank': [round(float(v), 4) for v in a[:, 0]], 'ms_per_step_min': float(a[:, 0].min()),
+                'ms_per_step_max': float(a[:, 0].max()),
+                'host_cpu_ms_per_step_by_rank': [round(float(v), 4) for v in a[:, 1]],
+                'host_cpu_cores': os.cpu_count(),
+                'note': 'wall time of each rank for the timed steps before the closing barrier; host CPU time = process_time of the '
+                        'rank (its launch threads: eager launches cost host time, %d host thread(s) per rank)' % n_streams}
 
     # ---------------------------------------------------------------- weak workload: this rank's own trajectories
     raw = synth.generate_channels(profile, nch, nt, nr, 0.5, seed=4321 + rank)        # per-rank channel batch
@@ -329,6 +361,7 @@ def main():
     K = STEPS_PER_CHANNEL - args.warmup if args.full_schedule else args.steps
     # headline: the launch mode and stream count the CLIs default to; nothing but the K steps inside the timed region
     dt = timed(alds, streams, K, use_graph, args.warmup)
+    rank_times = per_rank(K)
     other = None
     if not args.no_other_mode and not args.full_schedule:
         other = timed(alds, streams, K, not use_graph, args.warmup)
@@ -386,6 +419,25 @@ def main():
             a.close()
         del p_alds, pa
     range_flag = _lib.range_flag() if conv_mode == 'f16x2' else 0
+
+    # ---------------------------------------------------------------- the same steps in the exact mode (bf16x3), for comparison
+    exact = None
+    if conv_mode == 'f16x2' and not args.no_exact_mode and not args.full_schedule and not big:
+        net_f16x2 = net
+        net = net_f16x2.fallback_net()                    # same checkpoint, conv_mode bf16x3 (what a flagged batch is re-run with)
+        e_alds, e_streams = make_batches(H, Pm, idx, idx, ln, np.full(T, 3e-11), np.full(T, 0.01), rank * T + np.arange(T), init,
+                                         n_streams)
+        Ke = max(5, min(K, 20))
+        dte = timed(e_alds, e_streams, Ke, use_graph, 2)
+        exact = {'conv_mode': 'bf16x3', 'ms_per_step': dte / Ke * 1e3, 'value': world * T / (STEPS_PER_CHANNEL * dte / Ke),
+                 'steps': Ke, 'unit': 'channels/s',
+                 'what': 'the same workload with every product as an exact three-term bf16 split (six bf16 MFMAs per product block, '
+                         'ELU with relative accuracy everywhere): fp32\'s range and precision unconditionally -- the mode a batch that '
+                         'raises the f16x2 range flag is re-run in'}
+        for a in e_alds:
+            a.close()
+        del e_alds
+        net = net_f16x2
 
     # ---------------------------------------------------------------- strong workload: the tuner grid, sharded
     strong = None
@@ -461,6 +513,9 @@ def main():
                                         'value': world * T / (STEPS_PER_CHANNEL * other / K)}
         if strong is not None:
             out['strong'] = strong
+        if exact is not None:
+            out['exact_mode'] = exact
+        out['per_rank'] = rank_times
         out['config']['one_stream_ms_per_step'] = one_stream_ms
         if conv_mode == 'f16x2':
             out['config']['f16x2_range_flag'] = int(range_flag)          # 0: every staged activation stayed inside the fp16 range
@@ -543,11 +598,25 @@ def main():
                                        'the products, the direct fused pair all of them plus its halo rows, each as 3 fp16 MFMAs in f16x2), '
                                        'so frac IS the busy fraction of the matrix cores over the class; traffic = PMC bytes per launch '
                                        'averaged over the class' % mpeak}
+            # SURVEY section 8(d)'s fraction, next to the busy fraction: ALGORITHMIC (direct-convolution) FLOPs / time / dense peak of
+            # the matrix cores -- for the class above and for the whole step (= channels/s x 5.6904e12 / (n_gpus x peak))
+            rf['frac_algorithmic'] = fl_cls / t_cls / 1e12 / mpeak
+            rf['frac_algorithmic_step'] = flops_fwd / (ms_per_step * 1e-3) / 1e12 / mpeak
+            rf['frac_note'] = ('frac = executed matrix-instruction FLOPs / time / %.1f TFLOP/s (how busy the matrix pipe is; agrees with the '
+                               'PMC counter); frac_algorithmic = direct-convolution FLOPs of the class / time / the same peak (what SURVEY '
+                               'section 8(d) defines: Winograd F(2x2,3x3) needs 16/36 of those multiplications but each is three fp16 '
+                               'MFMAs in f16x2, so the two differ by 1.33x there and by 3.4x on the direct fused kernels); '
+                               'frac_algorithmic_step = the whole Langevin step the headline times' % mpeak)
             rf['kernels'] = {names[t]: {k: v for k, v in entries[t].items() if k != 'kernel'} for t in entries}
+            for t in entries:
+                rf['kernels'][names[t]]['frac_algorithmic'] = entries[t]['algorithmic_tflops'] / mpeak
             if traffic is not None:
                 rf['traffic_source'] = tsrc + ' (rocprofv3 --pmc passes of the one-stream command: FETCH_SIZE x 2 + WRITE_SIZE per launch)'
             out['roofline'] = rf
         if cpu_base is not None:
+            ref_rec = reference_cpu_record()
+            if ref_rec is not None:
+                cpu_base['reference_build_container'] = ref_rec
             out['cpu_baseline'] = cpu_base
         print(json.dumps(out))
     if use_dist:

@@ -395,6 +395,8 @@ int sbc_pack_conv_weight_winograd_f16x2(const float* src, int32_t cout, int32_t 
  * the whole device (every stream).  reset != 0 clears the word. */
 #define SBC_RANGE_OVERFLOW  1
 #define SBC_RANGE_UNDERFLOW 2
+#define SBC_RANGE_ELU       4   /* a fused RCU launch (SBC_OP_CONV_PAIR evaluates ELU as exp(x) - 1 only) ran on a layer whose calibrated
+                                   inputs are below 2^-4, where that form no longer has fp32's relative accuracy */
 int sbc_range_flag(int32_t* flag, int32_t reset);
 
 /* Per-layer activation scales of conv_mode f16x2 (ABI 11).  A two-term fp16 split x s = h + l is fp32-class only while l stays a

@@ -128,7 +128,7 @@ def check(rc):
         raise SbcError('libsbc_hip: %s (status %d)' % (lib().sbc_last_error().decode(), rc))
 
 
-RANGE_OVERFLOW, RANGE_UNDERFLOW = 1, 2
+RANGE_OVERFLOW, RANGE_UNDERFLOW, RANGE_ELU = 1, 2, 4
 
 
 def range_flag(reset=True, device=None):
@@ -152,6 +152,8 @@ def describe_range(bits):
         what.append('an activation left the fp16 range (|x| * act_scale >= 16000)')
     if bits & RANGE_UNDERFLOW:
         what.append('a region of an input stayed below 2^-6 of its layer\'s scale (denormal low terms)')
+    if bits & RANGE_ELU:
+        what.append('a fused RCU launch met inputs below 2^-4, where its exp(x) - 1 form of ELU loses relative accuracy')
     return '; '.join(what)
 
 

@@ -288,15 +288,15 @@ int sbc_f16x2_calibrate(const sbc_op* ops, int32_t n_ops, void* stream) {
         k = k < -24 ? -24 : k > 40 ? 40 : k;
         return ldexpf(1.f, k);
     };
-    // (fourth word: the layer's inputs are small -- maximum below 0.5 -- so its ELU prologue must keep RELATIVE accuracy for small
-    // negative values: SBC_PRO_ELU_ACC, common.h)
+    // (fourth word: the layer's inputs are small -- maximum below 2^-4: exp(x) - 1 then carries 6e-8 / 0.01 ~ 5e-6 of a typical
+    // value -- so its ELU prologue must keep RELATIVE accuracy for small negative values: SBC_PRO_ELU_ACC, common.h)
     auto set_trailer = [&](const void* w, int taps, int cin, int cout, float sc, float amax_in) -> int {
         if (!w) return SBC_OK;
         float* tr = (float*)((char*)const_cast<void*>(w) + (size_t)taps * cin * cout * 2 * sizeof(uint16_t));
         float old[4];
         SBC_CHECK_HIP(hipMemcpy(old, tr, sizeof(old), hipMemcpyDeviceToHost));
         const float wd = old[2] != 0.f ? old[2] : old[1] * old[0];          // the weights' own descale 2^-s
-        const float upd[4] = {sc, wd / sc, wd, (amax_in > 0.f && amax_in < 0.5f) ? 1.f : 0.f};
+        const float upd[4] = {sc, wd / sc, wd, (amax_in > 0.f && amax_in < 0.0625f) ? 1.f : 0.f};
         SBC_CHECK_HIP(hipMemcpy(tr, upd, sizeof(upd), hipMemcpyHostToDevice));
         return SBC_OK;
     };

@@ -114,7 +114,7 @@ __device__ __forceinline__ float4 elu4(float4 v) {
 // absolute error of 6e-8, i.e. 6e-5 of an activation of -1e-3, where the reference's expm1 is good to 1e-7 of the value.  For
 // -1/32 < x < 0 a fourth-order Taylor polynomial (truncation x^4 / 120 < 1e-8 relative), below that exp(x) - 1 (relative error
 // 6e-8 / |x| <= 2e-6, falling to 1e-7 at -0.5).  Ten vector instructions per value instead of four: used by the layers whose
-// calibrated input maximum is below 0.5 (sbc_f16x2_calibrate sets the request in the weight trailer), by the exact modes (the host
+// calibrated input maximum is below 2^-4 (sbc_f16x2_calibrate sets the request in the weight trailer), by the exact modes (the host
 // sets the flag: bf16x3 / f32) and by the two places ELU sits outside a convolution prologue (max pool, CRP residual operand).
 __device__ __forceinline__ float elu1_acc(float x) {
     // (the two coefficients that are not inline constants are pinned to scalar registers: hipcc would otherwise hoist them into

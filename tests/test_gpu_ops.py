@@ -546,9 +546,13 @@ def test_f16x2_library_calibration_sets_the_layer_scales(gpu, log2_scale):
     for dw, amax in ((dw0, v[0].abs().max()), (dw0w, v[0].abs().max()), (dw1, v[0].abs().max()), (dw2, te[0].abs().max())):
         tr = dw[-4:].cpu().numpy()                                    # (the trailer: act_scale, descale, weight descale, 0)
         assert tr[0] == _pow2_scale(float(amax)) and tr[1] == tr[2] / tr[0] and tr[2] > 0, (tr, float(amax))
-    for op in ops:
-        _launch(gpu, op)
+    _launch(gpu, ops[0])
     assert _lib.range_flag() == 0
+    _launch(gpu, ops[1])
+    # the fused kernel evaluates ELU as exp(x) - 1 only: where the calibration found one of its two inputs below 2^-4 it says so
+    # (SBC_RANGE_ELU; the host then runs the batch in bf16x3) -- here the inputs are positive, so the numbers are right anyway
+    small = min(float(v[0].abs().max()), float(te[0].abs().max())) < 2.0 ** -4
+    assert _lib.range_flag() == (_lib.RANGE_ELU if small else 0)
     ref0 = _f64_conv(torch, v, w0, 1)
     ref1 = _f64_conv(torch, te, w2, 1)
     assert float((o0.double() - ref0).norm() / ref0.norm()) < TOL

@@ -549,65 +549,88 @@ def test_forward_other_geometries_match_oracle(nt, nr, weights64):
         assert net.range_fallbacks == 0
 
 
-def _scaled_refine_weights(sd, factor):
-    """The state dict with every RCU / CRP convolution of refine4 and refine5 (no normalisation between them: layers.py:76-83,
-    126-134) multiplied by ``factor``: the intermediates of those chains then sit ``factor`` (and ``factor``^2) below O(1)."""
+def _scaled_msf_weights(sd, factor):
+    """The state dict with refine5's two MSF convolutions (weight and bias, layers.py:178-184) multiplied by ``factor``.  Everything
+    behind them -- the CRP block and the three output RCU blocks at full resolution, none of which normalises (layers.py:76-83,
+    126-134) -- then runs on activations ``factor`` times smaller, and the final InstanceNorm++ (ncsnv2.py:291) brings the result
+    back to O(1): every error made on the small tensors shows in the score at full size."""
     out = dict(sd)
     n = 0
     for k, v in sd.items():
-        if k.startswith(('refine4.', 'refine5.')) and k.endswith('.weight') and ('adapt_convs' in k or 'crp' in k or 'output_convs' in k):
+        if k.startswith('refine5.msf.convs.'):
             out[k] = (np.asarray(v, np.float32) * np.float32(factor)).astype(np.float32)
             n += 1
-    assert n >= 30
+    assert n == 4
     return out
 
 
-@pytest.mark.parametrize('log2_factor', [-6, -10, 4])
-def test_f16x2_holds_the_tolerance_with_small_and_large_refine_activations(weights64, log2_factor):
-    """The reference computes in IEEE fp32 (test_score.py:25-26): its relative precision does not depend on how large a
-    checkpoint's un-normalised RCU / CRP activations are.  The shipped default (f16x2 + fused pairs + folded statistics) must not
-    either: with the refine4 / refine5 chain weights scaled by 2^-6, 2^-10 (intermediates down to 1e-6 of O(1)) or 2^4 the forward
-    still agrees with the oracle on the SAME scaled weights at the tolerance of the unscaled golden -- through the per-layer
-    activation scales of sbc_f16x2_calibrate, with the range flag clear and no fallback to bf16x3."""
-    import torch
+def _forward_case(weights64, log2_factor):
     from oracle import ncsnv2_oracle
-    from score_based_channels_amd.scorenet import ScoreNet
     cfg, sd = weights64
-    sd2 = _scaled_refine_weights(sd, 2.0 ** log2_factor)
+    sd2 = _scaled_msf_weights(sd, 2.0 ** log2_factor)
     g = load_golden('forward_64x16.npz')
     x, labels = g['x'][:3], np.array([0, 1155, 2310])
-    ref = ncsnv2_oracle.score_forward(sd2, x, labels)
+    return cfg, sd2, x, labels, ncsnv2_oracle.score_forward(sd2, x, labels)
+
+
+@pytest.mark.parametrize('log2_factor', [-3, 3, 8])
+def test_f16x2_holds_the_tolerance_when_the_refine_activations_are_not_o1(weights64, log2_factor):
+    """The reference computes in IEEE fp32 (test_score.py:25-26): its relative precision does not depend on how large a
+    checkpoint's un-normalised activations are.  The shipped default (f16x2 + fused pairs + folded statistics) must not either:
+    with refine5's activations 8x smaller or 8x / 256x larger the forward agrees with the oracle on the SAME weights at the
+    tolerance of the unscaled golden -- through the per-layer activation scales of sbc_f16x2_calibrate, with the range flag clear
+    and no fallback."""
+    import torch
+    from score_based_channels_amd.scorenet import ScoreNet
+    cfg, sd2, x, labels, ref = _forward_case(weights64, log2_factor)
     net = ScoreNet(cfg).cuda().load_state_dict(sd2).eval()
     assert net.conv_mode == 'f16x2' and net.fuse_pairs and net.fold_stats
     out = net(torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda()).cpu().numpy()
     assert net.range_fallbacks == 0
+    assert rel_err(out, ref) < 2e-5, rel_err(out, ref)
+
+
+@pytest.mark.parametrize('log2_factor', [-7, -10, -13])
+def test_small_refine_activations_hold_the_tolerance_in_every_mode(weights64, log2_factor):
+    """refine5's activations 128x ... 8192x smaller (1e-2 ... 1e-4): below 2^-4 the hardware form of ELU, exp(x) - 1, no longer has
+    fp32's relative accuracy (6e-8 absolute), and with act_scale = 1 the two-term fp16 split would not either.
+      * bf16x3 (the exact mode: ELU with relative accuracy everywhere, SBC_PRO_ELU_ACC) agrees with the oracle;
+      * f16x2 without pair fusion does too, with NO fallback: calibrated activation scales + the accurate ELU its calibration
+        requests per layer;
+      * the shipped default meets its fused RCU kernels there, which evaluate ELU as exp(x) - 1 only: they raise the range flag
+        (SBC_RANGE_ELU) and the call is answered by the bf16x3 network in the same process -- still within tolerance."""
+    import torch
+    from score_based_channels_amd import _lib
+    from score_based_channels_amd.scorenet import ScoreNet
+    cfg, sd2, x, labels, ref = _forward_case(weights64, log2_factor)
+    xt, lt = torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda()
     exact = ScoreNet(cfg, conv_mode='bf16x3').cuda().load_state_dict(sd2).eval()
-    out_exact = exact(torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda()).cpu().numpy()
-    assert rel_err(out_exact, ref) < 2e-5
-    assert rel_err(out, ref) < 2e-5 and rel_err(out, out_exact) < 5e-6, (rel_err(out, ref), rel_err(out, out_exact))
+    assert rel_err(exact(xt, lt).cpu().numpy(), ref) < 2e-5
+    unfused = ScoreNet(cfg, conv_mode='f16x2', fuse_pairs=False).cuda().load_state_dict(sd2).eval()
+    out = unfused(xt, lt).cpu().numpy()
+    assert unfused.range_fallbacks == 0 and rel_err(out, ref) < 2e-5, (unfused.range_fallbacks, rel_err(out, ref))
+    net = ScoreNet(cfg).cuda().load_state_dict(sd2).eval()
+    out = net(xt, lt).cpu().numpy()
+    assert net.range_fallbacks == 1 and net.last_range_bits & _lib.RANGE_ELU
+    assert rel_err(out, ref) < 2e-5
 
 
 def test_f16x2_guard_reruns_in_bf16x3_in_process(weights64, monkeypatch):
-    """Without the calibration (act_scale = 1 everywhere, what rounds 2-3 shipped) the same scaled checkpoint drives whole
-    regions of the refine chains below 2^-6: the kernels raise the underflow bit, and the host answers the call from the bf16x3
-    network in the same process (module call) / re-runs the chunk (driver.run_trajectories) -- never silently degraded numbers."""
+    """Without the calibration (act_scale = 1 everywhere, what rounds 2-3 shipped) small refine5 activations put whole regions
+    below 2^-6: the kernels raise the underflow bit, and the host answers the call from the bf16x3 network in the same process
+    (module call) / re-runs the chunk (driver.run_trajectories) and says so -- never silently degraded numbers."""
     import torch
-    from oracle import ncsnv2_oracle
     from score_based_channels_amd import _lib, synth
     from score_based_channels_amd.ald import snr_to_noise
     from score_based_channels_amd.driver import run_trajectories
     from score_based_channels_amd.scorenet import ScoreNet
-    cfg, sd = weights64
-    sd2 = _scaled_refine_weights(sd, 2.0 ** -10)
-    g = load_golden('forward_64x16.npz')
-    x, labels = g['x'][:3], np.array([0, 1155, 2310])
-    ref = ncsnv2_oracle.score_forward(sd2, x, labels)
+    cfg, sd2, x, labels, ref = _forward_case(weights64, -10)
     monkeypatch.setenv('SBC_NO_CALIB', '1')
     net = ScoreNet(cfg).cuda().load_state_dict(sd2).eval()
     out = net(torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda()).cpu().numpy()
     assert net.range_fallbacks == 1 and net.last_range_bits & _lib.RANGE_UNDERFLOW
     assert rel_err(out, ref) < 2e-5
-    # the sampling loop: the chunk is run again, the result file entry says so, and the numbers are the bf16x3 run's
+    # the sampling loop: the chunk is run again, the result-file entry says so, and the numbers are the bf16x3 run's
     nch, nt, nr, npil = 3, 64, 16, 38
     raw = synth.generate_channels('CDL-C', nch, nt, nr, 0.5, seed=2)
     H = np.conj(np.transpose(raw / np.std(raw), (0, 2, 1))).astype(np.complex64)
