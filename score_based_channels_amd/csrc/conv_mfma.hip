@@ -278,6 +278,12 @@ int launch_conv(const sbc_op& op, hipStream_t stream, bool dry) {
     if (op.weight_wino_split && !f32_only && !no_wx3 && op.ksize == 3 && op.dil == 1) {
         ConvParams pw = p;
         pw.wpk = (const float4*)op.weight_wino_split;
+#ifdef SBC_WITH_WP   // tools/experiments/conv_wp.hip (round 4: 64 -> 64 with the transformed filter resident in registers; measured slower)
+        {
+            const int rc = launch_conv_wp(pw, op.cin, op.cout, stream, dry);
+            if (rc <= 0) return rc;
+        }
+#endif
         const int rc = launch_conv_wx3(pw, op.cin, op.cout, stream, dry);
         if (rc <= 0) return rc;                                                    // launched (0) or failed (< 0)
     }

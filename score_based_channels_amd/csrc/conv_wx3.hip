@@ -222,9 +222,9 @@ __global__ __launch_bounds__(256 * NG, WPE) void conv_wx3_kernel(ConvParams p) {
                 } else if constexpr (MODE == 2) {
                     uint4 vhu, vlu;
                     {
-                        uint2 ha, la, hb, lb;
-                        split_f16x2(make_float4(v[0], v[1], v[2], v[3]), act_scale, ha, la);
-                        split_f16x2(make_float4(v[4], v[5], v[6], v[7]), act_scale, hb, lb);
+                        uint2 ha, la, hb, lb;                     // (the tile was staged as x * act_scale: tile.h scale_stage)
+                        split_f16x2_unit(make_float4(v[0], v[1], v[2], v[3]), ha, la);
+                        split_f16x2_unit(make_float4(v[4], v[5], v[6], v[7]), hb, lb);
                         vhu = make_uint4(ha.x, ha.y, hb.x, hb.y);
                         vlu = make_uint4(la.x, la.y, lb.x, lb.y);
                     }

@@ -45,6 +45,13 @@ __device__ __forceinline__ void st_stream(float* p, float4 v) {
 struct StageScale { float scale; float amax; };
 constexpr float F16X2_LIMIT = 16000.f;                   // 65504 / 4, rounded down
 constexpr float F16X2_SMALL = 0.015625f;                 // 2^-6: below it the relative error of the split exceeds 2^-19
+// fp32-tile staging (conv_wx3): track, then multiply by act_scale (an exact power of two)
+__device__ __forceinline__ void scale_stage(float4& x, StageScale* ss) {
+    if (!ss) return;
+    ss->amax = __builtin_fmaxf(__builtin_fmaxf(ss->amax, __builtin_fabsf(x.x)), __builtin_fabsf(x.y));
+    ss->amax = __builtin_fmaxf(__builtin_fmaxf(ss->amax, __builtin_fabsf(x.z)), __builtin_fabsf(x.w));
+    x.x *= ss->scale; x.y *= ss->scale; x.z *= ss->scale; x.w *= ss->scale;
+}
 __device__ __forceinline__ void scale_track(const float4& x, StageScale* ss) {
     if (!ss) return;
     // (max(max(a, |x|), |y|): the shape hipcc turns into one v_max3_f32 with |.| source modifiers)
@@ -159,7 +166,7 @@ __device__ __forceinline__ void stage_put(float* lds, float4 x, int idx, const f
         x.w = (x.w - mu.w) * sc.w + sh.w;
     }
     if (flags & SBC_PRO_ELU) x = elu4(x, (flags & SBC_PRO_ELU_ACC) != 0);
-    scale_track(x, ss);
+    scale_stage(x, ss);
     *reinterpret_cast<float4*>(lds + pix * S + c4 * 4) = x;
 }
 
@@ -300,7 +307,7 @@ __device__ __forceinline__ void stage_commit_reg(float* lds, const float4 (&pf)[
         x.x = (x.x - rs.mu.x) * rs.sc.x + rs.sh.x; x.y = (x.y - rs.mu.y) * rs.sc.y + rs.sh.y;
         x.z = (x.z - rs.mu.z) * rs.sc.z + rs.sh.z; x.w = (x.w - rs.mu.w) * rs.sc.w + rs.sh.w;
         if (flags & SBC_PRO_ELU) x = elu4(x, (flags & SBC_PRO_ELU_ACC) != 0);
-        scale_track(x, ss);
+        scale_stage(x, ss);
         *reinterpret_cast<float4*>(lds + (idx / C4) * S + (idx % C4) * 4) = x;
     };
 #pragma unroll
@@ -378,6 +385,19 @@ __device__ __forceinline__ void split_f16x2(float4 x, float s, uint2& h, uint2& 
         "v_fma_mixhi_f16 %2, %5, %8, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
         "v_fma_mixhi_f16 %3, %7, %8, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
         : "=&v"(h.x), "=&v"(h.y), "=&v"(l.x), "=&v"(l.y) : "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w), "s"(s));
+}
+
+// ... and of four values that are ALREADY scaled (a = h + l): three instructions per pair.  The Winograd kernel stages its fp32
+// tile as x * act_scale (one multiply per staged value, scale_stage below) and splits the transformed values with this form: a
+// staged value feeds four transformed values, so the multiply at staging is half the price of the scaling split in the K loop.
+__device__ __forceinline__ void split_f16x2_unit(float4 x, uint2& h, uint2& l) {
+    asm("v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+        "v_cvt_pk_f16_f32 %1, %6, %7\n\t"
+        "v_fma_mixlo_f16 %2, %4, 1.0, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %3, %6, 1.0, -%1 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %2, %5, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %3, %7, 1.0, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(h.x), "=&v"(h.y), "=&v"(l.x), "=&v"(l.y) : "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w));
 }
 
 // lds16: LDS viewed as 16-bit elements; `plane` = elements per plane; TERMS = 3 (exact bf16 split), 2 (fp16 pair of a scaled

@@ -26,10 +26,32 @@ def init_distributed(backend=None):
         import torch.distributed as dist
         if not dist.is_initialized():
             if backend is None:
-                backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+                # SBC_DIST_BACKEND=gloo: more ranks than GPUs (smoke runs and tests that share one device; RCCL refuses that)
+                backend = os.environ.get('SBC_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
             kw = {'device_id': torch.device('cuda', local)} if backend == 'nccl' else {}
             dist.init_process_group(backend, **kw)
+        if torch.cuda.is_available() and local >= torch.cuda.device_count():
+            if os.environ.get('SBC_DIST_BACKEND') != 'gloo':
+                raise RuntimeError('LOCAL_RANK %d but only %d visible device(s): launch one rank per GPU (or set '
+                                   'SBC_DIST_BACKEND=gloo to share a device in a smoke test)' % (local, torch.cuda.device_count()))
+            local %= torch.cuda.device_count()
     return rank, world, local
+
+
+def collective_device(t):
+    """Where a collective's payload must live: on the tensor's device for RCCL, in host memory for a gloo group."""
+    import torch.distributed as dist
+    return t.device if dist.get_backend() == 'nccl' else 'cpu'
+
+
+def broadcast_int(value, src=0, device=None):
+    """Rank ``src``'s integer on every rank (seeds)."""
+    import torch
+    import torch.distributed as dist
+    dev = device if dist.get_backend() == 'nccl' else 'cpu'
+    t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+    dist.broadcast(t, src)
+    return int(t.item())
 
 
 def block_bounds(n_items, world):
@@ -55,11 +77,11 @@ def gather_trajectory_logs(local_log, n_items, rank, world):
     b = block_bounds(n_items, world)
     width = int(np.max(np.diff(b)))
     n_steps = local_log.shape[0]
-    pad = torch.zeros(n_steps, width, dtype=local_log.dtype, device=local_log.device)
+    pad = torch.zeros(n_steps, width, dtype=local_log.dtype, device=collective_device(local_log))
     pad[:, :local_log.shape[1]] = local_log
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad)
-    return torch.cat([parts[r][:, :int(b[r + 1] - b[r])] for r in range(world)], dim=1)
+    return torch.cat([parts[r][:, :int(b[r + 1] - b[r])] for r in range(world)], dim=1).to(local_log.device)
 
 
 def all_reduce_sum_(t, world):

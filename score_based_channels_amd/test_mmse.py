@@ -27,6 +27,7 @@ from .driver import level_subset, resolve_launch_mode, run_trajectories
 from .loaders import Channels
 from .noise import HostNoise
 from .scorenet import ScoreNet
+from . import shard
 from .shard import init_distributed
 from .weights import get_sigmas, seeded_state_dict
 
@@ -157,9 +158,7 @@ def main(argv=None):
 
     seed = int.from_bytes(os.urandom(4), 'little') if args.seed is None else args.seed
     if world > 1:
-        t = torch.tensor([seed], dtype=torch.int64, device=device)
-        torch.distributed.broadcast(t, 0)
-        seed = int(t.item())
+        seed = shard.broadcast_int(seed, 0, device)
     np.random.seed(seed % (2 ** 32))
 
     train_seed, val_seed = 1234, 4321

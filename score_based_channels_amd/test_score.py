@@ -81,9 +81,7 @@ def main(argv=None):
 
     seed = int.from_bytes(os.urandom(4), 'little') if args.seed is None else args.seed
     if world > 1:                                         # every rank must use rank 0's seed
-        t = torch.tensor([seed], dtype=torch.int64, device=device)
-        torch.distributed.broadcast(t, 0)
-        seed = int(t.item())
+        seed = shard.broadcast_int(seed, 0, device)
     np.random.seed(seed % (2 ** 32))                      # pilots come from numpy's legacy global RNG (loaders.py:52-55)
 
     train_seed, val_seed = 1234, 4321

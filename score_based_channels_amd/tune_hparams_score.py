@@ -91,9 +91,7 @@ def main(argv=None):
 
     seed = int.from_bytes(os.urandom(4), 'little') if args.seed is None else args.seed
     if world > 1:
-        t = torch.tensor([seed], dtype=torch.int64, device=device)
-        torch.distributed.broadcast(t, 0)
-        seed = int(t.item())
+        seed = shard.broadcast_int(seed, 0, device)
     np.random.seed(seed % (2 ** 32))
 
     train_seed, val_seed = 1234, 4321

@@ -406,6 +406,23 @@ def gen_cross_b():
     print('cli_cross_b: std(train)=%g |H| rms %g nmse[0,-1]=%s' % (dataset.std, np.sqrt(np.mean(np.abs(H) ** 2)), log[0, -1]))
 
 
+def gen_cross_a():
+    """BASELINE config 4, the third foreign profile: ``--train CDL-C --test CDL-A`` (as ``gen_cross``; seed 9, 2 noise levels, and
+    SIX channels x 17 SNR points = 102 trajectories, which the GPU test also runs in chunks of 40: chunk boundaries inside the
+    reference's result)."""
+    seed, B = 9, 6
+    cfg, dataset, make_val, DataLoader = _reference_datasets('CDL-C', 'CDL-A', seed, 38)
+    H, P = _first_batch(make_val(), DataLoader, B)
+    net = reference_net(cfg, seeded_state_dict(cfg, WEIGHT_SEED))
+    snr = np.arange(-10, 32.5, 2.5)
+    Y, X, log = reference_ald(net, cfg, H, P, snr, [0, 1], seed)
+    np.savez_compressed(os.path.join(GOLD, 'cli_cross_cdlc_cdla.npz'), H=H, P=P, nmse_log=log, X_final=X, snr_db=snr,
+                        train_std=np.float64(dataset.std), seed=seed, weight_seed=WEIGHT_SEED,
+                        argv=np.array('--train CDL-C --test CDL-A --synthetic --synthetic_weights 2024 --num_levels 2 '
+                                      '--num_channels 6 --seed 9 --noise host --no_plot'))
+    print('cli_cross_a: std(train)=%g |H| rms %g nmse[0,-1]=%s' % (dataset.std, np.sqrt(np.mean(np.abs(H) ** 2)), log[0, -1]))
+
+
 def gen_tunecli2():
     """BASELINE config 3 end to end over several noise levels: the 2 x 2 grid of ``gen_tunecli`` walked over the first TWO
     levels x 3 steps (the per-level scalars alpha / noise scale / dc divisor change between levels)."""

@@ -79,8 +79,10 @@ def test_c_built_score_network_equals_python_host(weights64, mode):
         L.sbc_score_destroy(h)
 
 
-def test_langevin_plan_composed_from_c_records(weights64):
-    """sbc_score_level_source + sbc_score_ops + SBC_OP_LANGEVIN + SBC_OP_STEP_INC = the plan AldBatch builds: same NMSE log."""
+@pytest.mark.parametrize('mode,pairs,fold', [('bf16x3', False, False), ('f16x2', True, True)])
+def test_langevin_plan_composed_from_c_records(weights64, mode, pairs, fold):
+    """sbc_score_level_source + sbc_score_ops + SBC_OP_LANGEVIN + SBC_OP_STEP_INC = the plan AldBatch builds: same NMSE log --
+    in the exact mode and in the shipped default (conv_mode 3 | SBC_SCORE_FUSE_PAIRS | SBC_SCORE_FOLD_STATS, calibrated scales)."""
     import torch
     from score_based_channels_amd import _lib, plan as P
     from score_based_channels_amd.ald import AldBatch, schedule_tables, snr_to_noise
@@ -97,7 +99,7 @@ def test_langevin_plan_composed_from_c_records(weights64):
     ln = float(snr_to_noise(g['snr_db'], nt)[0])
     steps = noise.step_block(0, H.shape, n_steps)
     # reference run through the Python host
-    net = ScoreNet(cfg, conv_mode='bf16x3', fold_stats=False).cuda().load_state_dict(sd)
+    net = ScoreNet(cfg, conv_mode=mode, fold_stats=fold, fuse_pairs=pairs).cuda().load_state_dict(sd)
     ald = AldBatch(net, H, Pm, np.arange(B), np.arange(B), ln, levels=levels, step_noise=torch.from_numpy(steps))
     ald.set_init(torch.from_numpy(noise.init(H.shape)))
     Y = ald.synthesize_measurements(torch.from_numpy(noise.measurement(0, (B, npil, nr)))).clone()
@@ -105,7 +107,7 @@ def test_langevin_plan_composed_from_c_records(weights64):
     torch.cuda.synchronize()
     want = ald.nmse_log().clone()
     # the same plan from C records
-    h = _create(sd, cfg, B, nt, nr, 'bf16x3')
+    h = _create(sd, cfg, B, nt, nr, mode, pairs, fold)
     try:
         sched, sig = schedule_tables(sd['sigmas'], cfg.model.sigma_end, levels, 3, [3e-11], [0.01], [ln])
         dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in dict(

@@ -764,3 +764,45 @@ def test_forward_does_not_depend_on_the_batch_size(weights64, mode):
     assert torch.isfinite(a).all()
     for n in (1200, 800, 100):
         assert torch.equal(net(x[:n], lab[:n]), a[:n]), n
+
+
+def _run_cli_ranks(tmp_path, world, module, argv, port):
+    """``python -m torch.distributed.run --nproc-per-node <world> -m score_based_channels_amd.<module> ...`` in its own directory
+    (both ranks on this box's one GPU: gloo carries the collectives, RCCL does on a node with a GPU per rank)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = tmp_path / ('w%d' % world)
+    out.mkdir(parents=True)
+    env = dict(os.environ, PYTHONPATH=ROOT, SBC_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+           '--master-port', str(port + world), '-m', 'score_based_channels_amd.' + module] + argv
+    r = subprocess.run(cmd, env=env, cwd=str(out), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return out
+
+
+def test_cli_two_ranks_equal_one_rank(tmp_path):
+    """What shard.py promises: trajectories are independent and their noise is keyed by GLOBAL trajectory id, so
+    ``torchrun --nproc-per-node 2 -m ...test_score`` (contiguous blocks per rank, one all_gather of the logs at the end) returns
+    the one-rank NMSE log and final estimates BIT FOR BIT -- here with 5 channels x 17 SNR points = 85 trajectories (blocks of
+    43 and 42), default conv_mode and streams.  The same for the tuner with a 3 x 1 grid x 17 x 3 = 153 trajectories (77 / 76)."""
+    import torch
+    argv = ['--synthetic', '--synthetic_weights', '2024', '--num_channels', '5', '--levels_stride', '1155', '--seed', '7',
+            '--save_channels', '1', '--no_plot']
+    res = {w: torch.load(_run_cli_ranks(tmp_path, w, 'test_score', argv, 29710) / 'results/score/train-CDL-C_test-CDL-C/results.pt',
+                         weights_only=False) for w in (1, 2)}
+    assert res[1]['nmse_log'].shape == (1, 1, 17, 9, 5) and np.isfinite(res[1]['nmse_log']).all()
+    assert np.array_equal(res[1]['nmse_log'], res[2]['nmse_log'])
+    assert np.array_equal(res[1]['saved_H'], res[2]['saved_H'])
+    assert res[1]['f16x2_fallback'] == [] and res[2]['f16x2_fallback'] == []
+    targv = ['--synthetic', '--synthetic_weights', '2024', '--num_channels', '3', '--levels_stride', '1155', '--seed', '8', '--no_plot',
+             '--alpha_step_range', '3e-11', '6e-11', '1e-10', '--beta_noise_range', '0.01']
+    tun = {w: torch.load(_run_cli_ranks(tmp_path / 'tune', w, 'tune_hparams_score', targv, 29720) / 'results/score/CDL-C-hyperparameters.pt',
+                         weights_only=False) for w in (1, 2)}
+    assert tun[1]['nmse_log'].shape == (3, 1, 17, 9, 3)
+    assert np.array_equal(tun[1]['nmse_log'], tun[2]['nmse_log'])
+    assert np.array_equal(tun[1]['best_alpha_snr'], tun[2]['best_alpha_snr'])

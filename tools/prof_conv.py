@@ -65,6 +65,15 @@ if os.environ.get('WINO_TIMING'):
     d = dbg.view(4096, 4, 6).cpu().numpy()
     names = ['stage', 'barrier', 'K loop', 'T write', 'barrier2', 'finish']
     print('wave 0 cycles/WG (mean):', {n: int(d[:, 0, i].mean()) for i, n in enumerate(names)}, 'sum', int(d[:, 0].sum(1).mean()))
+if os.environ.get('WP_TIMING'):
+    dbg = torch.zeros(256 * 10, device='cuda', dtype=torch.int64); op.up = dbg.data_ptr()
+    _lib.check(h.sbc_op_launch(C.byref(op), None)); torch.cuda.synchronize()
+    d = dbg.view(256, 10).cpu().numpy().astype(np.float64)
+    d = d[d[:, 9] > 0]
+    names = ['issue', 'V-form+MFMA', 'barrier1', 'ex write', 'commit', 'barrier2', 'last finish', 'finish']
+    nb = d[:, 9].mean()
+    print('conv_wp wave 0: blocks per WG %.1f; cycles per block (mean over WGs):' % nb,
+          {n: int((d[:, i] / d[:, 9]).mean()) for i, n in enumerate(names)}, 'loop total per block', int((d[:, 8] / d[:, 9]).mean()))
 if os.environ.get('DUMP'):
     _lib.check(h.sbc_op_launch(C.byref(op), None)); torch.cuda.synchronize()
     np.save(os.environ['DUMP'], out.cpu().numpy())
