@@ -48,6 +48,9 @@ def parse_args(argv=None):
                         'matrix cores, f32 is fp32 MFMA, f16w rounds the parameters to fp16 (BASELINE config 5; looser tolerance)')
     p.add_argument('--no_graph', action='store_true', help='launch kernels eagerly instead of hipGraph replay')
     p.add_argument('--graph', action='store_true', help='[added] replay each Langevin step as a hipGraph (default: driver.DEFAULT_USE_GRAPH)')
+    p.add_argument('--max_batch', type=int, default=4096,
+                   help='[added] largest lock-step batch per device (trajectories beyond it run as further chunks; results do not '
+                        'depend on it)')
     p.add_argument('--streams', type=int, default=DEFAULT_STREAMS,
                    help='[added] run each lock-step batch as this many concurrent sub-batches on their own HIP streams '
                         '(bit-identical results; +7 %% at 2 on MI355X for 1700 trajectories)')
@@ -127,7 +130,7 @@ def main(argv=None):
         idx = np.tile(np.arange(num_channels), S)                       # trajectory t = snr * B + channel
         out = run_trajectories(diffuser, val_H, val_P, idx, idx, np.repeat(noise_range, num_channels), alpha_step,
                                beta_noise, levels, config.sampling.steps_each, seed, init,
-                               traj_base=meta_idx * S * num_channels, use_graph=resolve_launch_mode(args),
+                               traj_base=meta_idx * S * num_channels, use_graph=resolve_launch_mode(args), max_batch=args.max_batch,
                                rank=rank, world=world, return_final=bool(args.save_channels), n_streams=args.streams,
                                step_noise=step_noise, meas_noise=meas_noise, info=run_info)
         if args.save_channels:

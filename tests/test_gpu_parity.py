@@ -464,7 +464,7 @@ def test_posterior_mean_chains_match_reference_golden(net64, start):
         assert rel_err(est, g['saved_H_' + start][s]) < 1e-5
 
 
-@pytest.mark.parametrize('foreign', ['CDL-D', 'CDL-B'])
+@pytest.mark.parametrize('foreign', ['CDL-D', 'CDL-B', 'CDL-A'])
 def test_cli_cross_profile_matches_reference_pipeline(net64, tmp_path, monkeypatch, foreign):
     """BASELINE config 4 (``--train CDL-C --test CDL-D`` / ``CDL-B``) end to end: the golden ran the reference's own loader
     (normalisation constants from the TRAIN profile, test_score.py:68-69,101), DataLoader batch and sampling loop on the
@@ -474,7 +474,7 @@ def test_cli_cross_profile_matches_reference_pipeline(net64, tmp_path, monkeypat
     monkeypatch.chdir(tmp_path)
     argv = str(g['argv']).split() + ['--conv_mode', net64.conv_mode]
     nmse_log, _, _ = test_score.main(argv)
-    assert nmse_log.shape == (1, 1, 17, g['nmse_log'].shape[1], 4)
+    assert nmse_log.shape == (1, 1, 17, g['nmse_log'].shape[1], g['H'].shape[0])
     assert np.max(np.abs(nmse_log[0, 0] / g['nmse_log'] - 1)) < NMSE_RTOL
     est = test_score.main(argv + ['--save_channels', '1', '--no_graph'])
     import torch
@@ -483,6 +483,11 @@ def test_cli_cross_profile_matches_reference_pipeline(net64, tmp_path, monkeypat
     # the same channels normalised by their OWN profile would differ: the train-profile constants really are used
     same, _, _ = test_score.main([a if a != 'CDL-C' else foreign for a in argv])
     assert np.max(np.abs(same[0, 0] / g['nmse_log'] - 1)) > 1e-3
+    if foreign == 'CDL-A':
+        # 6 channels x 17 SNR points = 102 trajectories in chunks of 40 (driver.run_trajectories: 40 + 40 + 22, each split over the
+        # sub-batch streams): chunk boundaries inside the reference's result change nothing, bit for bit
+        chunked, _, _ = test_score.main(argv + ['--max_batch', '40'])
+        assert np.array_equal(chunked, nmse_log)
 
 
 @pytest.mark.parametrize('name', ['cli_tune_grid.npz', 'cli_tune_grid_2levels.npz'])
