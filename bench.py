@@ -393,7 +393,7 @@ def main():
         p_alds, p_streams = make_batches(H, Pm, idx, idx, ln, np.full(T, 3e-11), np.full(T, 0.01), rank * T + np.arange(T), init, 1)
         pa = p_alds[0]
         run_all(p_alds, p_streams, 2, False)
-        for tag in (P.TAG_CONV_TOP, P.TAG_PAIR_TOP, P.TAG_CONV_MID):
+        for tag in (P.TAG_CONV_TOP, P.TAG_PAIR_TOP, P.TAG_POOL_TOP, P.TAG_CONV_MID):
             ops = [op for op in net.score_plan(nt, nr).ops if op.tag == tag]
             if not ops:
                 continue
@@ -529,16 +529,18 @@ def main():
                      # (16-pixel rows, at least 4096 tiles in the launch: the three-stage pipelined kernel, csrc/conv_pair.hip)
                      P.TAG_PAIR_TOP: '%s<%d, %d, %d, %d, 32>' % ('conv_pair_p3_kernel' if nr == 16 and T * (nt // 8) >= 4096 else 'conv_pair_kernel',
                                                                    nr, 4 if nr == 64 else 8, 2 if conv_mode == 'f16x2' else 1, 8 if nr == 64 else 4),
+                     P.TAG_POOL_TOP: 'conv_pool_kernel<%d, 8, %d, 32>' % (nr, 2 if conv_mode == 'f16x2' else 1),
                      P.TAG_CONV_MID: 'conv_wx3_kernel<64, 64, 1, true, 2, false, 2, 1, %d>' % {'bf16x3': 0, 'f16w': 1, 'f16x2': 2}.get(conv_mode, 0)}
             what = {P.TAG_CONV_TOP: 'the unfused 3x3 32->32 convolutions at %dx%d (Winograd F(2x2,3x3))' % (nt, nr),
                     P.TAG_PAIR_TOP: 'the fused RCU blocks at %dx%d: two direct 3x3 32->32 convolutions per launch, intermediate in LDS' % (nt, nr),
+                    P.TAG_POOL_TOP: 'the fused CRP stages at %dx%d: 5x5 max pool + direct 3x3 32->32 convolution + running sum per launch, pooled tensor in LDS' % (nt, nr),
                     P.TAG_CONV_MID: 'the undilated 3x3 64->64 convolutions of the %dx%d level (Winograd F(2x2,3x3))' % (nt // 2, nr // 2)}
             entries = {}
             for tag, kc in klass.items():
                 t_launch = kc['us_per_launch'] * 1e-6
                 fl = kc['flops_per_step'] / kc['launches_per_step']           # algorithmic FLOPs of an average launch of the class
                 by = kc['bytes_per_step'] / kc['launches_per_step']
-                ratio = (18.0 / 16.0 if tag == P.TAG_PAIR_TOP else 16.0 / 36.0) * (terms or 1.0)
+                ratio = (18.0 / 16.0 if tag == P.TAG_PAIR_TOP else 1.0 if tag == P.TAG_POOL_TOP else 16.0 / 36.0) * (terms or 1.0)
                 ach = fl / t_launch / 1e12
                 e = {'kernel': names[tag], 'what': what[tag], 'launches_per_step': kc['launches_per_step'],
                      'us_per_launch': kc['us_per_launch'], 'share_of_one_stream_step': kc['us_per_launch'] * kc['launches_per_step'] / 1e3 / one_stream_ms,
@@ -555,7 +557,7 @@ def main():
             # class rounds 1-2 reported as one kernel).  Since round 3 two kernels run it -- the unfused Winograd launches and the
             # fused RCU-pair launches (two convolutions each) -- so the entry aggregates both: algorithmic FLOPs (bytes) of the
             # class per step / its time per step; executed matrix FLOPs summed kernel by kernel.
-            cls = [t for t in (P.TAG_CONV_TOP, P.TAG_PAIR_TOP) if t in entries]
+            cls = [t for t in (P.TAG_CONV_TOP, P.TAG_PAIR_TOP, P.TAG_POOL_TOP) if t in entries]
             t_cls = sum(entries[t]['us_per_launch'] * entries[t]['launches_per_step'] for t in cls) * 1e-6
             n_launch = sum(entries[t]['launches_per_step'] for t in cls)
             fl_cls = sum(klass[t]['flops_per_step'] for t in cls)

@@ -67,9 +67,12 @@ typedef enum sbc_op_kind {
     SBC_OP_END_CONV_BWD = 18,/* backward of SBC_OP_END_CONV up to the ELU output  ncsnv2.py:291-298           */
     SBC_OP_BEGIN_CONV_BWD = 19, /* weight / bias gradient of SBC_OP_BEGIN_CONV    ncsnv2.py:270-275           */
     SBC_OP_ADAM_EMA = 20,    /* torch.optim.Adam step + EMAHelper.update          losses/__init__.py:3-7, ema.py:17-22 */
-    SBC_OP_CONV_PAIR = 21    /* one RCU block in one launch: out = x + conv2(ELU(conv1(ELU(x))))   layers.py:126-134;
+    SBC_OP_CONV_PAIR = 21,   /* one RCU block in one launch: out = x + conv2(ELU(conv1(ELU(x))))   layers.py:126-134;
                                 32 (or, fp16 weights, 64) channels, 3x3, no bias; the intermediate stays in LDS
                                 (csrc/conv_pair.hip)                                                                  */
+    SBC_OP_CONV_POOL = 22    /* (ABI 11) one CRP stage in one launch: out = conv3x3(ELU?(MaxPool5x5(x))) [+ (res2 + ELU?(res1))]
+                                layers.py:76-83; replaces an SBC_OP_MAXPOOL5 record and the SBC_OP_CONV that reads it: the
+                                pooled tensor never exists in memory (csrc/conv_pair.hip: conv_pool_kernel)                  */
 } sbc_op_kind;
 
 /* sbc_op.flags for SBC_OP_CONV / SBC_OP_MAXPOOL5 */
@@ -139,6 +142,10 @@ typedef enum sbc_op_kind {
  *               SBC_CONV_F16W; C = 32: W in {8, 16} with H % 8 == 0, or (SBC_CONV_F16W only) W in {32, 64} with H % 4 == 0;
  *               C = 64 (SBC_CONV_F16W only): W = 16 with H % 8 == 0 or W = 32 with H % 4 == 0.  The same numbers as the two CONV records it replaces
  *               (PRO_ELU; PRO_ELU + res1 = in) up to fp32 summation order.
+ *   CONV_POOL   in / out [B][H][16][32] (distinct buffers), weight_split (the form of CONV_PAIR), no bias; flags = SBC_CONV_F16X2 or
+ *               SBC_CONV_F16W, optionally SBC_PRO_ELU (ELU of the pooled values: pool(ELU(x)) = ELU(pool(x))) and SBC_EPI_RES1_ELU;
+ *               res1 / res2 as in CONV (r = res1 [ELU]; if res2: r = res2 + r; out = conv + r); H % 8 == 0.  The same numbers as
+ *               the MAXPOOL5 + CONV records it replaces up to fp32 summation order (direct instead of Winograd form).
  */
 typedef struct sbc_op {
     int32_t kind, flags;
@@ -358,8 +365,9 @@ typedef struct sbc_score_desc {
 } sbc_score_desc;
 #define SBC_SCORE_FOLD_STATS 0x2 /* InstanceNorm++ statistics of the full-resolution tensors from the tile moments their producers write
                                     (SBC_EPI_MOMENTS_OUT / SBC_PRO_NORM_MOMENTS; not conv_mode 1; scorenet.DEFAULT_FOLD_STATS) */
-#define SBC_SCORE_FUSE_PAIRS 0x1 /* every RCU block of 32 channels at a width of 16 as one SBC_OP_CONV_PAIR record (conv_mode 2 / 3);
-                                    what the Python host does by default in those modes (scorenet.DEFAULT_FUSE_PAIRS) */
+#define SBC_SCORE_FUSE_PAIRS 0x1 /* every RCU block of 32 channels at a width of 16 as one SBC_OP_CONV_PAIR record, and (ABI 11) every CRP
+                                    stage of that shape as one SBC_OP_CONV_POOL record (conv_mode 2 / 3); what the Python host does
+                                    by default in those modes (scorenet.DEFAULT_FUSE_PAIRS) */
 typedef struct sbc_score sbc_score;
 int sbc_score_create(const sbc_score_desc* desc, const sbc_tensor_ref* tensors, int32_t n_tensors, sbc_score** out);
 int sbc_score_buffers(sbc_score* score, float** x, float** out, int64_t** labels);

@@ -40,6 +40,7 @@ int range_flag_ptr(unsigned** out);
 // dry = true: validate, resolve the kernel variant and set its function attributes, but do not launch
 int launch_conv(const sbc_op& op, hipStream_t stream, bool dry = false);
 int launch_conv_pair(const sbc_op& op, hipStream_t stream, bool dry = false);
+int launch_conv_pool(const sbc_op& op, hipStream_t stream, bool dry = false);
 int launch_begin_conv(const sbc_op& op, hipStream_t stream);
 int launch_inorm_stats(const sbc_op& op, hipStream_t stream);
 int launch_maxpool5(const sbc_op& op, hipStream_t stream);

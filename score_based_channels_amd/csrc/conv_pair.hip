@@ -32,6 +32,9 @@ struct PairParams {
     const uint4* __restrict__ w2;
     unsigned* __restrict__ range_flag;
     float* __restrict__ calib;          // sbc_f16x2_calibrate: two amax slots (conv1's input, the intermediate), else NULL
+    const float* __restrict__ res1;     // conv_pool_kernel: residual operands of the CONV epilogue (or NULL)
+    const float* __restrict__ res2;
+    int flags;                          // conv_pool_kernel: SBC_PRO_ELU, SBC_EPI_RES1_ELU
     int B, H, ntiles, tiles_per_sample, wgs_per_xcd, tiles_per_xcd;
     unsigned long long* dbg;            // SBC_PAIR_TIMING builds: per-phase cycle sums of wave 0 of every workgroup
 };
@@ -613,6 +616,277 @@ __global__ __launch_bounds__(192 * NW, 3) void conv_pair_p3_kernel(PairParams p)
 
 
 
+// One stage of a CRP block in ONE launch (SBC_OP_CONV_POOL):
+//       out = conv3x3(ELU?(MaxPool5x5(x))) [+ (res2 + ELU(res1))]            ncsnv2/models/layers.py:76-83
+// for 32-channel NHWC fp32 tensors, 16 pixels wide.  Unfused, a stage is a max-pool launch (one tensor read, one written) and a
+// convolution launch (read it again, write the result, read two residual operands): at 223 MB per tensor the CRP block of the
+// full-resolution level moves 2.2 GB per step; here the pooled tensor never exists in memory.
+// The pipeline of conv_pair_p3_kernel with ONE convolution: a persistent workgroup per CU of twelve waves --
+//   conversion (4 waves, one per SIMD): keep the R + 6 raw rows of the next tile in flight by LDS-DMA; pool tile i -- the vertical
+//           5-maximum in registers from the LDS copy, the horizontal one by DPP row shifts (a 16-pixel row is one DPP row;
+//           out-of-image columns leave the lane's running maximum alone, rows outside the image were requested from the nearest row
+//           inside: both are what MaxPool2d's -inf padding computes) --, ELU, two fp16 terms -> operand planes X[i & 1];
+//   matrix (8 waves, two per SIMD): the K loop of the convolution on X[(i-1) & 1], two units (image rows) per wave, filter
+//           fragments resident in registers; + residual operands (requested before the K loop), store.
+// One workgroup barrier per tile.  The tile is bound by VECTOR-INSTRUCTION ISSUE, not by the matrix pipe: pooling costs ~20 vector
+// instructions per value (8 vertical v_max3 + 20 DPP maxima + ELU 16 + split 8 + ... per four values), and every arrangement of
+// the roles measured the same ~5-7 k cycles per tile (-DSBC_PAIR_TIMING: 4 conversion + 8 matrix waves 6.9 k with the builtins'
+// ten-instruction DPP maxima; 8 + 4: 6.2 k, one matrix wave per SIMD needs 46 cycles per matrix instruction; 8 + 8: 5.3 k).  Four
+// conversion waves issue the fewest instructions per tile (five pooled rows per lane share nine LDS reads).  Conversion wave w owns channel quads 2 (w & 3), + 1 and one half of the pooled rows: both pool passes of a value stay
+// inside one wave, so the role needs no synchronisation of its own.
+__device__ __forceinline__ float4 vmax5(float4 a, float4 b, float4 c, float4 d, float4 e) {
+    // (v_max3_f32 by hand: fmaxf() costs a canonicalising v_max per operand)
+    float4 m;
+    asm("v_max3_f32 %0, %4, %8, %12\n\tv_max3_f32 %1, %5, %9, %13\n\tv_max3_f32 %2, %6, %10, %14\n\tv_max3_f32 %3, %7, %11, %15\n\t"
+        "v_max3_f32 %0, %0, %16, %20\n\tv_max3_f32 %1, %1, %17, %21\n\tv_max3_f32 %2, %2, %18, %22\n\tv_max3_f32 %3, %3, %19, %23"
+        : "=&v"(m.x), "=&v"(m.y), "=&v"(m.z), "=&v"(m.w)
+        : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(c.x), "v"(c.y), "v"(c.z), "v"(c.w),
+          "v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w), "v"(e.x), "v"(e.y), "v"(e.z), "v"(e.w));
+    return m;
+}
+
+template <int W, int R, int MODE, int NWC = 4, int C = 32>
+__global__ __launch_bounds__(64 * (8 + NWC)) void conv_pool_kernel(PairParams p) {
+    constexpr int NWM = 8;                            // matrix waves (two per SIMD); NWC = 4 or 8 conversion waves
+    constexpr int KGS = C / 8, C4 = C / 4;
+    static_assert(C == 32 && W == 16, "instantiated for 32 channels, 16-pixel rows");
+    constexpr int NT = MODE == 2 ? 2 : 1;             // fp16 terms per operand
+    constexpr int RI = R + 6, RP = R + 2;             // raw rows (conv halo + pool halo), pooled rows
+    constexpr int WP = W + 2;
+    constexpr int XPS = (RP * WP * 16 + 255) / 256 * 256;
+    constexpr int RAW_BYTES = RI * W * C * 4;
+    constexpr int XSZ = NT * KGS * XPS;
+    constexpr int NRAW = 3;                           // raw tiles in LDS: in flight, being pooled, and one tile back (the matrix waves read
+                                                      // the residual operand res2 from it when it is the kernel's own input: CRP's path0)
+    constexpr int X_OFF = NRAW * RAW_BYTES;
+    constexpr int NPIECE = RAW_BYTES / 1024;          // LDS-DMA requests of a tile (1 KB each)
+    constexpr int NU = 2;                             // units (image rows of 16 pixels) per matrix wave: 8 waves x 2 = 2 halves x R
+    static_assert(R == 8, "eight output rows: four unit groups of two rows per output-channel half");
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);        // 0 .. 7: matrix waves, 8 .. 15: conversion waves
+    const bool matrix = wv < NWM;
+    const int lane = threadIdx.x & 63;
+    const int hf = wv & 1, sub = (wv >> 1) & 3;        // matrix: 16-output-channel half; unit group (rows sub, sub + 4)
+    const int kq = lane >> 4, c = lane & 15;
+    const int H = p.H;
+
+    float scale1 = 1.f, descale1 = 1.f;
+    unsigned rbits = 0;
+    if constexpr (MODE == 2) {
+        const float4 t1 = f16x2_trailer(reinterpret_cast<const float4*>(p.w1), 9 * (C / 16) * (C / 32) * NT);
+        scale1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t1.x)));
+        descale1 = t1.y;
+        if (t1.w != 0.f && (p.flags & SBC_PRO_ELU)) rbits |= 4u;   // small inputs: this kernel has the exp(x) - 1 form of ELU only (SBC_RANGE_ELU)
+    }
+    // padding columns of both plane sets
+    for (int i = threadIdx.x; i < 2 * NT * KGS * RP * 2; i += 64 * (NWM + NWC)) {
+        const int side = i & 1, row = (i >> 1) % RP, pl = (i >> 1) / RP;
+        *reinterpret_cast<uint4*>(smem + X_OFF + pl * XPS + (row * WP + side * (W + 1)) * 16) = make_uint4(0, 0, 0, 0);
+    }
+
+    const int xcd = blockIdx.x & 7, jw = blockIdx.x >> 3;
+    const int t_begin = xcd * p.tiles_per_xcd;
+    const int t_end = min(t_begin + p.tiles_per_xcd, p.ntiles);
+    const int first = t_begin + jw;
+    const int n_my = first < t_end ? (t_end - first + p.wgs_per_xcd - 1) / p.wgs_per_xcd : 0;
+    if (n_my == 0) return;
+    auto tile_of = [&](int k) { return first + k * p.wgs_per_xcd; };
+
+    // ---- conversion role
+    const int wc = wv - NWM;                           // 0 .. 7
+    auto issue_dma = [&](int tile, int buf) {
+        const int n = tile / p.tiles_per_sample, r0 = (tile - n * p.tiles_per_sample) * R;
+#pragma unroll
+        for (int k = 0; k < (NPIECE + NWC - 1) / NWC; ++k) {
+            const int j = k * NWC + wc;                                        // piece: chunks j * 64 .. + 63 of the raw tile
+            if (NPIECE % NWC == 0 || j < NPIECE) {
+                const int ri = (j * 64) / (W * C4), within = j * 64 - ri * (W * C4);
+                const int grow = min(max(r0 - 3 + ri, 0), H - 1);              // rows outside the image: the nearest row inside (see header)
+                const char* sbase = reinterpret_cast<const char*>(p.in) + ((size_t)(n * H + grow) * W * C) * 4 + (size_t)within * 16;
+                const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem + buf * RAW_BYTES + j * 1024;
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(lane * 16), "s"(dst), "s"(sbase) : "memory");
+            }
+        }
+    };
+    // lane = (column c, channel quad 2 (wc & 3) + ql, row group): the ten pooled rows in two groups of five (four conversion waves:
+    // group = lane half) or in groups of 3, 2, 3, 2 (eight waves: group = 2 (wc >> 2) + lane half)
+    const int ql = (lane >> 4) & 1, grp = NWC == 4 ? (lane >> 5) : 2 * (wc >> 2) + (lane >> 5);
+    const int cq_c = 2 * (wc & 3) + ql;
+    constexpr int NRG = NWC == 4 ? 5 : 3;              // pooled rows per lane (at most)
+    const int prow0 = NWC == 4 ? 5 * grp : (grp == 0 ? 0 : grp == 1 ? 3 : grp == 2 ? 5 : 8);
+    const bool full = NWC == 4 || (grp & 1) == 0;      // (uniform over a wave half: lanes 0..31 / 32..63)
+    auto convert_tile = [&](int k, int rb, int xb) {
+        const int tile = tile_of(k);
+        const int n = tile / p.tiles_per_sample, r0 = (tile - n * p.tiles_per_sample) * R;
+        (void)n;
+        const unsigned char* raw = smem + rb * RAW_BYTES + (c * C4 + cq_c) * 16 + prow0 * (W * C4 * 16);
+        // pooled row prow0 + j (image row r0 - 1 + prow0 + j) is the maximum over raw rows prow0 + j .. + 4 (image row r0 - 3 + ...)
+        float4 rv[NRG + 4];
+#pragma unroll
+        for (int i = 0; i < NRG + 4; ++i) rv[i] = *reinterpret_cast<const float4*>(raw + (i < NRG + 3 || full ? i : NRG + 2) * (W * C4 * 16));
+        float ta = 0.f;
+#pragma unroll
+        for (int j = 0; j < NRG; ++j) {
+            if (j == NRG - 1 && !full) break;
+            float4 v = vmax5(rv[j], rv[j + 1], rv[j + 2], rv[j + 3], rv[j + 4]);
+            // horizontal 5-maximum over the 16 lanes of the row (= the image row): v_max_f32 with a DPP row shift on its first source;
+            // a lane whose shifted source lies outside the row is disabled for that instruction and keeps its running maximum.  By hand:
+            // from the builtins hipcc emits a v_mov_b32_dpp, a copy for its `old` operand and a v_max per shift (ten instructions per
+            // value instead of five).  (vmax5 is an asm block too: the s_nop gives its last write the two wait states a DPP read needs.)
+            {
+                float4 m;
+                asm("s_nop 1\n\t"
+                    "v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7\n\t"
+                    "v_max_f32_dpp %0, %4, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %5, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                    "v_max_f32_dpp %2, %6, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %7, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                    "v_max_f32_dpp %0, %4, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %5, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                    "v_max_f32_dpp %2, %6, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %7, %3 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                    "v_max_f32_dpp %0, %4, %0 row_shl:1 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %5, %1 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                    "v_max_f32_dpp %2, %6, %2 row_shl:1 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %7, %3 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                    "v_max_f32_dpp %0, %4, %0 row_shl:2 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %5, %1 row_shl:2 row_mask:0xf bank_mask:0xf\n\t"
+                    "v_max_f32_dpp %2, %6, %2 row_shl:2 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %7, %3 row_shl:2 row_mask:0xf bank_mask:0xf"
+                    : "=&v"(m.x), "=&v"(m.y), "=&v"(m.z), "=&v"(m.w) : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+                v = m;
+            }
+            if (p.flags & SBC_PRO_ELU) v = elu4(v);
+            const int prow = prow0 + j;
+            const int grow = r0 - 1 + prow;
+            if (grow < 0 || grow >= H) v = make_float4(0.f, 0.f, 0.f, 0.f);        // zero padding of the convolution
+            unsigned char* dst = smem + X_OFF + xb * XSZ + (cq_c >> 1) * XPS + (prow * WP + c + 1) * 16 + (cq_c & 1) * 8;
+            if constexpr (MODE == 2) {
+                StageScale ss{scale1, ta};
+                scale_track(v, &ss);
+                ta = ss.amax;
+                uint2 h, l;
+                split_f16x2(v, scale1, h, l);
+                *reinterpret_cast<uint2*>(dst) = h;
+                *reinterpret_cast<uint2*>(dst + KGS * XPS) = l;
+            } else {
+                f16x4 h;
+                h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+                *reinterpret_cast<f16x4*>(dst) = h;
+            }
+        }
+        if constexpr (MODE == 2) pair_range_tile(ta, scale1, rbits, p.calib);
+    };
+#ifdef SBC_PAIR_TIMING
+    unsigned long long pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt_last = __builtin_readcyclecounter();
+#endif
+    // The two roles run SEPARATE loops with the same barrier sequence (n_my + 1 workgroup barriers each): in one loop the filter
+    // fragments (72 registers) would stay allocated through the conversion code, which then spills at 128 registers per wave.
+    if (!matrix) {
+        issue_dma(tile_of(0), 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int it = 0; it < n_my + 1; ++it) {
+            PT_MARK(3);                                  // (the role's work of the last iteration)
+            lds_barrier();
+            PT_MARK(0);
+            if (it + 1 < n_my) issue_dma(tile_of(it + 1), (it + 1) % NRAW);
+            PT_MARK(1);
+            if (it < n_my) convert_tile(it, it % NRAW, it & 1);
+            PT_MARK(2);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    } else {
+        uint4 wf[9][NT];
+        {
+            const int lsrc = (16 * hf + c) + 32 * (kq & 1);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    wf[tap][t] = p.w1[(((tap * (C / 16) + (kq >> 1)) * (C / 32)) * NT + t) * 64 + lsrc];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const bool res2_lds = p.res2 == p.in;            // CRP: the second residual operand is this launch's own input
+        for (int it = 0; it < n_my + 1; ++it) {
+            PT_MARK(7);
+            lds_barrier();
+            PT_MARK(4);
+            const int t1 = it - 1;
+            if (t1 < 0) continue;
+            const int tile = tile_of(t1);
+            const int n = tile / p.tiles_per_sample, r0 = (tile - n * p.tiles_per_sample) * R;
+            // this wave's two units: image rows r0 + sub and r0 + sub + 4, output channels 16 hf .. + 15
+            f32x4v acc[NU];
+            const int cq = 4 * hf + kq;
+            float4 x1[NU];
+            constexpr int DO = 4 * W * C;
+            const unsigned o0 = (unsigned)(((n * H + r0 + sub) * W + c) * C + cq * 4);
+            if (p.res1) {
+#pragma unroll
+                for (int i = 0; i < NU; ++i) x1[i] = *reinterpret_cast<const float4*>(p.res1 + o0 + i * DO);
+            }
+            {
+                constexpr int DU = 4 * WP * 16;                            // bytes from unit i to unit i + 1 (four plane rows)
+                const int ub0 = X_OFF + (t1 & 1) * XSZ + kq * XPS + (sub * WP + c) * 16;
+                constexpr int NS = 9 * NU, D = NT == 2 ? 3 : 6;
+                f16x8 ring[D][NT];
+                auto ld = [&](int s) {
+                    const int tap = s / NU, i = s % NU;
+                    const int off = i * DU + ((tap / 3) * WP + (tap % 3)) * 16;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) ring[s % D][t] = *reinterpret_cast<const f16x8*>(smem + ub0 + (off + t * KGS * XPS));
+                };
+#pragma unroll
+                for (int s = 0; s < D - 1; ++s) ld(s);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const int tap = s / NU, i = s % NU;
+                    if (s + D - 1 < NS) ld(s + D - 1);
+                    const f16x8 xh = ring[s % D][0];
+                    const f16x8 wh = __builtin_bit_cast(f16x8, wf[tap][0]);
+                    const f32x4v c0 = tap == 0 ? f32x4v{0.f, 0.f, 0.f, 0.f} : acc[i];
+                    if constexpr (NT == 2) {
+                        const f16x8 xl = ring[s % D][NT - 1];
+                        const f16x8 wl = __builtin_bit_cast(f16x8, wf[tap][NT - 1]);
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, c0, 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[i], 0, 0, 0);
+                    } else {
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, c0, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            PT_MARK(5);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PT_MARK(6);
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                float4 y = make_float4(acc[i][0] * descale1, acc[i][1] * descale1, acc[i][2] * descale1, acc[i][3] * descale1);
+                if (p.res1) {
+                    // r = res1 [ELU];  if res2: r = res2 + r;  y = y + r     (include/sbc_hip.h: the CONV epilogue)
+                    float4 rr = x1[i];
+                    // (the four-instruction ELU: a CRP block's res1 is the tensor its FIRST stage pools -- if the calibration found
+                    // that one small, the first stage has raised SBC_RANGE_ELU and the host re-runs the batch in bf16x3)
+                    if (p.flags & SBC_EPI_RES1_ELU) rr = elu4(rr);
+                    if (p.res2) {
+                        // (the tile's own raw copy, three rows down from its first row, when res2 is the launch's input; else memory)
+                        const float4 r2 = res2_lds ? *reinterpret_cast<const float4*>(smem + (t1 % NRAW) * RAW_BYTES +
+                                                                                      (((sub + 4 * i + 3) * W + c) * C4 + cq) * 16)
+                                                   : *reinterpret_cast<const float4*>(p.res2 + o0 + i * DO);
+                        rr.x = r2.x + rr.x; rr.y = r2.y + rr.y; rr.z = r2.z + rr.z; rr.w = r2.w + rr.w;
+                    }
+                    y.x += rr.x; y.y += rr.y; y.z += rr.z; y.w += rr.w;
+                }
+                st_stream(p.out + o0 + i * DO, y);
+            }
+        }
+    }
+    if constexpr (MODE == 2) {
+        if (rbits && (threadIdx.x & 63) == 0) atomicOr(p.range_flag, rbits);
+    }
+#ifdef SBC_PAIR_TIMING
+    // wave 0 of the matrix role and of the conversion role: [barrier, dma issue, convert, load wait | barrier, K loop, residual wait, store]
+    if (lane == 0 && (wv == 0 || wv == NWM) && p.dbg)
+        for (int k = 0; k < 8; ++k) atomicAdd(p.dbg + k, pt[k]);
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------ dispatch
 template <int W, int R, int MODE, int NW = 4, int C = 32>
 static int launch_pair(const PairParams& p0, hipStream_t stream, bool dry) {
@@ -659,6 +933,57 @@ static int launch_pair_p3(const PairParams& p0, hipStream_t stream, bool dry) {
     hipLaunchKernelGGL(kern, dim3(8 * p.wgs_per_xcd), dim3(192 * NW), lds, stream, p);
     SBC_CHECK_HIP(hipGetLastError());
     return SBC_OK;
+}
+
+template <int MODE>
+static int launch_pool(const PairParams& p0, hipStream_t stream, bool dry) {
+    constexpr int W = 16, R = 8, C = 32, NT = MODE == 2 ? 2 : 1;
+    constexpr int RI = R + 6, RP = R + 2, WP = W + 2;
+    constexpr int XPS = (RP * WP * 16 + 255) / 256 * 256;
+    constexpr size_t lds = (size_t)3 * RI * W * C * 4 + (size_t)2 * NT * (C / 8) * XPS;
+    static_assert(lds <= 160 * 1024, "LDS of the one resident workgroup");
+    constexpr int NWC = 4;
+    auto kern = conv_pool_kernel<W, R, MODE, NWC, C>;
+    { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds); if (rc) return rc; }
+    if (dry) return SBC_OK;
+    PairParams p = p0;
+    p.tiles_per_sample = p.H / R;
+    p.ntiles = p.B * p.tiles_per_sample;
+    int dev = 0, cus = 256;
+    SBC_CHECK_HIP(hipGetDevice(&dev));
+    SBC_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    p.tiles_per_xcd = (p.ntiles + 7) / 8;
+    p.wgs_per_xcd = max(1, min(cus / 8, p.tiles_per_xcd));
+    hipLaunchKernelGGL(kern, dim3(8 * p.wgs_per_xcd), dim3(64 * (8 + NWC)), lds, stream, p);
+    SBC_CHECK_HIP(hipGetLastError());
+    return SBC_OK;
+}
+
+int launch_conv_pool(const sbc_op& op, hipStream_t stream, bool dry) {
+    SBC_REQUIRE(op.in && op.out && op.weight_split, "conv_pool: in / out / weight_split must be set");
+    SBC_REQUIRE(op.cin == 32 && op.cout == 32 && op.ksize == 3 && op.dil == 1 && op.W == 16 && op.H % 8 == 0 && op.H >= 8,
+                "conv_pool: 32 -> 32 channels, 3x3, undilated, 16-pixel rows, H a multiple of 8 (got %d -> %d, %dx%d)", op.cin, op.cout, op.H, op.W);
+    SBC_REQUIRE(op.B > 0, "conv_pool: bad batch %d", op.B);
+    const bool x2 = (op.flags & SBC_CONV_F16X2) != 0, f16w = (op.flags & SBC_CONV_F16W) != 0;
+    SBC_REQUIRE(x2 != f16w, "conv_pool: exactly one of SBC_CONV_F16X2 / SBC_CONV_F16W (the forms of weight_split it reads)");
+    SBC_REQUIRE(!op.bias && !(op.flags & (SBC_PRO_NORM | SBC_EPI_POOL | SBC_EPI_UP | SBC_EPI_ELUGRAD | SBC_EPI_MOMENTS_OUT)),
+                "conv_pool: no bias, prologue = max pool [+ ELU], epilogue = residual operands only");
+    SBC_REQUIRE(!op.res2 || op.res1, "conv_pool: res2 only together with res1");
+    SBC_REQUIRE((long)op.B * op.H * op.W * op.cin <= 0x7fffffffL, "conv_pool: tensor exceeds the 32-bit element index");
+    PairParams p{};
+    p.in = (const float*)op.in; p.out = (float*)op.out;
+    p.w1 = (const uint4*)op.weight_split; p.w2 = nullptr;
+    p.res1 = (const float*)op.res1; p.res2 = (const float*)op.res2; p.flags = op.flags;
+    p.B = op.B; p.H = op.H;
+    p.calib = (float*)op.calib;
+    p.dbg = (unsigned long long*)op.aux;
+    if (x2) {
+        unsigned* word = nullptr;
+        const int rc = range_flag_ptr(&word);
+        if (rc) return rc;
+        p.range_flag = word;
+    }
+    return x2 ? launch_pool<2>(p, stream, dry) : launch_pool<1>(p, stream, dry);
 }
 
 int launch_conv_pair(const sbc_op& op, hipStream_t stream, bool dry) {

@@ -123,6 +123,21 @@ struct Builder {
         return x;
     }
     int crp(const std::string& p, int x) {                                                     // layers.py:76-83
+        if (fuse_pairs && t[x].c == 32 && t[x].w == 16 && t[x].h % 8 == 0) {                   // plan.pool_fusable: SBC_OP_CONV_POOL
+            const int path0 = tensor(p + "convs.0", t[x].h, t[x].w, t[x].c);
+            POp a;
+            a.kind = SBC_OP_CONV_POOL; a.src = x; a.dst = path0; a.weight = p + "convs.0.weight"; a.flags = SBC_PRO_ELU;
+            a.tag = t[x].h == nt ? 4 : 0;                                                       // plan.TAG_POOL_TOP
+            producer[path0] = (int)ops.size();
+            ops.push_back(a);
+            const int out = tensor(p + "convs.1", t[x].h, t[x].w, t[x].c);
+            POp b;
+            b.kind = SBC_OP_CONV_POOL; b.src = path0; b.dst = out; b.weight = p + "convs.1.weight"; b.flags = SBC_EPI_RES1_ELU;
+            b.res1 = x; b.res2 = path0; b.tag = a.tag;
+            producer[out] = (int)ops.size();
+            ops.push_back(b);
+            return out;
+        }
         const int p0 = maxpool(p + "pool0", x, true);
         const int path0 = conv(p + "convs.0", p0, p + "convs.0", t[x].c, false);
         const int p1 = maxpool(p + "pool1", path0, false);
@@ -303,8 +318,8 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
             w = rounded(w, wn);
             std::vector<float> wkeep(w, w + wn);          // `tmp` is reused below
             const std::string& okey = wkey;
-            if (o.kind == SBC_OP_CONV_PAIR) {
-                // the fused pair reads the direct fp16 forms only
+            if (o.kind == SBC_OP_CONV_PAIR || o.kind == SBC_OP_CONV_POOL) {
+                // the fused kernels read the direct fp16 forms only
                 if (f16x2) sbc_pack_conv_weight_f16x2(wkeep.data(), cout, cin, k, (uint16_t*)reserve(okey + "#split", sbc_f16x2_elems(k * k, cin, cout) / 2));
                 else sbc_pack_conv_weight_f16(wkeep.data(), cout, cin, k, (uint16_t*)reserve(okey + "#split", (wn + 1) / 2));
             } else if (o.kind != SBC_OP_CONV) {
@@ -366,6 +381,9 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
         if (o.kind == SBC_OP_CONV_PAIR) {
             r.weight_split = wp(o.weight + "#split");
             r.weight2_split = wp(o.weight2 + "#split");
+            r.flags |= f16w ? SBC_CONV_F16W : SBC_CONV_F16X2;
+        } else if (o.kind == SBC_OP_CONV_POOL) {
+            r.weight_split = wp(o.weight + "#split");
             r.flags |= f16w ? SBC_CONV_F16W : SBC_CONV_F16X2;
         } else if (o.kind != SBC_OP_CONV) {
             r.weight = wp(o.weight);

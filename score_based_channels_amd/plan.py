@@ -35,12 +35,14 @@ PRO_ELU_ACC = 0x20000         # ELU with fp32's relative accuracy for small nega
 (DSM_PERTURB, DSM_LOSS, GRAD_ADD, INORM_BWD, MAXPOOL5_BWD, UPSAMPLE_BWD, POOL_BWD, CONV_WGRAD, PACK_WEIGHT, END_CONV_BWD,
  BEGIN_CONV_BWD, ADAM_EMA) = range(9, 21)
 CONV_PAIR = 21
+CONV_POOL = 22
 BWD_ACCUM, PACK_ADJOINT, OP_SIDE, OP_JOIN, PACK_WINOGRAD = 0x200, 0x400, 0x800, 0x1000, 0x2000
 
 # profiling tags (sbc_op.tag; bench.py times each class by hipEvents in a single-stream segment after its timed region):
 TAG_CONV_TOP = 1        # 3x3 convs ngf -> ngf at full resolution (also their own kernel symbol in csrc/conv_wx3.hip)
 TAG_PAIR_TOP = 2        # fused RCU blocks (CONV_PAIR) at full resolution
 TAG_CONV_MID = 3        # undilated 3x3 convs 2 ngf -> 2 ngf at half resolution (the 32x8 level of a 64x16 array)
+TAG_POOL_TOP = 4        # fused CRP stages (CONV_POOL) at full resolution
 
 
 @dataclass
@@ -216,6 +218,18 @@ class _Builder:
 
     def crp(self, p, x):
         """layers.py:76-83 (two stages, max pooling)."""
+        if self.fuse_pairs and pool_fusable(x.h, x.w, x.c):
+            # each stage -- max pool, convolution, running sum -- as ONE launch (csrc/conv_pair.hip: conv_pool_kernel): the pooled
+            # tensors never exist in memory
+            path0 = self.t(p + 'convs.0', x.h, x.w, x.c)
+            self.ops.append(Op(CONV_POOL, p + 'pool_conv0', src=x, dst=path0, weight=p + 'convs.0.weight', flags=PRO_ELU,
+                               side=self.side_now, tag=TAG_POOL_TOP if x.h == self.nt else 0))
+            self.producer[id(path0)] = self.ops[-1]
+            out = self.t(p + 'convs.1', x.h, x.w, x.c)
+            self.ops.append(Op(CONV_POOL, p + 'pool_conv1', src=path0, dst=out, weight=p + 'convs.1.weight', flags=EPI_RES1_ELU,
+                               res1=x, res2=path0, side=self.side_now, tag=TAG_POOL_TOP if x.h == self.nt else 0))
+            self.producer[id(out)] = self.ops[-1]
+            return out
         p0 = self.maxpool(p + 'pool0', x, elu=True)
         path0 = self.conv(p + 'convs.0', p0, p + 'convs.0', x.c, bias=False)
         p1 = self.maxpool(p + 'pool1', path0, elu=False)
@@ -245,6 +259,14 @@ class _Builder:
 PAIR_SHAPES = ((32, 16),)
 # ... in the fp16-weight mode (BASELINE config 5, a 256 x 64 array): also 32-pixel and 64-pixel rows, and the 64-channel levels
 PAIR_SHAPES_F16W = ((32, 16), (32, 32), (32, 64), (64, 16), (64, 32))
+
+
+def pool_fusable(h, w, c):
+    """Shapes SBC_OP_CONV_POOL takes (a CRP stage as one launch): 32 channels, 16-pixel rows, heights that are multiples of 8."""
+    import os
+    if os.environ.get('SBC_NO_CONV_POOL'):           # A/B aid: max pool + convolution as separate launches
+        return False
+    return c == 32 and w == 16 and h % 8 == 0
 
 
 def pair_fusable(h, w, c, shapes=PAIR_SHAPES):
@@ -341,6 +363,8 @@ def count_conv_flops(plan):
             total += 2 * op.src.h * op.src.w * op.src.c * op.dst.c * op.ksize * op.ksize
         elif op.kind == CONV_PAIR:
             total += 2 * 2 * op.src.h * op.src.w * op.src.c * op.dst.c * 9
+        elif op.kind == CONV_POOL:
+            total += 2 * op.src.h * op.src.w * op.src.c * op.dst.c * 9
         elif op.kind in (BEGIN_CONV, END_CONV):
             total += 2 * op.src.h * op.src.w * op.src.c * op.dst.c * 9
     return total

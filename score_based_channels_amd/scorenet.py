@@ -251,6 +251,10 @@ class ScoreNet:
                 o.weight_split = _ptr(self._wdev, self._woff[op.weight + '#split'])
                 o.weight2_split = _ptr(self._wdev, self._woff[op.weight2 + '#split'])
                 o.flags |= P.CONV_F16W if self.conv_mode == 'f16w' else P.CONV_F16X2
+            elif op.kind == P.CONV_POOL:
+                o.ksize, o.dil = 3, 1
+                o.weight_split = _ptr(self._wdev, self._woff[op.weight + '#split'])
+                o.flags |= P.CONV_F16W if self.conv_mode == 'f16w' else P.CONV_F16X2
             elif op.weight is not None and op.kind != P.CONV:
                 o.weight = _ptr(self._wdev, self._woff[op.weight])
             elif op.weight is not None and self.conv_mode == 'f32':

@@ -77,6 +77,18 @@ def exec_op(op, sd, get, labels):
             out = _nhwc(O.max_pool5(_nchw(src)))
             if op.flags & P.PRO_ELU:
                 out = O.elu(out)
+        elif op.kind == P.CONV_POOL:             # one CRP stage (layers.py:76-83): pool -> [ELU] -> conv [+ residual operands]
+            v = _nhwc(O.max_pool5(_nchw(src)))
+            if op.flags & P.PRO_ELU:
+                v = O.elu(v)
+            out = _nhwc(O.conv2d(_nchw(v), sd[op.weight], None, 1))
+            if op.res1 is not None:
+                r = get(op.res1)
+                if op.flags & P.EPI_RES1_ELU:
+                    r = O.elu(r)
+                if op.res2 is not None:
+                    r = get(op.res2) + r
+                out = out + r
         elif op.kind == P.CONV_PAIR:             # one RCU block (layers.py:126-134)
             t = O.conv2d(_nchw(O.elu(src)), sd[op.weight], None, 1)
             out = src + _nhwc(O.conv2d(O.elu(t), sd[op.weight2], None, 1))

@@ -413,6 +413,70 @@ def test_conv_pair_matches_oracle(gpu, case, mode):
     assert rel_err(got - x, out2.cpu().numpy() - x) < tol
 
 
+@pytest.mark.parametrize('mode', ['f16x2', 'f16w'])
+@pytest.mark.parametrize('stage', ['pool_elu', 'pool_crp2'])
+@pytest.mark.parametrize('B,H', [(3, 64), (130, 64), (600, 64), (1, 8), (5, 16), (37, 24)])
+def test_conv_pool_matches_oracle(gpu, B, H, stage, mode):
+    """SBC_OP_CONV_POOL: one CRP stage, out = conv3x3(ELU?(MaxPool5x5(x))) [+ (res2 + ELU(res1))] (layers.py:76-83), with the pooled
+    tensor kept in LDS (csrc/conv_pair.hip: conv_pool_kernel) -- against the oracle's max pool + convolution, and against the
+    SBC_OP_MAXPOOL5 + SBC_OP_CONV launches it replaces.  Both stages of the block: `pool_elu` (ELU of the pooled input, no
+    residual) and `pool_crp2` (the running sum path + (path0 + ELU(x)) in the epilogue)."""
+    torch, _lib = gpu
+    from score_based_channels_amd import plan as P
+    from score_based_channels_amd.weights import (pack_conv_weight_f16, pack_conv_weight_f16x2, pack_conv_weight_winograd_f16,
+                                                  pack_conv_weight_winograd_f16x2, round_fp16)
+    W, Cc = 16, 32
+    rng = np.random.default_rng(B * 100 + H)
+    x = (rng.standard_normal((B, H, W, Cc)) * 1.5 + 0.3).astype(F32)
+    w = (rng.standard_normal((Cc, Cc, 3, 3)) / np.sqrt(9 * Cc)).astype(F32)
+    elu = stage == 'pool_elu'
+    v = O.max_pool5(x.transpose(0, 3, 1, 2))
+    if elu:
+        v = O.elu(v)
+    res1 = res2 = None
+    flags = P.PRO_ELU if elu else 0
+    if mode == 'f16x2':
+        pack, packw, mflag, tol = pack_conv_weight_f16x2, pack_conv_weight_winograd_f16x2, P.CONV_F16X2, TOL
+        ref = O.conv2d(v, w, None, 1).transpose(0, 2, 3, 1)
+    else:
+        pack, packw, mflag, tol = pack_conv_weight_f16, pack_conv_weight_winograd_f16, P.CONV_F16W, 2e-4
+        ref = O.conv2d(round_fp16(v), round_fp16(w), None, 1).transpose(0, 2, 3, 1)
+    conv_ref = ref
+    if not elu:
+        flags |= P.EPI_RES1_ELU
+        res1 = rng.standard_normal((B, H, W, Cc)).astype(F32)
+        res2 = rng.standard_normal((B, H, W, Cc)).astype(F32)
+        ref = ref + (res2 + O.elu(res1))
+    dx, dw = _dev(torch, x), _dev(torch, pack(w).view(np.float32))
+    out = torch.full((B, H, W, Cc), float('nan'), dtype=torch.float32, device='cuda')
+    op = _lib.sbc_op(kind=P.CONV_POOL, flags=flags | mflag, B=B, H=H, W=W, cin=Cc, cout=Cc, ksize=3, dil=1, in_=_p(dx), out=_p(out),
+                     weight_split=_p(dw))
+    keep = []
+    if res1 is not None:
+        keep = [_dev(torch, res1), _dev(torch, res2)]
+        op.res1, op.res2 = _p(keep[0]), _p(keep[1])
+    _launch(gpu, op)
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert rel_err(got - (ref - conv_ref), conv_ref) < tol            # (the residual operands must not mask the convolution's error)
+    assert _lib.range_flag() == 0
+    # the two launches it replaces
+    pooled = torch.empty_like(out)
+    out2 = torch.empty_like(out)
+    _launch(gpu, _lib.sbc_op(kind=P.MAXPOOL5, flags=P.PRO_ELU if elu else 0, B=B, H=H, W=W, cin=Cc, cout=Cc, in_=_p(dx), out=_p(pooled)))
+    dww = _dev(torch, packw(w).view(np.float32))
+    b = _lib.sbc_op(kind=P.CONV, flags=(flags & P.EPI_RES1_ELU) | mflag, B=B, H=H, W=W, cin=Cc, cout=Cc, ksize=3, dil=1, in_=_p(pooled),
+                    out=_p(out2), weight_split=_p(dw), weight_wino_split=_p(dww))
+    if res1 is not None:
+        b.res1, b.res2 = _p(keep[0]), _p(keep[1])
+    _launch(gpu, b)
+    # (f16w: the Winograd launch it replaces rounds the TRANSFORMED operands to fp16, this one the operands themselves)
+    assert rel_err(got, out2.cpu().numpy()) < (tol if mode == 'f16x2' else 4e-3)
+    with pytest.raises(_lib.SbcError):                                # shapes it does not take are refused, not mangled
+        _launch(gpu, _lib.sbc_op(kind=P.CONV_POOL, flags=mflag, B=B, H=H, W=8, cin=Cc, cout=Cc, ksize=3, dil=1, in_=_p(dx), out=_p(out),
+                                 weight_split=_p(dw)))
+
+
 @pytest.mark.parametrize('wino', [True, False])
 @pytest.mark.parametrize('mode', ['f16x2', 'bf16x3', 'f16w'])
 @pytest.mark.parametrize('cin,cout', [(32, 32), (32, 64), (64, 32), (64, 64), (64, 128), (128, 64), (128, 128)])

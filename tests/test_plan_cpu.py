@@ -90,7 +90,12 @@ def test_fused_pair_plan_matches_reference_forward(weights64):
     pl = P.build_score_plan(32, 64, 16, fuse_pairs=True)
     kinds = [op.kind for op in pl.ops]
     # refine5: adapt_convs.0 (2 blocks) + output_convs (3 blocks) at 64x16
-    assert kinds.count(P.CONV_PAIR) == 5 and kinds.count(P.CONV) == 111 - 10 and len(pl.ops) == 150 - 5
+    # ... and refine5's CRP block there: two fused stages (SBC_OP_CONV_POOL) instead of 2 x (max pool + convolution)
+    assert kinds.count(P.CONV_PAIR) == 5 and kinds.count(P.CONV_POOL) == 2 and kinds.count(P.CONV) == 111 - 10 - 2
+    assert kinds.count(P.MAXPOOL5) == 10 and len(pl.ops) == 150 - 5 - 2
+    pools = [op for op in pl.ops if op.kind == P.CONV_POOL]
+    assert pools[0].flags == P.PRO_ELU and pools[0].res1 is None and pools[1].flags == P.EPI_RES1_ELU
+    assert pools[1].src is pools[0].dst and pools[1].res2 is pools[0].dst and pools[1].res1 is pools[0].src
     assert P.count_conv_flops(pl) == 820772864
     assert sorted((op.src.h, op.src.w) for op in pl.ops if op.kind == P.CONV_PAIR) == [(64, 16)] * 5
     assert all(op.src.c == 32 and op.weight2 for op in pl.ops if op.kind == P.CONV_PAIR)
