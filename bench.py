@@ -529,7 +529,7 @@ def main():
                      # (16-pixel rows, at least 4096 tiles in the launch: the three-stage pipelined kernel, csrc/conv_pair.hip)
                      P.TAG_PAIR_TOP: '%s<%d, %d, %d, %d, 32>' % ('conv_pair_p3_kernel' if nr == 16 and T * (nt // 8) >= 4096 else 'conv_pair_kernel',
                                                                    nr, 4 if nr == 64 else 8, 2 if conv_mode == 'f16x2' else 1, 8 if nr == 64 else 4),
-                     P.TAG_POOL_TOP: 'conv_pool_kernel<%d, 8, %d, 32>' % (nr, 2 if conv_mode == 'f16x2' else 1),
+                     P.TAG_POOL_TOP: 'conv_pool_kernel<%d, 8, %d, 4, 32>' % (nr, 2 if conv_mode == 'f16x2' else 1),
                      P.TAG_CONV_MID: 'conv_wx3_kernel<64, 64, 1, true, 2, false, 2, 1, %d>' % {'bf16x3': 0, 'f16w': 1, 'f16x2': 2}.get(conv_mode, 0)}
             what = {P.TAG_CONV_TOP: 'the unfused 3x3 32->32 convolutions at %dx%d (Winograd F(2x2,3x3))' % (nt, nr),
                     P.TAG_PAIR_TOP: 'the fused RCU blocks at %dx%d: two direct 3x3 32->32 convolutions per launch, intermediate in LDS' % (nt, nr),

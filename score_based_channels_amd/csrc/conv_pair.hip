@@ -731,6 +731,9 @@ __global__ __launch_bounds__(64 * (8 + NWC)) void conv_pool_kernel(PairParams p)
 #pragma unroll
         for (int j = 0; j < NRG; ++j) {
             if (j == NRG - 1 && !full) break;
+#ifdef SBC_POOL_SKIP   // timing probe (wrong results): no pooling -- what a direct pipelined kernel for a plain 3x3 layer would cost
+            float4 v = rv[j + 2];
+#else
             float4 v = vmax5(rv[j], rv[j + 1], rv[j + 2], rv[j + 3], rv[j + 4]);
             // horizontal 5-maximum over the 16 lanes of the row (= the image row): v_max_f32 with a DPP row shift on its first source;
             // a lane whose shifted source lies outside the row is disabled for that instruction and keeps its running maximum.  By hand:
@@ -751,6 +754,7 @@ __global__ __launch_bounds__(64 * (8 + NWC)) void conv_pool_kernel(PairParams p)
                     : "=&v"(m.x), "=&v"(m.y), "=&v"(m.z), "=&v"(m.w) : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
                 v = m;
             }
+#endif
             if (p.flags & SBC_PRO_ELU) v = elu4(v);
             const int prow = prow0 + j;
             const int grow = r0 - 1 + prow;
