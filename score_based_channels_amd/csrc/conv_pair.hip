@@ -45,21 +45,6 @@ struct PairParams {
 #define PT_MARK(k) do { } while (0)
 #endif
 
-// range tracking of one tile (tile.h): the wave's verdict on what it just converted goes into `rbits` (wave-uniform, raised once
-// at the end of the launch); calibration launches (calib != NULL) fold the wave's maximum into the record's slot right away
-__device__ __forceinline__ void pair_range_tile(float t, float scale, unsigned& rbits, float* __restrict__ calib_slot) {
-    rbits |= f16x2_range_bits(t, scale);
-    if (calib_slot) {
-        for (int o = 32; o > 0; o >>= 1) t = __builtin_fmaxf(t, __shfl_xor(t, o));
-        if ((threadIdx.x & 63) == 0 && t > 0.f) atomicMax(reinterpret_cast<unsigned*>(calib_slot), __float_as_uint(t));
-    }
-}
-
-__device__ __forceinline__ void lds_barrier() {
-    // LDS traffic only: the tile in flight by LDS-DMA (vmcnt) must NOT be waited for here
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 // NW waves per workgroup: 4 (two workgroups per CU) for images 8 / 16 pixels wide; 8 (one workgroup per CU, its LDS) for 64-pixel
 // rows, where wave pair `sub` owns column block `sub` of every row of the tile.
 // C channels (input = intermediate = output): 32, or 64 in the fp16-weight mode (one term: 2 x 9 taps x 2 k-halves x 4 registers

@@ -535,6 +535,22 @@ __device__ __forceinline__ void tile_moments_out32(const float4 (&v)[4], float* 
     if (tid < 32) tile_moments_merge32(red, pm_tile, tid);
 }
 
+// ---- shared by the persistent direct kernels (conv_pair.hip, conv_dp.hip) ------------------------------------------------------
+// range tracking of one tile (tile.h): the wave's verdict on what it just converted goes into `rbits` (wave-uniform, raised once
+// at the end of the launch); calibration launches (calib != NULL) fold the wave's maximum into the record's slot right away
+__device__ __forceinline__ void pair_range_tile(float t, float scale, unsigned& rbits, float* __restrict__ calib_slot) {
+    rbits |= f16x2_range_bits(t, scale);
+    if (calib_slot) {
+        for (int o = 32; o > 0; o >>= 1) t = __builtin_fmaxf(t, __shfl_xor(t, o));
+        if ((threadIdx.x & 63) == 0 && t > 0.f) atomicMax(reinterpret_cast<unsigned*>(calib_slot), __float_as_uint(t));
+    }
+}
+
+__device__ __forceinline__ void lds_barrier() {
+    // LDS traffic only: the tile in flight by LDS-DMA (vmcnt) must NOT be waited for here
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // host side: log2 of a power of two, or -1
 inline int log2_exact(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;

@@ -81,6 +81,18 @@ CONV_CASES = [
     (128, 128, 3, 1, 19, 8, 2, 'selfnorm_elu_res'),
     (128, 128, 3, 2, 4100, 8, 2, 'selfnorm_elu'),
     (32, 32, 3, 1, 37, 8, 8, 'selfnorm_elu_res'),
+    # 64 -> 64 at the low-resolution levels without a norm prologue: in conv_mode f16x2 the direct persistent kernel (conv_dp.hip) --
+    # tiles of four whole 8x2 samples (ragged last tile), of one 16x4 sample, of 8 rows of a W = 8 image (halo rows, H not a power of
+    # two), every epilogue family, one tile per workgroup and several
+    (64, 64, 3, 1, 21, 8, 2, 'elu_res'),
+    (64, 64, 3, 1, 21, 8, 2, 'crp2'),
+    (64, 64, 3, 1, 1, 8, 2, 'plain'),
+    (64, 64, 3, 1, 2302, 8, 2, 'elu'),
+    (64, 64, 3, 1, 9, 16, 4, 'crp2'),
+    (64, 64, 3, 1, 700, 16, 4, 'elu'),
+    (64, 64, 3, 1, 5, 24, 8, 'elu_res'),
+    (64, 64, 3, 1, 3, 8, 8, 'crp2'),
+    (64, 64, 3, 1, 2500, 32, 8, 'elu_res'),
 ]
 
 

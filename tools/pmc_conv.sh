@@ -1,13 +1,13 @@
 #!/bin/bash
 # PMC counters of one convolution launch (GPU box): tools/pmc_conv.sh <out-name> "<prof_conv.py arguments>" [counter ...]
-# Default counters: matrix-pipe busy, issue / wait split, vector and LDS instruction counts, LDS bank conflicts.
+# PROF=prof_dp.py (or another tools/prof_*.py taking --iters) selects the launcher.  Default counters: matrix-pipe busy, issue / wait split, vector and LDS instruction counts, LDS bank conflicts.
 name=$1; args=$2; shift 2
 R=$PWD; OUT=$R/gpurun_out/pmc_$name; mkdir -p $OUT
 C1="${@:-SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE}"
 C2="SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_MFMA"
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc $C1 --output-format csv -d $OUT/a -o p -- python3 $R/tools/prof_conv.py $args --iters 3 > $OUT/a.log 2>&1
-rocprofv3 --kernel-trace --pmc $C2 --output-format csv -d $OUT/b -o p -- python3 $R/tools/prof_conv.py $args --iters 3 > $OUT/b.log 2>&1
+rocprofv3 --kernel-trace --pmc $C1 --output-format csv -d $OUT/a -o p -- python3 $R/tools/${PROF:-prof_conv.py} $args --iters 3 > $OUT/a.log 2>&1
+rocprofv3 --kernel-trace --pmc $C2 --output-format csv -d $OUT/b -o p -- python3 $R/tools/${PROF:-prof_conv.py} $args --iters 3 > $OUT/b.log 2>&1
 cd $R
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
