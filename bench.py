@@ -393,7 +393,7 @@ def main():
         p_alds, p_streams = make_batches(H, Pm, idx, idx, ln, np.full(T, 3e-11), np.full(T, 0.01), rank * T + np.arange(T), init, 1)
         pa = p_alds[0]
         run_all(p_alds, p_streams, 2, False)
-        for tag in (P.TAG_CONV_TOP, P.TAG_PAIR_TOP, P.TAG_POOL_TOP, P.TAG_CONV_MID):
+        for tag in (P.TAG_CONV_TOP, P.TAG_PAIR_TOP, P.TAG_POOL_TOP, P.TAG_CONV_MID, P.TAG_DIRECT_MID):
             ops = [op for op in net.score_plan(nt, nr).ops if op.tag == tag]
             if not ops:
                 continue
@@ -530,17 +530,25 @@ def main():
                      P.TAG_PAIR_TOP: '%s<%d, %d, %d, %d, 32>' % ('conv_pair_p3_kernel' if nr == 16 and T * (nt // 8) >= 4096 else 'conv_pair_kernel',
                                                                    nr, 4 if nr == 64 else 8, 2 if conv_mode == 'f16x2' else 1, 8 if nr == 64 else 4),
                      P.TAG_POOL_TOP: 'conv_pool_kernel<%d, 8, %d, 4, 32>' % (nr, 2 if conv_mode == 'f16x2' else 1),
-                     P.TAG_CONV_MID: 'conv_wx3_kernel<64, 64, 1, true, 2, false, 2, 1, %d>' % {'bf16x3': 0, 'f16w': 1, 'f16x2': 2}.get(conv_mode, 0)}
+                     P.TAG_CONV_MID: 'conv_wx3_kernel<64, 64, 1, true, 2, false, 2, 1, %d>' % {'bf16x3': 0, 'f16w': 1, 'f16x2': 2}.get(conv_mode, 0),
+                     # (conv_mode f16x2 with 8-pixel rows: the direct persistent kernel, csrc/conv_dp.hip; else the Winograd kernel)
+                     P.TAG_DIRECT_MID: ('conv_dp_kernel<64, 8, 8, 1, false, 4>' if conv_mode == 'f16x2' and nr == 16 else
+                                        'conv_wx3_kernel<64, 64, 1, true, 2, false, 2, 1, %d>' % {'bf16x3': 0, 'f16w': 1, 'f16x2': 2}.get(conv_mode, 0))}
+            direct_mid = names[P.TAG_DIRECT_MID].startswith('conv_dp')
             what = {P.TAG_CONV_TOP: 'the unfused 3x3 32->32 convolutions at %dx%d (Winograd F(2x2,3x3))' % (nt, nr),
                     P.TAG_PAIR_TOP: 'the fused RCU blocks at %dx%d: two direct 3x3 32->32 convolutions per launch, intermediate in LDS' % (nt, nr),
                     P.TAG_POOL_TOP: 'the fused CRP stages at %dx%d: 5x5 max pool + direct 3x3 32->32 convolution + running sum per launch, pooled tensor in LDS' % (nt, nr),
-                    P.TAG_CONV_MID: 'the undilated 3x3 64->64 convolutions of the %dx%d level (Winograd F(2x2,3x3))' % (nt // 2, nr // 2)}
+                    P.TAG_CONV_MID: 'the undilated 3x3 64->64 convolutions of the %dx%d level with a norm prologue, a resized operand or '
+                                    'a tile-moment output (Winograd F(2x2,3x3))' % (nt // 2, nr // 2),
+                    P.TAG_DIRECT_MID: 'the other undilated 3x3 64->64 convolutions of the %dx%d level (%s)'
+                                      % (nt // 2, nr // 2, 'direct, filter fragments in registers' if direct_mid else 'Winograd F(2x2,3x3)')}
             entries = {}
             for tag, kc in klass.items():
                 t_launch = kc['us_per_launch'] * 1e-6
                 fl = kc['flops_per_step'] / kc['launches_per_step']           # algorithmic FLOPs of an average launch of the class
                 by = kc['bytes_per_step'] / kc['launches_per_step']
-                ratio = (18.0 / 16.0 if tag == P.TAG_PAIR_TOP else 1.0 if tag == P.TAG_POOL_TOP else 16.0 / 36.0) * (terms or 1.0)
+                ratio = (18.0 / 16.0 if tag == P.TAG_PAIR_TOP else 1.0 if tag == P.TAG_POOL_TOP or (tag == P.TAG_DIRECT_MID and direct_mid)
+                         else 16.0 / 36.0) * (terms or 1.0)
                 ach = fl / t_launch / 1e12
                 e = {'kernel': names[tag], 'what': what[tag], 'launches_per_step': kc['launches_per_step'],
                      'us_per_launch': kc['us_per_launch'], 'share_of_one_stream_step': kc['us_per_launch'] * kc['launches_per_step'] / 1e3 / one_stream_ms,
@@ -609,9 +617,11 @@ def main():
                                'section 8(d) defines: Winograd F(2x2,3x3) needs 16/36 of those multiplications but each is three fp16 '
                                'MFMAs in f16x2, so the two differ by 1.33x there and by 3.4x on the direct fused kernels); '
                                'frac_algorithmic_step = the whole Langevin step the headline times' % mpeak)
-            rf['kernels'] = {names[t]: {k: v for k, v in entries[t].items() if k != 'kernel'} for t in entries}
+            # (outside conv_mode f16x2 both half-resolution classes run the same Winograd kernel: keep their entries apart)
+            key = {t: names[t] if list(names[u] for u in entries).count(names[t]) == 1 else '%s [class %d]' % (names[t], t) for t in entries}
+            rf['kernels'] = {key[t]: {k: v for k, v in entries[t].items() if k != 'kernel'} for t in entries}
             for t in entries:
-                rf['kernels'][names[t]]['frac_algorithmic'] = entries[t]['algorithmic_tflops'] / mpeak
+                rf['kernels'][key[t]]['frac_algorithmic'] = entries[t]['algorithmic_tflops'] / mpeak
             if traffic is not None:
                 rf['traffic_source'] = tsrc + ' (rocprofv3 --pmc passes of the one-stream command: FETCH_SIZE x 2 + WRITE_SIZE per launch)'
             out['roofline'] = rf

@@ -28,7 +28,10 @@
 #include <type_traits>
 #include "conv_common.h"
 #ifndef DP_RING
-#define DP_RING 3
+#define DP_RING 3      // operand ring depth of the K loop (4 and 5 measured: no gain)
+#endif
+#ifndef DP_SETPRIO
+#define DP_SETPRIO 3   // wave priority inside the K loop (88.2 us against 90.8 without at 1700 x 32 x 8)
 #endif
 
 namespace sbc {
@@ -56,27 +59,37 @@ struct DpParams {
 #endif
 
 // FULL: a tile is S whole samples (R = H): no halo rows are fetched, the plane rows above and below a sample stay zero.
-template <int W, int R, int S, bool FULL>
-__global__ __launch_bounds__(256, 2) void conv_dp_kernel(DpParams p) {
-    constexpr int C = 64, NW = 4, NTH = 64 * NW, KGS = C / 8, KH = C / 32, C4 = C / 4, NT = 2;
-    static_assert(W == 2 || W == 4 || W == 8, "image rows of 2, 4 or 8 pixels");
+// C = 32: eight waves (two output-channel groups x four unit groups, 128 registers a wave: the fragments are 72), still two
+// workgroups per CU -- four waves per SIMD.
+template <int C, int W, int R, int S, bool FULL, int NW>
+__global__ __launch_bounds__(64 * NW, (C == 32 ? 3 : 2) * NW / 4) void conv_dp_kernel(DpParams p) {
+    constexpr int NTH = 64 * NW, KGS = C / 8, KH = C / 32, C4 = C / 4, NT = 2;
+    constexpr int NHF = C / 16, NSUB = NW / NHF;      // 16-output-channel groups; unit groups (wave = (hf, sub))
+    static_assert(C == 32 || C == 64, "32 or 64 channels");
+    static_assert(W == 2 || W == 4 || W == 8 || W == 16, "image rows of 2, 4, 8 or 16 pixels");
     static_assert(FULL || S == 1, "tiles with halo rows belong to one sample");
-    constexpr int NU = S * R * W / 16;                // units per tile = units per wave
+    constexpr int NUT = S * R * W / 16;               // units per tile
+    static_assert(NUT % NSUB == 0 && (W != 4 || NSUB == 1), "units must divide over the unit groups");
+    constexpr int NU = NUT / NSUB;                    // units per wave: i NSUB + sub
     constexpr int RR = FULL ? R : R + 2;              // raw rows per sample
     constexpr int RP = R + 2;                         // plane rows per sample
-    constexpr int WP = W == 8 ? 10 : 6;               // slots per plane row (>= W + 2; see the header for the choice)
-    static_assert((W == 8 && R == 8 && S == 1) || (W == 4 && R == 16 && S == 1 && FULL) || (W == 2 && R == 8 && FULL), "tile shapes of the header");
+    constexpr int WP = W == 16 ? 18 : W == 8 ? 10 : 6;   // slots per plane row (>= W + 2; see the header for the choice)
+    static_assert((W == 16 && R == 8 && S == 1) || (W == 8 && R == 8 && S == 1) || (W == 4 && R == 16 && S == 1 && FULL) || (W == 2 && R == 8 && FULL),
+                  "tile shapes of the header");
+    constexpr int PP = 256 / C;                       // pixels of a 1 KB LDS-DMA piece
+    static_assert(FULL || W % PP == 0, "a piece must not straddle clamped rows");
     constexpr int XPS = (S * RP * WP * 16 + 255) / 256 * 256;
     constexpr int RAW_BYTES = S * RR * W * C * 4;
     constexpr int NPIECE = RAW_BYTES / 1024;
-    constexpr int X_OFF = 2 * RAW_BYTES;
+    constexpr int X_OFF = RAW_BYTES;
     constexpr int NCOMBO = S * RR * W / 8 * KGS;       // conversion work items: (8 pixels, k-group); 16 lanes each
-    static_assert(NCOMBO % (NTH / 16) == 0 && RAW_BYTES % 1024 == 0, "raw tile must divide over the workgroup");
-    constexpr int NIT = NCOMBO / (NTH / 16);
+    static_assert(NCOMBO % 4 == 0 && RAW_BYTES % 1024 == 0, "whole waves of conversion work, whole DMA pieces");
+    constexpr int NIT = (NCOMBO + NTH / 16 - 1) / (NTH / 16);
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int hf = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave = 16-output-channel group
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hf = wave % NHF, sub = wave / NHF;       // 16-output-channel group, unit group
     const int kq = lane >> 4, c = lane & 15;
     const int H = p.H;
 
@@ -99,8 +112,6 @@ __global__ __launch_bounds__(256, 2) void conv_dp_kernel(DpParams p) {
     const bool elu_acc = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tr.w)) != 0;
     const bool pro_elu = (p.flags & SBC_PRO_ELU) != 0;
     const int cq = 4 * hf + kq;                        // channel quad of this lane's four outputs
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias) bias = *reinterpret_cast<const float4*>(p.bias + cq * 4);
     unsigned rbits = 0;
 
     // ---- zero the planes once: padding columns (and, for whole-sample tiles, the rows above and below) are never written again
@@ -109,12 +120,12 @@ __global__ __launch_bounds__(256, 2) void conv_dp_kernel(DpParams p) {
     const int xcd = blockIdx.x & 7, jw = blockIdx.x >> 3;
     const int t_begin = xcd * p.tiles_per_xcd;
     const int t_end = min(t_begin + p.tiles_per_xcd, p.ntiles);
-    auto issue_dma = [&](int tile, int buf) {
+    auto issue_dma = [&](int tile) {
         int n, r0;
         if (FULL) { n = tile * S; r0 = 0; } else { n = tile / p.tiles_per_sample; r0 = (tile - n * p.tiles_per_sample) * R; }
 #pragma unroll
         for (int k = 0; k < (NPIECE + NW - 1) / NW; ++k) {
-            const int j = k * NW + hf;                                        // piece: chunks j * 64 .. + 63 of the raw tile
+            const int j = k * NW + wave;                                      // piece: chunks j * 64 .. + 63 of the raw tile
             if (NPIECE % NW != 0 && j >= NPIECE) continue;
             const char* sbase;
             if (FULL) {
@@ -123,27 +134,29 @@ __global__ __launch_bounds__(256, 2) void conv_dp_kernel(DpParams p) {
                 if (S > 1 && n + s >= p.B) continue;
                 sbase = reinterpret_cast<const char*>(p.in) + (size_t)n * H * W * C * 4 + (size_t)j * 1024;
             } else {
-                const int ri = (j * 4) / W, within = j * 4 - ri * W;           // raw row, first pixel of the piece in it
+                const int ri = (j * PP) / W, within = j * PP - ri * W;         // raw row, first pixel of the piece in it
                 const int grow = min(max(r0 - 1 + ri, 0), H - 1);             // rows outside the image: any row inside (zeroed below)
                 sbase = reinterpret_cast<const char*>(p.in) + ((size_t)(n * H + grow) * W + within) * C * 4;
             }
-            const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem + buf * RAW_BYTES + j * 1024;
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(lane * 16), "s"(dst), "s"(sbase) : "memory");
+            const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem + j * 1024;
+            // (the lane offset is made here, by hand: as a loop invariant of an eight-wave workgroup it is spilled, and its reload --
+            // a scratch load -- puts an s_waitcnt vmcnt(0) between the pieces)
+            unsigned keep, l16;
+            asm volatile("v_mbcnt_lo_u32_b32 %1, -1, 0\n\tv_mbcnt_hi_u32_b32 %1, -1, %1\n\tv_lshlrev_b32 %1, 4, %1\n\t"
+                         "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep), "=&v"(l16) : "s"(dst), "s"(sbase) : "memory");
         }
     };
     int tile = t_begin + jw;
-    if (tile < t_end) issue_dma(tile, 0);
+    if (tile < t_end) issue_dma(tile);
 #ifdef SBC_PAIR_TIMING
     unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_last = __builtin_readcyclecounter();
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // first tile (and the filter fragments) landed
 
-    for (int it = 0; tile < t_end; tile += p.wgs_per_xcd, ++it) {
+    for (; tile < t_end; tile += p.wgs_per_xcd) {
         int n, r0;
         if (FULL) { n = tile * S; r0 = 0; } else { n = tile / p.tiles_per_sample; r0 = (tile - n * p.tiles_per_sample) * R; }
-        const int rb = it & 1;
         // (1) raw tile landed, for every wave; and every wave is through the previous tile's K loop (the planes are free)
         DP_MARK(0);
         asm volatile("s_barrier" ::: "memory");
@@ -153,23 +166,30 @@ __global__ __launch_bounds__(256, 2) void conv_dp_kernel(DpParams p) {
         float ta = 0.f;
         auto convert = [&](auto eluc) {
             constexpr int ELU = decltype(eluc)::value;                        // 0: none, 1: exp(x) - 1 form, 2: accurate form
-            const int half = tid & 1, pj = (tid >> 1) & 7;
+            // (32 channels, 168 registers: the lane's read / write addresses are recomputed for every tile from an opaque copy of the thread index --
+            // hoisted out of the tile loop they are a dozen registers the 128-register budget does not have)
+            int tq = tid;
+            if (C == 32) asm volatile("" : "+v"(tq));
+            const int half = tq & 1, pj = (tq >> 1) & 7;
             int rrow[NIT], col, kgv[NIT];
 #pragma unroll
             for (int k = 0; k < NIT; ++k) {
-                const int m = k * (NTH / 16) + (tid >> 4);
-                const int G = m >> 3;                                          // group of 8 pixels
-                kgv[k] = m & 7;
-                if (W == 8) { rrow[k] = G; col = pj; }                                             // one raw row
+                const int m = k * (NTH / 16) + (tq >> 4);
+                const int G = m / KGS;                                         // group of 8 pixels
+                kgv[k] = m % KGS;
+                if (W == 16) { rrow[k] = G >> 1; col = 8 * (G & 1) + pj; }                         // half a raw row
+                else if (W == 8) { rrow[k] = G; col = pj; }                                        // one raw row
                 else if (W == 4) { rrow[k] = (G & 1) + 4 * (G >> 1) + 2 * (pj >> 2); col = pj & 3; }   // rows r, r + 2
                 else { rrow[k] = (G >> 1) * RR + 4 * (G & 1) + (pj >> 1); col = pj & 1; }          // four rows of one sample
             }
             float4 v[NIT];
 #pragma unroll
             for (int k = 0; k < NIT; ++k)
-                v[k] = *reinterpret_cast<const float4*>(smem + rb * RAW_BYTES + ((rrow[k] * W + col) * C4 + 2 * kgv[k] + half) * 16);
+                if (NCOMBO % (NTH / 16) == 0 || k * (NTH / 16) + 4 * wave < NCOMBO)
+                    v[k] = *reinterpret_cast<const float4*>(smem + ((rrow[k] * W + col) * C4 + 2 * kgv[k] + half) * 16);
 #pragma unroll
             for (int k = 0; k < NIT; ++k) {
+                if (NCOMBO % (NTH / 16) != 0 && k * (NTH / 16) + 4 * wave >= NCOMBO) continue;   // (wave-uniform: a wave is four items)
                 const int s = rrow[k] / RR, ri = rrow[k] % RR;                 // sample of the tile, raw row of the sample
                 bool inside;
                 if (FULL) inside = S == 1 || n + s < p.B;
@@ -196,19 +216,23 @@ __global__ __launch_bounds__(256, 2) void conv_dp_kernel(DpParams p) {
         DP_MARK(2);
         lds_barrier();
         DP_MARK(3);
-        // the other raw buffer is free (converted one tile ago): request the next tile; it flies during the K loop
-        if (tile + p.wgs_per_xcd < t_end) issue_dma(tile + p.wgs_per_xcd, rb ^ 1);
+        // the raw copy is consumed: request the next tile of this workgroup; it flies during the K loop
+        if (tile + p.wgs_per_xcd < t_end) issue_dma(tile + p.wgs_per_xcd);
 
         // (3) residual operands: requested before the K loop, used after it.  Unit i of the tile, lane pixel c: image row (counted through
         // the tile's samples) UMR(i) + lrow, column lcol; the top-left tap of that pixel is plane row UPR(i) + lrow, slot lcol.
-        auto UMR = [](int i) { return W == 8 ? i : W == 4 ? (i & 1) + 8 * (i >> 1) : i * R; };
-        auto UPR = [](int i) { return W == 8 ? i : W == 4 ? (i & 1) + 8 * (i >> 1) : i * RP; };
-        const int lrow = W == 8 ? 4 * (c >> 3) : W == 4 ? 2 * (c >> 2) : c >> 1, lcol = c & (W - 1);
-        const unsigned o0 = (unsigned)(((FULL ? n * H : n * H + r0) + lrow) * W + lcol) * C + cq * 4;
-        auto DO = [&](int i) { return UMR(i) * W * C; };
-        auto valid = [&](int i) { return S == 1 || n + i < p.B; };            // (S > 1: a unit is a sample)
+        // (wave (hf, sub) owns units i NSUB + sub; both maps are linear in the unit index unless W = 4, where NSUB = 1)
+        auto UMR = [](int u) { return W >= 8 ? u : W == 4 ? (u & 1) + 8 * (u >> 1) : u * R; };
+        auto UPR = [](int u) { return W >= 8 ? u : W == 4 ? (u & 1) + 8 * (u >> 1) : u * RP; };
+        const int lrow = W == 16 ? 0 : W == 8 ? 4 * (c >> 3) : W == 4 ? 2 * (c >> 2) : c >> 1, lcol = c & (W - 1);
+        const unsigned o0 = (unsigned)(((FULL ? n * H : n * H + r0) + lrow + UMR(1) * sub) * W + lcol) * C + cq * 4;
+        auto DO = [&](int i) { return UMR(i * NSUB) * W * C; };
+        auto valid = [&](int i) { return S == 1 || n + i * NSUB + sub < p.B; };   // (S > 1: a unit is a sample)
+        // (eight-wave workgroups have 128 registers a wave and no room to hold them through the K loop: requested after it, the
+        // other three waves of the SIMD cover the round trip)
+        constexpr bool PRE_RES = NW == 4;
         float4 x1[NU];
-        if (p.res1) {
+        if (PRE_RES && p.res1) {
 #pragma unroll
             for (int i = 0; i < NU; ++i)
                 if (valid(i)) x1[i] = *reinterpret_cast<const float4*>(p.res1 + o0 + DO(i));
@@ -216,17 +240,18 @@ __global__ __launch_bounds__(256, 2) void conv_dp_kernel(DpParams p) {
         // (4) K loop: acc[i] = D[16 couts of this wave][16 pixels of unit i]
         f32x4v acc[NU];
         {
-            const int ub0 = X_OFF + kq * XPS + (lrow * WP + lcol) * 16;
+            const int ub0 = X_OFF + kq * XPS + ((lrow + UPR(1) * sub) * WP + lcol) * 16;
             constexpr int NS = 9 * KH * NU, D = DP_RING;
             f16x8 ring[D][NT];
             auto ld = [&](int s) {                                            // s is a compile-time constant at every call
                 const int tap = s / (KH * NU), kh = (s / NU) % KH, i = s % NU;
-                const int off = (UPR(i) * WP + (tap / 3) * WP + (tap % 3)) * 16 + kh * 4 * XPS;
+                const int off = (UPR(i * NSUB) * WP + (tap / 3) * WP + (tap % 3)) * 16 + kh * 4 * XPS;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) ring[s % D][t] = *reinterpret_cast<const f16x8*>(smem + ub0 + (off + t * KGS * XPS));
             };
 #pragma unroll
             for (int s = 0; s < D - 1; ++s) ld(s);
+            __builtin_amdgcn_s_setprio(DP_SETPRIO);
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int tap = s / (KH * NU), kh = (s / NU) % KH, i = s % NU;
@@ -242,7 +267,19 @@ __global__ __launch_bounds__(256, 2) void conv_dp_kernel(DpParams p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         DP_MARK(4);
+        float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) {
+            int cqo = cq;
+            asm volatile("" : "+v"(cqo));                                     // (address formed here, not carried through the tile loop)
+            bias = *reinterpret_cast<const float4*>(p.bias + cqo * 4);
+        }
+        if (!PRE_RES && p.res1) {
+#pragma unroll
+            for (int i = 0; i < NU; ++i)
+                if (valid(i)) x1[i] = *reinterpret_cast<const float4*>(p.res1 + o0 + DO(i));
+        }
         float4 x2[NU];
         if (p.res2) {
 #pragma unroll
@@ -264,6 +301,9 @@ __global__ __launch_bounds__(256, 2) void conv_dp_kernel(DpParams p) {
                 if (p.res2) { rr.x = x2[i].x + rr.x; rr.y = x2[i].y + rr.y; rr.z = x2[i].z + rr.z; rr.w = x2[i].w + rr.w; }
                 y.x += rr.x; y.y += rr.y; y.z += rr.z; y.w += rr.w;
             }
+#ifdef DP_PROBE_NOSTORE   // timing probe (wrong results): everything but the output stores
+            if (y.x == 123456.f)
+#endif
             st_stream(p.out + o0 + DO(i), y);
         }
         DP_MARK(6);
@@ -276,13 +316,14 @@ __global__ __launch_bounds__(256, 2) void conv_dp_kernel(DpParams p) {
 #endif
 }
 
-template <int W, int R, int S, bool FULL>
+template <int C, int W, int R, int S, bool FULL, int NW>
 static int launch_dp(const DpParams& p0, hipStream_t stream, bool dry) {
-    constexpr int C = 64, NT = 2, RR = FULL ? R : R + 2, RP = R + 2, WP = W == 8 ? 10 : 6;
+    constexpr int NT = 2, RR = FULL ? R : R + 2, RP = R + 2, WP = W == 16 ? 18 : W == 8 ? 10 : 6;
     constexpr int XPS = (S * RP * WP * 16 + 255) / 256 * 256;
-    constexpr size_t lds = (size_t)2 * S * RR * W * C * 4 + (size_t)NT * (C / 8) * XPS;
-    static_assert(lds <= 160 * 1024 / 2, "LDS of the two resident workgroups");
-    auto kern = conv_dp_kernel<W, R, S, FULL>;
+    constexpr size_t lds = (size_t)S * RR * W * C * 4 + (size_t)NT * (C / 8) * XPS;
+    constexpr int WGPC = (C == 32 ? 3 : 2) * 4 / NW;                       // workgroups per CU (registers: 168 / 256 a wave)
+    static_assert(lds * WGPC <= 160 * 1024, "LDS of the resident workgroups");
+    auto kern = conv_dp_kernel<C, W, R, S, FULL, NW>;
     { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds); if (rc) return rc; }
     if (dry) return SBC_OK;
     DpParams p = p0;
@@ -292,8 +333,11 @@ static int launch_dp(const DpParams& p0, hipStream_t stream, bool dry) {
     SBC_CHECK_HIP(hipGetDevice(&dev));
     SBC_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     p.tiles_per_xcd = (p.ntiles + 7) / 8;
-    p.wgs_per_xcd = max(1, min(2 * cus / 8, p.tiles_per_xcd));
-    hipLaunchKernelGGL(kern, dim3(8 * p.wgs_per_xcd), dim3(256), lds, stream, p);
+    p.wgs_per_xcd = max(1, min(WGPC * cus / 8, p.tiles_per_xcd));
+#ifdef SBC_PAIR_TIMING
+    if (getenv("SBC_DP_WGS")) p.wgs_per_xcd = max(1, min(atoi(getenv("SBC_DP_WGS")), p.tiles_per_xcd));   // probe: workgroups per XCD
+#endif
+    hipLaunchKernelGGL(kern, dim3(8 * p.wgs_per_xcd), dim3(64 * NW), lds, stream, p);
     SBC_CHECK_HIP(hipGetLastError());
     return SBC_OK;
 }
@@ -301,20 +345,24 @@ static int launch_dp(const DpParams& p0, hipStream_t stream, bool dry) {
 // 1: not this kernel's layer (the caller goes on to the Winograd kernel); 0: launched; < 0: error
 int launch_conv_dp(const sbc_op& op, unsigned* range_flag, hipStream_t stream, bool dry) {
     static const bool off = getenv("SBC_NO_CONV_DP") != nullptr;             // A/B aid
-    if (off || !(op.flags & SBC_CONV_F16X2) || !op.weight_split || op.cin != 64 || op.cout != 64 || op.ksize != 3 || op.dil != 1) return 1;
+    static const bool off32 = getenv("SBC_NO_CONV_DP32") != nullptr;         // A/B aid: 32-channel layers only
+    if (off || !(op.flags & SBC_CONV_F16X2) || !op.weight_split || op.cin != op.cout || op.ksize != 3 || op.dil != 1) return 1;
+    if (op.cin != 64 && (op.cin != 32 || off32)) return 1;
     if (op.flags & (SBC_PRO_NORM | SBC_EPI_POOL | SBC_EPI_UP | SBC_EPI_ELUGRAD | SBC_EPI_MOMENTS_OUT)) return 1;
     if (op.res2 && !op.res1) return 1;
-    const bool w8 = op.W == 8 && op.H % 8 == 0, w4 = op.W == 4 && op.H == 16, w2 = op.W == 2 && op.H == 8;
-    if (!w8 && !w4 && !w2) return 1;
+    const bool w16 = op.W == 16 && op.H % 8 == 0 && op.cin == 32, w8 = op.W == 8 && op.H % 8 == 0;
+    const bool w4 = op.W == 4 && op.H == 16 && op.cin == 64, w2 = op.W == 2 && op.H == 8 && op.cin == 64;
+    if (!w16 && !w8 && !w4 && !w2) return 1;
     DpParams p{};
     p.in = (const float*)op.in; p.out = (float*)op.out; p.w = (const uint4*)op.weight_split;
     p.bias = (const float*)op.bias; p.res1 = (const float*)op.res1; p.res2 = (const float*)op.res2;
     p.flags = op.flags; p.B = op.B; p.H = op.H;
     p.range_flag = range_flag; p.calib = (float*)op.calib;
     p.dbg = (op.flags & SBC_EPI_MOMENTS_OUT) ? nullptr : (unsigned long long*)op.aux;
-    if (w8) return launch_dp<8, 8, 1, false>(p, stream, dry);
-    if (w4) return launch_dp<4, 16, 1, true>(p, stream, dry);
-    return launch_dp<2, 8, 2, true>(p, stream, dry);
+    if (op.cin == 32) return w16 ? launch_dp<32, 16, 8, 1, false, 4>(p, stream, dry) : launch_dp<32, 8, 8, 1, false, 4>(p, stream, dry);
+    if (w8) return launch_dp<64, 8, 8, 1, false, 4>(p, stream, dry);
+    if (w4) return launch_dp<64, 4, 16, 1, true, 4>(p, stream, dry);
+    return launch_dp<64, 2, 8, 2, true, 4>(p, stream, dry);
 }
 
 }  // namespace sbc

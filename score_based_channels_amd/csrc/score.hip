@@ -261,6 +261,8 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
     const int sn = b.stats("normalizer", ref5, "normalizer", false);
     const int o_t = b.tensor("score", nt, nr, d->channels);
     { POp o; o.kind = SBC_OP_END_CONV; o.src = ref5; o.dst = o_t; o.weight = "end_conv.weight"; o.bias = "end_conv.bias"; o.stats = sn; b.ops.push_back(o); }
+    for (auto& o : b.ops)                   // plan.TAG_DIRECT_MID
+        if (o.tag == 3 && !(o.flags & (SBC_PRO_NORM | SBC_EPI_UP | SBC_EPI_MOMENTS_OUT))) o.tag = 5;
     s->tensors = b.t; s->pops = b.ops; s->x_t = x; s->out_t = o_t;
     assign_slots(*s);
 

@@ -43,6 +43,8 @@ TAG_CONV_TOP = 1        # 3x3 convs ngf -> ngf at full resolution (also their ow
 TAG_PAIR_TOP = 2        # fused RCU blocks (CONV_PAIR) at full resolution
 TAG_CONV_MID = 3        # undilated 3x3 convs 2 ngf -> 2 ngf at half resolution (the 32x8 level of a 64x16 array)
 TAG_POOL_TOP = 4        # fused CRP stages (CONV_POOL) at full resolution
+TAG_DIRECT_MID = 5      # the TAG_CONV_MID layers without a norm prologue / resize / tile-moment output: in conv_mode f16x2 the direct
+                        # persistent kernel (csrc/conv_dp.hip) takes them, the Winograd kernel the rest
 
 
 @dataclass
@@ -303,6 +305,9 @@ def build_score_plan(ngf=32, nt=64, nr=16, channels=2, share_slots=True, overlap
     sn = b.stats('normalizer', ref5, 'normalizer', consumer_is_conv=False)
     out = b.t('score', nt, nr, channels)
     b.ops.append(Op(END_CONV, 'end_conv', src=ref5, dst=out, weight='end_conv.weight', bias='end_conv.bias', stats=sn))
+    for op in b.ops:                        # (after the statistics folding, which adds EPI_MOMENTS_OUT to producers)
+        if op.tag == TAG_CONV_MID and not op.flags & (PRO_NORM | EPI_UP | EPI_MOMENTS_OUT):
+            op.tag = TAG_DIRECT_MID
     plan = ScorePlan(b.ops, x, out, b.tensors)
     if share_slots:
         assign_slots(plan)

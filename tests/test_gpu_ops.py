@@ -93,6 +93,11 @@ CONV_CASES = [
     (64, 64, 3, 1, 5, 24, 8, 'elu_res'),
     (64, 64, 3, 1, 3, 8, 8, 'crp2'),
     (64, 64, 3, 1, 2500, 32, 8, 'elu_res'),
+    # ... and its 32-channel form (eight-wave workgroups) at 16- and 8-pixel rows
+    (32, 32, 3, 1, 3, 24, 16, 'elu_res'),
+    (32, 32, 3, 1, 7, 8, 8, 'plain'),
+    (32, 32, 3, 1, 1300, 32, 8, 'elu'),
+    (32, 32, 3, 1, 300, 64, 16, 'elu'),
 ]
 
 

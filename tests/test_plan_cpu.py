@@ -14,6 +14,9 @@ def test_plan_counts_and_flops():
     assert P.count_conv_flops(pl) == 820772864
     assert P.count_conv_flops(P.build_score_plan(32, 256, 64)) == 13132365824
     assert sum(1 for op in pl.ops if op.tag == P.TAG_CONV_TOP) == 18
+    # the half-resolution 64 -> 64 layers: those a direct kernel can take (no norm prologue / resize / tile moments) and the rest
+    assert sum(1 for op in pl.ops if op.tag == P.TAG_DIRECT_MID) == 4 and sum(1 for op in pl.ops if op.tag == P.TAG_CONV_MID) == 3
+    assert all(not op.flags & (P.PRO_NORM | P.EPI_UP | P.EPI_MOMENTS_OUT | P.EPI_POOL) for op in pl.ops if op.tag == P.TAG_DIRECT_MID)
 
 
 def test_plan_slots_never_alias_live_tensors():

@@ -11,16 +11,18 @@ ap = argparse.ArgumentParser()
 ap.add_argument('shape', nargs='*', type=int, default=[1700, 32, 8])
 ap.add_argument('--stage', default='elu_res')
 ap.add_argument('--iters', type=int, default=30)
+ap.add_argument('--channels', type=int, default=64)
 a = ap.parse_args()
 B, H, W = a.shape
 torch.manual_seed(3); np.random.seed(3)
-x = torch.randn(B, H, W, 64, device='cuda')
+CH = a.channels
+x = torch.randn(B, H, W, CH, device='cuda')
 r1, r2 = torch.randn_like(x), torch.randn_like(x)
 out = torch.empty_like(x)
-w1 = np.random.randn(64, 64, 3, 3).astype(np.float32) / 24
+w1 = np.random.randn(CH, CH, 3, 3).astype(np.float32) / (3 * CH ** 0.5)
 d = [torch.from_numpy(f(w1).view(np.float32)).cuda() for f in (pack_conv_weight_f16x2, pack_conv_weight_winograd_f16x2)]
 fl = {'elu': P.PRO_ELU, 'elu_res': P.PRO_ELU, 'crp2': P.EPI_RES1_ELU, 'plain': 0}[a.stage]
-cv = _lib.sbc_op(kind=P.CONV, flags=P.CONV_F16X2 | fl, B=B, H=H, W=W, cin=64, cout=64, ksize=3, dil=1, in_=x.data_ptr(),
+cv = _lib.sbc_op(kind=P.CONV, flags=P.CONV_F16X2 | fl, B=B, H=H, W=W, cin=CH, cout=CH, ksize=3, dil=1, in_=x.data_ptr(),
                  out=out.data_ptr(), weight_split=d[0].data_ptr(), weight_wino_split=d[1].data_ptr())
 if a.stage in ('elu_res', 'crp2'):
     cv.res1 = r1.data_ptr()
@@ -41,5 +43,5 @@ if 'pt' in os.environ.get('SBC_LIB_PATH', '') and which == 'conv_dp':
     v = dbg.tolist()
     names = ['tile wait', 'barrier', 'convert', 'barrier', 'K loop', 'load wait', 'store']
     tot = sum(v[:7]) or 1
-    print('wave 0, cycles per phase: ' + ', '.join('%s %.1f%%' % (names[i], 100.0 * v[i] / tot) for i in range(7)), '| per WG %.0f' % (tot / 512))
-print('%s %s %s: %.1f us' % (which, a.shape, a.stage, t))
+    print('wave 0, cycles per phase: ' + ', '.join('%s %.1f%%' % (names[i], 100.0 * v[i] / tot) for i in range(7)), '| per WG %.0f' % (tot / (8 * int(os.environ.get('SBC_DP_WGS', 64)))))
+print('%s %s x %d %s: %.1f us' % (which, a.shape, CH, a.stage, t))
