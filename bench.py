@@ -146,6 +146,8 @@ def parse_args():
     ap.add_argument('--fold-stats', type=int, default=None,
                     help='1: full-resolution InstanceNorm++ statistics from tile moments (no statistics launches there), '
                          '0: a statistics launch per norm; default: scorenet.DEFAULT_FOLD_STATS')
+    ap.add_argument('--fuse-res', type=int, default=None,
+                    help='1: the two ResidualBlocks of the full-resolution level as one launch each (csrc/conv_res.hip); default: scorenet.DEFAULT_FUSE_RES')
     ap.add_argument('--fuse-pairs', type=int, default=None,
                     help='1: 32-channel RCU blocks as one launch each (csrc/conv_pair.hip), 0: two convolution launches; '
                          'default: scorenet.DEFAULT_FUSE_PAIRS')
@@ -281,7 +283,8 @@ def main():
     net = ScoreNet(cfg, 'cuda:%d' % local, conv_mode=conv_mode,
                    overlap=None if args.overlap is None else bool(args.overlap),
                    fold_stats=None if args.fold_stats is None else bool(args.fold_stats),
-                   fuse_pairs=None if args.fuse_pairs is None else bool(args.fuse_pairs)).load_state_dict(sd)
+                   fuse_pairs=None if args.fuse_pairs is None else bool(args.fuse_pairs),
+                   fuse_res=None if args.fuse_res is None else bool(args.fuse_res)).load_state_dict(sd)
     use_graph = DEFAULT_USE_GRAPH if args.graph is None else bool(args.graph)
     snr = np.arange(-10, 32.5, 2.5)[:nsnr]
 
@@ -393,7 +396,7 @@ def main():
         p_alds, p_streams = make_batches(H, Pm, idx, idx, ln, np.full(T, 3e-11), np.full(T, 0.01), rank * T + np.arange(T), init, 1)
         pa = p_alds[0]
         run_all(p_alds, p_streams, 2, False)
-        for tag in (P.TAG_CONV_TOP, P.TAG_PAIR_TOP, P.TAG_POOL_TOP, P.TAG_CONV_MID, P.TAG_DIRECT_MID):
+        for tag in (P.TAG_CONV_TOP, P.TAG_PAIR_TOP, P.TAG_POOL_TOP, P.TAG_RES_TOP, P.TAG_CONV_MID, P.TAG_DIRECT_MID):
             ops = [op for op in net.score_plan(nt, nr).ops if op.tag == tag]
             if not ops:
                 continue
@@ -405,7 +408,7 @@ def main():
             pa.plan.profile(-1)
             if n:
                 klass[tag] = {'ms_total': ms, 'launches': n, 'launches_per_step': len(ops), 'us_per_launch': ms / n * 1e3,
-                              'flops_per_step': float(sum((2 if op.kind == P.CONV_PAIR else 1) * 2.0 * T * op.src.h * op.src.w * 9
+                              'flops_per_step': float(sum((2 if op.kind in (P.CONV_PAIR, P.RES_BLOCK) else 1) * 2.0 * T * op.src.h * op.src.w * 9
                                                           * op.src.c * op.dst.c for op in ops)),
                               'bytes_per_step': float(sum(4.0 * T * op.src.h * op.src.w * (op.src.c + op.dst.c * (1 + (op.res1 is not None)
                                                                                                              + (op.res2 is not None)))
@@ -494,7 +497,7 @@ def main():
                        'full_schedule_timed': bool(args.full_schedule), 'conv_mode': conv_mode,
                        'graph_replay': use_graph, 'launch_mode': 'hipGraph replay' if use_graph else 'eager launches',
                        'launch_mode_is_cli_default': use_graph == DEFAULT_USE_GRAPH, 'streams': n_streams,
-                       'streams_is_cli_default': n_streams == DEFAULT_STREAMS, 'fuse_pairs': bool(net.fuse_pairs),
+                       'streams_is_cli_default': n_streams == DEFAULT_STREAMS, 'fuse_pairs': bool(net.fuse_pairs), 'fuse_res': bool(net.fuse_res),
                        'world_size_seen_by_backend': dist.get_world_size() if use_dist else 1, 'dist_backend': backend,
                        'parallelism': 'independent trajectories sharded over %d rank(s) on %d device(s); one all_gather of '
                                       'NMSE curves at the end (%.2f ms, backend %s)'
@@ -530,6 +533,7 @@ def main():
                      P.TAG_PAIR_TOP: '%s<%d, %d, %d, %d, 32>' % ('conv_pair_p3_kernel' if nr == 16 and T * (nt // 8) >= 4096 else 'conv_pair_kernel',
                                                                    nr, 4 if nr == 64 else 8, 2 if conv_mode == 'f16x2' else 1, 8 if nr == 64 else 4),
                      P.TAG_POOL_TOP: 'conv_pool_kernel<%d, 8, %d, 4, 32>' % (nr, 2 if conv_mode == 'f16x2' else 1),
+                     P.TAG_RES_TOP: 'conv_res_kernel',
                      P.TAG_CONV_MID: 'conv_wx3_kernel<64, 64, 1, true, 2, false, 2, 1, %d>' % {'bf16x3': 0, 'f16w': 1, 'f16x2': 2}.get(conv_mode, 0),
                      # (conv_mode f16x2 with 8-pixel rows: the direct persistent kernel, csrc/conv_dp.hip; else the Winograd kernel)
                      P.TAG_DIRECT_MID: ('conv_dp_kernel<64, 8, 8, 1, false, 4>' if conv_mode == 'f16x2' and nr == 16 else
@@ -538,6 +542,8 @@ def main():
             what = {P.TAG_CONV_TOP: 'the unfused 3x3 32->32 convolutions at %dx%d (Winograd F(2x2,3x3))' % (nt, nr),
                     P.TAG_PAIR_TOP: 'the fused RCU blocks at %dx%d: two direct 3x3 32->32 convolutions per launch, intermediate in LDS' % (nt, nr),
                     P.TAG_POOL_TOP: 'the fused CRP stages at %dx%d: 5x5 max pool + direct 3x3 32->32 convolution + running sum per launch, pooled tensor in LDS' % (nt, nr),
+                    P.TAG_RES_TOP: 'the fused ResidualBlocks at %dx%d: norm, ELU, direct 3x3 32->32 convolution, InstanceNorm++ statistics of the whole '
+                                   'intermediate sample, norm, ELU, second convolution, + x per launch; one workgroup per sample' % (nt, nr),
                     P.TAG_CONV_MID: 'the undilated 3x3 64->64 convolutions of the %dx%d level with a norm prologue, a resized operand or '
                                     'a tile-moment output (Winograd F(2x2,3x3))' % (nt // 2, nr // 2),
                     P.TAG_DIRECT_MID: 'the other undilated 3x3 64->64 convolutions of the %dx%d level (%s)'
@@ -547,7 +553,7 @@ def main():
                 t_launch = kc['us_per_launch'] * 1e-6
                 fl = kc['flops_per_step'] / kc['launches_per_step']           # algorithmic FLOPs of an average launch of the class
                 by = kc['bytes_per_step'] / kc['launches_per_step']
-                ratio = (18.0 / 16.0 if tag == P.TAG_PAIR_TOP else 1.0 if tag == P.TAG_POOL_TOP or (tag == P.TAG_DIRECT_MID and direct_mid)
+                ratio = (18.0 / 16.0 if tag == P.TAG_PAIR_TOP else 1.0 if tag in (P.TAG_POOL_TOP, P.TAG_RES_TOP) or (tag == P.TAG_DIRECT_MID and direct_mid)
                          else 16.0 / 36.0) * (terms or 1.0)
                 ach = fl / t_launch / 1e12
                 e = {'kernel': names[tag], 'what': what[tag], 'launches_per_step': kc['launches_per_step'],
@@ -565,14 +571,14 @@ def main():
             # class rounds 1-2 reported as one kernel).  Since round 3 two kernels run it -- the unfused Winograd launches and the
             # fused RCU-pair launches (two convolutions each) -- so the entry aggregates both: algorithmic FLOPs (bytes) of the
             # class per step / its time per step; executed matrix FLOPs summed kernel by kernel.
-            cls = [t for t in (P.TAG_CONV_TOP, P.TAG_PAIR_TOP, P.TAG_POOL_TOP) if t in entries]
+            cls = [t for t in (P.TAG_CONV_TOP, P.TAG_PAIR_TOP, P.TAG_POOL_TOP, P.TAG_RES_TOP) if t in entries]
             t_cls = sum(entries[t]['us_per_launch'] * entries[t]['launches_per_step'] for t in cls) * 1e-6
             n_launch = sum(entries[t]['launches_per_step'] for t in cls)
             fl_cls = sum(klass[t]['flops_per_step'] for t in cls)
             by_cls = sum(klass[t]['bytes_per_step'] for t in cls)
             ex_cls = sum(entries[t]['executed_mfma_tflops'] * 1e12 * entries[t]['us_per_launch'] * 1e-6 * entries[t]['launches_per_step']
                          for t in cls)
-            n_convs = sum((2 if t == P.TAG_PAIR_TOP else 1) * entries[t]['launches_per_step'] for t in cls)
+            n_convs = sum((2 if t in (P.TAG_PAIR_TOP, P.TAG_RES_TOP) else 1) * entries[t]['launches_per_step'] for t in cls)
             tfile = os.path.join(ROOT, 'profiles', '%s_traffic_%s.json' % (PROFILE_ROUND, args.workload))
             traffic, tsrc = None, None
             if os.path.exists(tfile):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SBC_ABI_VERSION 11
+#define SBC_ABI_VERSION 12
 
 typedef enum sbc_status {
     SBC_OK = 0,
@@ -70,9 +70,13 @@ typedef enum sbc_op_kind {
     SBC_OP_CONV_PAIR = 21,   /* one RCU block in one launch: out = x + conv2(ELU(conv1(ELU(x))))   layers.py:126-134;
                                 32 (or, fp16 weights, 64) channels, 3x3, no bias; the intermediate stays in LDS
                                 (csrc/conv_pair.hip)                                                                  */
-    SBC_OP_CONV_POOL = 22    /* (ABI 11) one CRP stage in one launch: out = conv3x3(ELU?(MaxPool5x5(x))) [+ (res2 + ELU?(res1))]
+    SBC_OP_CONV_POOL = 22,   /* (ABI 11) one CRP stage in one launch: out = conv3x3(ELU?(MaxPool5x5(x))) [+ (res2 + ELU?(res1))]
                                 layers.py:76-83; replaces an SBC_OP_MAXPOOL5 record and the SBC_OP_CONV that reads it: the
                                 pooled tensor never exists in memory (csrc/conv_pair.hip: conv_pool_kernel)                  */
+    SBC_OP_RES_BLOCK = 23    /* (ABI 12) one ResidualBlock without resampling in one launch:
+                                out = x + conv2(ELU(norm2(conv1(ELU(norm1(x))))))   layers.py:443-456, normalization.py:150-176;
+                                32 channels, 64 x 16 samples: a workgroup owns a whole sample, so it forms the InstanceNorm++
+                                statistics of the intermediate itself (csrc/conv_res.hip)                                    */
 } sbc_op_kind;
 
 /* sbc_op.flags for SBC_OP_CONV / SBC_OP_MAXPOOL5 */
@@ -146,6 +150,11 @@ typedef enum sbc_op_kind {
  *               SBC_CONV_F16W, optionally SBC_PRO_ELU (ELU of the pooled values: pool(ELU(x)) = ELU(pool(x))) and SBC_EPI_RES1_ELU;
  *               res1 / res2 as in CONV (r = res1 [ELU]; if res2: r = res2 + r; out = conv + r); H % 8 == 0.  The same numbers as
  *               the MAXPOOL5 + CONV records it replaces up to fp32 summation order (direct instead of Winograd form).
+ *   RES_BLOCK   in / out [B][64][16][32] (distinct buffers); stats = the (mu, scale, shift) table of norm1 [B][3][32] (an INORM_STATS
+ *               output); weight_split / bias = conv1, weight2_split / bias2 = conv2 (sbc_pack_conv_weight_f16x2; flags =
+ *               SBC_CONV_F16X2); norm2 = alpha | gamma | beta of the second norm [3][32]; with SBC_EPI_MOMENTS_OUT, aux = the output's
+ *               tile moments [B][8][32][2] (what a CONV with that flag writes).  The same numbers as the CONV (PRO_NORM | PRO_ELU),
+ *               INORM_STATS, CONV (PRO_NORM | PRO_ELU, res1 = in) records it replaces up to fp32 summation order.
  */
 typedef struct sbc_op {
     int32_t kind, flags;
@@ -191,6 +200,9 @@ typedef struct sbc_op {
     /* --- ABI 11 --- */
     void* calib;                 /* NULL.  (Set by sbc_f16x2_calibrate on its private copies of the records: two device floats per
                                     f16x2 convolution that collect max |x| of what the launch stages.) */
+    /* --- ABI 12 --- */
+    const void* bias2;           /* RES_BLOCK: bias of the second convolution [cout] */
+    const void* norm2;           /* RES_BLOCK: alpha | gamma | beta of the second InstanceNorm++ [3][cout] */
 } sbc_op;
 
 /* Training operators.  The reverse of a forward record `y = epi(conv(pro(x)))` is built by the host
@@ -368,6 +380,8 @@ typedef struct sbc_score_desc {
 #define SBC_SCORE_FUSE_PAIRS 0x1 /* every RCU block of 32 channels at a width of 16 as one SBC_OP_CONV_PAIR record, and (ABI 11) every CRP
                                     stage of that shape as one SBC_OP_CONV_POOL record (conv_mode 2 / 3); what the Python host does
                                     by default in those modes (scorenet.DEFAULT_FUSE_PAIRS) */
+#define SBC_SCORE_FUSE_RES   0x4 /* (ABI 12) the ResidualBlocks without resampling at 64 x 16 as one SBC_OP_RES_BLOCK record each (conv_mode 3);
+                                    off by default in the Python host (scorenet.DEFAULT_FUSE_RES) */
 typedef struct sbc_score sbc_score;
 int sbc_score_create(const sbc_score_desc* desc, const sbc_tensor_ref* tensors, int32_t n_tensors, sbc_score** out);
 int sbc_score_buffers(sbc_score* score, float** x, float** out, int64_t** labels);

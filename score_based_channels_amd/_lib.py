@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SBC_LIB_PATH') or os.path.join(_HERE, 'libsbc_hip.so')   # env override: A/B builds (tools/)
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 EXPORTS = ('sbc_abi_version', 'sbc_last_error', 'sbc_device_count', 'sbc_op_launch', 'sbc_plan_create',
            'sbc_plan_run', 'sbc_plan_destroy', 'sbc_plan_profile', 'sbc_plan_profile_read',
@@ -37,7 +37,8 @@ class sbc_op(C.Structure):
                 # training operators (ABI 7)
                 ('grad', C.c_void_p), ('aux', C.c_void_p), ('wgrad', C.c_void_p), ('bgrad', C.c_void_p),
                 ('weight2_split', C.c_void_p),
-                ('calib', C.c_void_p)]                # ABI 11: NULL (set by sbc_f16x2_calibrate on its own copies)
+                ('calib', C.c_void_p),                # ABI 11: NULL (set by sbc_f16x2_calibrate on its own copies)
+                ('bias2', C.c_void_p), ('norm2', C.c_void_p)]   # ABI 12: RES_BLOCK (second convolution's bias, second norm's alpha|gamma|beta)
 
 
 class sbc_endconv(C.Structure):

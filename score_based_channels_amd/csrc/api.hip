@@ -98,6 +98,7 @@ static int dispatch(const sbc_op& op, const void* ext, hipStream_t s) {
         case SBC_OP_CONV: return launch_conv(op, s);
         case SBC_OP_CONV_PAIR: return launch_conv_pair(op, s);
         case SBC_OP_CONV_POOL: return launch_conv_pool(op, s);
+        case SBC_OP_RES_BLOCK: return launch_res_block(op, s);
         case SBC_OP_MAXPOOL5: return launch_maxpool5(op, s);
         case SBC_OP_END_CONV:
             SBC_REQUIRE(endc, "end_conv: ext (sbc_endconv) must be set");
@@ -260,7 +261,8 @@ int sbc_f16x2_calibrate(const sbc_op* ops, int32_t n_ops, void* stream) {
     for (int i = 0; i < n_ops; ++i) {
         run[i].B = 1;                                       // the first sample of every buffer
         run[i].flags &= ~(SBC_OP_SIDE | SBC_OP_JOIN);
-        if ((run[i].flags & SBC_CONV_F16X2) && (run[i].kind == SBC_OP_CONV || run[i].kind == SBC_OP_CONV_PAIR || run[i].kind == SBC_OP_CONV_POOL)) {
+        if ((run[i].flags & SBC_CONV_F16X2) && (run[i].kind == SBC_OP_CONV || run[i].kind == SBC_OP_CONV_PAIR || run[i].kind == SBC_OP_CONV_POOL ||
+                                                  run[i].kind == SBC_OP_RES_BLOCK)) {
             slot_of[i] = n_slots;
             n_slots += 2;
         }
@@ -306,7 +308,7 @@ int sbc_f16x2_calibrate(const sbc_op* ops, int32_t n_ops, void* stream) {
         const sbc_op& o = ops[i];
         const float s1 = scale_for(amax[slot_of[i]]), s2 = scale_for(amax[slot_of[i] + 1]);
         int rc = SBC_OK;
-        if (o.kind == SBC_OP_CONV_PAIR) {
+        if (o.kind == SBC_OP_CONV_PAIR || o.kind == SBC_OP_RES_BLOCK) {
             rc = set_trailer(o.weight_split, 9, o.cin, o.cout, s1, amax[slot_of[i]]);
             if (!rc) rc = set_trailer(o.weight2_split, 9, o.cout, o.cout, s2, amax[slot_of[i] + 1]);
         } else if (o.kind == SBC_OP_CONV_POOL) {
@@ -347,6 +349,7 @@ int sbc_plan_create(const sbc_op* ops, int32_t n_ops, sbc_plan** out_plan) {
         if (po.op.kind == SBC_OP_CONV) rc = launch_conv(po.op, nullptr, true);
         else if (po.op.kind == SBC_OP_CONV_PAIR) rc = launch_conv_pair(po.op, nullptr, true);
         else if (po.op.kind == SBC_OP_CONV_POOL) rc = launch_conv_pool(po.op, nullptr, true);
+        else if (po.op.kind == SBC_OP_RES_BLOCK) rc = launch_res_block(po.op, nullptr, true);
         else if (po.op.kind == SBC_OP_END_CONV) rc = launch_end_conv(po.op, po.ext.endc, nullptr, true);
         else if (po.op.kind == SBC_OP_LANGEVIN) rc = launch_langevin(po.op, po.ext.lang, nullptr, true);
         if (rc) { delete plan; return rc; }

@@ -41,6 +41,7 @@ int range_flag_ptr(unsigned** out);
 int launch_conv(const sbc_op& op, hipStream_t stream, bool dry = false);
 int launch_conv_pair(const sbc_op& op, hipStream_t stream, bool dry = false);
 int launch_conv_pool(const sbc_op& op, hipStream_t stream, bool dry = false);
+int launch_res_block(const sbc_op& op, hipStream_t stream, bool dry = false);   // conv_res.hip
 int launch_begin_conv(const sbc_op& op, hipStream_t stream);
 int launch_inorm_stats(const sbc_op& op, hipStream_t stream);
 int launch_maxpool5(const sbc_op& op, hipStream_t stream);

@@ -1,0 +1,382 @@
+// One whole ResidualBlock of the score network in ONE launch (SBC_OP_RES_BLOCK), for the blocks without resampling at 64 x 16 and
+// 32 channels (res1.0 / res1.1 of NCSNv2Deepest):
+//       out = x + conv2(ELU(norm2(conv1(ELU(norm1(x))))))          ncsnv2/models/layers.py:443-456 (both convolutions 3x3 with bias)
+// norm = InstanceNorm2dPlus (normalization.py:150-176).  InstanceNorm++ needs the statistics of the WHOLE intermediate sample before the
+// second convolution can start, so a tile kernel cannot fuse the block -- a workgroup that owns a whole sample can: 1024 pixels x 32
+// channels as two fp16 operand planes are 150 KB of LDS, and the first convolution's accumulators (64 registers a wave) wait in
+// registers across the two barriers that form the statistics.
+//
+// One 8-wave workgroup per CU walks samples.  Wave (hf, sub) owns output channels 16 hf .. + 15 of image rows 16 sub .. + 15 (16 units
+// of one row each) and holds the filter fragments of the convolution it is about to run in registers (72).  Per sample:
+//   A  x (requested from memory while the previous sample's epilogue ran: 16 float4 per lane) -> norm1 from the statistics table ->
+//      ELU -> x act_scale -> two fp16 terms -> operand planes [term][8-channel group][66 rows][18 slots][8 halves] (conv_dp.hip's lane
+//      mapping: 16 adjacent lanes write 8 pixels x the two halves of one k-group = 128 contiguous bytes, no bank conflict);
+//   B  conv1: direct implicit GEMM on v_mfma_f32_16x16x32_f16 (hh + hl + lh), K loop = LDS reads + matrix instructions only;
+//   C  t = conv1 + bias; per 128-pixel tile and channel (mean, M2) -- a wave holds two whole tiles of its 16 channels: in-lane sums
+//      over 8 rows, DPP sums over the 16 pixel lanes -- exchanged through LDS, merged per channel in a fixed order (the formulas of
+//      ops.hip: inorm_from_moments_kernel), then the cross-channel "++" term: (mu, scale, shift) of norm2 for the lane's 4 channels;
+//   D  t -> norm2 -> ELU -> x act_scale -> split -> the SAME planes (every wave is through conv1: phase C has two barriers); the
+//      residual operand x is requested into the registers that held t;
+//   E  conv2, accumulating onto (x + bias2) / descale2 (a power of two: exact);
+//   F  out = acc x descale2, streamed out; with SBC_EPI_MOMENTS_OUT also the (mean, M2) of the output's 128-pixel tiles for the
+//      InstanceNorm++ that reads it next (tile.h) -- whole tiles per wave, no exchange; then the next sample's x is requested.
+// Five workgroup barriers per sample.  Everything is summed in an order that depends on the layer's shape only.
+#include <stdlib.h>
+#include <type_traits>
+#include "conv_common.h"
+#ifndef RES_NPRE
+#define RES_NPRE 16
+#endif
+
+namespace sbc {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+struct ResParams {
+    const float* __restrict__ in;
+    float* __restrict__ out;
+    const uint4* __restrict__ w1;        // sbc_pack_conv_weight_f16x2 layout (32 -> 32, 3x3)
+    const uint4* __restrict__ w2;
+    const float* __restrict__ bias1;
+    const float* __restrict__ bias2;
+    const float* __restrict__ stats1;    // [B][3][32]: (mu, scale, shift) of norm1 (SBC_OP_INORM_STATS)
+    const float* __restrict__ norm2;     // alpha | gamma | beta of norm2, [3][32]
+    float* __restrict__ pm_out;          // [B][8][32][2] tile moments of the output, or NULL
+    unsigned* __restrict__ range_flag;
+    float* __restrict__ calib;           // sbc_f16x2_calibrate: two amax slots (conv1's input, conv2's input), else NULL
+    int B;
+    unsigned long long* dbg;             // SBC_PAIR_TIMING builds: per-phase cycle sums of wave 0 of every workgroup
+};
+
+#ifdef SBC_PAIR_TIMING
+#define RS_MARK(k) do { const unsigned long long _t = __builtin_readcyclecounter(); pt[k] += _t - pt_last; pt_last = _t; } while (0)
+#else
+#define RS_MARK(k) do { } while (0)
+#endif
+
+// sum over the 16 lanes of a DPP row (= the 16 pixels of a unit for one k-quarter); every lane of the row gets the total
+__device__ __forceinline__ float row_sum16(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124 /* row_ror:4 */, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122 /* row_ror:2 */, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121 /* row_ror:1 */, 0xf, 0xf, false));
+    return v;
+}
+
+__global__ __launch_bounds__(512, 2) void conv_res_kernel(ResParams p) {
+    constexpr int C = 32, W = 16, H = 64, NT = 2, KGS = C / 8;
+    constexpr int WP = W + 2, PR = H + 2;              // slots per plane row, plane rows
+    constexpr int PS = (PR * WP * 16 + 255) / 256 * 256;   // bytes of one (term, k-group) plane
+    constexpr int RED_OFF = NT * KGS * PS;             // [8 tiles][32 channels][(mean, M2)]
+    constexpr int MV_OFF = RED_OFF + 8 * C * 2 * 4;    // mean_s[32], var_s[32]
+    constexpr int NU = 16;                             // units (image rows) per wave
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hf = wave & 1, sub = wave >> 1;          // 16-output-channel half; rows 16 sub .. + 15
+    const int kq = lane >> 4, c = lane & 15;
+    const int cq = 4 * hf + kq;                        // channel quad of this lane's four outputs
+
+    // ---- filter fragments: ONE convolution's at a time (72 registers), re-read from L2 for every sample -- both sets (144) beside 64
+    // accumulators and the operand ring spill.  The request for conv2's goes out when conv1's K loop ends and lands during the
+    // statistics; conv1's for the next sample when conv2's K loop ends.  (The lane index is made opaque per request: the loads are
+    // invariant in the sample loop and hipcc would hoist them out of it, back to 144 live registers.)
+    uint4 wf[9][NT];
+    auto load_w = [&](const uint4* __restrict__ w) {
+        int lo = lane;
+        asm volatile("" : "+v"(lo));                   // (per-lane offsets formed here: hoisted out of the sample loop they are spilled)
+        const int lsrc = (16 * hf + (lo & 15)) + 32 * ((lo >> 4) & 1);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) wf[tap][t] = w[((tap * (C / 16) + (lo >> 5)) * NT + t) * 64 + lsrc];
+    };
+    load_w(p.w1);
+    const float4 t1 = f16x2_trailer(reinterpret_cast<const float4*>(p.w1), 9 * (C / 16) * (C / 32) * NT);
+    const float4 t2 = f16x2_trailer(reinterpret_cast<const float4*>(p.w2), 9 * (C / 16) * (C / 32) * NT);
+    const float scale1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t1.x)));
+    const float scale2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t2.x)));
+    const float descale1 = t1.y, descale2 = t2.y;
+    // sample-invariant parameters of the lane's four output channels (a global load inside a phase is a round trip nobody hides)
+    const float4 b1 = *reinterpret_cast<const float4*>(p.bias1 + cq * 4), b2 = *reinterpret_cast<const float4*>(p.bias2 + cq * 4);
+    const float4 al = *reinterpret_cast<const float4*>(p.norm2 + cq * 4), ga = *reinterpret_cast<const float4*>(p.norm2 + C + cq * 4),
+                 be = *reinterpret_cast<const float4*>(p.norm2 + 2 * C + cq * 4);
+    unsigned rbits = 0;
+    // the calibration found one of the two convolutions' inputs below 2^-4: this kernel has the exp(x) - 1 form of ELU only
+    if (t1.w != 0.f || t2.w != 0.f) rbits |= 4u;
+
+    // ---- zero the planes once: the padding columns and the rows above and below the image are never written again
+    for (int i = tid; i < NT * KGS * PS / 16; i += 512) *reinterpret_cast<uint4*>(smem + i * 16) = make_uint4(0, 0, 0, 0);
+
+    // phase A's lane mapping: 16 adjacent lanes = (8 pixels pj, two halves) of k-group kgA; wave w takes the 8-pixel groups w, w + 8, ...
+    auto x_addr = [&](int n, int k, int tq) {          // element offset of chunk k (0 .. 15) of sample n for thread tq
+        const int G = k * 8 + wave, row = G >> 1, col = 8 * (G & 1) + ((tq >> 1) & 7);
+        return (unsigned)(((n * H + row) * W + col) * C + (2 * ((tq >> 4) & 3) + (tq & 1)) * 4);
+    };
+    // (NPRE of a sample's 16 chunks per lane are requested while the previous sample's epilogue runs, the rest at the start of phase A)
+    constexpr int NPRE = RES_NPRE;
+    float4 xv[NPRE], mu, sc, sh;                       // ... and norm1's (mu, scale, shift) of the lane's phase-A channel quad
+    auto st_addr = [&](int n, int tq) { return (size_t)n * 3 * C + (2 * ((tq >> 4) & 3) + (tq & 1)) * 4; };
+    int n = blockIdx.x;
+    if (n < p.B) {
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) xv[k] = *reinterpret_cast<const float4*>(p.in + x_addr(n, k, tid));
+        const float* st = p.stats1 + st_addr(n, tid);
+        mu = *reinterpret_cast<const float4*>(st); sc = *reinterpret_cast<const float4*>(st + C); sh = *reinterpret_cast<const float4*>(st + 2 * C);
+    }
+#ifdef SBC_PAIR_TIMING
+    unsigned long long pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt_last = __builtin_readcyclecounter();
+#endif
+
+    for (; n < p.B; n += gridDim.x) {
+        // every wave is through the previous sample's conv2 (first sample: the planes are zeroed)
+        RS_MARK(0);
+        __syncthreads();
+        RS_MARK(1);
+        // ---- A: x -> norm1 -> ELU -> split -> planes
+        float ta = 0.f, tb = 0.f;
+        int tq = tid;
+        asm volatile("" : "+v"(tq));                       // (the lane's plane addresses are formed per sample, see load_w)
+        {
+            const int half = tq & 1, pj = (tq >> 1) & 7, kgA = (tq >> 4) & 3;
+            auto convert_chunk = [&](int k, float4 v) {
+                const int G = k * 8 + wave, row = G >> 1, col = 8 * (G & 1) + pj;
+                v.x = fmaf(v.x - mu.x, sc.x, sh.x); v.y = fmaf(v.y - mu.y, sc.y, sh.y);
+                v.z = fmaf(v.z - mu.z, sc.z, sh.z); v.w = fmaf(v.w - mu.w, sc.w, sh.w);
+                v = elu4(v);
+                StageScale ss{scale1, ta};
+                scale_track(v, &ss);
+                ta = ss.amax;
+                uint2 h, l;
+                split_f16x2(v, scale1, h, l);
+                unsigned char* dst = smem + kgA * PS + ((row + 1) * WP + col + 1) * 16 + half * 8;
+                *reinterpret_cast<uint2*>(dst) = h;
+                *reinterpret_cast<uint2*>(dst + KGS * PS) = l;
+            };
+            float4 xw[16 - NPRE > 0 ? 16 - NPRE : 1];
+#pragma unroll
+            for (int k = NPRE; k < 16; ++k) xw[k - NPRE] = *reinterpret_cast<const float4*>(p.in + x_addr(n, k, tq));
+#pragma unroll
+            for (int k = 0; k < NPRE; ++k) convert_chunk(k, xv[k]);
+#pragma unroll
+            for (int k = NPRE; k < 16; ++k) convert_chunk(k, xw[k - NPRE]);
+        }
+        pair_range_tile(ta, scale1, rbits, p.calib);
+        RS_MARK(2);
+        lds_barrier();
+        RS_MARK(3);
+
+        // one convolution over this wave's 16 rows: acc[i] (+)= D[16 couts][16 pixels of row 16 sub + i]
+        f32x4v acc[NU];
+        auto conv = [&](bool zero_init) {
+            // top-left tap of row u = 16 sub + i, pixel c: plane row u (image row u - 1), slot c (column c - 1)
+            const int ub0 = kq * PS + ((sub * NU) * WP + c) * 16;
+            constexpr int NS = 9 * NU, D = 3;
+            f16x8 ring[D][NT];
+            auto ld = [&](int s) {                                            // s is a compile-time constant at every call
+                const int tap = s / NU, i = s % NU;
+                const int off = ((i + tap / 3) * WP + (tap % 3)) * 16;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) ring[s % D][t] = *reinterpret_cast<const f16x8*>(smem + ub0 + (off + t * KGS * PS));
+            };
+#pragma unroll
+            for (int s = 0; s < D - 1; ++s) ld(s);
+            __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int tap = s / NU, i = s % NU;
+                if (s + D - 1 < NS) ld(s + D - 1);
+                const f16x8 xh = ring[s % D][0], xl = ring[s % D][1];
+                const f16x8 wh = __builtin_bit_cast(f16x8, wf[tap][0]), wl = __builtin_bit_cast(f16x8, wf[tap][1]);
+                const f32x4v c0 = (tap == 0 && zero_init) ? f32x4v{0.f, 0.f, 0.f, 0.f} : acc[i];
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, c0, 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        };
+        // (mean, M2) of the lane's 4 channels over one 128-pixel tile = units 8 T .. 8 T + 7 of this wave (every lane of a row gets them)
+        auto tile_moments = [&](int T, float (&mean)[4], float (&m2)[4]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s += acc[8 * T + i][r];
+                mean[r] = row_sum16(s) * (1.f / 128.f);
+                float q = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float d = acc[8 * T + i][r] - mean[r]; q = fmaf(d, d, q); }
+                m2[r] = row_sum16(q);
+            }
+        };
+
+        // ---- B: conv1
+        conv(true);
+        load_w(p.w2);
+        RS_MARK(4);
+        // ---- C: t = conv1 + bias1 (in place), statistics of t over the whole sample
+        {
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                acc[i][0] = fmaf(acc[i][0], descale1, b1.x); acc[i][1] = fmaf(acc[i][1], descale1, b1.y);
+                acc[i][2] = fmaf(acc[i][2], descale1, b1.z); acc[i][3] = fmaf(acc[i][3], descale1, b1.w);
+            }
+        }
+        float* red = reinterpret_cast<float*>(smem + RED_OFF);
+        float* mv = reinterpret_cast<float*>(smem + MV_OFF);
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+            float mean[4], m2[4];
+            tile_moments(T, mean, m2);
+            if (c == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    *reinterpret_cast<float2*>(red + ((2 * sub + T) * C + cq * 4 + r) * 2) = make_float2(mean[r], m2[r]);
+            }
+        }
+        lds_barrier();
+        if (tid < C) {                                                        // one channel each: the 8 tiles in order (ops.hip)
+            float mw[8], mu = 0.f, q = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { const float2 v = *reinterpret_cast<const float2*>(red + (t * C + tid) * 2); mw[t] = v.x; mu += v.x; q += v.y; }
+            mu *= 0.125f;
+            float dd = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { const float d = mw[t] - mu; dd = fmaf(d, d, dd); }
+            mv[tid] = mu;
+            mv[C + tid] = fmaf(128.f, dd, q) * (1.f / (float)(H * W));
+        }
+        lds_barrier();
+        float4 nmu, nsc, nsh;                                                 // norm2 for the lane's four channels
+        {
+            float m = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < C; ++k) m += mv[k];
+            m *= 1.f / (float)C;
+            float v = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < C; ++k) { const float d = mv[k] - m; v = fmaf(d, d, v); }
+            v *= 1.f / (float)(C - 1);
+            const float rs = 1.f / sqrtf(v + 1e-5f);
+            const float4 mean = *reinterpret_cast<const float4*>(mv + cq * 4), var = *reinterpret_cast<const float4*>(mv + C + cq * 4);
+            nmu = mean;
+            nsc = make_float4(ga.x / sqrtf(fmaxf(var.x, 0.f) + 1e-5f), ga.y / sqrtf(fmaxf(var.y, 0.f) + 1e-5f),
+                              ga.z / sqrtf(fmaxf(var.z, 0.f) + 1e-5f), ga.w / sqrtf(fmaxf(var.w, 0.f) + 1e-5f));
+            nsh = make_float4(fmaf(ga.x, (mean.x - m) * rs * al.x, be.x), fmaf(ga.y, (mean.y - m) * rs * al.y, be.y),
+                              fmaf(ga.z, (mean.z - m) * rs * al.z, be.z), fmaf(ga.w, (mean.w - m) * rs * al.w, be.w));
+        }
+        RS_MARK(5);
+        // ---- D: t -> norm2 -> ELU -> split -> the same planes (conv2's operand); then request the residual operand x
+        const unsigned o0 = (unsigned)(((n * H + sub * NU) * W + c) * C + cq * 4);
+        {
+            int lq = lane;
+            asm volatile("" : "+v"(lq));                   // (the write addresses are formed per sample, see load_w)
+            const int cqd = 4 * hf + (lq >> 4);
+            unsigned char* dst0 = smem + (cqd >> 1) * PS + ((sub * NU + 1) * WP + (lq & 15) + 1) * 16 + (cqd & 1) * 8;
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                float4 v = make_float4(fmaf(acc[i][0] - nmu.x, nsc.x, nsh.x), fmaf(acc[i][1] - nmu.y, nsc.y, nsh.y),
+                                       fmaf(acc[i][2] - nmu.z, nsc.z, nsh.z), fmaf(acc[i][3] - nmu.w, nsc.w, nsh.w));
+                v = elu4(v);
+                StageScale ss{scale2, tb};
+                scale_track(v, &ss);
+                tb = ss.amax;
+                uint2 h, l;
+                split_f16x2(v, scale2, h, l);
+                *reinterpret_cast<uint2*>(dst0 + i * WP * 16) = h;
+                *reinterpret_cast<uint2*>(dst0 + i * WP * 16 + KGS * PS) = l;
+            }
+        }
+        pair_range_tile(tb, scale2, rbits, p.calib ? p.calib + 1 : nullptr);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {                                        // (lands while the workgroup meets at the barrier)
+            const float4 xr = *reinterpret_cast<const float4*>(p.in + o0 + i * W * C);
+            acc[i] = f32x4v{xr.x, xr.y, xr.z, xr.w};
+        }
+        RS_MARK(6);
+        lds_barrier();
+        RS_MARK(7);
+        {
+            const float inv2 = 1.f / descale2;                                 // (a power of two)
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                acc[i][0] = (acc[i][0] + b2.x) * inv2; acc[i][1] = (acc[i][1] + b2.y) * inv2;
+                acc[i][2] = (acc[i][2] + b2.z) * inv2; acc[i][3] = (acc[i][3] + b2.w) * inv2;
+            }
+        }
+        // ---- E: conv2 onto (x + bias2) / descale2
+        conv(false);
+        if (n + (int)gridDim.x < p.B) load_w(p.w1);
+        RS_MARK(8);
+        // ---- F: out = acc x descale2; tile moments of the output; next sample's x
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            acc[i][0] *= descale2; acc[i][1] *= descale2; acc[i][2] *= descale2; acc[i][3] *= descale2;
+            st_stream(p.out + o0 + i * W * C, make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]));
+        }
+        if (p.pm_out) {
+#pragma unroll
+            for (int T = 0; T < 2; ++T) {
+                float mean[4], m2[4];
+                tile_moments(T, mean, m2);
+                if (c == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        *reinterpret_cast<float2*>(p.pm_out + (((size_t)n * 8 + 2 * sub + T) * C + cq * 4 + r) * 2) = make_float2(mean[r], m2[r]);
+                }
+            }
+        }
+        if (n + (int)gridDim.x < p.B) {
+#pragma unroll
+            for (int k = 0; k < NPRE; ++k) xv[k] = *reinterpret_cast<const float4*>(p.in + x_addr(n + gridDim.x, k, tq));
+            const float* st = p.stats1 + st_addr(n + gridDim.x, tq);
+            mu = *reinterpret_cast<const float4*>(st); sc = *reinterpret_cast<const float4*>(st + C); sh = *reinterpret_cast<const float4*>(st + 2 * C);
+        }
+        RS_MARK(9);
+    }
+    if (rbits && lane == 0) atomicOr(p.range_flag, rbits);
+#ifdef SBC_PAIR_TIMING
+    // [wait, barrier, convert x, barrier, conv1, statistics, convert t + residual request, barrier, conv2, store + moments + prefetch]
+    if (tid == 0 && p.dbg)
+        for (int k = 0; k < 10; ++k) atomicAdd(p.dbg + k, pt[k]);
+#endif
+}
+
+int launch_res_block(const sbc_op& op, hipStream_t stream, bool dry) {
+    SBC_REQUIRE(op.in && op.out && op.weight_split && op.weight2_split && op.bias && op.bias2 && op.stats && op.norm2,
+                "res_block: in / out / weight_split / weight2_split / bias / bias2 / stats / norm2 must be set");
+    SBC_REQUIRE(op.cin == 32 && op.cout == 32 && op.ksize == 3 && op.dil == 1 && op.H == 64 && op.W == 16,
+                "res_block: 32 -> 32 -> 32 channels, 3x3, undilated, 64 x 16 samples (got %d -> %d, %dx%d)", op.cin, op.cout, op.H, op.W);
+    SBC_REQUIRE(op.B > 0, "res_block: bad batch %d", op.B);
+    SBC_REQUIRE((op.flags & SBC_CONV_F16X2) && !(op.flags & SBC_CONV_F16W), "res_block: SBC_CONV_F16X2 only (the weight forms it reads)");
+    SBC_REQUIRE(!(op.flags & SBC_EPI_MOMENTS_OUT) || op.aux, "res_block: SBC_EPI_MOMENTS_OUT without aux");
+    SBC_REQUIRE(!(op.flags & (SBC_EPI_POOL | SBC_EPI_UP | SBC_EPI_ELUGRAD | SBC_EPI_RES1_ELU)) && !op.res1 && !op.res2 && !op.up,
+                "res_block: the residual operand is the input itself; no other epilogue");
+    SBC_REQUIRE((long)op.B * op.H * op.W * op.cin <= 0x7fffffffL, "res_block: tensor exceeds the 32-bit element index");
+    constexpr size_t lds = (size_t)2 * 4 * ((66 * 18 * 16 + 255) / 256 * 256) + 8 * 32 * 2 * 4 + 2 * 32 * 4;
+    static_assert(lds <= 160 * 1024, "LDS of the one resident workgroup");
+    { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(conv_res_kernel), lds); if (rc) return rc; }
+    unsigned* word = nullptr;
+    { const int rc = range_flag_ptr(&word); if (rc) return rc; }
+    if (dry) return SBC_OK;
+    ResParams p{};
+    p.in = (const float*)op.in; p.out = (float*)op.out;
+    p.w1 = (const uint4*)op.weight_split; p.w2 = (const uint4*)op.weight2_split;
+    p.bias1 = (const float*)op.bias; p.bias2 = (const float*)op.bias2;
+    p.stats1 = (const float*)op.stats; p.norm2 = (const float*)op.norm2;
+    p.pm_out = (op.flags & SBC_EPI_MOMENTS_OUT) ? (float*)op.aux : nullptr;
+    p.range_flag = word; p.calib = (float*)op.calib; p.B = op.B;
+#ifdef SBC_PAIR_TIMING
+    p.dbg = (op.flags & SBC_EPI_MOMENTS_OUT) ? nullptr : (unsigned long long*)op.aux;
+#endif
+    int dev = 0, cus = 256;
+    SBC_CHECK_HIP(hipGetDevice(&dev));
+    SBC_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    hipLaunchKernelGGL(conv_res_kernel, dim3(min(op.B, cus)), dim3(512), lds, stream, p);
+    SBC_CHECK_HIP(hipGetLastError());
+    return SBC_OK;
+}
+
+}  // namespace sbc

@@ -25,13 +25,15 @@ struct POp {
     int moments = -1;                // second output: tile moments of dst (SBC_EPI_MOMENTS_OUT)
     int geom = -1;                   // INORM_STATS from tile moments: the tensor whose (H, W, C) the launch describes
     std::string norm_key;            // CONV with SBC_PRO_NORM_SELF: the norm whose (alpha | gamma | beta) `stats` points at (plan.py)
-    std::string weight, bias, weight2;       // weight2: the second convolution of an SBC_OP_CONV_PAIR
+    std::string weight, bias, weight2;       // weight2: the second convolution of an SBC_OP_CONV_PAIR / SBC_OP_RES_BLOCK
+    std::string bias2, norm2;                // SBC_OP_RES_BLOCK: the second convolution's bias, the second norm (plan.py)
 };
 
 // ---- wiring: a transcription of plan.py's _Builder (reference lines cited there) --------------------------------
 struct Builder {
     int ngf, nt, nr;
     bool fuse_pairs = false;         // plan.py: fuse_pairs / pair_fusable
+    bool fuse_res = false;           // plan.py: fuse_res / res_fusable (SBC_OP_RES_BLOCK; conv_mode f16x2 with fused pairs)
     bool f16w = false;               // ... the fp16-weight mode also fuses 64-pixel rows (plan.PAIR_WIDTHS_F16W)
     bool fold_stats = false;         // plan.py: fold_stats (statistics of full-resolution tensors from their producers' tile moments)
     std::map<int, int> producer;     // tensor -> index of the record that writes it
@@ -70,7 +72,7 @@ struct Builder {
             128 % (2 * sw) == 0 && t[src].h % (128 / sw > 0 ? 128 / sw : 1) == 0) {
             POp& pr = ops[it->second];
             if ((pr.kind == SBC_OP_BEGIN_CONV && t[src].c == 32) ||
-                (pr.kind == SBC_OP_CONV && pr.ksize == 3 && pr.dil == 1 && !(pr.flags & SBC_EPI_POOL))) {
+                (pr.kind == SBC_OP_CONV && pr.ksize == 3 && pr.dil == 1 && !(pr.flags & SBC_EPI_POOL)) || pr.kind == SBC_OP_RES_BLOCK) {
                 if (pr.moments < 0) {
                     pr.moments = tensor(t[src].name + ".moments", hw / 128, t[src].c, 2);
                     pr.flags |= SBC_EPI_MOMENTS_OUT;
@@ -92,6 +94,17 @@ struct Builder {
         const bool pooled = down && !dilation;
         const int c1 = down ? t[x].c : cout;
         const int s1 = stats(p + "normalize1", x, p + "normalize1");
+        if (fuse_res && t[x].c == 32 && cout == 32 && !down && !dilation && t[x].h == 64 && t[x].w == 16 && s1 != SELF_NORM) {   // plan.res_fusable
+            const int out = tensor(p + "conv2", t[x].h, t[x].w, cout);
+            POp o;
+            o.kind = SBC_OP_RES_BLOCK; o.src = x; o.dst = out; o.stats = s1;
+            o.weight = p + "conv1.weight"; o.weight2 = p + "conv2.weight"; o.bias = p + "conv1.bias"; o.bias2 = p + "conv2.bias";
+            o.norm2 = p + "normalize2";
+            o.tag = t[x].h == nt ? 6 : 0;                                                       // plan.TAG_RES_TOP
+            producer[out] = (int)ops.size();
+            ops.push_back(o);
+            return out;
+        }
         const int a = conv(p + "conv1", x, p + "conv1", c1, true, SBC_PRO_NORM | SBC_PRO_ELU, s1, -1, -1, -1, 3, d);
         const int s2 = stats(p + "normalize2", a, p + "normalize2");
         if (pooled) {
@@ -225,6 +238,7 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
                 "sbc_score_create: Nt and Nr must be multiples of 8 (three 2x mean pools), got %dx%d", d->nt, d->nr);
     SBC_REQUIRE(d->batch > 0 && d->conv_mode >= 0 && d->conv_mode <= 3 && d->sigmas && d->num_classes > 0,
                 "sbc_score_create: batch, conv_mode in {0 bf16x3, 1 f32, 2 f16w, 3 f16x2}, sigmas required");
+    SBC_REQUIRE(!(d->flags & SBC_SCORE_FUSE_RES) || d->conv_mode == 3, "sbc_score_create: SBC_SCORE_FUSE_RES needs conv_mode 3 (f16x2)");
     SBC_REQUIRE(!(d->flags & SBC_SCORE_FUSE_PAIRS) || d->conv_mode >= 2,
                 "sbc_score_create: SBC_SCORE_FUSE_PAIRS needs the fp16 weight forms (conv_mode 2 or 3)");
     std::map<std::string, const sbc_tensor_ref*> sd;
@@ -239,6 +253,7 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
     Builder b{ngf, nt, nr};
     b.fuse_pairs = (d->flags & SBC_SCORE_FUSE_PAIRS) != 0;
     b.f16w = d->conv_mode == 2;
+    b.fuse_res = (d->flags & SBC_SCORE_FUSE_RES) != 0;
     b.fold_stats = (d->flags & SBC_SCORE_FOLD_STATS) != 0 && d->conv_mode != 1 && !(nt & (nt - 1)) && !(nr & (nr - 1));
     const int x = b.tensor("x", nt, nr, d->channels);
     int h = b.tensor("begin_conv", nt, nr, ngf);
@@ -297,7 +312,7 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
     for (const POp& o : s->pops) {
         const Tn& src = s->tensors[o.geom >= 0 ? o.geom : o.src];
         const Tn& dst = s->tensors[o.dst];
-        const std::string& nkey = o.kind == SBC_OP_INORM_STATS ? o.weight : o.norm_key;
+        const std::string& nkey = o.kind == SBC_OP_INORM_STATS ? o.weight : o.kind == SBC_OP_RES_BLOCK ? o.norm2 : o.norm_key;
         if (!nkey.empty() && !off.count(nkey)) {             // a norm's (alpha | gamma | beta), [3][C]
             for (int k = 0; k < 3; ++k) {
                 const char* suffix[3] = {".alpha", ".gamma", ".beta"};
@@ -320,7 +335,7 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
             w = rounded(w, wn);
             std::vector<float> wkeep(w, w + wn);          // `tmp` is reused below
             const std::string& okey = wkey;
-            if (o.kind == SBC_OP_CONV_PAIR || o.kind == SBC_OP_CONV_POOL) {
+            if (o.kind == SBC_OP_CONV_PAIR || o.kind == SBC_OP_CONV_POOL || o.kind == SBC_OP_RES_BLOCK) {
                 // the fused kernels read the direct fp16 forms only
                 if (f16x2) sbc_pack_conv_weight_f16x2(wkeep.data(), cout, cin, k, (uint16_t*)reserve(okey + "#split", sbc_f16x2_elems(k * k, cin, cout) / 2));
                 else sbc_pack_conv_weight_f16(wkeep.data(), cout, cin, k, (uint16_t*)reserve(okey + "#split", (wn + 1) / 2));
@@ -344,11 +359,12 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
             }
         }
         }
-        if (!o.bias.empty() && !off.count(o.bias)) {
-            const float* bv = find(o.bias, cout);
+        for (const std::string& bkey : {o.bias, o.bias2}) {
+            if (bkey.empty() || off.count(bkey)) continue;
+            const float* bv = find(bkey, cout);
             if (!bv) return fail();
             bv = rounded(bv, cout);
-            memcpy(reserve(o.bias, cout), bv, sizeof(float) * cout);
+            memcpy(reserve(bkey, cout), bv, sizeof(float) * cout);
         }
     }
     // ---- device memory
@@ -387,6 +403,12 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
         } else if (o.kind == SBC_OP_CONV_POOL) {
             r.weight_split = wp(o.weight + "#split");
             r.flags |= f16w ? SBC_CONV_F16W : SBC_CONV_F16X2;
+        } else if (o.kind == SBC_OP_RES_BLOCK) {
+            r.weight_split = wp(o.weight + "#split");
+            r.weight2_split = wp(o.weight2 + "#split");
+            r.bias2 = wp(o.bias2);
+            r.norm2 = wp(o.norm2);
+            r.flags |= SBC_CONV_F16X2;
         } else if (o.kind != SBC_OP_CONV) {
             r.weight = wp(o.weight);
         } else if (d->conv_mode == 1) {

@@ -20,6 +20,7 @@ Fusion rules (reference lines in brackets):
   * ``h = 2x - 1`` [ncsnv2.py:270-273] lives in the begin conv; normalizer -> ELU -> end_conv -> / sigma
     [ncsnv2.py:291-298] is one kernel.
 """
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional
 
@@ -36,6 +37,7 @@ PRO_ELU_ACC = 0x20000         # ELU with fp32's relative accuracy for small nega
  BEGIN_CONV_BWD, ADAM_EMA) = range(9, 21)
 CONV_PAIR = 21
 CONV_POOL = 22
+RES_BLOCK = 23
 BWD_ACCUM, PACK_ADJOINT, OP_SIDE, OP_JOIN, PACK_WINOGRAD = 0x200, 0x400, 0x800, 0x1000, 0x2000
 
 # profiling tags (sbc_op.tag; bench.py times each class by hipEvents in a single-stream segment after its timed region):
@@ -43,6 +45,7 @@ TAG_CONV_TOP = 1        # 3x3 convs ngf -> ngf at full resolution (also their ow
 TAG_PAIR_TOP = 2        # fused RCU blocks (CONV_PAIR) at full resolution
 TAG_CONV_MID = 3        # undilated 3x3 convs 2 ngf -> 2 ngf at half resolution (the 32x8 level of a 64x16 array)
 TAG_POOL_TOP = 4        # fused CRP stages (CONV_POOL) at full resolution
+TAG_RES_TOP = 6         # fused ResidualBlocks (RES_BLOCK) at full resolution
 TAG_DIRECT_MID = 5      # the TAG_CONV_MID layers without a norm prologue / resize / tile-moment output: in conv_mode f16x2 the direct
                         # persistent kernel (csrc/conv_dp.hip) takes them, the Winograd kernel the rest
 
@@ -74,7 +77,9 @@ class Op:
     src: Optional[Tensor] = None
     dst: Optional[Tensor] = None
     weight: Optional[str] = None        # state_dict key of the conv weight / norm prefix
-    weight2: Optional[str] = None       # CONV_PAIR: state_dict key of the second convolution's weight
+    weight2: Optional[str] = None       # CONV_PAIR / RES_BLOCK: state_dict key of the second convolution's weight
+    bias2: Optional[str] = None         # RES_BLOCK: state_dict key of the second convolution's bias
+    norm2: Optional[str] = None         # RES_BLOCK: state_dict prefix of the second norm (its alpha | gamma | beta)
     bias: Optional[str] = None
     stats: Optional[Tensor] = None
     res1: Optional[Tensor] = None
@@ -109,6 +114,7 @@ class ScorePlan:
 class _Builder:
     def __init__(self, ngf, nt, nr, overlap=False, fold_stats=False, fuse_pairs=False):
         self.ngf, self.nt, self.nr = ngf, nt, nr
+        self.fuse_res = False           # ResidualBlocks without resampling at 64x16, 32 channels as one RES_BLOCK record (csrc/conv_res.hip)
         self.fuse_pairs = fuse_pairs    # RCU blocks as one CONV_PAIR record (csrc/conv_pair.hip): True / a tuple of (channels, width)
         self.ops, self.tensors = [], []
         self.fold_stats = fold_stats    # full-resolution InstanceNorm++ statistics from tile moments (no statistics launch)
@@ -160,7 +166,8 @@ class _Builder:
         if (self.fold_stats and prod is not None and src.c in (32, 64) and hw % 128 == 0 and hw >= 256
                 and 128 % (2 * src.w) == 0 and src.h % max(1, 128 // src.w) == 0
                 and ((prod.kind == BEGIN_CONV and src.c == 32)
-                     or (prod.kind == CONV and prod.ksize == 3 and prod.dil == 1 and not prod.flags & EPI_POOL))):
+                     or (prod.kind == CONV and prod.ksize == 3 and prod.dil == 1 and not prod.flags & EPI_POOL)
+                     or prod.kind == RES_BLOCK)):
             if prod.moments is None:
                 prod.moments = self.t(src.name + '.moments', hw // 128, src.c, 2)     # [tile][channel][(mean, M2)]
                 prod.flags |= EPI_MOMENTS_OUT
@@ -181,6 +188,15 @@ class _Builder:
         pooled = resample == 'down' and dilation is None
         c1 = x.c if resample == 'down' else cout
         s1 = self.stats(p + 'normalize1', x, p + 'normalize1')
+        if self.fuse_res and res_fusable(x.h, x.w, x.c, cout, resample, dilation) and not isinstance(s1, SelfNorm):
+            # the whole block in one launch: a workgroup owns a sample and forms normalize2's statistics itself; the intermediate
+            # tensor, its statistics record and two tensor round trips do not exist
+            out = self.t(p + 'conv2', x.h, x.w, cout)
+            self.ops.append(Op(RES_BLOCK, p + 'block', src=x, dst=out, weight=p + 'conv1.weight', weight2=p + 'conv2.weight',
+                               bias=p + 'conv1.bias', bias2=p + 'conv2.bias', stats=s1, norm2=p + 'normalize2',
+                               side=self.side_now, tag=TAG_RES_TOP if x.h == self.nt else 0))
+            self.producer[id(out)] = self.ops[-1]
+            return out
         a = self.conv(p + 'conv1', x, p + 'conv1', c1, flags=PRO_NORM | PRO_ELU, stats=s1, dil=d)
         s2 = self.stats(p + 'normalize2', a, p + 'normalize2')
         has_sc = pooled or x.c != cout or resample is not None
@@ -263,9 +279,16 @@ PAIR_SHAPES = ((32, 16),)
 PAIR_SHAPES_F16W = ((32, 16), (32, 32), (32, 64), (64, 16), (64, 32))
 
 
+def res_fusable(h, w, cin, cout, resample, dilation):
+    """ResidualBlocks SBC_OP_RES_BLOCK takes: 32 -> 32 channels, no resampling or dilation, 64 x 16 samples (two fp16 operand planes
+    of a whole sample fill the LDS of a CU)."""
+    if os.environ.get('SBC_NO_RES_BLOCK'):           # A/B aid: the two convolutions and the statistics record as separate launches
+        return False
+    return cin == 32 and cout == 32 and resample is None and dilation is None and h == 64 and w == 16
+
+
 def pool_fusable(h, w, c):
     """Shapes SBC_OP_CONV_POOL takes (a CRP stage as one launch): 32 channels, 16-pixel rows, heights that are multiples of 8."""
-    import os
     if os.environ.get('SBC_NO_CONV_POOL'):           # A/B aid: max pool + convolution as separate launches
         return False
     return c == 32 and w == 16 and h % 8 == 0
@@ -277,13 +300,14 @@ def pair_fusable(h, w, c, shapes=PAIR_SHAPES):
     return (c, w) in shapes and h % (8 if w == 16 else 4) == 0
 
 
-def build_score_plan(ngf=32, nt=64, nr=16, channels=2, share_slots=True, overlap=False, fold_stats=False, fuse_pairs=False):
+def build_score_plan(ngf=32, nt=64, nr=16, channels=2, share_slots=True, overlap=False, fold_stats=False, fuse_pairs=False, fuse_res=False):
     """Op list of one ``NCSNv2Deepest.forward`` for ``[B, 2, nt, nr]`` inputs (ncsnv2.py:269-300).
     ``share_slots=False`` gives every logical tensor its own storage (a training step reads every activation again on
     the way back, ``train.py``)."""
     if nt % 8 or nr % 8:
         raise ValueError('Nt and Nr must be multiples of 8 (three 2x mean-pools), got %dx%d' % (nt, nr))
     b = _Builder(ngf, nt, nr, overlap, fold_stats, fuse_pairs)
+    b.fuse_res = bool(fuse_res)
     x = b.t('x', nt, nr, channels)
     h = b.t('begin_conv', nt, nr, ngf)
     b.ops.append(Op(BEGIN_CONV, 'begin_conv', src=x, dst=h, weight='begin_conv.weight', bias='begin_conv.bias'))
@@ -366,7 +390,7 @@ def count_conv_flops(plan):
     for op in plan.ops:
         if op.kind == CONV:
             total += 2 * op.src.h * op.src.w * op.src.c * op.dst.c * op.ksize * op.ksize
-        elif op.kind == CONV_PAIR:
+        elif op.kind in (CONV_PAIR, RES_BLOCK):
             total += 2 * 2 * op.src.h * op.src.w * op.src.c * op.dst.c * 9
         elif op.kind == CONV_POOL:
             total += 2 * op.src.h * op.src.w * op.src.c * op.dst.c * 9

@@ -39,6 +39,10 @@ class BoundScore:
 DEFAULT_OVERLAP = False
 DEFAULT_FOLD_STATS = True       # not conv_mode 'f32' (the tile moments are written by the Winograd split kernels); +2 %
 DEFAULT_FUSE_PAIRS = True       # applies to the fp16-form modes only ('f16x2', 'f16w')
+# ResidualBlocks without resampling at 64x16 as ONE launch (SBC_OP_RES_BLOCK, csrc/conv_res.hip; conv_mode 'f16x2' only).  Measured
+# (DESIGN.md section 13): 264-280 us per block against 2 x 150 + 10 for the launches it replaces, 1 % of a ONE-stream step -- and
+# nothing with the default two sub-batch streams, because its one workgroup per CU holds the whole LDS while it runs.  Off by default.
+DEFAULT_FUSE_RES = False
 
 
 class ScoreNet:
@@ -68,7 +72,7 @@ class ScoreNet:
                             ``.half()``, layers.py:179); tolerance stated in tests/test_gpu_parity.py.
     """
 
-    def __init__(self, config, device=None, conv_mode=None, overlap=None, fold_stats=None, fuse_pairs=None):
+    def __init__(self, config, device=None, conv_mode=None, overlap=None, fold_stats=None, fuse_pairs=None, fuse_res=None):
         conv_mode = DEFAULT_CONV_MODE if conv_mode is None else conv_mode
         if conv_mode not in CONV_MODES:
             raise ValueError('conv_mode must be one of %s, got %r' % (CONV_MODES, conv_mode))
@@ -84,6 +88,7 @@ class ScoreNet:
         # fuse_pairs: RCU blocks (act -> conv -> act -> conv, + x; layers.py:126-134; shapes: plan.PAIR_SHAPES*) are ONE launch that keeps
         # the intermediate tensor in LDS (csrc/conv_pair.hip); the kernel reads the fp16 weight forms of 'f16x2' / 'f16w'
         self.fuse_pairs = (DEFAULT_FUSE_PAIRS if fuse_pairs is None else bool(fuse_pairs)) and conv_mode in ('f16x2', 'f16w')
+        self.fuse_res = (DEFAULT_FUSE_RES if fuse_res is None else bool(fuse_res)) and conv_mode == 'f16x2'
         self.config = config
         m, d = config.model, config.data
         if str(m.normalization) != 'InstanceNorm++' or str(m.nonlinearity).lower() != 'elu':
@@ -219,7 +224,8 @@ class ScoreNet:
         if key not in self._plans:
             fold = self.fold_stats and not (nt & (nt - 1)) and not (nr & (nr - 1))     # conv_wx3 takes power-of-two images
             self._plans[key] = P.build_score_plan(self.ngf, nt, nr, self.channels, overlap=self.overlap, fold_stats=fold,
-                                                  fuse_pairs=(P.PAIR_SHAPES_F16W if self.conv_mode == 'f16w' else P.PAIR_SHAPES) if self.fuse_pairs else False)
+                                                  fuse_pairs=(P.PAIR_SHAPES_F16W if self.conv_mode == 'f16w' else P.PAIR_SHAPES) if self.fuse_pairs else False,
+                                                  fuse_res=self.fuse_res)
         return self._plans[key]
 
     def bind(self, B, nt, nr, *, step=None, sigma_of_step=None, use_labels=True):
@@ -255,6 +261,13 @@ class ScoreNet:
                 o.ksize, o.dil = 3, 1
                 o.weight_split = _ptr(self._wdev, self._woff[op.weight + '#split'])
                 o.flags |= P.CONV_F16W if self.conv_mode == 'f16w' else P.CONV_F16X2
+            elif op.kind == P.RES_BLOCK:
+                o.ksize, o.dil = 3, 1
+                o.weight_split = _ptr(self._wdev, self._woff[op.weight + '#split'])
+                o.weight2_split = _ptr(self._wdev, self._woff[op.weight2 + '#split'])
+                o.bias2 = _ptr(self._wdev, self._woff[op.bias2])
+                o.norm2 = _ptr(self._wdev, self._woff[op.norm2])
+                o.flags |= P.CONV_F16X2
             elif op.weight is not None and op.kind != P.CONV:
                 o.weight = _ptr(self._wdev, self._woff[op.weight])
             elif op.weight is not None and self.conv_mode == 'f32':

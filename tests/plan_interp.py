@@ -89,6 +89,14 @@ def exec_op(op, sd, get, labels):
                 if op.res2 is not None:
                     r = get(op.res2) + r
                 out = out + r
+        elif op.kind == P.RES_BLOCK:             # one ResidualBlock without resampling (layers.py:443-456)
+            st = get(op.stats)[:, 0]
+            v = O.elu((src - st[:, None, None, 0]) * st[:, None, None, 1] + st[:, None, None, 2])
+            t = _nhwc(O.conv2d(_nchw(v), sd[op.weight], sd[op.bias], 1))
+            k = op.norm2
+            st2 = inorm_stats(t, sd[k + '.alpha'], sd[k + '.gamma'], sd[k + '.beta'])
+            u = O.elu((t - st2[:, None, None, 0]) * st2[:, None, None, 1] + st2[:, None, None, 2])
+            out = src + _nhwc(O.conv2d(_nchw(u), sd[op.weight2], sd[op.bias2], 1))
         elif op.kind == P.CONV_PAIR:             # one RCU block (layers.py:126-134)
             t = O.conv2d(_nchw(O.elu(src)), sd[op.weight], None, 1)
             out = src + _nhwc(O.conv2d(O.elu(t), sd[op.weight2], None, 1))

@@ -13,20 +13,21 @@ pytestmark = pytest.mark.gpu
 MODES = {'bf16x3': 0, 'f32': 1, 'f16w': 2, 'f16x2': 3}
 
 
-def _create(sd, cfg, B, nt, nr, mode, pairs=False, fold=False):
+def _create(sd, cfg, B, nt, nr, mode, pairs=False, fold=False, res=False):
     from score_based_channels_amd import _lib
     keep = {k: np.ascontiguousarray(v, np.float32) for k, v in sd.items() if k != 'sigmas'}
     refs = (_lib.sbc_tensor_ref * len(keep))(*[
         _lib.sbc_tensor_ref(name=k.encode(), data=v.ctypes.data, numel=v.size) for k, v in keep.items()])
     sig = np.ascontiguousarray(sd['sigmas'], np.float32)
     desc = _lib.sbc_score_desc(ngf=32, channels=2, nt=nt, nr=nr, batch=B, conv_mode=MODES[mode], sigmas=sig.ctypes.data,
-                               num_classes=sig.size, flags=(1 if pairs else 0) | (2 if fold else 0))
+                               num_classes=sig.size, flags=(1 if pairs else 0) | (2 if fold else 0) | (4 if res else 0))
     h = C.c_void_p()
     _lib.check(_lib.lib().sbc_score_create(C.byref(desc), refs, len(keep), C.byref(h)))
     return h
 
 
-@pytest.mark.parametrize('mode', ['bf16x3', 'f32', 'f16w', 'f16x2', 'f16x2+pairs', 'f16w+pairs', 'f16x2+pairs+fold', 'bf16x3+fold'])
+@pytest.mark.parametrize('mode', ['bf16x3', 'f32', 'f16w', 'f16x2', 'f16x2+pairs', 'f16w+pairs', 'f16x2+pairs+fold', 'bf16x3+fold',
+                                  'f16x2+pairs+fold+res'])
 def test_c_built_score_network_equals_python_host(weights64, mode):
     import torch
     from score_based_channels_amd import _lib
@@ -35,12 +36,12 @@ def test_c_built_score_network_equals_python_host(weights64, mode):
     L = _lib.lib()
     B, nt, nr = 3, 64, 16
     mode, *opts = mode.split('+')
-    pairs, fold = 'pairs' in opts, 'fold' in opts
-    h = _create(sd, cfg, B, nt, nr, mode, pairs, fold)
+    pairs, fold, res = 'pairs' in opts, 'fold' in opts, 'res' in opts
+    h = _create(sd, cfg, B, nt, nr, mode, pairs, fold, res)
     try:
         ops_p, n = C.POINTER(_lib.sbc_op)(), C.c_int32()
         _lib.check(L.sbc_score_ops(h, C.byref(ops_p), C.byref(n)))
-        net = ScoreNet(cfg, conv_mode=mode, fuse_pairs=pairs, fold_stats=fold).cuda().load_state_dict(sd)
+        net = ScoreNet(cfg, conv_mode=mode, fuse_pairs=pairs, fold_stats=fold, fuse_res=res).cuda().load_state_dict(sd)
         bound = net.bind(B, nt, nr)
         assert n.value == len(bound.ops)
         # identical records: every scalar field, and the same storage-sharing pattern (pointers renamed by first use)
@@ -54,7 +55,7 @@ def test_c_built_score_network_equals_python_host(weights64, mode):
                 assert (a is None) == (b is None), (i, f)
                 if a is not None:
                     assert ids_c.setdefault(a, len(ids_c)) == ids_p.setdefault(b, len(ids_p)), (i, f)
-            for f in ('weight', 'bias', 'weight_wino', 'weight_split', 'weight_wino_split', 'weight2_split'):
+            for f in ('weight', 'bias', 'weight_wino', 'weight_split', 'weight_wino_split', 'weight2_split', 'bias2', 'norm2'):
                 assert (getattr(got, f) is None) == (getattr(ref, f) is None), (i, f)
         # bit-identical forward
         g = load_golden('forward_64x16.npz')

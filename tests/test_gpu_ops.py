@@ -494,6 +494,68 @@ def test_conv_pool_matches_oracle(gpu, B, H, stage, mode):
                                  weight_split=_p(dw)))
 
 
+@pytest.mark.parametrize('B', [1, 3, 300, 700])
+def test_res_block_matches_oracle(gpu, B):
+    """SBC_OP_RES_BLOCK: one whole ResidualBlock without resampling (layers.py:443-456) in one launch -- a workgroup owns a sample and
+    forms the InstanceNorm++ statistics of the intermediate itself (csrc/conv_res.hip) -- against the oracle's norm -> ELU -> conv ->
+    norm -> ELU -> conv -> + x, against the three records it replaces, and the tile moments of its output against numpy.  Batches
+    below and above the number of CUs (one / several samples per workgroup)."""
+    torch, _lib = gpu
+    from score_based_channels_amd import plan as P
+    from score_based_channels_amd.weights import pack_conv_weight_f16x2, pack_conv_weight_winograd_f16x2
+    H, W, Cc = 64, 16, 32
+    rng = np.random.default_rng(77 + B)
+    x = (rng.standard_normal((B, H, W, Cc)) * 1.5 + 0.3).astype(F32)
+    w1, w2 = [(rng.standard_normal((Cc, Cc, 3, 3)) / np.sqrt(9 * Cc)).astype(F32) for _ in range(2)]
+    b1, b2 = [(0.3 * rng.standard_normal(Cc)).astype(F32) for _ in range(2)]
+    agb1, agb2 = [[(1 + 0.1 * rng.standard_normal(Cc)).astype(F32), (1 + 0.1 * rng.standard_normal(Cc)).astype(F32),
+                   (0.1 * rng.standard_normal(Cc)).astype(F32)] for _ in range(2)]
+    norm = lambda v, st: (v - st[:, None, None, 0]) * st[:, None, None, 1] + st[:, None, None, 2]
+    s1 = inorm_stats(x, *agb1)
+    t = O.conv2d(O.elu(norm(x, s1)).transpose(0, 3, 1, 2), w1, b1, 1).transpose(0, 2, 3, 1)
+    s2 = inorm_stats(t, *agb2)
+    main = O.conv2d(O.elu(norm(t, s2)).transpose(0, 3, 1, 2), w2, b2, 1).transpose(0, 2, 3, 1)
+    ref = x + main
+    d = {k: _dev(torch, a) for k, a in dict(x=x, s1=s1, w1=pack_conv_weight_f16x2(w1).view(np.float32),
+                                              w2=pack_conv_weight_f16x2(w2).view(np.float32), b1=b1, b2=b2,
+                                              n2=np.concatenate(agb2)).items()}
+    out = torch.full((B, H, W, Cc), float('nan'), dtype=torch.float32, device='cuda')
+    pm = torch.full((B, 8, Cc, 2), float('nan'), dtype=torch.float32, device='cuda')
+    op = _lib.sbc_op(kind=P.RES_BLOCK, flags=P.CONV_F16X2 | P.EPI_MOMENTS_OUT, B=B, H=H, W=W, cin=Cc, cout=Cc, ksize=3, dil=1,
+                     in_=_p(d['x']), out=_p(out), stats=_p(d['s1']), weight_split=_p(d['w1']), weight2_split=_p(d['w2']),
+                     bias=_p(d['b1']), bias2=_p(d['b2']), norm2=_p(d['n2']), aux=_p(pm))
+    _launch(gpu, op)
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all() and _lib.range_flag() == 0
+    assert rel_err(got - x, main) < TOL                               # (the residual operand must not mask the error of the main path)
+    assert rel_err_elementwise(got - x, main, 0.05) < 4 * TOL
+    # tile moments of the output: (mean, M2) of each channel over the 8 tiles of 128 pixels
+    tiles = got.astype(np.float64).reshape(B, 8, 128, Cc)
+    gm = pm.cpu().numpy()
+    assert np.abs(gm[..., 0] - tiles.mean(2)).max() < 1e-5 * max(1.0, np.abs(tiles.mean(2)).max())
+    assert rel_err(gm[..., 1], ((tiles - tiles.mean(2, keepdims=True)) ** 2).sum(2)) < 1e-5
+    # the records it replaces: conv (norm, ELU) -> statistics -> conv (norm, ELU, + x)
+    wino = [_dev(torch, pack_conv_weight_winograd_f16x2(w).view(np.float32)) for w in (w1, w2)]
+    tt, st2, out2 = torch.empty_like(out), torch.empty((B, 3, Cc), dtype=torch.float32, device='cuda'), torch.empty_like(out)
+    fl = P.CONV_F16X2 | P.PRO_NORM | P.PRO_ELU
+    _launch(gpu, _lib.sbc_op(kind=P.CONV, flags=fl, B=B, H=H, W=W, cin=Cc, cout=Cc, ksize=3, dil=1, in_=_p(d['x']), out=_p(tt),
+                             stats=_p(d['s1']), bias=_p(d['b1']), weight_split=_p(d['w1']), weight_wino_split=_p(wino[0])))
+    _launch(gpu, _lib.sbc_op(kind=P.INORM_STATS, B=B, H=H, W=W, cin=Cc, cout=Cc, in_=_p(tt), out=_p(st2), weight=_p(d['n2'])))
+    _launch(gpu, _lib.sbc_op(kind=P.CONV, flags=fl, B=B, H=H, W=W, cin=Cc, cout=Cc, ksize=3, dil=1, in_=_p(tt), out=_p(out2),
+                             stats=_p(st2), bias=_p(d['b2']), res1=_p(d['x']), weight_split=_p(d['w2']), weight_wino_split=_p(wino[1])))
+    assert rel_err(got - x, out2.cpu().numpy() - x) < TOL
+    # batch independence, bit for bit: sample 0 alone
+    if B > 1:
+        out1 = torch.empty((1, H, W, Cc), dtype=torch.float32, device='cuda')
+        op.B, op.out, op.aux, op.flags = 1, _p(out1), None, P.CONV_F16X2
+        _launch(gpu, op)
+        assert torch.equal(out1[0], out[0])
+    with pytest.raises(_lib.SbcError):                                # shapes it does not take are refused
+        _launch(gpu, _lib.sbc_op(kind=P.RES_BLOCK, flags=P.CONV_F16X2, B=B, H=32, W=16, cin=Cc, cout=Cc, ksize=3, dil=1, in_=_p(d['x']),
+                                 out=_p(out), stats=_p(d['s1']), weight_split=_p(d['w1']), weight2_split=_p(d['w2']), bias=_p(d['b1']),
+                                 bias2=_p(d['b2']), norm2=_p(d['n2'])))
+
+
 @pytest.mark.parametrize('wino', [True, False])
 @pytest.mark.parametrize('mode', ['f16x2', 'bf16x3', 'f16w'])
 @pytest.mark.parametrize('cin,cout', [(32, 32), (32, 64), (64, 32), (64, 64), (64, 128), (128, 64), (128, 128)])

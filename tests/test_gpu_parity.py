@@ -13,16 +13,17 @@ pytestmark = pytest.mark.gpu
 NMSE_RTOL = 1e-5      # BASELINE.json north_star: NMSE within 1e-5 relative of the reference
 
 
-@pytest.fixture(scope='module', params=['bf16x3', 'f32', 'f16x2', 'f16x2+pairs'])
+@pytest.fixture(scope='module', params=['bf16x3', 'f32', 'f16x2', 'f16x2+pairs', 'f16x2+pairs+res'])
 def net64(weights64, request):
-    """Every parity case runs with every fp32-class convolution multiplier (scorenet.CONV_MODES), and with the 32-channel RCU
-    blocks fused into single launches (``fuse_pairs``, csrc/conv_pair.hip)."""
+    """Every parity case runs with every fp32-class convolution multiplier (scorenet.CONV_MODES), with the 32-channel RCU
+    blocks and CRP stages fused into single launches (``fuse_pairs``, csrc/conv_pair.hip), and with the two ResidualBlocks of the
+    full-resolution level as one launch each (``fuse_res``, csrc/conv_res.hip; optional)."""
     import torch
     from score_based_channels_amd.scorenet import ScoreNet
     assert torch.cuda.is_available(), 'these tests need the MI355X'
     cfg, sd = weights64
-    mode, _, pairs = request.param.partition('+')
-    return ScoreNet(cfg, conv_mode=mode, fuse_pairs=bool(pairs)).cuda().load_state_dict(sd).eval()
+    mode, *opts = request.param.split('+')
+    return ScoreNet(cfg, conv_mode=mode, fuse_pairs='pairs' in opts, fuse_res='res' in opts).cuda().load_state_dict(sd).eval()
 
 
 def test_forward_every_op_matches_cpu_interpretation(net64, weights64):

@@ -17,6 +17,11 @@ def test_plan_counts_and_flops():
     # the half-resolution 64 -> 64 layers: those a direct kernel can take (no norm prologue / resize / tile moments) and the rest
     assert sum(1 for op in pl.ops if op.tag == P.TAG_DIRECT_MID) == 4 and sum(1 for op in pl.ops if op.tag == P.TAG_CONV_MID) == 3
     assert all(not op.flags & (P.PRO_NORM | P.EPI_UP | P.EPI_MOMENTS_OUT | P.EPI_POOL) for op in pl.ops if op.tag == P.TAG_DIRECT_MID)
+    # the two ResidualBlocks of the full-resolution level as one record each (optional): 4 convolution and 2 statistics records fewer
+    fr = P.build_score_plan(32, 64, 16, fuse_res=True)
+    kf = [op.kind for op in fr.ops]
+    assert kf.count(P.RES_BLOCK) == 2 and kf.count(P.CONV) == 107 and kf.count(P.INORM_STATS) == 23
+    assert P.count_conv_flops(fr) == 820772864 and P.build_score_plan(32, 32, 32, fuse_res=True).ops[3].kind != P.RES_BLOCK
 
 
 def test_plan_slots_never_alias_live_tensors():

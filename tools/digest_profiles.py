@@ -12,7 +12,7 @@ CANDIDATES = (['conv_wx3_kernel<32, 32, 1, true, 3, true, 1, 1, 1>', 'conv_pair_
                'conv_wx3_kernel<64, 64, 1, true, 2, false, 2, 1, 1>'] if BIG else
               ['conv_wx3_kernel<32, 32, 1, true, 4, true, 1, 1, 2>', 'conv_pair_p3_kernel<16, 8, 2, 4, 32>',
                'conv_pool_kernel<16, 8, 2, 4, 32>', 'conv_wx3_kernel<64, 64, 1, true, 2, false, 2, 1, 2>',
-               'conv_dp_kernel<64, 8, 8, 1, false, 4>'])
+               'conv_dp_kernel<64, 8, 8, 1, false, 4>', 'conv_res_kernel'])
 PX = (256 * 64) if BIG else (64 * 16)
 T = 1024 if BIG else 1700
 CMD = '--workload %s --streams 1 --no-cpu-baseline --no-strong --no-other-mode --no-exact-mode --sustained 0' % W
