@@ -85,6 +85,8 @@ class ScoreNet:
         # writes (plan.py `stats`): the statistics launches of those tensors read a few KB per sample instead of the tensor.
         # Needs the Winograd split kernels (not conv_mode 'f32').
         self.fold_stats = (DEFAULT_FOLD_STATS if fold_stats is None else bool(fold_stats)) and conv_mode != 'f32'
+        if os.environ.get('SBC_NO_WX3'):          # (A/B switch of the library: no Winograd split kernel, hence nobody to write tile moments)
+            self.fold_stats = False
         # fuse_pairs: RCU blocks (act -> conv -> act -> conv, + x; layers.py:126-134; shapes: plan.PAIR_SHAPES*) are ONE launch that keeps
         # the intermediate tensor in LDS (csrc/conv_pair.hip); the kernel reads the fp16 weight forms of 'f16x2' / 'f16w'
         self.fuse_pairs = (DEFAULT_FUSE_PAIRS if fuse_pairs is None else bool(fuse_pairs)) and conv_mode in ('f16x2', 'f16w')
