@@ -309,6 +309,11 @@ typedef struct sbc_plan sbc_plan;
 
 /* --- library ----------------------------------------------------------------------------------- */
 int sbc_abi_version(void);
+/* (ABI 12) The persistent kernels (SBC_OP_CONV_PAIR / CONV_POOL / RES_BLOCK and the direct kernel behind SBC_OP_CONV) size their grids for
+ * `n` CUs instead of all of them; 0 = all (the default).  A host that keeps TWO independent launch streams busy sets half the device's
+ * CUs, so that the two streams' persistent launches are resident side by side instead of one after the other (measured: -0.7 % per
+ * two-stream Langevin step; results do not depend on it).  Process-wide; takes effect for launches issued after the call. */
+int sbc_set_persistent_cus(int32_t n);
 const char* sbc_last_error(void);
 /* number of visible HIP devices, or a negative sbc_status (does not initialise a device context) */
 int sbc_device_count(void);

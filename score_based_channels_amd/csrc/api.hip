@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <string.h>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -114,6 +115,13 @@ static int dispatch(const sbc_op& op, const void* ext, hipStream_t s) {
     }
 }
 
+static std::atomic<int> g_persistent_cus{0};           // sbc_set_persistent_cus
+int persistent_cus(int cus) {
+    static const int env = getenv("SBC_PERSIST_CUS") ? atoi(getenv("SBC_PERSIST_CUS")) : 0;      // A/B aid: overrides the setting
+    const int n = env > 0 ? env : g_persistent_cus.load(std::memory_order_relaxed);
+    return n > 0 && n < cus ? n : cus;
+}
+
 }  // namespace sbc
 
 struct sbc_plan {
@@ -211,6 +219,12 @@ static int run_eager(sbc_plan* plan, hipStream_t s) {
 extern "C" {
 
 int sbc_abi_version(void) { return SBC_ABI_VERSION; }
+
+int sbc_set_persistent_cus(int32_t n) {
+    SBC_REQUIRE(n >= 0, "sbc_set_persistent_cus: negative CU count %d", n);
+    sbc::g_persistent_cus.store(n, std::memory_order_relaxed);
+    return SBC_OK;
+}
 
 const char* sbc_last_error(void) { return g_err; }
 

