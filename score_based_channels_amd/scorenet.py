@@ -39,10 +39,10 @@ class BoundScore:
 DEFAULT_OVERLAP = False
 DEFAULT_FOLD_STATS = True       # not conv_mode 'f32' (the tile moments are written by the Winograd split kernels); +2 %
 DEFAULT_FUSE_PAIRS = True       # applies to the fp16-form modes only ('f16x2', 'f16w')
-# ResidualBlocks without resampling at 64x16 as ONE launch (SBC_OP_RES_BLOCK, csrc/conv_res.hip; conv_mode 'f16x2' only).  Measured
-# (DESIGN.md section 13): 264-280 us per block against 2 x 150 + 10 for the launches it replaces, 1 % of a ONE-stream step -- and
-# nothing with the default two sub-batch streams, because its one workgroup per CU holds the whole LDS while it runs.  Off by default.
-DEFAULT_FUSE_RES = False
+# ResidualBlocks without resampling at 64x16 as ONE launch (SBC_OP_RES_BLOCK, csrc/conv_res.hip; conv_mode 'f16x2' with fused pairs).
+# Measured: 264-280 us per block against 2 x 150 + 10 for the launches it replaces; 1.2 % of a one-stream step,
+# 0.6 % of the default two-stream step (three interleaved A/B pairs, sustained 1000 steps: 5.55 against 5.58 ms).
+DEFAULT_FUSE_RES = True
 
 
 class ScoreNet:
@@ -90,7 +90,7 @@ class ScoreNet:
         # fuse_pairs: RCU blocks (act -> conv -> act -> conv, + x; layers.py:126-134; shapes: plan.PAIR_SHAPES*) are ONE launch that keeps
         # the intermediate tensor in LDS (csrc/conv_pair.hip); the kernel reads the fp16 weight forms of 'f16x2' / 'f16w'
         self.fuse_pairs = (DEFAULT_FUSE_PAIRS if fuse_pairs is None else bool(fuse_pairs)) and conv_mode in ('f16x2', 'f16w')
-        self.fuse_res = (DEFAULT_FUSE_RES if fuse_res is None else bool(fuse_res)) and conv_mode == 'f16x2'
+        self.fuse_res = ((DEFAULT_FUSE_RES and self.fuse_pairs) if fuse_res is None else bool(fuse_res)) and conv_mode == 'f16x2'
         self.config = config
         m, d = config.model, config.data
         if str(m.normalization) != 'InstanceNorm++' or str(m.nonlinearity).lower() != 'elu':

@@ -31,7 +31,7 @@ def test_bench_line_contract_single_gpu():
     assert 'workload' in d['config'] and 'model' not in d['config'] and d['config']['nmse_finite']
     r = d['roofline']
     assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
-    assert len(r['kernels']) == 5 and any(k.startswith('conv_dp_kernel') for k in r['kernels']) and d['config']['streams_is_cli_default'] and d['config']['f16x2_range_flag'] == 0
+    assert len(r['kernels']) == 6 and any(k.startswith('conv_dp_kernel') for k in r['kernels']) and 'conv_res_kernel' in r['kernels'] and d['config']['streams_is_cli_default'] and d['config']['f16x2_range_flag'] == 0
     assert 0 < r['frac_algorithmic'] < r['frac'] and 0 < r['frac_algorithmic_step'] < 1
     assert d['exact_mode']['conv_mode'] == 'bf16x3' and d['exact_mode']['value'] > 0 and len(d['per_rank']['ms_per_step_by_rank']) == 1
     assert d['sustained_steps'] == 6 and d['sustained_ms_per_step'] > 0 and 'other_launch_mode' in d

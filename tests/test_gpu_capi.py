@@ -100,7 +100,7 @@ def test_langevin_plan_composed_from_c_records(weights64, mode, pairs, fold):
     ln = float(snr_to_noise(g['snr_db'], nt)[0])
     steps = noise.step_block(0, H.shape, n_steps)
     # reference run through the Python host
-    net = ScoreNet(cfg, conv_mode=mode, fold_stats=fold, fuse_pairs=pairs).cuda().load_state_dict(sd)
+    net = ScoreNet(cfg, conv_mode=mode, fold_stats=fold, fuse_pairs=pairs, fuse_res=False).cuda().load_state_dict(sd)
     ald = AldBatch(net, H, Pm, np.arange(B), np.arange(B), ln, levels=levels, step_noise=torch.from_numpy(steps))
     ald.set_init(torch.from_numpy(noise.init(H.shape)))
     Y = ald.synthesize_measurements(torch.from_numpy(noise.measurement(0, (B, npil, nr)))).clone()
