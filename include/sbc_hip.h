@@ -386,7 +386,7 @@ typedef struct sbc_score_desc {
                                     stage of that shape as one SBC_OP_CONV_POOL record (conv_mode 2 / 3); what the Python host does
                                     by default in those modes (scorenet.DEFAULT_FUSE_PAIRS) */
 #define SBC_SCORE_FUSE_RES   0x4 /* (ABI 12) the ResidualBlocks without resampling at 64 x 16 as one SBC_OP_RES_BLOCK record each (conv_mode 3);
-                                    off by default in the Python host (scorenet.DEFAULT_FUSE_RES) */
+                                    what the Python host does by default next to SBC_SCORE_FUSE_PAIRS (scorenet.DEFAULT_FUSE_RES) */
 typedef struct sbc_score sbc_score;
 int sbc_score_create(const sbc_score_desc* desc, const sbc_tensor_ref* tensors, int32_t n_tensors, sbc_score** out);
 int sbc_score_buffers(sbc_score* score, float** x, float** out, int64_t** labels);

@@ -74,7 +74,10 @@ def run_concurrently(batches, streams, n_steps, use_graph=False):
     # two (or more) streams: the persistent kernels take half the CUs each, so that both streams' launches are resident side by side
     # (include/sbc_hip.h: sbc_set_persistent_cus; -0.7 % per step, identical results)
     dev = batches[0].net.device
-    _lib.check(_lib.lib().sbc_set_persistent_cus(torch.cuda.get_device_properties(dev).multi_processor_count // 2))
+    # (eager launches only: replayed graphs of two host threads do not overlap at kernel level, DESIGN.md section 13, and would just run
+    # at half width)
+    if not use_graph:
+        _lib.check(_lib.lib().sbc_set_persistent_cus(torch.cuda.get_device_properties(dev).multi_processor_count // 2))
 
     def work(b, st):
         try:
