@@ -17,7 +17,11 @@
 //      ops.hip: inorm_from_moments_kernel), then the cross-channel "++" term: (mu, scale, shift) of norm2 for the lane's 4 channels;
 //   D  t -> norm2 -> ELU -> x act_scale -> split -> the SAME planes (every wave is through conv1: phase C has two barriers); the
 //      residual operand x is requested into the registers that held t;
-//   E  conv2, accumulating onto (x + bias2) / descale2 (a power of two: exact);
+//   E  conv2, accumulating onto (x + bias2) / descale2 (a power of two: exact).  (Adding x after the K loop instead -- one rounding at the
+//      output's magnitude, as the unfused records do -- was built and measured: the 16 float4 of x per lane do not fit beside the K loop's
+//      registers, and requested after it they cost a memory round trip per sample that nothing hides: 291-299 us against 264.
+//      Accumulating onto x rounds once per matrix instruction at the magnitude of x + conv2 instead of conv2: at most ~5 ulp of the
+//      OUTPUT when |x| >> |conv2| (tests/test_gpu_ops.py::test_res_block_is_calibrated_and_guarded), nothing measurable otherwise);
 //   F  out = acc x descale2, streamed out; with SBC_EPI_MOMENTS_OUT also the (mean, M2) of the output's 128-pixel tiles for the
 //      InstanceNorm++ that reads it next (tile.h) -- whole tiles per wave, no exchange; then the next sample's x is requested.
 // Five workgroup barriers per sample.  Everything is summed in an order that depends on the layer's shape only.
