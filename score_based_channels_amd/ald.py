@@ -125,6 +125,7 @@ class AldBatch:
         inc = _lib.sbc_op(kind=P.STEP_INC, B=1, out=_ptr(self.d_step))
         self.plan = _lib.Plan(list(self.bound.ops) + [lang, inc], keepalive=self)
         self.score_plan = _lib.Plan(list(self.bound.ops), keepalive=self)
+        self._lag_plan = None           # run_lagged: the records of the first ~45 % of a score evaluation
 
     def _stream(self):
         return torch.cuda.current_stream(self.net.device).cuda_stream
@@ -133,9 +134,10 @@ class AldBatch:
         """Destroy the two plans and drop their back-references: ``AldBatch`` <-> ``Plan(keepalive=self)`` is a reference
         cycle, so without this the slot buffers of a finished chunk (GBs) live until the cyclic collector runs.  The
         tensors already handed out (``X``, ``nmse_log()``) stay valid; the batch cannot run again."""
-        for pl in (self.plan, self.score_plan):
-            pl.close()
-            pl._keep = None
+        for pl in (self.plan, self.score_plan, self._lag_plan):
+            if pl is not None:
+                pl.close()
+                pl._keep = None
 
     # --- inputs -------------------------------------------------------------------------------------
     def set_init(self, X0):
@@ -180,6 +182,22 @@ class AldBatch:
         else:
             self.plan.run(self._stream(), n, False)
         self._done = done + n
+
+    def run_lagged(self, n_steps=None):
+        """``run(n_steps)`` for the SECOND of two concurrent sub-batch streams (``driver.run_concurrently``): before its first step the
+        stream evaluates the first part of the score network once for nothing (the records up to the middle of the low-resolution
+        stretch: they write activation slots only, which the real step rewrites), so it walks the schedule ~0.45 of a step behind the
+        first stream -- one stream is in the high-resolution, issue-bound part of a step while the other is in the dozens of small
+        low-resolution launches.  No event, no timer: the lag is made of the work itself, whatever the array size.  Measured
+        (DESIGN.md section 13.5): sustained two-stream step 5.47 -> 5.38 ms for lags of 0.38-0.52 of a step, nothing outside."""
+        if self.net.overlap:                       # (side-stream records must stay inside one plan)
+            return self.run(n_steps)
+        if self._lag_plan is None:
+            names = [op.name for op in self.net.score_plan(self.nt, self.nr).ops]
+            k = next((i for i, nm in enumerate(names) if nm.startswith('refine31.')), len(names) // 2)
+            self._lag_plan = _lib.Plan(list(self.bound.ops)[:k], keepalive=self)
+        self._lag_plan.run(self._stream(), 1, False)
+        self.run(n_steps)
 
     def steps_done(self):
         return self._done

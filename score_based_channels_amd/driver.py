@@ -4,6 +4,8 @@ them through ``AldBatch`` (in chunks that fit the device), gather the NMSE logs.
 Replaces the triple loop of ``test_score.py:118-171`` / ``tune_hparams_score.py:100-148`` (SNR point -> noise
 level -> inner step, one host synchronisation per step) by one asynchronous ``plan.run`` per chunk.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -76,17 +78,28 @@ def run_concurrently(batches, streams, n_steps, use_graph=False):
     dev = batches[0].net.device
     # (eager launches only: replayed graphs of two host threads do not overlap at kernel level, DESIGN.md section 13, and would just run
     # at half width)
-    if not use_graph:
+    # (... and small sub-batches only: at 10 200 trajectories per stream every launch fills the chip for a millisecond, the streams
+    # gain nothing from each other and half-width grids cost 20 % -- 74.6 against 62.1 ms per step of the 20 400-trajectory workload)
+    small = max(b.T * b.nt * b.nr for b in batches) <= 1 << 20
+    if not use_graph and small:
         _lib.check(_lib.lib().sbc_set_persistent_cus(torch.cuda.get_device_properties(dev).multi_processor_count // 2))
 
-    def work(b, st):
+    # ... and every second stream walks the schedule ~0.45 of a step behind (AldBatch.run_lagged: the lag is a throw-away evaluation of
+    # the first part of the network, 0.45 of a step once per call -- so only for runs long enough to forget it; the schedule of
+    # test_score is 6933 steps)
+    lag = not use_graph and small and n_steps >= 200 and not os.environ.get('SBC_NO_STREAM_LAG')
+
+    def work(b, st, k):
         try:
             torch.cuda.set_device(b.net.device)
             with torch.cuda.stream(st):
-                b.run(n_steps, use_graph=use_graph)
+                if lag and k % 2:
+                    b.run_lagged(n_steps)
+                else:
+                    b.run(n_steps, use_graph=use_graph)
         except BaseException as e:                        # surfaced in the caller's thread
             errors.append(e)
-    threads = [threading.Thread(target=work, args=(b, st)) for b, st in zip(batches, streams)]
+    threads = [threading.Thread(target=work, args=(b, st, k)) for k, (b, st) in enumerate(zip(batches, streams))]
     for t in threads:
         t.start()
     for t in threads:
