@@ -535,6 +535,31 @@ def test_concurrent_sub_batch_streams_do_not_change_results(net64):
         assert np.array_equal(log, out[0][0]) and np.array_equal(est, out[0][1]), (n, g)
 
 
+def test_lagging_second_stream_does_not_change_results(net64, monkeypatch):
+    """In runs of 200+ steps the second sub-batch stream starts with a throw-away evaluation of the first half of the network, so that
+    it walks the schedule behind the first one (``AldBatch.run_lagged``, driver.run_concurrently).  The throw-away records write
+    activation slots only: logs and estimates equal the one-stream run bit for bit (the threshold is lowered so that a 9-step run
+    takes the path)."""
+    import torch
+    from score_based_channels_amd import synth
+    from score_based_channels_amd.ald import snr_to_noise
+    from score_based_channels_amd.driver import run_trajectories
+    nch, nt, nr, npil = 12, 64, 16, 38
+    raw = synth.generate_channels('CDL-C', nch, nt, nr, 0.5, seed=43)
+    H = np.conj(np.transpose(raw / np.std(raw), (0, 2, 1))).astype(np.complex64)
+    Pm = np.conj(np.transpose(synth.qpsk_pilots(np.random.default_rng(44), nch, nt, npil), (0, 2, 1)))
+    snr = np.array([-5.0, 20.0])
+    idx = np.tile(np.arange(nch), len(snr))
+    ln = np.repeat(snr_to_noise(snr, nt), nch)
+    init = torch.randn(nch, nt, nr, dtype=torch.complex64, generator=torch.Generator().manual_seed(8))
+    args = (net64, H, Pm, idx, idx, ln, 3e-11, 0.01, [0, 1155, 2310], 3, 13, init)
+    one = run_trajectories(*args, n_streams=1, return_final=True)
+    monkeypatch.setenv('SBC_STREAM_LAG_MIN_STEPS', '1')
+    for _ in range(3):
+        two = run_trajectories(*args, n_streams=2, return_final=True)
+        assert np.array_equal(two[0], one[0]) and np.array_equal(two[1], one[1])
+
+
 @pytest.mark.parametrize('nt,nr', [(16, 64), (32, 32), (128, 8)])
 def test_forward_other_geometries_match_oracle(nt, nr, weights64):
     """Array shapes the reference goldens do not cover (wide images, square images, 8-column images): every level still
