@@ -304,7 +304,7 @@ __global__ __launch_bounds__(64 * NW, (C == 32 ? 3 : 2) * NW / 4) void conv_dp_k
 #ifdef DP_PROBE_NOSTORE   // timing probe (wrong results): everything but the output stores
             if (y.x == 123456.f)
 #endif
-            st_stream(p.out + o0 + DO(i), y);
+            st_out(p.out + o0 + DO(i), y);
         }
         DP_MARK(6);
     }

@@ -300,7 +300,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_pair_kernel(PairParams p) {
                     float4 y;
                     y.x = fmaf(acc[i][0], descale2, xr[i].x); y.y = fmaf(acc[i][1], descale2, xr[i].y);
                     y.z = fmaf(acc[i][2], descale2, xr[i].z); y.w = fmaf(acc[i][3], descale2, xr[i].w);
-                    st_stream(p.out + o0 + i * DO, y);
+                    st_out(p.out + o0 + i * DO, y);
                 }
             }
             PT_MARK(7);
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(192 * NW, 3) void conv_pair_p3_kernel(PairParams p)
                     float4 y;
                     y.x = fmaf(acc[i][0], descale2, xr[i].x); y.y = fmaf(acc[i][1], descale2, xr[i].y);
                     y.z = fmaf(acc[i][2], descale2, xr[i].z); y.w = fmaf(acc[i][3], descale2, xr[i].w);
-                    st_stream(p.out + o0 + i * DO, y);
+                    st_out(p.out + o0 + i * DO, y);
                 }
             }
         }
@@ -862,7 +862,7 @@ __global__ __launch_bounds__(64 * (8 + NWC)) void conv_pool_kernel(PairParams p)
                     }
                     y.x += rr.x; y.y += rr.y; y.z += rr.z; y.w += rr.w;
                 }
-                st_stream(p.out + o0 + i * DO, y);
+                st_out(p.out + o0 + i * DO, y);
             }
         }
     }

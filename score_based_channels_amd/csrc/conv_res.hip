@@ -318,7 +318,7 @@ __global__ __launch_bounds__(512, 2) void conv_res_kernel(ResParams p) {
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
             acc[i][0] *= descale2; acc[i][1] *= descale2; acc[i][2] *= descale2; acc[i][3] *= descale2;
-            st_stream(p.out + o0 + i * W * C, make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]));
+            st_out(p.out + o0 + i * W * C, make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]));
         }
         if (p.pm_out) {
 #pragma unroll

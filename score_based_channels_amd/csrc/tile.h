@@ -23,6 +23,12 @@ __device__ __forceinline__ float4 ld_stream(const float* p) {
     return make_float4(v.x, v.y, v.z, v.w);
 #endif
 }
+// Output store of the direct kernels (conv_pair, conv_pool, conv_dp, conv_res): a wave writes 64 of a pixel's 128 or 256 bytes, the
+// wave with the other output channels the rest a little later.  As plain (cached) stores the pieces meet in L2 and reach memory as
+// whole lines; as non-temporal stores they did not: WRITE_SIZE 308 MB for a 223 MB tensor (pair), 279 (CRP stage), 276 (ResidualBlock),
+// 144 for 111 (64 -> 64) -- 218 / 218 / 229 / 109 MB now, and the sustained two-stream step 5.42 -> 5.21 ms.  (The Winograd kernels
+// write whole lines per thread group and keep st_stream: with plain stores everywhere the step was 5.32-5.37.)
+__device__ __forceinline__ void st_out(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ void st_stream(float* p, float4 v) {
 #ifdef SBC_NO_STREAM
     *reinterpret_cast<float4*>(p) = v;
