@@ -12,11 +12,15 @@
 
 namespace sbc {
 
-// Streaming (non-temporal) 16-byte accesses for activations: each element is touched once per kernel, so it
-// should not displace the L1/L2-resident weight fragments the MFMA loops of co-resident workgroups re-read.
+// 16-byte accesses for activations.  Rounds 1-3 made all of them non-temporal ("touched once per kernel").  Round 4 measured it
+// (DESIGN.md section 13.6): a tensor is read by the NEXT launch, usually out of L2 / the 256 MB MALL, so
+//   * loads are plain (cached) loads now: sustained two-stream step 5.05 -> 5.00 ms (-DSBC_NT_LD restores the hint);
+//   * stores of the kernels that write whole 128-byte lines per thread group (Winograd, statistics, ...) stay non-temporal (plain:
+//     5.05 -> 5.05, and with the loads plain as well 5.32-5.37 against 5.21 in the first A/B);
+//   * stores of the direct kernels, which write lines in two pieces, are plain: st_out below.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ld_stream(const float* p) {
-#ifdef SBC_NO_STREAM
+#ifndef SBC_NT_LD
     return *reinterpret_cast<const float4*>(p);
 #else
     const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
@@ -30,7 +34,7 @@ __device__ __forceinline__ float4 ld_stream(const float* p) {
 // write whole lines per thread group and keep st_stream: with plain stores everywhere the step was 5.32-5.37.)
 __device__ __forceinline__ void st_out(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ void st_stream(float* p, float4 v) {
-#ifdef SBC_NO_STREAM
+#if defined(SBC_NO_STREAM) || defined(SBC_PLAIN_ST)
     *reinterpret_cast<float4*>(p) = v;
 #else
     f32x4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
