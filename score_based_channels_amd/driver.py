@@ -79,8 +79,9 @@ def run_concurrently(batches, streams, n_steps, use_graph=False):
     # (eager launches only: replayed graphs of two host threads do not overlap at kernel level, DESIGN.md section 13, and would just run
     # at half width)
     # (... and small sub-batches only: at 10 200 trajectories per stream every launch fills the chip for a millisecond, the streams
-    # gain nothing from each other and half-width grids cost 20 % -- 74.6 against 62.1 ms per step of the 20 400-trajectory workload)
-    small = max(b.T * b.nt * b.nr for b in batches) <= 1 << 20
+    # gain nothing from each other and half-width grids cost 20 % -- 74.6 against 62.1 ms per step of the 20 400-trajectory workload;
+    # sustained gain +2.3 % at 1275 trajectories per stream, +0.9 % at 1700, +0.5 % at 2550 where a 20-step segment already loses 1 %)
+    small = max(b.T * b.nt * b.nr for b in batches) <= int(os.environ.get('SBC_STREAM_SMALL_PX', 1 << 21))   # (the variable: A/B aid)
     if not use_graph and small:
         _lib.check(_lib.lib().sbc_set_persistent_cus(torch.cuda.get_device_properties(dev).multi_processor_count // 2))
 
