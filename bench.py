@@ -38,7 +38,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3       # v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2516.6     # v_mfma_f32_32x32x16_bf16 / _f16 dense ("~2.5 PF"), 16x the fp32 MFMA rate
 PEAK_HBM_TBS = 8.0                 # HBM3E spec (6.3 TB/s achievable by a float4 copy)
 STEPS_PER_CHANNEL = 2311 * 3
-PROFILE_ROUND = 'r04'
+PROFILE_ROUND = 'r05'
 REFERENCE_CPU_FILE = os.path.join(ROOT, 'profiles', PROFILE_ROUND + '_reference_cpu.json')   # written by tools/time_reference_cpu.py
 
 
@@ -82,20 +82,29 @@ def _cpu_worker(job):
         return time.perf_counter() - t0
 
 
-def cpu_baseline(n_steps=20, per_worker=8):
+def cpu_baseline(n_steps=10, per_worker=8):
     """The numpy oracle (oracle/, a port of the reference loop) timed on this host's cores: W single-threaded worker
     processes, each running `n_steps` Langevin steps of its own `per_worker` channels (trajectories are independent, so
     this is how the reference's CPU path would be spread over a multi-core host).  Called BEFORE anything touches the
     GPU: the workers are spawned processes.  Reported, never used by the GPU path."""
     import multiprocessing as mp
-    W = max(1, min(64, (os.cpu_count() or 2) // 2))
+    # one worker per PHYSICAL core (logical / 2).  Measured on the GPU box's host (256 logical cores), round 5: 64 workers 0.087
+    # channels/s, 256 workers (every logical core) 0.051 -- hyper-threads and memory bandwidth make the full count slower, so
+    # "all host cores" is read as all physical cores; SBC_CPU_BASELINE_WORKERS overrides
+    W = max(1, (os.cpu_count() or 2) // 2)
+    try:                                                                    # ... that the host's free memory can carry (~0.6 GB per worker)
+        import psutil
+        W = max(1, min(W, int(psutil.virtual_memory().available / 0.8e9)))
+    except ImportError:
+        pass
+    W = int(os.environ.get('SBC_CPU_BASELINE_WORKERS', W))
     t0 = time.perf_counter()
     with mp.get_context('spawn').Pool(W) as pool:
         times = pool.map(_cpu_worker, [(w, per_worker, n_steps) for w in range(W)])
     wall = time.perf_counter() - t0
     dt = max(times) / n_steps                                               # all workers run concurrently
     n = W * per_worker
-    return {'value': n / (STEPS_PER_CHANNEL * dt), 'unit': 'channels/s', 'cores': W, 'kind': 'port',
+    return {'value': n / (STEPS_PER_CHANNEL * dt), 'unit': 'channels/s', 'cores': W, 'host_logical_cores': os.cpu_count(), 'kind': 'port',
             'sample': '%d Langevin steps of %d channels with the numpy oracle on %d single-threaded worker processes '
                       '(%.2f s/step for all of them, %.0f s wall including start-up), scaled to the 6933-step '
                       'schedule' % (n_steps, n, W, dt, wall)}
@@ -472,12 +481,40 @@ def main():
             a.close()
         del s_alds
 
+    # ---------------------------------------------------------------- what ONE rank sees when test_score's own 1700 trajectories are
+    # strong-sharded over 2 / 4 / 8 GPUs (shard.my_block of the flattened SNR x channel list: 850 / 425 / 213 trajectories): the
+    # only strong-scaling evidence a one-GPU box can give for BASELINE configs[1] -- an upper bound on the 2/4/8-GPU rate of that
+    # workload (the final gather is a few ms once per run), not a measured scaling curve
+    strong_small = None
+    if world == 1 and not args.no_strong and not big and not args.full_schedule:
+        strong_small = {'what': 'ms per Langevin step of rank 0\'s block when the %d trajectories of the default test_score run '
+                                '(BASELINE configs[1]) are sharded over W ranks (shard.my_block), timed on this ONE GPU with the CLI '
+                                'defaults; channels_per_s_if_all_ranks_alike = %d / (6933 x s_per_step): a projection, not a '
+                                'multi-GPU measurement' % (T, T), 'by_world_size': {}}
+        for w in (2, 4, 8):
+            lo, hi = shard.my_block(T, 0, w)
+            sel = np.arange(lo, hi)
+            q_alds, q_streams = make_batches(H, Pm, idx[sel], idx[sel], ln[sel], np.full(len(sel), 3e-11), np.full(len(sel), 0.01),
+                                             sel, init, n_streams)
+            Kq = max(5, min(K, 30))
+            dtq = timed(q_alds, q_streams, Kq, use_graph, 3)
+            for a in q_alds:
+                a.close()
+            del q_alds
+            strong_small['by_world_size'][str(w)] = {
+                'trajectories_per_gpu': int(hi - lo), 'ms_per_step': dtq / Kq * 1e3, 'steps': Kq,
+                'channels_per_s_this_gpu': (hi - lo) / (STEPS_PER_CHANNEL * dtq / Kq),
+                'channels_per_s_if_all_ranks_alike': T / (STEPS_PER_CHANNEL * dtq / Kq),
+                'efficiency_vs_one_gpu': (dt / K) / (w * dtq / Kq)}
+
     if rank == 0:
         ms_per_step = dt / K * 1e3
         value = world * T / (STEPS_PER_CHANNEL * dt / K)
         flops_fwd = P.count_conv_flops(net.score_plan(nt, nr)) * T          # conv FLOPs of one step on this GPU
-        dtype = {'f32': 'f32 (v_mfma_f32_32x32x2_f32)', 'bf16x3': 'f32 (products as exact 3-term bf16 splits on the bf16 matrix cores, fp32 accumulate)',
-                 'f16x2': 'f32 (operands as two fp16 terms of a power-of-two-scaled value, hh + hl + lh on the fp16 matrix cores, fp32 accumulate)',
+        dtype = {'f32': 'f32 (v_mfma_f32_32x32x2_f32)', 'bf16x3': 'bf16x3 (every fp32 operand as an exact 3-term bf16 split, 6 bf16 MFMAs per product block, fp32 accumulate: fp32-exact)',
+                 'f16x2': 'f16x2 (every fp32 operand as two fp16 terms of a power-of-two-scaled value = 22-bit significand, hh + hl + lh on the fp16 '
+                          'matrix cores, fp32 accumulate; fp32-class by the gate tests/test_gpu_parity.py::test_f16x2_is_fp32_class and held to every '
+                          'reference golden at the north_star tolerance; unconditional fp32-exact mode: exact_mode.value)',
                  'f16w': 'f16 weights x f16-rounded activations on the fp16 matrix cores, fp32 accumulate, fp32 tensors in HBM'}
         out = {
             'metric': 'channels/s full ALD inference, %s Nt%dxNr%d' % ('CDL-C' if not big else 'ULA', nt, nr),
@@ -516,6 +553,8 @@ def main():
                                         'value': world * T / (STEPS_PER_CHANNEL * other / K)}
         if strong is not None:
             out['strong'] = strong
+        if strong_small is not None:
+            out['strong_small'] = strong_small
         if exact is not None:
             out['exact_mode'] = exact
         out['per_rank'] = rank_times
@@ -567,62 +606,52 @@ def main():
                     e.update(executed_mfma_tflops=ach * ratio, mfma_peak_tflops=PEAK_BF16_MFMA_TFLOPS,
                              mfma_busy=ach * ratio / PEAK_BF16_MFMA_TFLOPS)
                 entries[tag] = e
-            # Top-level entry: the LAYER CLASS that dominates the step, the 3x3 ngf -> ngf convolutions at full resolution (the
-            # class rounds 1-2 reported as one kernel).  Since round 3 two kernels run it -- the unfused Winograd launches and the
-            # fused RCU-pair launches (two convolutions each) -- so the entry aggregates both: algorithmic FLOPs (bytes) of the
-            # class per step / its time per step; executed matrix FLOPs summed kernel by kernel.
-            cls = [t for t in (P.TAG_CONV_TOP, P.TAG_PAIR_TOP, P.TAG_POOL_TOP, P.TAG_RES_TOP) if t in entries]
-            t_cls = sum(entries[t]['us_per_launch'] * entries[t]['launches_per_step'] for t in cls) * 1e-6
-            n_launch = sum(entries[t]['launches_per_step'] for t in cls)
-            fl_cls = sum(klass[t]['flops_per_step'] for t in cls)
-            by_cls = sum(klass[t]['bytes_per_step'] for t in cls)
-            ex_cls = sum(entries[t]['executed_mfma_tflops'] * 1e12 * entries[t]['us_per_launch'] * 1e-6 * entries[t]['launches_per_step']
-                         for t in cls)
-            n_convs = sum((2 if t in (P.TAG_PAIR_TOP, P.TAG_RES_TOP) else 1) * entries[t]['launches_per_step'] for t in cls)
-            tfile = os.path.join(ROOT, 'profiles', '%s_traffic_%s.json' % (PROFILE_ROUND, args.workload))
+            # Top-level entry: the DOMINANT KERNEL -- the tagged class with the largest share of a one-stream step (round 5; rounds
+            # 3-4 aggregated the four full-resolution 32 -> 32 classes here and called the busy fraction `frac`).  SURVEY section 8(d):
+            # achieved = ALGORITHMIC (direct-convolution) FLOPs of one launch / its average duration; peak = the dense fp16 MFMA
+            # peak; frac = achieved / peak.  How busy the matrix pipe is (executed instructions) is `mfma_busy`, next to it.
+            dom = max(entries, key=lambda t: entries[t]['share_of_one_stream_step'])
+            cls = [dom]
+            t_cls = entries[dom]['us_per_launch'] * 1e-6
+            fl_cls = klass[dom]['flops_per_step'] / klass[dom]['launches_per_step']
+            by_cls = klass[dom]['bytes_per_step'] / klass[dom]['launches_per_step']
             traffic, tsrc = None, None
-            if os.path.exists(tfile):
+            for rnd in (PROFILE_ROUND, 'r04'):
+                tfile = os.path.join(ROOT, 'profiles', '%s_traffic_%s.json' % (rnd, args.workload))
+                if not os.path.exists(tfile):
+                    continue
                 with open(tfile) as f:
                     tj = json.load(f)
                 if (tj.get('trajectories_per_launch') == T and tj.get('conv_mode') == conv_mode
-                        and all(entries[t]['kernel'] in tj.get('kernels', {}) for t in cls)):
-                    traffic = sum(tj['kernels'][entries[t]['kernel']]['hbm_bytes_per_launch'] * entries[t]['launches_per_step']
-                                  for t in cls) / n_launch
+                        and entries[dom]['kernel'] in tj.get('kernels', {})):
+                    traffic = tj['kernels'][entries[dom]['kernel']]['hbm_bytes_per_launch']
                     tsrc = 'profiles/' + os.path.basename(tfile)
+                    break
             hbm_bound = conv_mode == 'f16w'
             mpeak = PEAK_F32_MFMA_TFLOPS if conv_mode == 'f32' else PEAK_BF16_MFMA_TFLOPS
-            note = ('dominant layer class: the %d 3x3 32->32 convolutions at %dx%d of every step (%.0f %% of a one-stream step), run by '
-                    '%s.  Each kernel is timed by hipEvents on the launch stream in a one-stream eager segment AFTER the timed region; '
-                    'profiles/%s_kernel_stats_%s_steps10.csv is rocprofv3 --kernel-trace --stats of the same one-stream command.  '
-                    % (n_convs, nt, nr, 100 * t_cls * 1e3 / one_stream_ms,
-                       ' + '.join('%d launches of %s (avg %.1f us)' % (entries[t]['launches_per_step'], entries[t]['kernel'],
-                                                                       entries[t]['us_per_launch']) for t in cls),
-                       PROFILE_ROUND, args.workload))
+            note = ('dominant kernel: %s -- %s; %d launches per step, avg %.1f us, %.0f %% of a one-stream step.  Timed by hipEvents on the '
+                    'launch stream in a one-stream eager segment AFTER the timed region; profiles/%s_kernel_stats_%s_steps10.csv is '
+                    'rocprofv3 --kernel-trace --stats of the same one-stream command.  '
+                    % (entries[dom]['kernel'], what[dom], entries[dom]['launches_per_step'], entries[dom]['us_per_launch'],
+                       100 * entries[dom]['share_of_one_stream_step'], PROFILE_ROUND, args.workload))
             if hbm_bound:
                 rf = {'bound': 'hbm', 'achieved': by_cls / t_cls / 1e9, 'peak': PEAK_HBM_TBS * 1e3, 'unit': 'GB/s',
                       'frac': by_cls / t_cls / 1e12 / PEAK_HBM_TBS, 'traffic': traffic,
-                      'kernel': note + 'achieved = algorithmic bytes of the class per step (fp32 input + output + residual operands of every '
-                                       'launch; a fused pair moves its input and its output only) / its time per step, against the 8 TB/s '
-                                       'HBM3E peak (6.3 TB/s achievable); traffic = PMC bytes per launch averaged over the class'}
+                      'kernel': note + 'achieved = algorithmic bytes of one launch (fp32 input + output + residual operands; a fused pair '
+                                       'moves its input and its output only) / its average duration, against the 8 TB/s HBM3E peak '
+                                       '(6.3 TB/s achievable); traffic = PMC bytes per launch'}
             else:
-                rf = {'bound': 'mfma', 'achieved': fl_cls / t_cls / 1e12, 'peak': mpeak * fl_cls / ex_cls, 'unit': 'TFLOP/s',
-                      'frac': ex_cls / t_cls / 1e12 / mpeak, 'traffic': traffic,
-                      'executed_mfma_tflops': ex_cls / t_cls / 1e12, 'mfma_peak_tflops': mpeak,
-                      'kernel': note + 'achieved = algorithmic (direct-convolution) FLOPs of the class per step / its time per step; peak = '
-                                       'the algorithmic rate at which the matrix pipe would be 100 %% busy with the algorithms the class runs '
-                                       '(dense f16 MFMA peak %.1f TFLOP/s x algorithmic / executed FLOPs: Winograd F(2x2,3x3) executes 16/36 of '
-                                       'the products, the direct fused pair all of them plus its halo rows, each as 3 fp16 MFMAs in f16x2), '
-                                       'so frac IS the busy fraction of the matrix cores over the class; traffic = PMC bytes per launch '
-                                       'averaged over the class' % mpeak}
-            # SURVEY section 8(d)'s fraction, next to the busy fraction: ALGORITHMIC (direct-convolution) FLOPs / time / dense peak of
-            # the matrix cores -- for the class above and for the whole step (= channels/s x 5.6904e12 / (n_gpus x peak))
-            rf['frac_algorithmic'] = fl_cls / t_cls / 1e12 / mpeak
-            rf['frac_algorithmic_step'] = flops_fwd / (ms_per_step * 1e-3) / 1e12 / mpeak
-            rf['frac_note'] = ('frac = executed matrix-instruction FLOPs / time / %.1f TFLOP/s (how busy the matrix pipe is; agrees with the '
-                               'PMC counter); frac_algorithmic = direct-convolution FLOPs of the class / time / the same peak (what SURVEY '
-                               'section 8(d) defines: Winograd F(2x2,3x3) needs 16/36 of those multiplications but each is three fp16 '
-                               'MFMAs in f16x2, so the two differ by 1.33x there and by 3.4x on the direct fused kernels); '
-                               'frac_algorithmic_step = the whole Langevin step the headline times' % mpeak)
+                rf = {'bound': 'mfma', 'achieved': fl_cls / t_cls / 1e12, 'peak': mpeak, 'unit': 'TFLOP/s',
+                      'frac': fl_cls / t_cls / 1e12 / mpeak, 'traffic': traffic,
+                      'mfma_busy': entries[dom]['mfma_busy'], 'executed_mfma_tflops': entries[dom]['executed_mfma_tflops'],
+                      'kernel': note + 'achieved = algorithmic (direct-convolution, 2 x MACs) FLOPs of one launch / its average duration; '
+                                       'peak = dense f16 MFMA peak; frac = achieved / peak (SURVEY section 8(d)).  mfma_busy = EXECUTED '
+                                       'matrix-instruction FLOPs / time / peak: in f16x2 every product is 3 fp16 MFMAs (hh + hl + lh), a direct '
+                                       'fused pair also computes its halo rows (x 18/16), Winograd F(2x2,3x3) executes 16/36 of the products'}
+            # the whole Langevin step the headline times, by the same definition (= channels/s x 5.6904e12 / (n_gpus x peak))
+            rf['frac_step'] = flops_fwd / (ms_per_step * 1e-3) / 1e12 / mpeak
+            rf['frac_note'] = ('frac, frac_step and kernels[*].frac_algorithmic: direct-convolution FLOPs / time / %.1f TFLOP/s; mfma_busy: '
+                               'executed matrix-instruction FLOPs / time / the same peak (agrees with SQ_VALU_MFMA_BUSY_CYCLES)' % mpeak)
             # (outside conv_mode f16x2 both half-resolution classes run the same Winograd kernel: keep their entries apart)
             key = {t: names[t] if list(names[u] for u in entries).count(names[t]) == 1 else '%s [class %d]' % (names[t], t) for t in entries}
             rf['kernels'] = {key[t]: {k: v for k, v in entries[t].items() if k != 'kernel'} for t in entries}

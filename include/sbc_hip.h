@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SBC_ABI_VERSION 12
+#define SBC_ABI_VERSION 13
 
 typedef enum sbc_status {
     SBC_OK = 0,
@@ -203,6 +203,11 @@ typedef struct sbc_op {
     /* --- ABI 12 --- */
     const void* bias2;           /* RES_BLOCK: bias of the second convolution [cout] */
     const void* norm2;           /* RES_BLOCK: alpha | gamma | beta of the second InstanceNorm++ [3][cout] */
+    /* --- ABI 13 --- */
+    const void* weight2_wino_split; /* CONV_PAIR / RES_BLOCK: the second convolution's Winograd f16x2 form, or NULL.  No kernel of a fused
+                                    record reads it (nor `weight_wino_split` there): sbc_f16x2_calibrate writes the layer's activation
+                                    scale into the trailer of EVERY form it is handed, so that a host which shares one weight buffer
+                                    between array sizes -- fused at one, unfused Winograd at another -- finds the same scale in both */
 } sbc_op;
 
 /* Training operators.  The reverse of a forward record `y = epi(conv(pro(x)))` is built by the host
@@ -312,7 +317,8 @@ int sbc_abi_version(void);
 /* (ABI 12) The persistent kernels (SBC_OP_CONV_PAIR / CONV_POOL / RES_BLOCK and the direct kernel behind SBC_OP_CONV) size their grids for
  * `n` CUs instead of all of them; 0 = all (the default).  A host that keeps TWO independent launch streams busy sets half the device's
  * CUs, so that the two streams' persistent launches are resident side by side instead of one after the other (measured: -0.7 % per
- * two-stream Langevin step; results do not depend on it).  Process-wide; takes effect for launches issued after the call. */
+ * two-stream Langevin step; results do not depend on it).  Process-wide DEFAULT; takes effect for launches issued after the call.
+ * Prefer sbc_plan_set_persistent_cus (below): a plan's own width does not race with other threads, handles or devices. */
 int sbc_set_persistent_cus(int32_t n);
 const char* sbc_last_error(void);
 /* number of visible HIP devices, or a negative sbc_status (does not initialise a device context) */
@@ -330,6 +336,11 @@ int sbc_op_launch(const sbc_op* op, void* stream);
  * device tables through the device step counter. */
 int sbc_plan_create(const sbc_op* ops, int32_t n_ops, sbc_plan** out_plan);
 int sbc_plan_run(sbc_plan* plan, void* stream, int32_t n_iters, int32_t use_graph);
+/* (ABI 13) Grid width, in CUs, of the persistent kernels of THIS plan's launches (0 = the process default above).  The setting is a
+ * field of the plan, applied on the calling host thread for the duration of sbc_plan_run (and baked into a captured graph; changing
+ * it drops the captured graph): plans driven from different host threads, for different streams or devices, are independent of each
+ * other -- the library holds no mutable state shared between handles on this path.  Results never depend on it. */
+int sbc_plan_set_persistent_cus(sbc_plan* plan, int32_t n);
 void sbc_plan_destroy(sbc_plan* plan);
 
 /* Per-kernel timing for the roofline report: while enabled (tag >= 0), every launch of an op whose

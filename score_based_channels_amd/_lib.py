@@ -8,10 +8,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SBC_LIB_PATH') or os.path.join(_HERE, 'libsbc_hip.so')   # env override: A/B builds (tools/)
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 EXPORTS = ('sbc_abi_version', 'sbc_set_persistent_cus', 'sbc_last_error', 'sbc_device_count', 'sbc_op_launch', 'sbc_plan_create',
-           'sbc_plan_run', 'sbc_plan_destroy', 'sbc_plan_profile', 'sbc_plan_profile_read',
+           'sbc_plan_run', 'sbc_plan_set_persistent_cus', 'sbc_plan_destroy', 'sbc_plan_profile', 'sbc_plan_profile_read',
            'sbc_pack_conv_weight', 'sbc_pack_conv_weight_winograd',
            'sbc_pack_conv_weight_split', 'sbc_pack_conv_weight_winograd_split',
            'sbc_pack_conv_weight_f16', 'sbc_pack_conv_weight_winograd_f16',
@@ -38,7 +38,8 @@ class sbc_op(C.Structure):
                 ('grad', C.c_void_p), ('aux', C.c_void_p), ('wgrad', C.c_void_p), ('bgrad', C.c_void_p),
                 ('weight2_split', C.c_void_p),
                 ('calib', C.c_void_p),                # ABI 11: NULL (set by sbc_f16x2_calibrate on its own copies)
-                ('bias2', C.c_void_p), ('norm2', C.c_void_p)]   # ABI 12: RES_BLOCK (second convolution's bias, second norm's alpha|gamma|beta)
+                ('bias2', C.c_void_p), ('norm2', C.c_void_p),   # ABI 12: RES_BLOCK (second convolution's bias, second norm's alpha|gamma|beta)
+                ('weight2_wino_split', C.c_void_p)]             # ABI 13: calibration only (every form of a layer gets the same scale)
 
 
 class sbc_endconv(C.Structure):
@@ -92,6 +93,7 @@ def lib():
     h.sbc_op_launch.argtypes = [C.POINTER(sbc_op), C.c_void_p]
     h.sbc_plan_create.argtypes = [C.POINTER(sbc_op), C.c_int32, C.POINTER(C.c_void_p)]
     h.sbc_plan_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+    h.sbc_plan_set_persistent_cus.argtypes = [C.c_void_p, C.c_int32]
     h.sbc_plan_destroy.argtypes = [C.c_void_p]
     h.sbc_plan_destroy.restype = None
     h.sbc_plan_profile.argtypes = [C.c_void_p, C.c_int32]
@@ -194,6 +196,10 @@ class Plan:
 
     def run(self, stream, n_iters=1, use_graph=False):
         check(lib().sbc_plan_run(self._h, C.c_void_p(stream), int(n_iters), 1 if use_graph else 0))
+
+    def set_persistent_cus(self, n):
+        """Grid width (CUs) of this plan's persistent kernels; 0 = the process default (``sbc_plan_set_persistent_cus``)."""
+        check(lib().sbc_plan_set_persistent_cus(self._h, int(n)))
 
     def profile(self, tag):
         check(lib().sbc_plan_profile(self._h, int(tag)))

@@ -196,8 +196,17 @@ class AldBatch:
             names = [op.name for op in self.net.score_plan(self.nt, self.nr).ops]
             k = next((i for i, nm in enumerate(names) if nm.startswith('refine31.')), len(names) // 2)
             self._lag_plan = _lib.Plan(list(self.bound.ops)[:k], keepalive=self)
+            self._lag_plan.set_persistent_cus(getattr(self, '_persist', 0))
         self._lag_plan.run(self._stream(), 1, False)
         self.run(n_steps)
+
+    def set_persistent_cus(self, n):
+        """Grid width (CUs) of the persistent kernels of THIS batch's launches, 0 = all CUs (``sbc_plan_set_persistent_cus``: a
+        field of the batch's plans, not process state -- batches on other threads / streams / devices are unaffected)."""
+        self._persist = int(n)
+        for pl in (self.plan, self.score_plan, self._lag_plan):
+            if pl is not None:
+                pl.set_persistent_cus(n)
 
     def steps_done(self):
         return self._done

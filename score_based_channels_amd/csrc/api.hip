@@ -115,12 +115,20 @@ static int dispatch(const sbc_op& op, const void* ext, hipStream_t s) {
     }
 }
 
-static std::atomic<int> g_persistent_cus{0};           // sbc_set_persistent_cus
+static std::atomic<int> g_persistent_cus{0};           // sbc_set_persistent_cus: the process default
+// sbc_plan_set_persistent_cus: while a plan with its own setting runs (or is captured) on this host thread, that setting wins --
+// two plans driven from two threads, or two handles on two devices, do not see each other's width (ABI 13)
+static thread_local int tls_persistent_cus = 0;
 int persistent_cus(int cus) {
     static const int env = getenv("SBC_PERSIST_CUS") ? atoi(getenv("SBC_PERSIST_CUS")) : 0;      // A/B aid: overrides the setting
-    const int n = env > 0 ? env : g_persistent_cus.load(std::memory_order_relaxed);
+    const int n = env > 0 ? env : tls_persistent_cus > 0 ? tls_persistent_cus : g_persistent_cus.load(std::memory_order_relaxed);
     return n > 0 && n < cus ? n : cus;
 }
+struct PersistentCusScope {                              // RAII: a plan's width for the duration of its launches on this thread
+    int saved;
+    explicit PersistentCusScope(int n) : saved(tls_persistent_cus) { if (n > 0) tls_persistent_cus = n; }
+    ~PersistentCusScope() { tls_persistent_cus = saved; }
+};
 
 }  // namespace sbc
 
@@ -138,6 +146,7 @@ struct sbc_plan {
     size_t ev_used = 0;
     double prof_ms = 0.0;
     int64_t prof_n = 0;
+    int persistent_cus = 0;              // sbc_plan_set_persistent_cus (0: the process default)
 };
 
 using namespace sbc;
@@ -322,11 +331,16 @@ int sbc_f16x2_calibrate(const sbc_op* ops, int32_t n_ops, void* stream) {
         const sbc_op& o = ops[i];
         const float s1 = scale_for(amax[slot_of[i]]), s2 = scale_for(amax[slot_of[i] + 1]);
         int rc = SBC_OK;
+        // (every form of a layer the record carries gets the scale, read by this record's kernel or not: a weight buffer shared
+        // between array sizes must not hold two scales for one layer -- fused direct form here, unfused Winograd form there)
         if (o.kind == SBC_OP_CONV_PAIR || o.kind == SBC_OP_RES_BLOCK) {
             rc = set_trailer(o.weight_split, 9, o.cin, o.cout, s1, amax[slot_of[i]]);
+            if (!rc) rc = set_trailer(o.weight_wino_split, 16, o.cin, o.cout, s1, amax[slot_of[i]]);
             if (!rc) rc = set_trailer(o.weight2_split, 9, o.cout, o.cout, s2, amax[slot_of[i] + 1]);
+            if (!rc) rc = set_trailer(o.weight2_wino_split, 16, o.cout, o.cout, s2, amax[slot_of[i] + 1]);
         } else if (o.kind == SBC_OP_CONV_POOL) {
             rc = set_trailer(o.weight_split, 9, o.cin, o.cout, s1, amax[slot_of[i]]);
+            if (!rc) rc = set_trailer(o.weight_wino_split, 16, o.cin, o.cout, s1, amax[slot_of[i]]);
         } else {
             rc = set_trailer(o.weight_split, o.ksize * o.ksize, o.cin, o.cout, s1, amax[slot_of[i]]);
             if (!rc && o.ksize == 3 && o.dil == 1) rc = set_trailer(o.weight_wino_split, 16, o.cin, o.cout, s1, amax[slot_of[i]]);
@@ -375,6 +389,7 @@ int sbc_plan_create(const sbc_op* ops, int32_t n_ops, sbc_plan** out_plan) {
 int sbc_plan_run(sbc_plan* plan, void* stream, int32_t n_iters, int32_t use_graph) {
     SBC_REQUIRE(plan && n_iters >= 0, "sbc_plan_run: bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    PersistentCusScope width(plan->persistent_cus);
     if (!use_graph || plan->prof_tag >= 0) {
         for (int it = 0; it < n_iters; ++it) {
             const int rc = run_eager(plan, s);
@@ -396,6 +411,16 @@ int sbc_plan_run(sbc_plan* plan, void* stream, int32_t n_iters, int32_t use_grap
         plan->graph_stream = s;
     }
     for (int it = 0; it < n_iters; ++it) SBC_CHECK_HIP(hipGraphLaunch(plan->exec, s));
+    return SBC_OK;
+}
+
+int sbc_plan_set_persistent_cus(sbc_plan* plan, int32_t n) {
+    SBC_REQUIRE(plan && n >= 0, "sbc_plan_set_persistent_cus: bad arguments");
+    if (n != plan->persistent_cus && plan->exec) {       // a captured graph has the old grids baked in
+        (void)hipGraphExecDestroy(plan->exec);
+        plan->exec = nullptr;
+    }
+    plan->persistent_cus = n;
     return SBC_OK;
 }
 

@@ -958,6 +958,8 @@ int launch_conv_pool(const sbc_op& op, hipStream_t stream, bool dry) {
     SBC_REQUIRE(!op.bias && !(op.flags & (SBC_PRO_NORM | SBC_EPI_POOL | SBC_EPI_UP | SBC_EPI_ELUGRAD | SBC_EPI_MOMENTS_OUT)),
                 "conv_pool: no bias, prologue = max pool [+ ELU], epilogue = residual operands only");
     SBC_REQUIRE(!op.res2 || op.res1, "conv_pool: res2 only together with res1");
+    // (persistent workgroups read the 3-row halos of neighbouring tiles by LDS-DMA while other workgroups store: no aliasing)
+    SBC_REQUIRE(op.out != op.in && op.out != op.res1 && op.out != op.res2, "conv_pool: out must not alias in / res1 / res2");
     SBC_REQUIRE((long)op.B * op.H * op.W * op.cin <= 0x7fffffffL, "conv_pool: tensor exceeds the 32-bit element index");
     PairParams p{};
     p.in = (const float*)op.in; p.out = (float*)op.out;
@@ -982,6 +984,7 @@ int launch_conv_pair(const sbc_op& op, hipStream_t stream, bool dry) {
     SBC_REQUIRE(op.B > 0 && op.H > 0 && op.W > 0, "conv_pair: bad shape B=%d H=%d W=%d", op.B, op.H, op.W);
     const bool x2 = (op.flags & SBC_CONV_F16X2) != 0, f16w = (op.flags & SBC_CONV_F16W) != 0;
     SBC_REQUIRE(x2 != f16w, "conv_pair: exactly one of SBC_CONV_F16X2 / SBC_CONV_F16W (the forms of weight_split it reads)");
+    SBC_REQUIRE(op.out != op.in, "conv_pair: out must not alias in (tiles read their neighbours' halo rows while others store)");
     SBC_REQUIRE((long)op.B * op.H * op.W * op.cin <= 0x7fffffffL, "conv_pair: tensor exceeds the 32-bit element index");
     PairParams p{};
     p.in = (const float*)op.in; p.out = (float*)op.out;

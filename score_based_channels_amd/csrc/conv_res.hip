@@ -354,6 +354,7 @@ int launch_res_block(const sbc_op& op, hipStream_t stream, bool dry) {
     SBC_REQUIRE(op.cin == 32 && op.cout == 32 && op.ksize == 3 && op.dil == 1 && op.H == 64 && op.W == 16,
                 "res_block: 32 -> 32 -> 32 channels, 3x3, undilated, 64 x 16 samples (got %d -> %d, %dx%d)", op.cin, op.cout, op.H, op.W);
     SBC_REQUIRE(op.B > 0, "res_block: bad batch %d", op.B);
+    SBC_REQUIRE(op.out != op.in, "res_block: out must not alias in (the next sample is requested while the epilogue stores)");
     SBC_REQUIRE((op.flags & SBC_CONV_F16X2) && !(op.flags & SBC_CONV_F16W), "res_block: SBC_CONV_F16X2 only (the weight forms it reads)");
     SBC_REQUIRE(!(op.flags & SBC_EPI_MOMENTS_OUT) || op.aux, "res_block: SBC_EPI_MOMENTS_OUT without aux");
     SBC_REQUIRE(!(op.flags & (SBC_EPI_POOL | SBC_EPI_UP | SBC_EPI_ELUGRAD | SBC_EPI_RES1_ELU)) && !op.res1 && !op.res2 && !op.up,

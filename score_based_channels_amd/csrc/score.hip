@@ -399,13 +399,16 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
         if (o.kind == SBC_OP_CONV_PAIR) {
             r.weight_split = wp(o.weight + "#split");
             r.weight2_split = wp(o.weight2 + "#split");
+            if (f16x2) { r.weight_wino_split = wp(o.weight + "#winograd_split"); r.weight2_wino_split = wp(o.weight2 + "#winograd_split"); }   // calibration only
             r.flags |= f16w ? SBC_CONV_F16W : SBC_CONV_F16X2;
         } else if (o.kind == SBC_OP_CONV_POOL) {
             r.weight_split = wp(o.weight + "#split");
+            if (f16x2) r.weight_wino_split = wp(o.weight + "#winograd_split");
             r.flags |= f16w ? SBC_CONV_F16W : SBC_CONV_F16X2;
         } else if (o.kind == SBC_OP_RES_BLOCK) {
             r.weight_split = wp(o.weight + "#split");
             r.weight2_split = wp(o.weight2 + "#split");
+            r.weight_wino_split = wp(o.weight + "#winograd_split"); r.weight2_wino_split = wp(o.weight2 + "#winograd_split");
             r.bias2 = wp(o.bias2);
             r.norm2 = wp(o.norm2);
             r.flags |= SBC_CONV_F16X2;

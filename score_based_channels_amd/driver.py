@@ -53,8 +53,13 @@ def batch_limit(net, nt, nr, requested, reserve=0.25):
     """Largest lock-step batch for an ``nt x nr`` array: bounded by the caller's ``requested`` size, by the 32-bit element
     index of the convolution kernels (``B * Nt * Nr * ngf`` elements in the largest tensor) and by the free device memory
     (the activation slots of ``plan.assign_slots`` dominate: ~1 MB per trajectory at 64x16, 16 MB at 256x64), keeping
-    ``reserve`` of it for the rest of the process."""
-    per_traj = 4 * sum(net.score_plan(nt, nr).slot_elems) + 64 * nt * nr
+    ``reserve`` of it for the rest of the process.  In ``conv_mode f16x2`` a flagged chunk is re-run with the UNFUSED ``bf16x3``
+    plan (``net.fallback_plan_slot_elems``: ~15 % more slot memory at 64x16): the chunk is sized for the larger of the two, so the
+    re-run cannot run out of memory exactly when it is needed."""
+    slot_elems = sum(net.score_plan(nt, nr).slot_elems)
+    if getattr(net, 'conv_mode', None) == 'f16x2' and hasattr(net, 'fallback_plan_slot_elems'):
+        slot_elems = max(slot_elems, net.fallback_plan_slot_elems(nt, nr))
+    per_traj = 4 * slot_elems + 64 * nt * nr
     free, _ = torch.cuda.mem_get_info(net.device)
     by_mem = int(free * (1.0 - reserve)) // per_traj
     by_index = 0x7fffffff // (nt * nr * net.ngf)                       # wider tensors exist only at lower resolution
@@ -82,8 +87,9 @@ def run_concurrently(batches, streams, n_steps, use_graph=False):
     # gain nothing from each other and half-width grids cost 20 % -- 74.6 against 62.1 ms per step of the 20 400-trajectory workload;
     # sustained gain +2.3 % at 1275 trajectories per stream, +0.9 % at 1700, +0.5 % at 2550 where a 20-step segment already loses 1 %)
     small = max(b.T * b.nt * b.nr for b in batches) <= int(os.environ.get('SBC_STREAM_SMALL_PX', 1 << 21))   # (the variable: A/B aid)
-    if not use_graph and small:
-        _lib.check(_lib.lib().sbc_set_persistent_cus(torch.cuda.get_device_properties(dev).multi_processor_count // 2))
+    # (the width is a field of each batch's plans -- sbc_plan_set_persistent_cus -- not process state: concurrent calls on other host
+    # threads or devices do not see it, and it is reset in the `finally` below whatever happens in between)
+    half = torch.cuda.get_device_properties(dev).multi_processor_count // 2 if (not use_graph and small) else 0
 
     # ... and every second stream walks the schedule ~0.45 of a step behind (AldBatch.run_lagged: the lag is a throw-away evaluation of
     # the first part of the network, 0.45 of a step once per call, and buys ~4 % of every step after it: even, or better, from ~12
@@ -102,11 +108,18 @@ def run_concurrently(batches, streams, n_steps, use_graph=False):
         except BaseException as e:                        # surfaced in the caller's thread
             errors.append(e)
     threads = [threading.Thread(target=work, args=(b, st, k)) for k, (b, st) in enumerate(zip(batches, streams))]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    _lib.check(_lib.lib().sbc_set_persistent_cus(0))
+    started = []
+    try:
+        for b in batches:
+            b.set_persistent_cus(half)
+        for t in threads:
+            t.start()
+            started.append(t)
+    finally:
+        for t in started:
+            t.join()
+        for b in batches:
+            b.set_persistent_cus(0)
     if errors:
         raise errors[0]
 
@@ -127,10 +140,11 @@ def host_noise_streams(seed, combo, shape, n_snr, n_steps, meas_shape):
 def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, beta_noise, levels, steps_each,
                      seed, init, traj_base=0, max_batch=4096, use_graph=None, rank=0, world=1, n_streams=None,
                      return_final=False, n_steps=None, dc_boost=1.0, init_index=None, Y=None, y_index=None,
-                     step_noise=None, meas_noise=None, info=None):
+                     step_noise=None, meas_noise=None, info=None, traj_id=None):
     """Run ``T = len(h_index)`` trajectories, sharded over ``world`` ranks; returns the full NMSE log
     ``[n_steps, T]`` (float32 numpy, identical on every rank).  ``init``: ``[nH, Nt, Nr]`` complex64 initial
-    estimates indexed by ``h_index``.  Trajectory ``t`` draws its noise from Philox stream ``traj_base + t``.
+    estimates indexed by ``h_index``.  Trajectory ``t`` draws its noise from Philox stream ``traj_base + t`` (or ``traj_id[t]``
+    when the array is given: several test profiles in one list reuse the ids of their single-profile runs, ``test_score --test A B``).
 
     ``n_streams`` > 1 runs a chunk as independent sub-batches on concurrent HIP streams, one host thread each
     (``run_concurrently``; results do not depend on the split: per-trajectory noise keys, per-sample normalisation).
@@ -145,7 +159,12 @@ def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, b
 
     ``conv_mode f16x2``: a chunk whose launches raised the device's range flag (an activation outside the window in which the
     two-term fp16 split is fp32-class, ``sbc_range_flag``) is run again with ``net.fallback_net()`` (``bf16x3``) before its
-    results are used; ``info`` (a dict) receives one ``'f16x2_fallback'`` record per such chunk (rank-local)."""
+    results are used -- a warning is printed, and ``info`` (a dict) receives one ``'f16x2_fallback'`` record per such chunk, gathered
+    from EVERY rank (each record carries its ``rank``).  (A re-run replaces the whole chunk, so with a fallback the results of the
+    chunk's other trajectories are the ``bf16x3`` ones: fp32-class either way, but no longer independent of ``max_batch`` bit for bit.)
+
+    Multi-rank failure protocol (``shard.check_peers``): the ranks agree that nobody failed before they enter the final gather; a rank
+    whose run raised makes the others raise ``shard.PeerFailure`` instead of waiting for the collective timeout."""
     from . import _lib
     use_graph = DEFAULT_USE_GRAPH if use_graph is None else bool(use_graph)
     n_streams = DEFAULT_STREAMS if n_streams is None else int(n_streams)
@@ -154,6 +173,9 @@ def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, b
     bc = lambda a: np.broadcast_to(np.asarray(a), (T,))            # noqa: E731
     p_index, local_noise, alpha_step, beta_noise = bc(p_index), bc(local_noise), bc(alpha_step), bc(beta_noise)
     init_index = h_index if init_index is None else np.asarray(init_index, np.int64)
+    traj_id = traj_base + np.arange(T, dtype=np.int64) if traj_id is None else np.asarray(traj_id, np.int64)
+    if traj_id.shape != (T,):
+        raise ValueError('traj_id must have one entry per trajectory')
     lo, hi = shard.my_block(T, rank, world)
     n_all = len(levels) * steps_each
     n_steps = n_all if n_steps is None else min(int(n_steps), n_all)
@@ -174,7 +196,7 @@ def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, b
                 sn = None if step_noise is None else torch.from_numpy(np.ascontiguousarray(step_noise[:n_steps, part]))
                 ald = AldBatch(use_net, Htrue, P, h_index[part], p_index[part], local_noise[part], alpha_step[part],
                                beta_noise[part], levels=levels, steps_each=steps_each, seed=seed,
-                               traj_id=traj_base + part, dc_boost=dc_boost, step_noise=sn)
+                               traj_id=traj_id[part], dc_boost=dc_boost, step_noise=sn)
                 ald.set_init(init[torch.from_numpy(init_index[part])])
                 if Y is None:
                     ald.synthesize_measurements(None if meas_noise is None else torch.from_numpy(meas_noise[part]))
@@ -192,7 +214,10 @@ def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, b
             ald.close()
         del running
 
+    if os.environ.get('SBC_TEST_FAIL_RANK') == str(rank) and world > 1:      # tests/test_gpu_parity.py: the failure protocol end to end
+        raise RuntimeError('SBC_TEST_FAIL_RANK: rank %d fails before the gather, on request' % rank)
     f16x2 = getattr(net, 'conv_mode', None) == 'f16x2'
+    fallbacks = []
     if f16x2:
         _lib.range_flag(True, net.device)               # whatever an earlier, unrelated run left behind
     for c0 in range(lo, hi, max_batch):
@@ -203,12 +228,18 @@ def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, b
             if bits:
                 # an activation of this chunk left the window in which the two-term fp16 split is fp32-class (sbc_range_flag):
                 # the same trajectories again in bf16x3 -- same noise keys, same measurements -- in this process
+                rec = {'rank': int(rank), 'trajectories': [int(c0), int(c1)], 'traj_id_first': int(traj_id[c0]),
+                       'range_flag': int(bits), 'reason': _lib.describe_range(bits), 'rerun_in': 'bf16x3'}
+                import sys
+                print('WARNING [rank %d]: f16x2 range flag %d on trajectories [%d, %d) -- %s; re-running the chunk in bf16x3'
+                      % (rank, bits, c0, c1, rec['reason']), file=sys.stderr, flush=True)
                 run_chunk(net.fallback_net(), c0, c1)
-                if info is not None:
-                    info.setdefault('f16x2_fallback', []).append(
-                        {'trajectories': [int(traj_base + c0), int(traj_base + c1)], 'range_flag': int(bits),
-                         'reason': _lib.describe_range(bits), 'rerun_in': 'bf16x3'})
+                fallbacks.append(rec)
     torch.cuda.synchronize(net.device)
+    shard.check_peers(world, 'the gather of the NMSE logs')        # a rank that raised above never gets here: see shard.report_failure
+    if info is not None:
+        for recs in shard.gather_objects(fallbacks, world):
+            info.setdefault('f16x2_fallback', []).extend(recs)
     full = shard.gather_trajectory_logs(local, T, rank, world)
     if not return_final:
         return full.cpu().numpy()

@@ -112,6 +112,7 @@ class ScoreNet:
         self._plans = {}
         self._sd_host = None            # the loaded state dict (host arrays): what fallback_net() loads
         self._calibrated = False        # conv_mode f16x2: per-layer activation scales set on the device copy of the weights
+        self._calibrating = False
         self._fallback = None
         self.range_fallbacks = 0        # module calls answered by the bf16x3 fallback because the f16x2 range flag was raised
         self.last_range_bits = 0
@@ -197,18 +198,27 @@ class ScoreNet:
         self._fallback = None
         return self
 
-    def _ensure_calibrated(self, nt, nr):
+    def _ensure_calibrated(self, nt=None, nr=None):
         """conv_mode f16x2: one pass over the library's fixed calibration input sets every layer's activation scale
-        (``sbc_f16x2_calibrate``, include/sbc_hip.h) -- once per loaded checkpoint, at the first array size that is bound, before
-        anything else uses the weights.  The input is fixed, so the scales (and with them every later result) depend on the
-        checkpoint only, never on the data or the batch."""
-        if self.conv_mode != 'f16x2' or self._calibrated or os.environ.get('SBC_NO_CALIB'):   # (env: A/B aid, scales stay 1)
+        (``sbc_f16x2_calibrate``, include/sbc_hip.h) -- once per loaded checkpoint, before anything else uses the weights, ALWAYS
+        at the array size of the checkpoint's configuration (``config.data.image_size`` = [Nr, Nt], train_score.py:60), whatever
+        size is bound first, and into EVERY packed form of every layer (direct and Winograd).  Input and size are fixed, so the
+        scales -- and with them every later result -- depend on the checkpoint only: not on the data, the batch, or the order in
+        which array sizes are bound in the process."""
+        if self.conv_mode != 'f16x2' or self._calibrated or self._calibrating or os.environ.get('SBC_NO_CALIB'):   # (env: A/B aid, scales stay 1)
             return
-        self._calibrated = True                       # (bind below comes back here)
-        b = self.bind(1, nt, nr)
-        b.x.view(-1).copy_(torch.from_numpy(_lib.calibration_input(nt * nr * self.channels)))
-        with torch.cuda.device(self.device):
-            _lib.calibrate_f16x2(b.ops, torch.cuda.current_stream(self.device).cuda_stream)
+        nr0, nt0 = (int(v) for v in self.config.data.image_size[:2])
+        if nt0 % 8 or nr0 % 8:                        # (a configuration the kernels cannot run: fall back to the size being bound)
+            nt0, nr0 = nt, nr
+        self._calibrating = True                      # (bind below comes back here)
+        try:
+            b = self.bind(1, nt0, nr0)
+            b.x.view(-1).copy_(torch.from_numpy(_lib.calibration_input(nt0 * nr0 * self.channels)))
+            with torch.cuda.device(self.device):
+                _lib.calibrate_f16x2(b.ops, torch.cuda.current_stream(self.device).cuda_stream)
+            self._calibrated = True                   # only now: a failed pass is retried by the next bind
+        finally:
+            self._calibrating = False
 
     def fallback_net(self):
         """The same checkpoint in ``bf16x3`` (fp32's range and precision everywhere): what a batch that raised the f16x2 range
@@ -219,6 +229,16 @@ class ScoreNet:
             self._fallback = ScoreNet(self.config, self.device, conv_mode='bf16x3', overlap=self.overlap,
                                       fold_stats=self.fold_stats).load_state_dict(self._sd_host, strict=False)
         return self._fallback
+
+    def fallback_plan_slot_elems(self, nt, nr):
+        """Activation-slot elements per trajectory of the ``bf16x3`` plan a flagged batch is re-run with (unfused: more slots than
+        the fused f16x2 plan) -- ``driver.batch_limit`` sizes chunks for the larger of the two.  Builds no device state."""
+        key = ('fallback', nt, nr)
+        if key not in self._plans:
+            fold = self.fold_stats and not (nt & (nt - 1)) and not (nr & (nr - 1))
+            self._plans[key] = sum(P.build_score_plan(self.ngf, nt, nr, self.channels, overlap=self.overlap, fold_stats=fold,
+                                                      fuse_pairs=False, fuse_res=False).slot_elems)
+        return self._plans[key]
 
     # --- binding ----------------------------------------------------------------------------------
     def score_plan(self, nt, nr):
@@ -246,27 +266,36 @@ class ScoreNet:
                                sigma_of_step=_ptr(sigma_of_step) if sigma_of_step is not None else None,
                                step=_ptr(step) if step is not None else None)
         ops = []
+        skip_h = int(os.environ.get('SBC_EXP_SKIP_H', '0'))                  # timing experiment only (wrong results): drop a level's records
         for op in pl.ops:
             o = _lib.sbc_op()
             shape = op.geom if op.geom is not None else op.src              # (statistics from tile moments: the image's dims)
+            if skip_h and shape.h == skip_h and op.dst.h == skip_h:
+                continue
             o.kind, o.flags, o.B, o.H, o.W = op.kind, op.flags, B, shape.h, shape.w
             o.flags |= (P.OP_SIDE if op.side else 0) | (P.OP_JOIN if op.join else 0)
             o.cin, o.cout, o.ksize, o.dil, o.tag = shape.c, op.dst.c, op.ksize, op.dil, op.tag
             o.in_ = _ptr(slots[op.src.slot])
             o.out = _ptr(slots[op.dst.slot])
+            # (fused records in f16x2 also carry the layers' Winograd forms: no fused kernel reads them, sbc_f16x2_calibrate writes the
+            # activation scale into every form of a layer -- this weight buffer is shared by every array size the net is bound at)
+            wino = (lambda key: _ptr(self._wdev, self._woff[key + '#winograd_split'])) if self.conv_mode == 'f16x2' else (lambda key: None)
             if op.kind == P.CONV_PAIR:
                 o.ksize, o.dil = 3, 1
                 o.weight_split = _ptr(self._wdev, self._woff[op.weight + '#split'])
                 o.weight2_split = _ptr(self._wdev, self._woff[op.weight2 + '#split'])
+                o.weight_wino_split, o.weight2_wino_split = wino(op.weight), wino(op.weight2)
                 o.flags |= P.CONV_F16W if self.conv_mode == 'f16w' else P.CONV_F16X2
             elif op.kind == P.CONV_POOL:
                 o.ksize, o.dil = 3, 1
                 o.weight_split = _ptr(self._wdev, self._woff[op.weight + '#split'])
+                o.weight_wino_split = wino(op.weight)
                 o.flags |= P.CONV_F16W if self.conv_mode == 'f16w' else P.CONV_F16X2
             elif op.kind == P.RES_BLOCK:
                 o.ksize, o.dil = 3, 1
                 o.weight_split = _ptr(self._wdev, self._woff[op.weight + '#split'])
                 o.weight2_split = _ptr(self._wdev, self._woff[op.weight2 + '#split'])
+                o.weight_wino_split, o.weight2_wino_split = wino(op.weight), wino(op.weight2)
                 o.bias2 = _ptr(self._wdev, self._woff[op.bias2])
                 o.norm2 = _ptr(self._wdev, self._woff[op.norm2])
                 o.flags |= P.CONV_F16X2
@@ -311,7 +340,12 @@ class ScoreNet:
     def __call__(self, x, labels):
         """``diffuser(current_real, labels)`` (test_score.py:151).  ``x``: float32 ``[B, 2, Nt, Nr]`` (any
         strides; the permuted ``view_as_real`` of the reference is consumed without a copy kernel beyond the
-        one staging copy), ``labels``: integer ``[B]``.  Returns a fresh ``[B, 2, Nt, Nr]`` tensor (channels-last strides)."""
+        one staging copy), ``labels``: integer ``[B]``.  Returns a fresh ``[B, 2, Nt, Nr]`` tensor (channels-last strides).
+
+        Non-finite inputs: the reference's ``F.instance_norm`` spreads a NaN / Inf of a sample over that sample's whole score; the
+        fused kernels' ``max``-based ELU and pooling would swallow a NaN instead, so samples whose input is not finite are answered
+        with NaN here (one small reduction on this non-hot path).  Inside the Langevin plan no such step is needed: a non-finite
+        estimate X stays non-finite through the update kernel and shows in the NMSE log, as in the reference."""
         if x.dim() != 4 or x.shape[1] != self.channels:
             raise ValueError('expected x of shape [B, %d, Nt, Nr], got %s' % (self.channels, tuple(x.shape)))
         B, _, nt, nr = x.shape
@@ -324,6 +358,9 @@ class ScoreNet:
         bound.labels.copy_(labels.to(self.device).long())
         plan.run(torch.cuda.current_stream(self.device).cuda_stream)
         out = bound.out.permute(0, 3, 1, 2).clone()
+        bad = ~torch.isfinite(bound.x).view(B, -1).all(dim=1)
+        if bool(bad.any()):
+            out[bad] = float('nan')
         if self.conv_mode == 'f16x2':
             # (waits for every stream of the device; the module-call path is not the hot loop)
             bits = _lib.range_flag(True, self.device)

@@ -38,6 +38,71 @@ def init_distributed(backend=None):
     return rank, world, local
 
 
+class PeerFailure(RuntimeError):
+    """Another rank reported a failure at an agreement point (``check_peers``): this rank stops too instead of waiting in the next
+    collective until the process-group timeout."""
+
+
+def _flag_all_reduce(value):
+    import torch
+    import torch.distributed as dist
+    dev = 'cpu'
+    if dist.get_backend() == 'nccl':
+        dev = torch.device('cuda', torch.cuda.current_device())
+    t = torch.tensor([int(value)], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
+
+
+def check_peers(world, where=''):
+    """Agreement point in front of every collective of the CLIs: an all-reduce (MAX) of an error flag.  A rank that failed since
+    the last agreement point does not arrive here -- its handler (``report_failure``) contributes 1 to this very all-reduce instead
+    -- and every healthy rank raises ``PeerFailure`` rather than entering a gather the failed rank will never join."""
+    if world > 1 and _flag_all_reduce(0):
+        raise PeerFailure('another rank failed before %s; stopping this rank too' % (where or 'the next collective'))
+
+
+def report_failure(world):
+    """The failing rank's half of ``check_peers``: contributes 1 to the agreement all-reduce its peers are waiting in (or will
+    reach).  Call once, from the handler of whatever exception ended this rank's work; never for a ``PeerFailure``."""
+    if world > 1:
+        try:
+            _flag_all_reduce(1)
+        except Exception:                                  # the group itself is gone: nothing more to tell anybody
+            pass
+
+
+def run_guarded(world, body):
+    """``body()`` with the failure protocol around it: on an exception of THIS rank tell the peers (``report_failure``), on a
+    ``PeerFailure`` just leave; either way the process group is torn down and the exception propagates (non-zero exit on every
+    rank within seconds, not after the collective timeout)."""
+    try:
+        return body()
+    except PeerFailure:
+        raise
+    except BaseException:
+        report_failure(world)
+        raise
+    finally:
+        if world > 1:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                try:
+                    dist.destroy_process_group()
+                except Exception:
+                    pass
+
+
+def gather_objects(obj, world):
+    """Every rank's picklable ``obj`` as a list indexed by rank (``all_gather_object``; one rank: ``[obj]``)."""
+    if world == 1:
+        return [obj]
+    import torch.distributed as dist
+    out = [None] * world
+    dist.all_gather_object(out, obj)
+    return out
+
+
 def collective_device(t):
     """Where a collective's payload must live: on the tensor's device for RCCL, in host memory for a gloo group."""
     import torch.distributed as dist
@@ -48,6 +113,7 @@ def broadcast_int(value, src=0, device=None):
     """Rank ``src``'s integer on every rank (seeds)."""
     import torch
     import torch.distributed as dist
+    check_peers(dist.get_world_size(), 'the seed broadcast')
     dev = device if dist.get_backend() == 'nccl' else 'cpu'
     t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
     dist.broadcast(t, src)

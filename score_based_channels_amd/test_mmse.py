@@ -136,6 +136,11 @@ def posterior_chains(diffuser, val_H, val_P, local_noise, step, noise_boost, n_r
 def main(argv=None):
     args = parse_args(argv)
     rank, world, local = init_distributed()
+    # (a rank that fails tells the others at their next agreement point instead of leaving them in a collective: shard.run_guarded)
+    return shard.run_guarded(world, lambda: _main(args, rank, world, local))
+
+
+def _main(args, rank, world, local):
     if not torch.cuda.is_available():
         raise RuntimeError('test_mmse needs a HIP device (there is no CPU fallback)')
     device = 'cuda:%d' % (local if world > 1 else min(args.gpu, torch.cuda.device_count() - 1))
@@ -234,8 +239,6 @@ def main(argv=None):
                     'oracle_H': oracle_H, 'saved_H': saved_H, 'mmse_H': mmse_H, 'mmse_nmse': mmse_nmse, 'seed': seed},
                    os.path.join(result_dir, 'model_%s_channel_%s.pt' % (args.model, args.channel)))
         print('MMSE-estimate NMSE [dB] per SNR:', np.round(10 * np.log10(mmse_nmse[0, 0].mean(-1)), 2))
-    if world > 1:
-        torch.distributed.destroy_process_group()
     return oracle_log, saved_H, mmse_nmse
 
 

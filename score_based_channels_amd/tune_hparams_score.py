@@ -65,6 +65,13 @@ def select_best(best_nmse, alpha_step_range, beta_noise_range):
 
 def main(argv=None):
     args = parse_args(argv)
+    from . import shard
+    rank, world, local = shard.init_distributed()
+    # (a rank that fails tells the others at their next agreement point instead of leaving them in a collective: shard.run_guarded)
+    return shard.run_guarded(world, lambda: _main(args, rank, world, local))
+
+
+def _main(args, rank, world, local):
     import torch
     from . import shard
     from .checkpoint import load_checkpoint
@@ -74,7 +81,6 @@ def main(argv=None):
     from .scorenet import ScoreNet
     from .weights import seeded_state_dict
 
-    rank, world, local = shard.init_distributed()
     device = 'cuda:%d' % (local if world > 1 else args.gpu)
     torch.cuda.set_device(device)
     if args.synthetic_weights is not None:
@@ -176,8 +182,6 @@ def main(argv=None):
                    os.path.join(result_dir, '%s-hyperparameters.pt' % args.channel))
         print('best alpha per SNR:', best_alpha_snr)
         print('best beta  per SNR:', best_beta_snr)
-    if world > 1:
-        torch.distributed.destroy_process_group()
     return nmse_log, best_alpha_snr, best_beta_snr
 
 

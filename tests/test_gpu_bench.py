@@ -32,7 +32,11 @@ def test_bench_line_contract_single_gpu():
     r = d['roofline']
     assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
     assert len(r['kernels']) == 6 and any(k.startswith('conv_dp_kernel') for k in r['kernels']) and 'conv_res_kernel' in r['kernels'] and d['config']['streams_is_cli_default'] and d['config']['f16x2_range_flag'] == 0
-    assert 0 < r['frac_algorithmic'] < r['frac'] and 0 < r['frac_algorithmic_step'] < 1
+    # frac is the ALGORITHMIC fraction of the dense fp16 MFMA peak; the matrix pipe's busy fraction is a separate field
+    assert r['peak'] == 2516.6 and 0 < r['frac'] < r['mfma_busy'] < 1 and 0 < r['frac_step'] < 1
+    assert d['dtype'].startswith('f16x2')
+    ss = d['strong_small']['by_world_size']
+    assert [ss[w]['trajectories_per_gpu'] for w in ('2', '4', '8')] == [16, 8, 4] and all(ss[w]['ms_per_step'] > 0 for w in ss)
     assert d['exact_mode']['conv_mode'] == 'bf16x3' and d['exact_mode']['value'] > 0 and len(d['per_rank']['ms_per_step_by_rank']) == 1
     assert d['sustained_steps'] == 6 and d['sustained_ms_per_step'] > 0 and 'other_launch_mode' in d
     assert d['strong']['scaling'] == 'strong' and d['strong']['trajectories_total'] == 20400

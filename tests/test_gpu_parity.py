@@ -839,3 +839,140 @@ def test_cli_two_ranks_equal_one_rank(tmp_path):
     assert tun[1]['nmse_log'].shape == (3, 1, 17, 9, 3)
     assert np.array_equal(tun[1]['nmse_log'], tun[2]['nmse_log'])
     assert np.array_equal(tun[1]['best_alpha_snr'], tun[2]['best_alpha_snr'])
+
+
+def test_cli_several_test_profiles_are_one_sharded_list(tmp_path, monkeypatch):
+    """BASELINE configs[3] as worded: ``--test CDL-A CDL-B CDL-C CDL-D`` flattens (profile x SNR x channel) into ONE trajectory list
+    (4 x 17 x 3 = 204 trajectories) that shard.my_block splits over the ranks.  Every profile's results.pt equals the one its own
+    single-profile invocation writes (normalisation constants from the train profile, pilots, noise keys: test_score.py:15-22,91-101)
+    bit for bit, and two ranks (blocks of 102 cut through profile CDL-B / CDL-C) equal one rank bit for bit."""
+    import torch
+    from score_based_channels_amd import test_score
+    profiles = ['CDL-A', 'CDL-B', 'CDL-C', 'CDL-D']
+    base = ['--synthetic', '--synthetic_weights', '2024', '--num_channels', '3', '--levels_stride', '1155', '--seed', '11',
+            '--save_channels', '1', '--no_plot']
+    monkeypatch.chdir(tmp_path)
+    single = {}
+    for p in profiles:
+        test_score.main(base + ['--test', p])
+        single[p] = torch.load(tmp_path / ('results/score/train-CDL-C_test-%s/results.pt' % p), weights_only=False)
+    multi = test_score.main(base + ['--test'] + profiles)
+    assert sorted(multi) == sorted(profiles)
+    for p in profiles:
+        r = torch.load(tmp_path / ('results/score/train-CDL-C_test-%s/results.pt' % p), weights_only=False)
+        assert r['nmse_log'].shape == (1, 1, 17, 9, 3) and np.array_equal(r['nmse_log'], multi[p][0])
+        assert np.array_equal(r['nmse_log'], single[p]['nmse_log']), p
+        assert np.array_equal(r['saved_H'], single[p]['saved_H']), p
+        assert r['val_config'].data.channel == p
+    assert not np.array_equal(single['CDL-A']['nmse_log'], single['CDL-D']['nmse_log'])
+    out = _run_cli_ranks(tmp_path / 'ranks', 2, 'test_score', base + ['--test'] + profiles, 29740)
+    for p in profiles:
+        r2 = torch.load(out / ('results/score/train-CDL-C_test-%s/results.pt' % p), weights_only=False)
+        assert np.array_equal(r2['nmse_log'], single[p]['nmse_log']) and np.array_equal(r2['saved_H'], single[p]['saved_H']), p
+
+
+def test_cli_rank_failure_ends_every_rank_quickly(tmp_path):
+    """A rank that raises before the final gather must not leave the others in the all_gather until the 300 s collective timeout
+    (shard.run_guarded / check_peers): SBC_TEST_FAIL_RANK makes rank 1 raise inside its run; the job exits non-zero within seconds."""
+    import os
+    import subprocess
+    import sys
+    import time
+    from conftest import ROOT
+    env = dict(os.environ, PYTHONPATH=ROOT, SBC_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', SBC_TEST_FAIL_RANK='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29761', '-m', 'score_based_channels_amd.test_score', '--synthetic', '--synthetic_weights', '2024',
+           '--num_channels', '2', '--levels_stride', '2310', '--seed', '1', '--no_plot']
+    t0 = time.time()
+    r = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert time.time() - t0 < 150, 'the healthy rank waited for the collective timeout'
+    assert 'SBC_TEST_FAIL_RANK' in r.stderr and 'PeerFailure' in r.stderr
+
+
+@pytest.mark.parametrize('mode', ['f16x2', 'bf16x3'])
+def test_module_call_propagates_nan_like_the_reference(weights64, mode):
+    """F.instance_norm / F.elu / MaxPool2d of the reference propagate a NaN in a sample's input through that sample's whole
+    score; the fused kernels' max-based ELU and pooling would swallow it, so the module call restores the reference's
+    behaviour for samples whose input is not finite.  The other samples are untouched, bit for bit."""
+    import torch
+    from score_based_channels_amd.scorenet import ScoreNet
+    cfg, sd = weights64
+    net = ScoreNet(cfg, conv_mode=mode).cuda().load_state_dict(sd)
+    x = torch.randn(3, 2, 64, 16, generator=torch.Generator().manual_seed(2))
+    lab = torch.full((3,), 100)
+    clean = net(x, lab)
+    xn = x.clone()
+    xn[1, 0, 17, 5] = float('nan')
+    out = net(xn, lab)
+    assert torch.isnan(out[1]).all()
+    assert torch.equal(out[0], clean[0]) and torch.equal(out[2], clean[2])
+
+
+def test_f16x2_scales_do_not_depend_on_which_size_is_bound_first(weights64):
+    """one weight buffer serves every array size; a layer that runs fused (direct form) at 64 x 16 runs as an
+    unfused Winograd launch at other sizes, and the calibration used to write only the form the first-bound plan reads.  Now the pass
+    always runs at the configuration's size and writes every form: binding 128 x 8 first or 64 x 16 first gives the same numbers."""
+    import torch
+    from score_based_channels_amd.scorenet import ScoreNet
+    cfg, sd = weights64
+    g = torch.Generator().manual_seed(9)
+    xa, xb = torch.randn(2, 2, 64, 16, generator=g), torch.randn(2, 2, 128, 8, generator=g)
+    lab = torch.full((2,), 7)
+    n1 = ScoreNet(cfg, conv_mode='f16x2').cuda().load_state_dict(sd)
+    a1, b1 = n1(xa, lab), n1(xb, lab)
+    n2 = ScoreNet(cfg, conv_mode='f16x2').cuda().load_state_dict(sd)
+    b2, a2 = n2(xb, lab), n2(xa, lab)
+    assert torch.equal(a1, a2) and torch.equal(b1, b2)
+    assert n1.range_fallbacks == 0 and n2.range_fallbacks == 0
+    # both packed forms of a fused layer carry the same calibrated scale (first trailer word), and it is not the initial 1.0
+    key = 'refine5.output_convs.0_1_conv.weight'
+    w = sd[key]
+    for form, taps in (('#split', 9), ('#winograd_split', 16)):
+        off = n1._woff[key + form] + taps * w.shape[0] * w.shape[1] // 2        # fp16 pairs per float32 word: taps*cin*cout*2 halves
+        tr = n1._wdev[off:off + 4].cpu().numpy()
+        if form == '#split':
+            first = tr
+        assert tr[0] == first[0] and tr[0] != 1.0, (form, tr)
+
+
+def test_persistent_grid_width_is_a_property_of_the_plan(weights64):
+    """sbc_set_persistent_cus was process-global state toggled by driver.run_concurrently.  The width is now a field of
+    the plan (sbc_plan_set_persistent_cus): two batches driven from two host threads with different widths give the results of a
+    default run bit for bit, and nothing leaks into the process default."""
+    import threading
+    import torch
+    from score_based_channels_amd import synth
+    from score_based_channels_amd.ald import AldBatch
+    from score_based_channels_amd.scorenet import ScoreNet
+    cfg, sd = weights64
+    net = ScoreNet(cfg).cuda().load_state_dict(sd)
+    raw = synth.generate_channels('CDL-C', 16, 64, 16, 0.5, 3)
+    H = np.conj(np.transpose(raw / np.std(raw), (0, 2, 1))).astype(np.complex64)
+    Pm = np.conj(np.transpose(synth.qpsk_pilots(np.random.default_rng(1), 16, 64, 38), (0, 2, 1)))
+    init = torch.randn(16, 64, 16, dtype=torch.complex64, generator=torch.Generator().manual_seed(4))
+
+    def batch():
+        a = AldBatch(net, H, Pm, np.arange(16), np.arange(16), 64.0, levels=[0, 1155], steps_each=2, seed=5)
+        a.set_init(init)
+        a.synthesize_measurements()
+        return a
+    ref = batch()
+    ref.run()
+    torch.cuda.synchronize()
+    want = ref.nmse_log().cpu().numpy()
+    outs = {}
+
+    def work(width):
+        a = batch()
+        a.set_persistent_cus(width)
+        with torch.cuda.stream(torch.cuda.Stream()):
+            a.run()
+        torch.cuda.synchronize()
+        outs[width] = a.nmse_log().cpu().numpy()
+    ths = [threading.Thread(target=work, args=(w,)) for w in (32, 200)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert np.array_equal(outs[32], want) and np.array_equal(outs[200], want)

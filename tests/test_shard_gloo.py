@@ -36,3 +36,46 @@ def test_sharded_logs_gather_to_the_full_log():
         [p.join(60) for p in procs]
         assert [ok for _, ok, _ in res] == [True, True]
         assert res[0][2][0] == 0 and res[0][2][1] == res[1][2][0] and res[1][2][1] == n_items
+
+
+def _failing_worker(rank, world, port, q):
+    """Rank 1 raises before the gather; rank 0 must learn of it at its agreement point (shard.check_peers) instead of sitting in the
+    all_gather until the process-group timeout.  Also: the fallback records of every rank reach every rank (gather_objects)."""
+    import time
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from score_based_channels_amd import shard
+    r, w, _ = shard.init_distributed('gloo')
+    t0 = time.time()
+
+    def body():
+        shard.check_peers(w, 'round 1')                     # everybody healthy: passes
+        recs = shard.gather_objects([{'rank': r, 'chunk': [r * 10, r * 10 + 5]}] if r == 1 else [], w)
+        assert [len(x) for x in recs] == [0, 1] and recs[1][0]['rank'] == 1
+        if r == 1:
+            raise ValueError('rank 1 broke before the gather')
+        shard.check_peers(w, 'the gather of the NMSE logs')
+        shard.gather_trajectory_logs(torch.zeros(2, 3), 6, r, w)      # never reached on the healthy rank either
+        return 'gathered'
+
+    try:
+        out = shard.run_guarded(w, body)
+    except shard.PeerFailure as e:
+        out = 'peer failure: %s' % e
+    except ValueError as e:
+        out = 'own failure: %s' % e
+    q.put((rank, out, time.time() - t0, dist.is_initialized()))
+
+
+def test_a_failing_rank_stops_the_others_at_the_agreement_point():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29100 + os.getpid() % 500
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=120) for _ in procs)
+    [p.join(60) for p in procs]
+    assert res[0][1].startswith('peer failure') and 'the gather of the NMSE logs' in res[0][1]
+    assert res[1][1].startswith('own failure')
+    assert max(r[2] for r in res) < 60                       # seconds, not the 300 s collective timeout
+    assert not res[0][3] and not res[1][3]                   # both tore their process group down

@@ -9,7 +9,7 @@ per-step cost does not depend on the level: the network is unconditional and the
 ``torch.set_num_threads`` = every core.  Writes ``profiles/<round>_reference_cpu.json``; ``bench.py`` embeds that record as
 ``cpu_baseline.reference_build_container`` of its cdlc line.
 
-    python tools/time_reference_cpu.py [--steps 20] [--round r04]
+    python tools/time_reference_cpu.py [--steps 20] [--round r05] [--reps 7]
 """
 import argparse
 import json
@@ -26,8 +26,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--batch', type=int, default=100)
-    ap.add_argument('--round', default='r04')
-    ap.add_argument('--reps', type=int, default=3)
+    ap.add_argument('--round', default='r05')
+    ap.add_argument('--reps', type=int, default=7)
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -48,9 +48,10 @@ def main():
         _, _, log = G.reference_ald(net, cfg, H, P, [0.0], [0], seed=1, steps_each=args.steps)
         reps.append((time.perf_counter() - t0) / args.steps)
         assert np.isfinite(log).all()
-    dt = min(reps)
+    dt, med = min(reps), float(np.median(reps))
     rec = {'value': args.batch / (steps_per_channel * dt), 'unit': 'channels/s', 'cores': n_threads, 'kind': 'reference',
-           's_per_step': dt, 's_per_step_all_repetitions': [round(r, 4) for r in reps], 'batch': args.batch, 'steps_timed': args.steps,
+           's_per_step': dt, 's_per_step_median': med, 'value_at_median': args.batch / (steps_per_channel * med),
+           's_per_step_all_repetitions': [round(r, 4) for r in reps], 'load_average_1min': os.getloadavg()[0], 'batch': args.batch, 'steps_timed': args.steps,
            'torch': torch.__version__, 'host': 'build container (%d vCPU)' % n_threads,
            'what': 'the reference itself: imported NCSNv2Deepest (ncsnv2/models/ncsnv2.py) inside the transcription of '
                    'test_score.py:118-171 (tests/gen_golden.py: reference_ald), B = %d channels, 1 SNR point, %d timed Langevin '
