@@ -73,10 +73,14 @@ typedef enum sbc_op_kind {
     SBC_OP_CONV_POOL = 22,   /* (ABI 11) one CRP stage in one launch: out = conv3x3(ELU?(MaxPool5x5(x))) [+ (res2 + ELU?(res1))]
                                 layers.py:76-83; replaces an SBC_OP_MAXPOOL5 record and the SBC_OP_CONV that reads it: the
                                 pooled tensor never exists in memory (csrc/conv_pair.hip: conv_pool_kernel)                  */
-    SBC_OP_RES_BLOCK = 23    /* (ABI 12) one ResidualBlock without resampling in one launch:
+    SBC_OP_RES_BLOCK = 23,   /* (ABI 12) one ResidualBlock without resampling in one launch:
                                 out = x + conv2(ELU(norm2(conv1(ELU(norm1(x))))))   layers.py:443-456, normalization.py:150-176;
                                 32 channels, 64 x 16 samples: a workgroup owns a whole sample, so it forms the InstanceNorm++
                                 statistics of the intermediate itself (csrc/conv_res.hip)                                    */
+    SBC_OP_CHAIN = 24        /* (ABI 13) a CHAIN of RCU blocks and CRP blocks of one RefineBlock in ONE launch, for the lowest
+                                resolution level (8 x 2 samples, 64 or 128 channels; layers.py:76-83,126-134,234-249): a workgroup
+                                owns eight samples, the running tensor x stays in registers between the blocks and the
+                                convolution operands in LDS; only the filters stream (csrc/conv_chain.hip).  ext = sbc_chain  */
 } sbc_op_kind;
 
 /* sbc_op.flags for SBC_OP_CONV / SBC_OP_MAXPOOL5 */
@@ -263,6 +267,24 @@ typedef struct sbc_adam {
     const int32_t* step;         /* device counter: number of optimiser steps already taken (t - 1) */
 } sbc_adam;
 
+/* Extension of SBC_OP_CHAIN: the blocks, in execution order.  Every block is two 3x3 convolutions cin = cout = op.cin without bias:
+ *   SBC_CHAIN_RCU   x <- x + conv_w2(ELU(conv_w1(ELU(x))))                                           layers.py:126-134
+ *   SBC_CHAIN_CRP   x <- ELU(x); p = conv_w1(maxpool5(x)); x <- p + x; q = conv_w2(maxpool5(p)); x <- q + x   layers.py:76-83
+ * w1 / w2: sbc_pack_conv_weight_f16x2 forms (SBC_CONV_F16X2 must be set: the only multiplier the kernel has).  w1_wino / w2_wino:
+ * the same layers' sbc_pack_conv_weight_winograd_f16x2 forms or NULL -- never read by a kernel, but sbc_f16x2_calibrate writes the
+ * layer's activation scale into every form it is handed (see sbc_op.weight2_wino_split). */
+#define SBC_CHAIN_MAX_BLOCKS 4
+#define SBC_CHAIN_RCU 0
+#define SBC_CHAIN_CRP 1
+typedef struct sbc_chain {
+    int32_t n_blocks;
+    int32_t type[SBC_CHAIN_MAX_BLOCKS];
+    const void* w1[SBC_CHAIN_MAX_BLOCKS];
+    const void* w2[SBC_CHAIN_MAX_BLOCKS];
+    const void* w1_wino[SBC_CHAIN_MAX_BLOCKS];
+    const void* w2_wino[SBC_CHAIN_MAX_BLOCKS];
+} sbc_chain;
+
 /* Extension of SBC_OP_END_CONV: where the noise level comes from (ncsnv2.py:295-298). */
 typedef struct sbc_endconv {
     const float* sigmas;         /* [num_classes] device, float32 (models/__init__.py:4-8) */
@@ -398,6 +420,8 @@ typedef struct sbc_score_desc {
                                     by default in those modes (scorenet.DEFAULT_FUSE_PAIRS) */
 #define SBC_SCORE_FUSE_RES   0x4 /* (ABI 12) the ResidualBlocks without resampling at 64 x 16 as one SBC_OP_RES_BLOCK record each (conv_mode 3);
                                     what the Python host does by default next to SBC_SCORE_FUSE_PAIRS (scorenet.DEFAULT_FUSE_RES) */
+#define SBC_SCORE_FUSE_CHAIN 0x8 /* (ABI 13) the RCU / CRP runs of the 8 x 2 level as SBC_OP_CHAIN records (conv_mode 3); what the Python host does by
+                                    default next to SBC_SCORE_FUSE_PAIRS (scorenet.DEFAULT_FUSE_CHAIN) */
 typedef struct sbc_score sbc_score;
 int sbc_score_create(const sbc_score_desc* desc, const sbc_tensor_ref* tensors, int32_t n_tensors, sbc_score** out);
 int sbc_score_buffers(sbc_score* score, float** x, float** out, int64_t** labels);

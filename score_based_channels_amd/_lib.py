@@ -66,6 +66,11 @@ class sbc_adam(C.Structure):
                 ('ema_mu', C.c_double), ('step', C.c_void_p)]
 
 
+class sbc_chain(C.Structure):
+    _fields_ = [('n_blocks', C.c_int32), ('type', C.c_int32 * 4), ('w1', C.c_void_p * 4), ('w2', C.c_void_p * 4),
+                ('w1_wino', C.c_void_p * 4), ('w2_wino', C.c_void_p * 4)]
+
+
 class sbc_tensor_ref(C.Structure):
     _fields_ = [('name', C.c_char_p), ('data', C.c_void_p), ('numel', C.c_int64)]
 

@@ -59,6 +59,7 @@ union OpExt {
     sbc_endconv endc;      // END_CONV / END_CONV_BWD
     sbc_dsm dsm;           // DSM_PERTURB / DSM_LOSS
     sbc_adam adam;         // ADAM_EMA
+    sbc_chain chain;       // CHAIN
 };
 
 struct PlanOp {
@@ -73,6 +74,7 @@ static size_t ext_size(int kind) {
         case SBC_OP_END_CONV: case SBC_OP_END_CONV_BWD: return sizeof(sbc_endconv);
         case SBC_OP_DSM_PERTURB: case SBC_OP_DSM_LOSS: return sizeof(sbc_dsm);
         case SBC_OP_ADAM_EMA: return sizeof(sbc_adam);
+        case SBC_OP_CHAIN: return sizeof(sbc_chain);
         default: return 0;
     }
 }
@@ -100,6 +102,7 @@ static int dispatch(const sbc_op& op, const void* ext, hipStream_t s) {
         case SBC_OP_CONV_PAIR: return launch_conv_pair(op, s);
         case SBC_OP_CONV_POOL: return launch_conv_pool(op, s);
         case SBC_OP_RES_BLOCK: return launch_res_block(op, s);
+        case SBC_OP_CHAIN: return launch_chain(op, *(const sbc_chain*)ext, s);
         case SBC_OP_MAXPOOL5: return launch_maxpool5(op, s);
         case SBC_OP_END_CONV:
             SBC_REQUIRE(endc, "end_conv: ext (sbc_endconv) must be set");
@@ -288,6 +291,9 @@ int sbc_f16x2_calibrate(const sbc_op* ops, int32_t n_ops, void* stream) {
                                                   run[i].kind == SBC_OP_RES_BLOCK)) {
             slot_of[i] = n_slots;
             n_slots += 2;
+        } else if ((run[i].flags & SBC_CONV_F16X2) && run[i].kind == SBC_OP_CHAIN && run[i].ext) {
+            slot_of[i] = n_slots;                           // two per block: the inputs of its two convolutions
+            n_slots += 2 * SBC_CHAIN_MAX_BLOCKS;
         }
     }
     if (n_slots == 0) return SBC_OK;                        // nothing to calibrate in this record list
@@ -333,7 +339,16 @@ int sbc_f16x2_calibrate(const sbc_op* ops, int32_t n_ops, void* stream) {
         int rc = SBC_OK;
         // (every form of a layer the record carries gets the scale, read by this record's kernel or not: a weight buffer shared
         // between array sizes must not hold two scales for one layer -- fused direct form here, unfused Winograd form there)
-        if (o.kind == SBC_OP_CONV_PAIR || o.kind == SBC_OP_RES_BLOCK) {
+        if (o.kind == SBC_OP_CHAIN) {
+            const sbc_chain& c = *(const sbc_chain*)o.ext;
+            for (int b = 0; b < c.n_blocks && !rc; ++b) {
+                const float a1 = amax[slot_of[i] + 2 * b], a2 = amax[slot_of[i] + 2 * b + 1];
+                rc = set_trailer(c.w1[b], 9, o.cin, o.cout, scale_for(a1), a1);
+                if (!rc) rc = set_trailer(c.w1_wino[b], 16, o.cin, o.cout, scale_for(a1), a1);
+                if (!rc) rc = set_trailer(c.w2[b], 9, o.cin, o.cout, scale_for(a2), a2);
+                if (!rc) rc = set_trailer(c.w2_wino[b], 16, o.cin, o.cout, scale_for(a2), a2);
+            }
+        } else if (o.kind == SBC_OP_CONV_PAIR || o.kind == SBC_OP_RES_BLOCK) {
             rc = set_trailer(o.weight_split, 9, o.cin, o.cout, s1, amax[slot_of[i]]);
             if (!rc) rc = set_trailer(o.weight_wino_split, 16, o.cin, o.cout, s1, amax[slot_of[i]]);
             if (!rc) rc = set_trailer(o.weight2_split, 9, o.cout, o.cout, s2, amax[slot_of[i] + 1]);
@@ -378,6 +393,7 @@ int sbc_plan_create(const sbc_op* ops, int32_t n_ops, sbc_plan** out_plan) {
         else if (po.op.kind == SBC_OP_CONV_PAIR) rc = launch_conv_pair(po.op, nullptr, true);
         else if (po.op.kind == SBC_OP_CONV_POOL) rc = launch_conv_pool(po.op, nullptr, true);
         else if (po.op.kind == SBC_OP_RES_BLOCK) rc = launch_res_block(po.op, nullptr, true);
+        else if (po.op.kind == SBC_OP_CHAIN) rc = launch_chain(po.op, po.ext.chain, nullptr, true);
         else if (po.op.kind == SBC_OP_END_CONV) rc = launch_end_conv(po.op, po.ext.endc, nullptr, true);
         else if (po.op.kind == SBC_OP_LANGEVIN) rc = launch_langevin(po.op, po.ext.lang, nullptr, true);
         if (rc) { delete plan; return rc; }

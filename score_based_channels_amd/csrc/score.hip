@@ -27,6 +27,8 @@ struct POp {
     std::string norm_key;            // CONV with SBC_PRO_NORM_SELF: the norm whose (alpha | gamma | beta) `stats` points at (plan.py)
     std::string weight, bias, weight2;       // weight2: the second convolution of an SBC_OP_CONV_PAIR / SBC_OP_RES_BLOCK
     std::string bias2, norm2;                // SBC_OP_RES_BLOCK: the second convolution's bias, the second norm (plan.py)
+    struct Block { int type; std::string w1, w2; };
+    std::vector<Block> blocks;               // SBC_OP_CHAIN: the RCU / CRP blocks in execution order (plan.py: Op.blocks)
 };
 
 // ---- wiring: a transcription of plan.py's _Builder (reference lines cited there) --------------------------------
@@ -36,6 +38,7 @@ struct Builder {
     bool fuse_res = false;           // plan.py: fuse_res / res_fusable (SBC_OP_RES_BLOCK; conv_mode f16x2 with fused pairs)
     bool f16w = false;               // ... the fp16-weight mode also fuses 64-pixel rows (plan.PAIR_WIDTHS_F16W)
     bool fold_stats = false;         // plan.py: fold_stats (statistics of full-resolution tensors from their producers' tile moments)
+    bool fuse_chain = false;         // plan.py: fuse_chain / chain_fusable (SBC_OP_CHAIN at the 8 x 2 level; conv_mode f16x2)
     std::map<int, int> producer;     // tensor -> index of the record that writes it
     std::vector<Tn> t;
     std::vector<POp> ops;
@@ -115,7 +118,27 @@ struct Builder {
         if (t[x].c != cout || down) sc = conv(p + "shortcut", x, p + "shortcut", cout, true, 0, -1, -1, -1, -1, 3, d);
         return conv(p + "conv2", a, p + "conv2", cout, true, SBC_PRO_NORM | SBC_PRO_ELU, s2, sc, -1, -1, 3, d);
     }
+    bool chain_fusable(int x) const { return fuse_chain && t[x].h == 8 && t[x].w == 2 && (t[x].c == 64 || t[x].c == 128); }
+    static std::vector<POp::Block> rcu_blocks(const std::string& p, int n_blocks) {             // plan._Builder.rcu_blocks
+        std::vector<POp::Block> v;
+        for (int i = 1; i <= n_blocks; ++i)
+            v.push_back({SBC_CHAIN_RCU, p + std::to_string(i) + "_1_conv.weight", p + std::to_string(i) + "_2_conv.weight"});
+        return v;
+    }
+    int chain(const std::string& name, int x, const std::vector<POp::Block>& blocks) {          // plan._Builder.chain
+        for (size_t k = 0; k < blocks.size(); k += SBC_CHAIN_MAX_BLOCKS) {
+            const int dst = tensor(name + "." + std::to_string(k / SBC_CHAIN_MAX_BLOCKS), t[x].h, t[x].w, t[x].c);
+            POp o;
+            o.kind = SBC_OP_CHAIN; o.src = x; o.dst = dst;
+            o.blocks.assign(blocks.begin() + k, blocks.begin() + std::min(blocks.size(), k + (size_t)SBC_CHAIN_MAX_BLOCKS));
+            producer[dst] = (int)ops.size();
+            ops.push_back(o);
+            x = dst;
+        }
+        return x;
+    }
     int rcu(const std::string& p, int x, int n_blocks) {                                        // layers.py:126-134
+        if (chain_fusable(x)) return chain(p + "chain", x, rcu_blocks(p, n_blocks));
         for (int i = 1; i <= n_blocks; ++i) {
             const std::string a = p + std::to_string(i) + "_1_conv", b = p + std::to_string(i) + "_2_conv";
             const int pc = t[x].c, pw = t[x].w, ph = t[x].h;                                // plan.pair_fusable / PAIR_SHAPES*
@@ -160,6 +183,13 @@ struct Builder {
     // first (they do not depend on the first input's; plan.py issues them as side records when asked to overlap)
     int refine(const std::string& p, const std::vector<int>& xs, int features, bool end = false) {
         int h;
+        const POp::Block crp_block{SBC_CHAIN_CRP, p + "crp.convs.0.weight", p + "crp.convs.1.weight"};
+        if (xs.size() == 1 && chain_fusable(xs[0]) && features == t[xs[0]].c) {              // the whole RefineBlock is one chain
+            std::vector<POp::Block> bl = rcu_blocks(p + "adapt_convs.0.", 2);
+            bl.push_back(crp_block);
+            for (const auto& r : rcu_blocks(p + "output_convs.", end ? 3 : 1)) bl.push_back(r);
+            return chain(p + "chain", xs[0], bl);
+        }
         if (xs.size() == 1) {
             h = rcu(p + "adapt_convs.0.", xs[0], 2);
         } else {
@@ -167,6 +197,11 @@ struct Builder {
             const int t1 = conv(p + "msf.convs.1", h1, p + "msf.convs.1", features);
             const int h0 = rcu(p + "adapt_convs.0.", xs[0], 2);
             h = conv(p + "msf.convs.0", h0, p + "msf.convs.0", features, true, 0, -1, -1, -1, t1);
+        }
+        if (chain_fusable(h)) {
+            std::vector<POp::Block> bl{crp_block};
+            for (const auto& r : rcu_blocks(p + "output_convs.", end ? 3 : 1)) bl.push_back(r);
+            return chain(p + "tail", h, bl);
         }
         h = crp(p + "crp.", h);
         return rcu(p + "output_convs.", h, end ? 3 : 1);
@@ -186,6 +221,7 @@ struct sbc_score {
     int64_t* labels = nullptr;           // device [B]
     sbc_endconv endc;
     std::vector<sbc_op> ops;
+    std::vector<sbc_chain> chains;       // ext structs of the SBC_OP_CHAIN records (sized before the records point into it)
     sbc_plan* plan = nullptr;
     int x_t = -1, out_t = -1;
 };
@@ -239,6 +275,7 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
     SBC_REQUIRE(d->batch > 0 && d->conv_mode >= 0 && d->conv_mode <= 3 && d->sigmas && d->num_classes > 0,
                 "sbc_score_create: batch, conv_mode in {0 bf16x3, 1 f32, 2 f16w, 3 f16x2}, sigmas required");
     SBC_REQUIRE(!(d->flags & SBC_SCORE_FUSE_RES) || d->conv_mode == 3, "sbc_score_create: SBC_SCORE_FUSE_RES needs conv_mode 3 (f16x2)");
+    SBC_REQUIRE(!(d->flags & SBC_SCORE_FUSE_CHAIN) || d->conv_mode == 3, "sbc_score_create: SBC_SCORE_FUSE_CHAIN needs conv_mode 3 (f16x2)");
     SBC_REQUIRE(!(d->flags & SBC_SCORE_FUSE_PAIRS) || d->conv_mode >= 2,
                 "sbc_score_create: SBC_SCORE_FUSE_PAIRS needs the fp16 weight forms (conv_mode 2 or 3)");
     std::map<std::string, const sbc_tensor_ref*> sd;
@@ -254,6 +291,7 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
     b.fuse_pairs = (d->flags & SBC_SCORE_FUSE_PAIRS) != 0;
     b.f16w = d->conv_mode == 2;
     b.fuse_res = (d->flags & SBC_SCORE_FUSE_RES) != 0;
+    b.fuse_chain = (d->flags & SBC_SCORE_FUSE_CHAIN) != 0;
     b.fold_stats = (d->flags & SBC_SCORE_FOLD_STATS) != 0 && d->conv_mode != 1 && !(nt & (nt - 1)) && !(nr & (nr - 1));
     const int x = b.tensor("x", nt, nr, d->channels);
     int h = b.tensor("begin_conv", nt, nr, ngf);
@@ -324,10 +362,12 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
             }
         }
         if (o.kind == SBC_OP_INORM_STATS) continue;
-        if (o.weight.empty()) continue;                  // max pooling has no parameters
+        if (o.weight.empty() && o.blocks.empty()) continue;   // max pooling has no parameters
         const int k = o.ksize, cin = src.c, cout = dst.c;
         const size_t wn = (size_t)cout * cin * k * k;
-        for (const std::string& wkey : {o.weight, o.weight2}) {
+        std::vector<std::string> wkeys{o.weight, o.weight2};
+        for (const auto& bl : o.blocks) { wkeys.push_back(bl.w1); wkeys.push_back(bl.w2); }
+        for (const std::string& wkey : wkeys) {
         if (wkey.empty()) continue;
         if (!off.count(wkey) && !off.count(wkey + "#split")) {
             const float* w = find(wkey, (int64_t)wn);
@@ -335,7 +375,7 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
             w = rounded(w, wn);
             std::vector<float> wkeep(w, w + wn);          // `tmp` is reused below
             const std::string& okey = wkey;
-            if (o.kind == SBC_OP_CONV_PAIR || o.kind == SBC_OP_CONV_POOL || o.kind == SBC_OP_RES_BLOCK) {
+            if (o.kind == SBC_OP_CONV_PAIR || o.kind == SBC_OP_CONV_POOL || o.kind == SBC_OP_RES_BLOCK || o.kind == SBC_OP_CHAIN) {
                 // the fused kernels read the direct fp16 forms only
                 if (f16x2) sbc_pack_conv_weight_f16x2(wkeep.data(), cout, cin, k, (uint16_t*)reserve(okey + "#split", sbc_f16x2_elems(k * k, cin, cout) / 2));
                 else sbc_pack_conv_weight_f16(wkeep.data(), cout, cin, k, (uint16_t*)reserve(okey + "#split", (wn + 1) / 2));
@@ -386,6 +426,9 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
             return hip_fail(e, "hipMalloc(activation slot)");
     s->endc.sigmas = s->sigmas; s->endc.labels = s->labels; s->endc.sigma_of_step = nullptr; s->endc.step = nullptr;
     // ---- records (scorenet.ScoreNet.bind)
+    size_t n_chains = 0;
+    for (const POp& o : s->pops) n_chains += o.kind == SBC_OP_CHAIN;
+    s->chains.reserve(n_chains);
     for (const POp& o : s->pops) {
         sbc_op r;
         memset(&r, 0, sizeof(r));
@@ -405,6 +448,18 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
             r.weight_split = wp(o.weight + "#split");
             if (f16x2) r.weight_wino_split = wp(o.weight + "#winograd_split");
             r.flags |= f16w ? SBC_CONV_F16W : SBC_CONV_F16X2;
+        } else if (o.kind == SBC_OP_CHAIN) {
+            sbc_chain ch;
+            memset(&ch, 0, sizeof(ch));
+            ch.n_blocks = (int32_t)o.blocks.size();
+            for (size_t k = 0; k < o.blocks.size(); ++k) {
+                ch.type[k] = o.blocks[k].type;
+                ch.w1[k] = wp(o.blocks[k].w1 + "#split"); ch.w2[k] = wp(o.blocks[k].w2 + "#split");
+                ch.w1_wino[k] = wp(o.blocks[k].w1 + "#winograd_split"); ch.w2_wino[k] = wp(o.blocks[k].w2 + "#winograd_split");
+            }
+            s->chains.push_back(ch);
+            r.ext = &s->chains.back();
+            r.flags |= SBC_CONV_F16X2;
         } else if (o.kind == SBC_OP_RES_BLOCK) {
             r.weight_split = wp(o.weight + "#split");
             r.weight2_split = wp(o.weight2 + "#split");

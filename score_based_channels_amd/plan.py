@@ -38,6 +38,8 @@ PRO_ELU_ACC = 0x20000         # ELU with fp32's relative accuracy for small nega
 CONV_PAIR = 21
 CONV_POOL = 22
 RES_BLOCK = 23
+CHAIN = 24               # a chain of RCU / CRP blocks at the 8 x 2 level in one launch (csrc/conv_chain.hip)
+CHAIN_RCU, CHAIN_CRP, CHAIN_MAX_BLOCKS = 0, 1, 4
 BWD_ACCUM, PACK_ADJOINT, OP_SIDE, OP_JOIN, PACK_WINOGRAD = 0x200, 0x400, 0x800, 0x1000, 0x2000
 
 # profiling tags (sbc_op.tag; bench.py times each class by hipEvents in a single-stream segment after its timed region):
@@ -94,6 +96,7 @@ class Op:
     moments: Optional[Tensor] = None    # second output: tile moments of dst (EPI_MOMENTS_OUT), [HW/128][C][2] per sample
     geom: Optional[Tensor] = None       # INORM_STATS from tile moments: the tensor whose (H, W, C) the launch describes
     norm_key: Optional[str] = None      # CONV with PRO_NORM_SELF: state_dict prefix of the norm whose (alpha, gamma, beta) `stats` points at
+    blocks: Optional[list] = None       # CHAIN: [(CHAIN_RCU | CHAIN_CRP, weight key of conv 1, weight key of conv 2), ...]
 
     def inputs(self):
         return [t for t in (self.src, self.stats, self.res1, self.res2, self.up) if t is not None]
@@ -114,6 +117,7 @@ class ScorePlan:
 class _Builder:
     def __init__(self, ngf, nt, nr, overlap=False, fold_stats=False, fuse_pairs=False):
         self.ngf, self.nt, self.nr = ngf, nt, nr
+        self.fuse_chain = False         # RCU / CRP runs of the 8 x 2 level as CHAIN records (csrc/conv_chain.hip)
         self.fuse_res = False           # ResidualBlocks without resampling at 64x16, 32 channels as one RES_BLOCK record (csrc/conv_res.hip)
         self.fuse_pairs = fuse_pairs    # RCU blocks as one CONV_PAIR record (csrc/conv_pair.hip): True / a tuple of (channels, width)
         self.ops, self.tensors = [], []
@@ -218,8 +222,24 @@ class _Builder:
         self.ops[-1].join = joined
         return out
 
+    def chain(self, name, x, blocks):
+        """``blocks`` (RCU / CRP blocks in execution order) on ``x`` as CHAIN records of at most CHAIN_MAX_BLOCKS blocks each."""
+        for k in range(0, len(blocks), CHAIN_MAX_BLOCKS):
+            part = blocks[k:k + CHAIN_MAX_BLOCKS]
+            dst = self.t('%s.%d' % (name, k // CHAIN_MAX_BLOCKS), x.h, x.w, x.c)
+            self.ops.append(Op(CHAIN, dst.name, src=x, dst=dst, blocks=part, side=self.side_now))
+            self.producer[id(dst)] = self.ops[-1]
+            x = dst
+        return x
+
+    @staticmethod
+    def rcu_blocks(p, n_blocks):
+        return [(CHAIN_RCU, p + '%d_1_conv.weight' % i, p + '%d_2_conv.weight' % i) for i in range(1, n_blocks + 1)]
+
     def rcu(self, p, x, n_blocks):
         """layers.py:126-134 (n_stages = 2, no bias)."""
+        if self.fuse_chain and chain_fusable(x.h, x.w, x.c):
+            return self.chain(p + 'chain', x, self.rcu_blocks(p, n_blocks))
         for i in range(1, n_blocks + 1):
             if self.fuse_pairs and pair_fusable(x.h, x.w, x.c, self.fuse_pairs if isinstance(self.fuse_pairs, tuple) else PAIR_SHAPES):
                 # x + conv2(ELU(conv1(ELU(x)))) in one launch, the intermediate tensor never exists in memory
@@ -257,6 +277,11 @@ class _Builder:
         """layers.py:234-249; MSF (layers.py:178-184) for two inputs, the second may be at half resolution.  The second
         input's adapt convolutions and its MSF convolution do not depend on the first input's: with ``overlap`` they are
         issued first as side records and the first input's MSF convolution (which adds their result) joins them."""
+        if len(xs) == 1 and self.fuse_chain and chain_fusable(xs[0].h, xs[0].w, xs[0].c) and features == xs[0].c:
+            # the whole RefineBlock is one chain: adapt RCU x 2, CRP, output RCU (layers.py:234-249 without the MSF of several inputs)
+            return self.chain(p + 'chain', xs[0], self.rcu_blocks(p + 'adapt_convs.0.', 2)
+                              + [(CHAIN_CRP, p + 'crp.convs.0.weight', p + 'crp.convs.1.weight')]
+                              + self.rcu_blocks(p + 'output_convs.', 3 if end else 1))
         if len(xs) == 1:
             h = self.rcu(p + 'adapt_convs.0.', xs[0], 2)
         else:
@@ -268,6 +293,9 @@ class _Builder:
             h0 = self.rcu(p + 'adapt_convs.0.', xs[0], 2)
             h = self.conv(p + 'msf.convs.0', h0, p + 'msf.convs.0', features, up=t1)
             self.ops[-1].join = joined
+        if self.fuse_chain and chain_fusable(h.h, h.w, h.c):
+            return self.chain(p + 'tail', h, [(CHAIN_CRP, p + 'crp.convs.0.weight', p + 'crp.convs.1.weight')]
+                              + self.rcu_blocks(p + 'output_convs.', 3 if end else 1))
         h = self.crp(p + 'crp.', h)
         return self.rcu(p + 'output_convs.', h, 3 if end else 1)
 
@@ -277,6 +305,13 @@ class _Builder:
 PAIR_SHAPES = ((32, 16),)
 # ... in the fp16-weight mode (BASELINE config 5, a 256 x 64 array): also 32-pixel and 64-pixel rows, and the 64-channel levels
 PAIR_SHAPES_F16W = ((32, 16), (32, 32), (32, 64), (64, 16), (64, 32))
+
+
+def chain_fusable(h, w, c):
+    """Shapes SBC_OP_CHAIN takes: 8 x 2 samples of 64 or 128 channels (the lowest level of a 64 x 16 array)."""
+    if os.environ.get('SBC_NO_CHAIN'):               # A/B aid: every convolution and max pool of the level as its own launch
+        return False
+    return h == 8 and w == 2 and c in (64, 128)
 
 
 def res_fusable(h, w, cin, cout, resample, dilation):
@@ -300,7 +335,8 @@ def pair_fusable(h, w, c, shapes=PAIR_SHAPES):
     return (c, w) in shapes and h % (8 if w == 16 else 4) == 0
 
 
-def build_score_plan(ngf=32, nt=64, nr=16, channels=2, share_slots=True, overlap=False, fold_stats=False, fuse_pairs=False, fuse_res=False):
+def build_score_plan(ngf=32, nt=64, nr=16, channels=2, share_slots=True, overlap=False, fold_stats=False, fuse_pairs=False, fuse_res=False,
+                     fuse_chain=False):
     """Op list of one ``NCSNv2Deepest.forward`` for ``[B, 2, nt, nr]`` inputs (ncsnv2.py:269-300).
     ``share_slots=False`` gives every logical tensor its own storage (a training step reads every activation again on
     the way back, ``train.py``)."""
@@ -308,6 +344,7 @@ def build_score_plan(ngf=32, nt=64, nr=16, channels=2, share_slots=True, overlap
         raise ValueError('Nt and Nr must be multiples of 8 (three 2x mean-pools), got %dx%d' % (nt, nr))
     b = _Builder(ngf, nt, nr, overlap, fold_stats, fuse_pairs)
     b.fuse_res = bool(fuse_res)
+    b.fuse_chain = bool(fuse_chain)
     x = b.t('x', nt, nr, channels)
     h = b.t('begin_conv', nt, nr, ngf)
     b.ops.append(Op(BEGIN_CONV, 'begin_conv', src=x, dst=h, weight='begin_conv.weight', bias='begin_conv.bias'))
@@ -394,6 +431,8 @@ def count_conv_flops(plan):
             total += 2 * 2 * op.src.h * op.src.w * op.src.c * op.dst.c * 9
         elif op.kind == CONV_POOL:
             total += 2 * op.src.h * op.src.w * op.src.c * op.dst.c * 9
+        elif op.kind == CHAIN:
+            total += len(op.blocks) * 2 * 2 * op.src.h * op.src.w * op.src.c * op.dst.c * 9
         elif op.kind in (BEGIN_CONV, END_CONV):
             total += 2 * op.src.h * op.src.w * op.src.c * op.dst.c * 9
     return total

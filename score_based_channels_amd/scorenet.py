@@ -43,6 +43,9 @@ DEFAULT_FUSE_PAIRS = True       # applies to the fp16-form modes only ('f16x2', 
 # Measured: 264-280 us per block against 2 x 150 + 10 for the launches it replaces; 1.2 % of a one-stream step,
 # 0.6 % of the default two-stream step (three interleaved A/B pairs, sustained 1000 steps: 5.55 against 5.58 ms).
 DEFAULT_FUSE_RES = True
+# RCU / CRP runs of the 8 x 2 level as SBC_OP_CHAIN records (csrc/conv_chain.hip: eight samples resident per workgroup, only the
+# filters stream): conv_mode f16x2 with fused pairs
+DEFAULT_FUSE_CHAIN = True
 
 
 class ScoreNet:
@@ -72,7 +75,7 @@ class ScoreNet:
                             ``.half()``, layers.py:179); tolerance stated in tests/test_gpu_parity.py.
     """
 
-    def __init__(self, config, device=None, conv_mode=None, overlap=None, fold_stats=None, fuse_pairs=None, fuse_res=None):
+    def __init__(self, config, device=None, conv_mode=None, overlap=None, fold_stats=None, fuse_pairs=None, fuse_res=None, fuse_chain=None):
         conv_mode = DEFAULT_CONV_MODE if conv_mode is None else conv_mode
         if conv_mode not in CONV_MODES:
             raise ValueError('conv_mode must be one of %s, got %r' % (CONV_MODES, conv_mode))
@@ -91,6 +94,7 @@ class ScoreNet:
         # the intermediate tensor in LDS (csrc/conv_pair.hip); the kernel reads the fp16 weight forms of 'f16x2' / 'f16w'
         self.fuse_pairs = (DEFAULT_FUSE_PAIRS if fuse_pairs is None else bool(fuse_pairs)) and conv_mode in ('f16x2', 'f16w')
         self.fuse_res = ((DEFAULT_FUSE_RES and self.fuse_pairs) if fuse_res is None else bool(fuse_res)) and conv_mode == 'f16x2'
+        self.fuse_chain = ((DEFAULT_FUSE_CHAIN and self.fuse_pairs) if fuse_chain is None else bool(fuse_chain)) and conv_mode == 'f16x2'
         self.config = config
         m, d = config.model, config.data
         if str(m.normalization) != 'InstanceNorm++' or str(m.nonlinearity).lower() != 'elu':
@@ -247,7 +251,7 @@ class ScoreNet:
             fold = self.fold_stats and not (nt & (nt - 1)) and not (nr & (nr - 1))     # conv_wx3 takes power-of-two images
             self._plans[key] = P.build_score_plan(self.ngf, nt, nr, self.channels, overlap=self.overlap, fold_stats=fold,
                                                   fuse_pairs=(P.PAIR_SHAPES_F16W if self.conv_mode == 'f16w' else P.PAIR_SHAPES) if self.fuse_pairs else False,
-                                                  fuse_res=self.fuse_res)
+                                                  fuse_res=self.fuse_res, fuse_chain=self.fuse_chain and not self.overlap)
         return self._plans[key]
 
     def bind(self, B, nt, nr, *, step=None, sigma_of_step=None, use_labels=True):
@@ -266,6 +270,7 @@ class ScoreNet:
                                sigma_of_step=_ptr(sigma_of_step) if sigma_of_step is not None else None,
                                step=_ptr(step) if step is not None else None)
         ops = []
+        keep = []                                                            # ext structs the records point at
         skip_h = int(os.environ.get('SBC_EXP_SKIP_H', '0'))                  # timing experiment only (wrong results): drop a level's records
         for op in pl.ops:
             o = _lib.sbc_op()
@@ -291,6 +296,16 @@ class ScoreNet:
                 o.weight_split = _ptr(self._wdev, self._woff[op.weight + '#split'])
                 o.weight_wino_split = wino(op.weight)
                 o.flags |= P.CONV_F16W if self.conv_mode == 'f16w' else P.CONV_F16X2
+            elif op.kind == P.CHAIN:
+                o.ksize, o.dil = 3, 1
+                ch = _lib.sbc_chain(n_blocks=len(op.blocks))
+                for k, (typ, k1, k2) in enumerate(op.blocks):
+                    ch.type[k] = typ
+                    ch.w1[k], ch.w2[k] = _ptr(self._wdev, self._woff[k1 + '#split']), _ptr(self._wdev, self._woff[k2 + '#split'])
+                    ch.w1_wino[k], ch.w2_wino[k] = wino(k1), wino(k2)
+                keep.append(ch)
+                o.ext = C.cast(C.pointer(ch), C.c_void_p)
+                o.flags |= P.CONV_F16X2
             elif op.kind == P.RES_BLOCK:
                 o.ksize, o.dil = 3, 1
                 o.weight_split = _ptr(self._wdev, self._woff[op.weight + '#split'])
@@ -334,7 +349,7 @@ class ScoreNet:
             ops.append(o)
         x = slots[pl.x.slot].view(B, nt, nr, self.channels)
         out = slots[pl.out.slot].view(B, nt, nr, self.channels)
-        return BoundScore(ops, x, out, slots, labels, [ext, self._wdev, self.sigmas, sigma_of_step, step])
+        return BoundScore(ops, x, out, slots, labels, [ext, self._wdev, self.sigmas, sigma_of_step, step, keep])
 
     # --- module call --------------------------------------------------------------------------------
     def __call__(self, x, labels):

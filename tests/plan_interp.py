@@ -97,6 +97,18 @@ def exec_op(op, sd, get, labels):
             st2 = inorm_stats(t, sd[k + '.alpha'], sd[k + '.gamma'], sd[k + '.beta'])
             u = O.elu((t - st2[:, None, None, 0]) * st2[:, None, None, 1] + st2[:, None, None, 2])
             out = src + _nhwc(O.conv2d(_nchw(u), sd[op.weight2], sd[op.bias2], 1))
+        elif op.kind == P.CHAIN:                 # RCU / CRP blocks in sequence (layers.py:76-83, 126-134)
+            out = src
+            for typ, k1, k2 in op.blocks:
+                if typ == P.CHAIN_RCU:
+                    t = O.conv2d(_nchw(O.elu(out)), sd[k1], None, 1)
+                    out = out + _nhwc(O.conv2d(O.elu(t), sd[k2], None, 1))
+                else:
+                    out = O.elu(out)
+                    path = O.conv2d(O.max_pool5(_nchw(out)), sd[k1], None, 1)
+                    out = _nhwc(path) + out
+                    path = O.conv2d(O.max_pool5(path), sd[k2], None, 1)
+                    out = _nhwc(path) + out
         elif op.kind == P.CONV_PAIR:             # one RCU block (layers.py:126-134)
             t = O.conv2d(_nchw(O.elu(src)), sd[op.weight], None, 1)
             out = src + _nhwc(O.conv2d(O.elu(t), sd[op.weight2], None, 1))

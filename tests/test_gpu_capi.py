@@ -13,21 +13,21 @@ pytestmark = pytest.mark.gpu
 MODES = {'bf16x3': 0, 'f32': 1, 'f16w': 2, 'f16x2': 3}
 
 
-def _create(sd, cfg, B, nt, nr, mode, pairs=False, fold=False, res=False):
+def _create(sd, cfg, B, nt, nr, mode, pairs=False, fold=False, res=False, chain=False):
     from score_based_channels_amd import _lib
     keep = {k: np.ascontiguousarray(v, np.float32) for k, v in sd.items() if k != 'sigmas'}
     refs = (_lib.sbc_tensor_ref * len(keep))(*[
         _lib.sbc_tensor_ref(name=k.encode(), data=v.ctypes.data, numel=v.size) for k, v in keep.items()])
     sig = np.ascontiguousarray(sd['sigmas'], np.float32)
     desc = _lib.sbc_score_desc(ngf=32, channels=2, nt=nt, nr=nr, batch=B, conv_mode=MODES[mode], sigmas=sig.ctypes.data,
-                               num_classes=sig.size, flags=(1 if pairs else 0) | (2 if fold else 0) | (4 if res else 0))
+                               num_classes=sig.size, flags=(1 if pairs else 0) | (2 if fold else 0) | (4 if res else 0) | (8 if chain else 0))
     h = C.c_void_p()
     _lib.check(_lib.lib().sbc_score_create(C.byref(desc), refs, len(keep), C.byref(h)))
     return h
 
 
 @pytest.mark.parametrize('mode', ['bf16x3', 'f32', 'f16w', 'f16x2', 'f16x2+pairs', 'f16w+pairs', 'f16x2+pairs+fold', 'bf16x3+fold',
-                                  'f16x2+pairs+fold+res'])
+                                  'f16x2+pairs+fold+res', 'f16x2+pairs+fold+res+chain'])
 def test_c_built_score_network_equals_python_host(weights64, mode):
     import torch
     from score_based_channels_amd import _lib
@@ -36,14 +36,15 @@ def test_c_built_score_network_equals_python_host(weights64, mode):
     L = _lib.lib()
     B, nt, nr = 3, 64, 16
     mode, *opts = mode.split('+')
-    pairs, fold, res = 'pairs' in opts, 'fold' in opts, 'res' in opts
-    h = _create(sd, cfg, B, nt, nr, mode, pairs, fold, res)
+    pairs, fold, res, chain = 'pairs' in opts, 'fold' in opts, 'res' in opts, 'chain' in opts
+    h = _create(sd, cfg, B, nt, nr, mode, pairs, fold, res, chain)
     try:
         ops_p, n = C.POINTER(_lib.sbc_op)(), C.c_int32()
         _lib.check(L.sbc_score_ops(h, C.byref(ops_p), C.byref(n)))
-        net = ScoreNet(cfg, conv_mode=mode, fuse_pairs=pairs, fold_stats=fold, fuse_res=res).cuda().load_state_dict(sd)
+        net = ScoreNet(cfg, conv_mode=mode, fuse_pairs=pairs, fold_stats=fold, fuse_res=res, fuse_chain=chain).cuda().load_state_dict(sd)
         bound = net.bind(B, nt, nr)
         assert n.value == len(bound.ops)
+        assert chain == any(o.kind == 24 for o in bound.ops)
         # identical records: every scalar field, and the same storage-sharing pattern (pointers renamed by first use)
         ids_c, ids_p = {}, {}
         for i, ref in enumerate(bound.ops):
@@ -55,8 +56,14 @@ def test_c_built_score_network_equals_python_host(weights64, mode):
                 assert (a is None) == (b is None), (i, f)
                 if a is not None:
                     assert ids_c.setdefault(a, len(ids_c)) == ids_p.setdefault(b, len(ids_p)), (i, f)
-            for f in ('weight', 'bias', 'weight_wino', 'weight_split', 'weight_wino_split', 'weight2_split', 'bias2', 'norm2'):
+            for f in ('weight', 'bias', 'weight_wino', 'weight_split', 'weight2_split', 'bias2', 'norm2'):
                 assert (getattr(got, f) is None) == (getattr(ref, f) is None), (i, f)
+            if ref.kind == 24:                      # SBC_OP_CHAIN: the same blocks in the same order
+                cg, cr = C.cast(got.ext, C.POINTER(_lib.sbc_chain)).contents, C.cast(ref.ext, C.POINTER(_lib.sbc_chain)).contents
+                assert cg.n_blocks == cr.n_blocks and list(cg.type)[:cg.n_blocks] == list(cr.type)[:cr.n_blocks]
+                assert all(cg.w1[k] and cg.w2[k] and cr.w1[k] and cr.w2[k] for k in range(cg.n_blocks))
+            elif ref.kind == 3:                     # (fused records carry the Winograd forms for the calibration only where the host packed them)
+                assert (got.weight_wino_split is None) == (ref.weight_wino_split is None), (i, 'weight_wino_split')
         # bit-identical forward
         g = load_golden('forward_64x16.npz')
         x = torch.from_numpy(g['x'][:B]).cuda()
@@ -80,8 +87,8 @@ def test_c_built_score_network_equals_python_host(weights64, mode):
         L.sbc_score_destroy(h)
 
 
-@pytest.mark.parametrize('mode,pairs,fold', [('bf16x3', False, False), ('f16x2', True, True)])
-def test_langevin_plan_composed_from_c_records(weights64, mode, pairs, fold):
+@pytest.mark.parametrize('mode,pairs,fold,chain', [('bf16x3', False, False, False), ('f16x2', True, True, False), ('f16x2', True, True, True)])
+def test_langevin_plan_composed_from_c_records(weights64, mode, pairs, fold, chain):
     """sbc_score_level_source + sbc_score_ops + SBC_OP_LANGEVIN + SBC_OP_STEP_INC = the plan AldBatch builds: same NMSE log --
     in the exact mode and in the shipped default (conv_mode 3 | SBC_SCORE_FUSE_PAIRS | SBC_SCORE_FOLD_STATS, calibrated scales)."""
     import torch
@@ -100,7 +107,7 @@ def test_langevin_plan_composed_from_c_records(weights64, mode, pairs, fold):
     ln = float(snr_to_noise(g['snr_db'], nt)[0])
     steps = noise.step_block(0, H.shape, n_steps)
     # reference run through the Python host
-    net = ScoreNet(cfg, conv_mode=mode, fold_stats=fold, fuse_pairs=pairs, fuse_res=False).cuda().load_state_dict(sd)
+    net = ScoreNet(cfg, conv_mode=mode, fold_stats=fold, fuse_pairs=pairs, fuse_res=False, fuse_chain=chain).cuda().load_state_dict(sd)
     ald = AldBatch(net, H, Pm, np.arange(B), np.arange(B), ln, levels=levels, step_noise=torch.from_numpy(steps))
     ald.set_init(torch.from_numpy(noise.init(H.shape)))
     Y = ald.synthesize_measurements(torch.from_numpy(noise.measurement(0, (B, npil, nr)))).clone()
@@ -108,7 +115,7 @@ def test_langevin_plan_composed_from_c_records(weights64, mode, pairs, fold):
     torch.cuda.synchronize()
     want = ald.nmse_log().clone()
     # the same plan from C records
-    h = _create(sd, cfg, B, nt, nr, mode, pairs, fold)
+    h = _create(sd, cfg, B, nt, nr, mode, pairs, fold, False, chain)
     try:
         sched, sig = schedule_tables(sd['sigmas'], cfg.model.sigma_end, levels, 3, [3e-11], [0.01], [ln])
         dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in dict(

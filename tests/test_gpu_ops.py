@@ -797,3 +797,58 @@ def test_f16x2_calibration_input_is_fixed():
     from score_based_channels_amd import _lib
     a, b = _lib.calibration_input(4096), _lib.calibration_input(8192)
     assert np.array_equal(a, b[:4096]) and abs(float(b.mean())) < 0.03 and abs(float(b.var()) - 0.5) < 0.03
+
+
+def _chain_reference(x, blocks, ws):
+    """RCU / CRP blocks in sequence with the oracle's primitives (layers.py:76-83, 126-134); x NHWC."""
+    out = x
+    for (typ, _, _), (w1, w2) in zip(blocks, ws):
+        if typ == 0:
+            t = O.conv2d(O.elu(out).transpose(0, 3, 1, 2), w1, None, 1)
+            out = out + O.conv2d(O.elu(t), w2, None, 1).transpose(0, 2, 3, 1)
+        else:
+            out = O.elu(out)
+            path = O.conv2d(O.max_pool5(out.transpose(0, 3, 1, 2)), w1, None, 1)
+            out = path.transpose(0, 2, 3, 1) + out
+            path = O.conv2d(O.max_pool5(path), w2, None, 1)
+            out = path.transpose(0, 2, 3, 1) + out
+    return out.astype(F32)
+
+
+@pytest.mark.parametrize('blocks', ['R', 'C', 'RR', 'CR', 'RRCR'])
+@pytest.mark.parametrize('B', [1, 8, 13, 203])
+@pytest.mark.parametrize('Cc', [64, 128])
+def test_chain_matches_oracle(gpu, Cc, B, blocks):
+    """SBC_OP_CHAIN (csrc/conv_chain.hip): runs of RCU and CRP blocks at the 8 x 2 level in one launch -- eight samples per
+    workgroup, the running tensor in registers, operands in LDS, column-parity units that skip the taps which only read padding --
+    against the oracle's convolutions / max pools / ELUs block by block, with a different weight scale per convolution, ragged
+    last groups, and bit-identical results for a sample whatever batch it is part of."""
+    torch, _lib = gpu
+    from score_based_channels_amd import plan as P
+    from score_based_channels_amd.weights import pack_conv_weight_f16x2
+    rng = np.random.default_rng(B * 1000 + Cc + len(blocks))
+    x = (rng.standard_normal((B, 8, 2, Cc)) * 1.5 + 0.3).astype(F32)
+    spec = [(0 if b == 'R' else 1, None, None) for b in blocks]
+    ws = [((rng.standard_normal((Cc, Cc, 3, 3)) / np.sqrt(9 * Cc) * (0.6 if k % 2 else 1.3)).astype(F32),
+           (rng.standard_normal((Cc, Cc, 3, 3)) / np.sqrt(9 * Cc) * (0.05 if k % 2 else 0.4)).astype(F32)) for k in range(len(blocks))]
+    ref = _chain_reference(x, spec, ws)
+    dx = _dev(torch, x)
+    dws = [(_dev(torch, pack_conv_weight_f16x2(a).view(np.float32)), _dev(torch, pack_conv_weight_f16x2(b).view(np.float32))) for a, b in ws]
+    ch = _lib.sbc_chain(n_blocks=len(blocks))
+    for k, ((typ, _, _), (a, b)) in enumerate(zip(spec, dws)):
+        ch.type[k], ch.w1[k], ch.w2[k] = typ, a.data_ptr(), b.data_ptr()
+
+    def run(xin):
+        out = torch.full(tuple(xin.shape), float('nan'), dtype=torch.float32, device='cuda')
+        op = _lib.sbc_op(kind=P.CHAIN, flags=P.CONV_F16X2, B=xin.shape[0], H=8, W=2, cin=Cc, cout=Cc, ksize=3, dil=1, in_=_p(xin), out=_p(out),
+                         ext=C.cast(C.pointer(ch), C.c_void_p))
+        _launch(gpu, op)
+        return out.cpu().numpy()
+    got = run(dx)
+    assert np.isfinite(got).all()
+    base = O.elu(x) if blocks[0] == 'C' and len(blocks) == 1 else x     # what the convolutions' sum is added to
+    assert rel_err(got - base, ref - base) < TOL, rel_err(got - base, ref - base)
+    assert rel_err(got, ref) < TOL
+    assert _lib.range_flag() == 0
+    if B >= 8:
+        assert np.array_equal(run(dx[:5].contiguous()), got[:5])       # batch independence, bit for bit

@@ -119,3 +119,24 @@ def test_fused_pair_plan_matches_reference_forward(weights64):
     assert P.count_conv_flops(big) == 13132365824
     small = P.build_score_plan(32, 64, 16, fuse_pairs=P.PAIR_SHAPES_F16W)                   # config 2 geometry in f16w mode
     assert sorted((op.src.c, op.src.h, op.src.w) for op in small.ops if op.kind == P.CONV_PAIR) == [(32, 64, 16)] * 5 + [(64, 16, 4)] * 0
+
+
+def test_chain_plan_matches_reference_forward(weights64):
+    """``build_score_plan(fuse_chain=True)``: the RCU / CRP runs of the 8 x 2 level are CHAIN records (csrc/conv_chain.hip) -- refine1
+    as ONE record of four blocks, the adapt convolutions and CRP + output convolutions of refine2 / refine31 and the low-resolution
+    adapt convolutions of refine3 as one record each: 34 records fewer, the same FLOPs, and interpreted on the CPU the same forward."""
+    _, sd = weights64
+    g = load_golden('forward_64x16.npz')
+    base = P.build_score_plan(32, 64, 16, fold_stats=True, fuse_pairs=P.PAIR_SHAPES, fuse_res=True)
+    pl = P.build_score_plan(32, 64, 16, fold_stats=True, fuse_pairs=P.PAIR_SHAPES, fuse_res=True, fuse_chain=True)
+    chains = [op for op in pl.ops if op.kind == P.CHAIN]
+    assert len(base.ops) == 125 and len(pl.ops) == 91 and len(chains) == 8
+    assert [len(op.blocks) for op in chains] == [4, 2, 2, 2, 2, 2, 2, 2] and [op.src.c for op in chains] == [128, 128, 128, 64, 64, 64, 64, 64]
+    assert all(op.src.h == 8 and op.src.w == 2 and op.dst.c == op.src.c for op in chains)
+    assert sum(len(op.blocks) for op in chains) == 18              # 15 RCU blocks + 3 CRP blocks = 36 of the level's 53 convolutions
+    assert not any(op.kind == P.MAXPOOL5 and op.src.h == 8 for op in pl.ops)
+    assert P.count_conv_flops(pl) == 820772864
+    assert not any(op.kind == P.CHAIN for op in P.build_score_plan(32, 256, 64, fuse_chain=True).ops)
+    x = np.ascontiguousarray(g['x'][:2].transpose(0, 2, 3, 1))
+    out = run_plan(pl, sd, x, np.full((2,), 1155))
+    assert rel_err(out.transpose(0, 3, 1, 2), g['out'][1][:2]) < 2e-5
