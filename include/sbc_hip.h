@@ -77,10 +77,11 @@ typedef enum sbc_op_kind {
                                 out = x + conv2(ELU(norm2(conv1(ELU(norm1(x))))))   layers.py:443-456, normalization.py:150-176;
                                 32 channels, 64 x 16 samples: a workgroup owns a whole sample, so it forms the InstanceNorm++
                                 statistics of the intermediate itself (csrc/conv_res.hip)                                    */
-    SBC_OP_CHAIN = 24        /* (ABI 13) a CHAIN of RCU blocks and CRP blocks of one RefineBlock in ONE launch, for the lowest
-                                resolution level (8 x 2 samples, 64 or 128 channels; layers.py:76-83,126-134,234-249): a workgroup
-                                owns eight samples, the running tensor x stays in registers between the blocks and the
-                                convolution operands in LDS; only the filters stream (csrc/conv_chain.hip).  ext = sbc_chain  */
+    SBC_OP_CHAIN = 24        /* (ABI 13) a CHAIN of RCU blocks, CRP blocks and ResidualBlocks in ONE launch, for the two lowest
+                                resolution levels (8 x 2 samples of 64 or 128 channels, 16 x 4 samples of 64; layers.py:76-83,
+                                126-134,234-249,443-456): a workgroup owns eight (four) samples, the running tensor x stays in
+                                registers between the blocks and the convolution operands in LDS; only the filters stream
+                                (csrc/conv_chain.hip).  ext = sbc_chain                                                       */
 } sbc_op_kind;
 
 /* sbc_op.flags for SBC_OP_CONV / SBC_OP_MAXPOOL5 */
@@ -267,22 +268,35 @@ typedef struct sbc_adam {
     const int32_t* step;         /* device counter: number of optimiser steps already taken (t - 1) */
 } sbc_adam;
 
-/* Extension of SBC_OP_CHAIN: the blocks, in execution order.  Every block is two 3x3 convolutions cin = cout = op.cin without bias:
- *   SBC_CHAIN_RCU   x <- x + conv_w2(ELU(conv_w1(ELU(x))))                                           layers.py:126-134
- *   SBC_CHAIN_CRP   x <- ELU(x); p = conv_w1(maxpool5(x)); x <- p + x; q = conv_w2(maxpool5(p)); x <- q + x   layers.py:76-83
- * w1 / w2: sbc_pack_conv_weight_f16x2 forms (SBC_CONV_F16X2 must be set: the only multiplier the kernel has).  w1_wino / w2_wino:
+/* Extension of SBC_OP_CHAIN: the blocks, in execution order.  Every convolution is 3x3, cin = cout = op.cin:
+ *   SBC_CHAIN_RCU   x <- x + conv_w2(ELU(conv_w1(ELU(x))))                      (no bias)                 layers.py:126-134
+ *   SBC_CHAIN_CRP   x <- ELU(x); p = conv_w1(maxpool5(x)); x <- p + x; q = conv_w2(maxpool5(p)); x <- q + x   (no bias)   layers.py:76-83
+ *   SBC_CHAIN_RES   a ResidualBlock without resampling or channel change (layers.py:443-456, normalization.py:163-176):
+ *                   x <- shortcut + conv_w2(ELU(norm2(conv_w1(ELU(norm1(x))) + bias1))) + bias2, every convolution with dilation
+ *                   dil (1, or 2 / 4 at a width of two); shortcut = x, or conv_w3(x) + bias3 when w3 is set (the dilated 'down'
+ *                   blocks); norm1 / norm2 = alpha | gamma | beta [3][cin] of the two InstanceNorm++ layers: the launch forms their
+ *                   statistics itself, a workgroup holds whole samples
+ * w1 / w2 / w3: sbc_pack_conv_weight_f16x2 forms (SBC_CONV_F16X2 must be set: the only multiplier the kernel has).  w1_wino / w2_wino:
  * the same layers' sbc_pack_conv_weight_winograd_f16x2 forms or NULL -- never read by a kernel, but sbc_f16x2_calibrate writes the
  * layer's activation scale into every form it is handed (see sbc_op.weight2_wino_split). */
-#define SBC_CHAIN_MAX_BLOCKS 4
+#define SBC_CHAIN_MAX_BLOCKS 6
 #define SBC_CHAIN_RCU 0
 #define SBC_CHAIN_CRP 1
+#define SBC_CHAIN_RES 2
 typedef struct sbc_chain {
     int32_t n_blocks;
     int32_t type[SBC_CHAIN_MAX_BLOCKS];
+    int32_t dil[SBC_CHAIN_MAX_BLOCKS];             /* RES blocks; 0 or 1 = undilated */
     const void* w1[SBC_CHAIN_MAX_BLOCKS];
     const void* w2[SBC_CHAIN_MAX_BLOCKS];
     const void* w1_wino[SBC_CHAIN_MAX_BLOCKS];
     const void* w2_wino[SBC_CHAIN_MAX_BLOCKS];
+    const void* w3[SBC_CHAIN_MAX_BLOCKS];          /* RES: shortcut convolution or NULL */
+    const float* bias1[SBC_CHAIN_MAX_BLOCKS];      /* RES */
+    const float* bias2[SBC_CHAIN_MAX_BLOCKS];
+    const float* bias3[SBC_CHAIN_MAX_BLOCKS];
+    const float* norm1[SBC_CHAIN_MAX_BLOCKS];
+    const float* norm2[SBC_CHAIN_MAX_BLOCKS];
 } sbc_chain;
 
 /* Extension of SBC_OP_END_CONV: where the noise level comes from (ncsnv2.py:295-298). */

@@ -67,8 +67,9 @@ class sbc_adam(C.Structure):
 
 
 class sbc_chain(C.Structure):
-    _fields_ = [('n_blocks', C.c_int32), ('type', C.c_int32 * 4), ('w1', C.c_void_p * 4), ('w2', C.c_void_p * 4),
-                ('w1_wino', C.c_void_p * 4), ('w2_wino', C.c_void_p * 4)]
+    _fields_ = [('n_blocks', C.c_int32), ('type', C.c_int32 * 6), ('dil', C.c_int32 * 6), ('w1', C.c_void_p * 6), ('w2', C.c_void_p * 6),
+                ('w1_wino', C.c_void_p * 6), ('w2_wino', C.c_void_p * 6), ('w3', C.c_void_p * 6), ('bias1', C.c_void_p * 6),
+                ('bias2', C.c_void_p * 6), ('bias3', C.c_void_p * 6), ('norm1', C.c_void_p * 6), ('norm2', C.c_void_p * 6)]
 
 
 class sbc_tensor_ref(C.Structure):

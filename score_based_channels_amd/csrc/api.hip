@@ -292,8 +292,8 @@ int sbc_f16x2_calibrate(const sbc_op* ops, int32_t n_ops, void* stream) {
             slot_of[i] = n_slots;
             n_slots += 2;
         } else if ((run[i].flags & SBC_CONV_F16X2) && run[i].kind == SBC_OP_CHAIN && run[i].ext) {
-            slot_of[i] = n_slots;                           // two per block: the inputs of its two convolutions
-            n_slots += 2 * SBC_CHAIN_MAX_BLOCKS;
+            slot_of[i] = n_slots;                           // three per block: the inputs of conv 1, conv 2 and the shortcut conv
+            n_slots += 3 * SBC_CHAIN_MAX_BLOCKS;
         }
     }
     if (n_slots == 0) return SBC_OK;                        // nothing to calibrate in this record list
@@ -342,11 +342,12 @@ int sbc_f16x2_calibrate(const sbc_op* ops, int32_t n_ops, void* stream) {
         if (o.kind == SBC_OP_CHAIN) {
             const sbc_chain& c = *(const sbc_chain*)o.ext;
             for (int b = 0; b < c.n_blocks && !rc; ++b) {
-                const float a1 = amax[slot_of[i] + 2 * b], a2 = amax[slot_of[i] + 2 * b + 1];
+                const float a1 = amax[slot_of[i] + 3 * b], a2 = amax[slot_of[i] + 3 * b + 1], a3 = amax[slot_of[i] + 3 * b + 2];
                 rc = set_trailer(c.w1[b], 9, o.cin, o.cout, scale_for(a1), a1);
                 if (!rc) rc = set_trailer(c.w1_wino[b], 16, o.cin, o.cout, scale_for(a1), a1);
                 if (!rc) rc = set_trailer(c.w2[b], 9, o.cin, o.cout, scale_for(a2), a2);
                 if (!rc) rc = set_trailer(c.w2_wino[b], 16, o.cin, o.cout, scale_for(a2), a2);
+                if (!rc && c.type[b] == SBC_CHAIN_RES) rc = set_trailer(c.w3[b], 9, o.cin, o.cout, scale_for(a3), a3);
             }
         } else if (o.kind == SBC_OP_CONV_PAIR || o.kind == SBC_OP_RES_BLOCK) {
             rc = set_trailer(o.weight_split, 9, o.cin, o.cout, s1, amax[slot_of[i]]);

@@ -20,6 +20,10 @@
 // LDS planes [term][8-channel group][sample][column][12 row slots][8 halves]: slots 1 .. 8 = rows, 0 and 9 stay zero (the padding
 // above and below); 24 slots per sample put the second sample of a unit 8 slots (mod 16) behind the first, so the 16 lanes of each
 // ds_read_b128 service group hit 16 different 16-byte slots: conflict-free, for every tap (conv_dp.hip has the rule).
+//
+// The 16 x 4 level (64 channels: refine3 and the low-resolution input of refine4) runs the same kernel with W = 4: a unit is ONE
+// column of ONE sample (its 16 rows; 18 row slots per column), four samples per workgroup, a wave owns all four columns of two
+// samples; the units of column 0 skip the dx = -1 taps and those of column 3 the dx = +1 taps (a sixth of the matrix work).
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
@@ -32,11 +36,14 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 struct ChainParams {
     const float* __restrict__ in;
     float* __restrict__ out;
-    const uint4* w[SBC_CHAIN_MAX_BLOCKS][2];
+    const uint4* w[SBC_CHAIN_MAX_BLOCKS][3];        // conv 1, conv 2, [shortcut conv of a RES block or NULL]
+    const float* bias[SBC_CHAIN_MAX_BLOCKS][3];     // RES blocks: their biases
+    const float* norm[SBC_CHAIN_MAX_BLOCKS][2];     // RES blocks: alpha | gamma | beta of normalize1 / normalize2, [3][C]
     int type[SBC_CHAIN_MAX_BLOCKS];
+    int dil[SBC_CHAIN_MAX_BLOCKS];
     int n_blocks;
     unsigned* __restrict__ range_flag;
-    float* __restrict__ calib;          // sbc_f16x2_calibrate: 2 amax slots per block (conv1's input, conv2's input), else NULL
+    float* __restrict__ calib;          // sbc_f16x2_calibrate: 3 amax slots per block (inputs of conv 1, conv 2, shortcut conv), else NULL
     int B;
 };
 
@@ -58,46 +65,64 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-// The K loop's micro-steps.  K step s = (tap, 32-channel slice kh), tap-major; within a K step the units are taken in pairs:
-//   dx =  0: NU / 2 micro-steps, (column 0, column 1) of sample pair q;
-//   dx = -1: NU / 4 micro-steps, column 1 of sample pairs 2q, 2q + 1 (column 0 would read padding: skipped);  dx = +1: column 0.
+// The K loop's micro-steps.  K step s = (tap, 32-channel slice kh), tap-major; within a K step the units whose source column
+// x + dx lies inside the image (x = unit index mod W) are taken in pairs, in ascending order:
+//   W = 2:  dx = 0: all NU units;  dx = -1: the column-1 units;  dx = +1: the column-0 units (NU / 2 each)
+//   W = 4:  dx = 0: all NU units;  dx = -1: columns 1 .. 3;      dx = +1: columns 0 .. 2     (3 NU / 4 each)
 struct MicroStep { int s, ua, ub; bool first_of_step; };
-template <int NU, int KH>
-__host__ __device__ constexpr int micro_steps() { return 3 * (NU / 2 + 2 * (NU / 4)) * KH; }
-template <int NU, int KH>
+template <int W, int NU>
+__host__ __device__ constexpr int valid_units(int dx) { return dx == 0 ? NU : NU * (W - 1) / W; }
+template <int W, int NU>
+__host__ __device__ constexpr int valid_unit(int dx, int k) {          // the k-th unit (ascending) with 0 <= x + dx < W
+    int seen = 0;
+    for (int i = 0; i < NU; ++i) {
+        const int xx = i % W + dx;
+        if (xx < 0 || xx >= W) continue;
+        if (seen == k) return i;
+        ++seen;
+    }
+    return -1;
+}
+template <int W, int NU, int KH>
+__host__ __device__ constexpr int micro_steps() { return 3 * (valid_units<W, NU>(0) + 2 * valid_units<W, NU>(1)) / 2 * KH; }
+template <int W, int NU, int KH>
 __host__ __device__ constexpr MicroStep micro_step(int m) {
-    constexpr int M0 = NU / 2, M1 = NU / 4, ROW = (M0 + 2 * M1) * KH;
+    constexpr int M0 = valid_units<W, NU>(0) / 2, M1 = valid_units<W, NU>(1) / 2, ROW = (M0 + 2 * M1) * KH;
+    static_assert(valid_units<W, NU>(0) % 2 == 0 && valid_units<W, NU>(1) % 2 == 0, "units are taken in pairs");
     const int row = m / ROW;
     int r = m % ROW, tapc = 0, kh = 0, q = 0;
     if (r < M1 * KH) { tapc = 0; kh = r / M1; q = r % M1; }
     else if (r < (M1 + M0) * KH) { r -= M1 * KH; tapc = 1; kh = r / M0; q = r % M0; }
     else { r -= (M1 + M0) * KH; tapc = 2; kh = r / M1; q = r % M1; }
-    MicroStep d{(3 * row + tapc) * KH + kh, 0, 0, q == 0};
-    if (tapc == 1) { d.ua = 2 * q; d.ub = 2 * q + 1; }
-    else if (tapc == 0) { d.ua = 4 * q + 1; d.ub = 4 * q + 3; }
-    else { d.ua = 4 * q; d.ub = 4 * q + 2; }
-    return d;
+    return MicroStep{(3 * row + tapc) * KH + kh, valid_unit<W, NU>(tapc - 1, 2 * q), valid_unit<W, NU>(tapc - 1, 2 * q + 1), q == 0};
 }
 
-// C channels in = out; G = 8 samples of 8 x 2 pixels per workgroup; 8 waves:
-//   C = 128: wave = 16-output-channel block cb, all 8 units (4 sample pairs x 2 column parities);
-//   C =  64: wave = (cb, half): 4 output-channel blocks x 2 halves of the sample pairs, 4 units each.
-template <int C>
-__global__ __launch_bounds__(512, 2) void conv_chain_w2_kernel(ChainParams p) {
-    constexpr int G = 8, CG = C / 8, KH = C / 32, NCB = C / 16;
-    constexpr int NP = C == 128 ? 4 : 2;                  // sample pairs per wave
-    constexpr int NU = 2 * NP;                            // units per wave: i = 2 * pair + column
-    constexpr int PS = G * 24 * 16;                       // bytes of one (term, channel group) plane: 3072 = 12 bank rows
+// C channels in = out; 8 waves; unit i of a wave = (sample group i / W, column i % W):
+//   W = 2 (8 x 2 samples), G = 8 samples per workgroup, a unit = one column of TWO samples (lane n: sample n >> 3, row n & 7);
+//          C = 128: wave = 16-output-channel block cb, all 8 units;  C = 64: wave = (cb, half), the 4 units of two sample pairs;
+//   W = 4 (16 x 4 samples, C = 64), G = 4: a unit = one column of ONE sample (lane n: row n); wave = (cb, half), 8 units.
+template <int C, int W>
+__global__ __launch_bounds__(512, 2) void conv_chain_kernel(ChainParams p) {
+    constexpr int H = W == 2 ? 8 : 16;
+    constexpr int G = W == 2 ? 8 : 4;
+    constexpr int CG = C / 8, KH = C / 32, NCB = C / 16, NHALF = 8 / NCB;
+    constexpr int SPU = W == 2 ? 2 : 1;                   // samples per unit
+    constexpr int NSG = G / SPU / NHALF;                  // sample groups (pairs at W = 2, samples at W = 4) per wave
+    constexpr int NU = NSG * W;                           // units per wave
+    constexpr int CP = H + (W == 2 ? 4 : 2);              // row slots per column: H rows + a zero slot above and below (+ alignment)
+    constexpr int SP = W * CP;                            // slots per sample
+    constexpr int PS = G * SP * 16;                       // bytes of one (term, channel group) plane
     constexpr int TERM = CG * PS;                         // low-term planes behind the high-term planes
-    static_assert(C == 64 || C == 128, "64 or 128 channels");
+    static_assert((C == 64 || C == 128) && (W == 2 || (W == 4 && C == 64)), "8 x 2 samples of 64 / 128 channels, 16 x 4 samples of 64");
+    static_assert(PS % 256 == 0 && (W != 2 || (SP % 16) == 8), "plane stride = whole bank rows; second sample of a W = 2 unit 8 slots (mod 16) on");
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cb = wave % NCB, uh = wave / NCB;
-    const int j0 = uh * NP;                               // first sample pair of this wave
+    const int w0 = uh * NSG * SPU;                        // first sample (within the workgroup's G) of this wave
     const int kq = lane >> 4, n = lane & 15;
-    const int sp = n >> 3, y = n & 7;                     // sample of the pair, image row of this lane's pixel
+    const int sp = W == 2 ? n >> 3 : 0, y = W == 2 ? n & 7 : n;   // sample of the unit, image row of this lane's pixel
     const int s0 = blockIdx.x * G;
 
     // ---- zero the planes once: the slots above and below every column are never written
@@ -108,13 +133,14 @@ __global__ __launch_bounds__(512, 2) void conv_chain_w2_kernel(ChainParams p) {
     const int ch0 = 16 * cb + 4 * kq;
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
-        const int s = s0 + 2 * (j0 + (i >> 1)) + sp;
+        const int s = s0 + w0 + (i / W) * SPU + sp;
         xs[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
-        if (s < p.B) xs[i] = *reinterpret_cast<const f32x4v*>(p.in + ((size_t)(s * 8 + y) * 2 + (i & 1)) * C + ch0);
+        if (s < p.B) xs[i] = *reinterpret_cast<const f32x4v*>(p.in + ((size_t)(s * H + y) * W + (i % W)) * C + ch0);
     }
-    // lane parts of the LDS addresses (bytes); the rest are compile-time constants
-    const int rd_base = kq * PS + ((2 * j0 + sp) * 24 + y) * 16;
-    const int wr_base = (2 * cb + (kq >> 1)) * PS + ((2 * j0 + sp) * 24 + 1 + y) * 16 + (kq & 1) * 8;
+    // lane parts of the LDS addresses (bytes); the rest are compile-time constants: unit i, source column xx, tap row dy ->
+    // (((i / W) * SPU) * SP + xx * CP + 1 + dy) * 16
+    const int rd_base = kq * PS + ((w0 + sp) * SP + y) * 16;
+    const int wr_base = (2 * cb + (kq >> 1)) * PS + ((w0 + sp) * SP + 1 + y) * 16 + (kq & 1) * 8;
     // lane part of the filter-fragment index (packed layout [tap][C/16 input groups][C/32 output blocks][2 terms][64 lanes], conv_pair.hip)
     const int wl_base = (((kq >> 1) * (C / 32) + (cb >> 1)) * 2) * 64 + (16 * (cb & 1) + n) + 32 * (kq & 1);
 
@@ -123,42 +149,143 @@ __global__ __launch_bounds__(512, 2) void conv_chain_w2_kernel(ChainParams p) {
     for (int i = 0; i < NU; ++i) acc[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
     float prev_descale = 1.f;
     unsigned rbits = 0;
+    float* const nscr = reinterpret_cast<float*>(smem + 2 * TERM);       // InstanceNorm++ scratch: mu [G][C], then (m, 1 / sqrt(v + eps)) [G][2]
     __syncthreads();
 
+    // ---- InstanceNorm2dPlus (normalization.py:163-176) + ELU of a tensor held in the accumulator layout, for the RES blocks: every
+    // statistic is formed in a fixed order that depends on the layout only (a sample's numbers do not depend on its neighbours):
+    //   per (sample, channel): mean and biased variance over the H W pixels -- the W units of the sample group in this lane, then the
+    //   rows (lanes of the same sample) by xor shuffles -- two passes, as F.instance_norm computes them;
+    //   per sample: mean m and UNBIASED variance v of the channel means -- every wave publishes its 16 channels' means in LDS, wave s
+    //   reduces sample s, everybody reads (m, 1 / sqrt(v + 1e-5)) back: two workgroup barriers.
+    auto norm_elu = [&](f32x4v (&v)[NU], const float* __restrict__ agb, bool elu_accurate) {
+        constexpr int RL = W == 2 ? 8 : 16;                           // lanes (rows) of one sample in a 16-lane group
+        const float inv_hw = 1.f / (float)(H * W);
+        f32x4v mu[NSG], rs[NSG];
+#pragma unroll
+        for (int g = 0; g < NSG; ++g) {
+            f32x4v sum = v[g * W];
+#pragma unroll
+            for (int x = 1; x < W; ++x) sum = vadd4(sum, v[g * W + x]);
+#pragma unroll
+            for (int m = 1; m < RL; m <<= 1)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sum[e] += __shfl_xor(sum[e], m);
+            mu[g] = vscale4(sum, inv_hw);
+            f32x4v m2 = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int x = 0; x < W; ++x)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float t = v[g * W + x][e] - mu[g][e]; m2[e] = fmaf(t, t, m2[e]); }
+#pragma unroll
+            for (int m = 1; m < RL; m <<= 1)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m2[e] += __shfl_xor(m2[e], m);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rs[g][e] = 1.f / sqrtf(m2[e] * inv_hw + 1e-5f);
+            if (y == 0) *reinterpret_cast<f32x4v*>(nscr + (w0 + g * SPU + sp) * C + ch0) = mu[g];
+        }
+        lds_barrier();
+        if (wave < G) {                                                // wave s: mean and unbiased variance over the channels of sample s
+            float a = 0.f;
+            for (int c = lane; c < C; c += 64) a += nscr[wave * C + c];
+            for (int m = 1; m < 64; m <<= 1) a += __shfl_xor(a, m);
+            const float mm = a * (1.f / (float)C);
+            float q = 0.f;
+            for (int c = lane; c < C; c += 64) { const float t = nscr[wave * C + c] - mm; q = fmaf(t, t, q); }
+            for (int m = 1; m < 64; m <<= 1) q += __shfl_xor(q, m);
+            if (lane == 0) { nscr[G * C + 2 * wave] = mm; nscr[G * C + 2 * wave + 1] = 1.f / sqrtf(q * (1.f / (float)(C - 1)) + 1e-5f); }
+        }
+        lds_barrier();
+        const f32x4v al = *reinterpret_cast<const f32x4v*>(agb + ch0), ga = *reinterpret_cast<const f32x4v*>(agb + C + ch0),
+                     be = *reinterpret_cast<const f32x4v*>(agb + 2 * C + ch0);
+#pragma unroll
+        for (int g = 0; g < NSG; ++g) {
+            const float mm = nscr[G * C + 2 * (w0 + g * SPU + sp)], rv = nscr[G * C + 2 * (w0 + g * SPU + sp) + 1];
+            f32x4v sc, sh;                                              // out = (x - mu) * sc + sh,  sc = gamma rstd,  sh = gamma mhat alpha + beta
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float mhat = (mu[g][e] - mm) * rv;
+                sc[e] = ga[e] * rs[g][e];
+                sh[e] = fmaf(ga[e], mhat * al[e], be[e]);
+            }
+#pragma unroll
+            for (int x = 0; x < W; ++x) {
+                f32x4v o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = fmaf(v[g * W + x][e] - mu[g][e], sc[e], sh[e]);
+                v[g * W + x] = to_v4(elu4(to_f4(o), elu_accurate));
+            }
+        }
+    };
+
+    // phases of a block: every phase is one convolution; what feeds it and what happens to its result depends on the block type
+    enum { PH_R1, PH_R2, PH_P1, PH_P2, PH_SC, PH_C1, PH_C2 };
 #pragma unroll 1
     for (int blk = 0; blk < p.n_blocks; ++blk) {
         const int type = p.type[blk];
+        const bool has_sc = type == SBC_CHAIN_RES && p.w[blk][2] != nullptr;
+        const int n_ph = has_sc ? 3 : 2;
+        const int dil = p.dil[blk];
 #pragma unroll 1
-        for (int cv = 0; cv < 2; ++cv) {
-            const uint4* __restrict__ w = p.w[blk][cv];
+        for (int ph = 0; ph < n_ph; ++ph) {
+            // phase kind and its filter: RCU (conv 1, conv 2), CRP (conv 1, conv 2), RES ([shortcut conv,] conv 1, conv 2)
+            const int kind = type == SBC_CHAIN_RCU ? PH_R1 + ph : type == SBC_CHAIN_CRP ? PH_P1 + ph : (has_sc ? PH_SC + ph : PH_C1 + ph);
+            const int wi = kind == PH_SC ? 2 : (kind == PH_R2 || kind == PH_P2 || kind == PH_C2) ? 1 : 0;
+            const uint4* __restrict__ w = p.w[blk][wi];
             const float4 tr = f16x2_trailer(reinterpret_cast<const float4*>(w), 9 * (C / 16) * (C / 32) * 2);
             const float scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tr.x)));
             const float descale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tr.y)));
             const bool elu_acc = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tr.w)) != 0;
+            const bool dx0 = W == 2 && dil > 1;                         // dilated at a width of two: only the dx = 0 taps touch the image
 
-            // ---- filter ring: K step s = (tap, 32-channel slice kh); the first three steps are requested before the operand work
-            constexpr int NS = 9 * KH, WD = 4;
+            // ---- filter ring: K step s = (tap, 32-channel slice kh); the first three steps are requested behind the operand work, in
+            // front of the two barriers of the plane update
+            constexpr int WD = 4;
             uint4 wr[WD][2];
-            auto ldw = [&](int s) {                                     // s is a compile-time constant at every call
-                const int tap = s / KH, kh = s % KH;
+            auto ldw = [&](int tap, int kh, int slot) {                 // compile-time constants at every call
                 const int idx = wl_base + ((tap * (C / 16) + 2 * kh) * (C / 32) * 2) * 64;
-                wr[s % WD][0] = w[idx];
-                wr[s % WD][1] = w[idx + 64];
+                wr[slot][0] = w[idx];
+                wr[slot][1] = w[idx + 64];
             };
-            ldw(0);
-            ldw(1);
-            ldw(2);
 
             // ---- the operand of this convolution, from registers
             f32x4v v[NU];
-            if (type == SBC_CHAIN_RCU) {
+            if (kind == PH_R1 || kind == PH_R2) {
 #pragma unroll
                 for (int i = 0; i < NU; ++i) {
-                    const f32x4v src = cv == 0 ? xs[i] : vscale4(acc[i], prev_descale);
+                    const f32x4v src = kind == PH_R1 ? xs[i] : vscale4(acc[i], prev_descale);
                     v[i] = to_v4(elu4(to_f4(src), elu_acc));
                 }
+            } else if (kind == PH_SC) {
+                // the shortcut convolution of a RES block reads x as it is (layers.py:453-456)
+#pragma unroll
+                for (int i = 0; i < NU; ++i) v[i] = xs[i];
+            } else if (kind == PH_C1 || kind == PH_C2) {
+                if (kind == PH_C1) {
+                    // normalize1 -> ELU of x; with a shortcut convolution its result (accumulators of the phase before, + bias) then
+                    // takes x's place: x itself is not needed again
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) v[i] = xs[i];
+                    norm_elu(v, p.norm[blk][0], elu_acc);
+                    if (has_sc) {
+                        const f32x4v b3 = *reinterpret_cast<const f32x4v*>(p.bias[blk][2] + ch0);
+#pragma unroll
+                        for (int i = 0; i < NU; ++i)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) xs[i][e] = fmaf(acc[i][e], prev_descale, b3[e]);
+                    }
+                } else {
+                    // t = conv1 + bias1; normalize2 -> ELU
+                    const f32x4v b1 = *reinterpret_cast<const f32x4v*>(p.bias[blk][0] + ch0);
+#pragma unroll
+                    for (int i = 0; i < NU; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[i][e] = fmaf(acc[i][e], prev_descale, b1[e]);
+                    norm_elu(v, p.norm[blk][1], elu_acc);
+                }
             } else {
-                if (cv == 0) {
+                if (kind == PH_P1) {
                     // x = act(x) (layers.py:77): the activated tensor is both the running sum and the first pooling input.  ELU in
                     // its accurate form: it sits outside a convolution prologue here (common.h)
 #pragma unroll
@@ -168,23 +295,36 @@ __global__ __launch_bounds__(512, 2) void conv_chain_w2_kernel(ChainParams p) {
 #pragma unroll
                     for (int i = 0; i < NU; ++i) { acc[i] = vscale4(acc[i], prev_descale); xs[i] = vadd4(acc[i], xs[i]); v[i] = acc[i]; }
                 }
-                // nn.MaxPool2d(5, 1, 2) on an 8 x 2 image: both columns (same lane of the pair's two units) x rows y - 2 .. y + 2
-                // (lanes n - 2 .. n + 2 of the same sample; -inf outside, as PyTorch pads)
+                // nn.MaxPool2d(5, 1, 2), separable: rows y - 2 .. y + 2 of the lane's own column (lanes n - 2 .. n + 2 of the same
+                // sample; -inf outside, as PyTorch pads), then columns x - 2 .. x + 2: the same lane of the sample group's other units
 #pragma unroll
-                for (int jp = 0; jp < NP; ++jp) {
-                    const f32x4v m = vmax4(v[2 * jp], v[2 * jp + 1]);
+                for (int i = 0; i < NU; ++i) {
+                    const f32x4v m = v[i];
                     f32x4v r = m;
 #pragma unroll
                     for (int d = -2; d <= 2; ++d) {
                         if (d == 0) continue;
-                        const bool ok = (unsigned)(y + d) < 8u;
+                        const bool ok = (unsigned)(y + d) < (unsigned)H;
                         f32x4v o;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = __shfl(m[e], lane + d);
                         if (ok) r = vmax4(r, o);
                     }
-                    v[2 * jp] = r;
-                    v[2 * jp + 1] = r;
+                    v[i] = r;
+                }
+#pragma unroll
+                for (int g = 0; g < NSG; ++g) {
+                    f32x4v c[W];
+#pragma unroll
+                    for (int x = 0; x < W; ++x) c[x] = v[g * W + x];
+#pragma unroll
+                    for (int x = 0; x < W; ++x) {
+                        f32x4v r = c[x];
+#pragma unroll
+                        for (int x2 = 0; x2 < W; ++x2)
+                            if (x2 != x && x2 >= x - 2 && x2 <= x + 2) r = vmax4(r, c[x2]);
+                        v[g * W + x] = r;
+                    }
                 }
             }
             float ta = 0.f;
@@ -197,12 +337,14 @@ __global__ __launch_bounds__(512, 2) void conv_chain_w2_kernel(ChainParams p) {
                 ta = ss.amax;
                 split_f16x2(f, scale, vh[i], vl[i]);
             }
-            pair_range_tile(ta, scale, rbits, p.calib ? p.calib + 2 * blk + cv : nullptr);
+            pair_range_tile(ta, scale, rbits, p.calib ? p.calib + 3 * blk + wi : nullptr);
+            if (dx0) { ldw(1, 0, 0); ldw(KH > 1 ? 1 : 4, KH > 1 ? 1 : 0, 1); ldw(KH > 2 ? 1 : 4, KH > 2 ? 2 : 0, 2); }
+            else { ldw(0, 0, 0); ldw(1 / KH, 1 % KH, 1); ldw(2 / KH, 2 % KH, 2); }
             // every wave has left the previous K loop: the planes may be rewritten
             lds_barrier();
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
-                unsigned char* dst = smem + wr_base + ((2 * (i >> 1)) * 24 + (i & 1) * 12) * 16;
+                unsigned char* dst = smem + wr_base + (((i / W) * SPU) * SP + (i % W) * CP) * 16;
                 *reinterpret_cast<uint2*>(dst) = vh[i];
                 *reinterpret_cast<uint2*>(dst + TERM) = vl[i];
             }
@@ -213,97 +355,145 @@ __global__ __launch_bounds__(512, 2) void conv_chain_w2_kernel(ChainParams p) {
             // micro-steps ahead of its six matrix instructions through a ring of statically indexed registers (left to itself the
             // scheduler reads each fragment right in front of its first use: one LDS round trip per unit), and the two units' matrix
             // instructions alternate, so no instruction waits for the accumulator of the one before.
-            // A K step has NU / 2 micro-steps when dx = 0 (all units), half as many otherwise (the units of one column parity).
+            // Lane base of tap row dy: row y + dy * dil of the lane's column, or the column's zero slot when that row is outside the
+            // image (undilated: the slots above and below the column are the padding, no select needed).
+            int rb[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int yy = y + (r - 1) * dil;
+                rb[r] = dil == 1 ? rd_base + r * 16 : ((unsigned)yy < (unsigned)H ? rd_base + (1 + (r - 1) * dil) * 16 : rd_base - y * 16);
+            }
             constexpr int XD = 4;
             f16x8 xr[XD][4];
-            // micro-step m -> (K step, first unit, second unit); everything folds at compile time (all callers pass constants)
-            auto ldx = [&](int m) {
-                const MicroStep d = micro_step<NU, KH>(m);
-                const int tap = d.s / KH, kh = d.s % KH, dy = tap / 3 - 1, dx = tap % 3 - 1;
-                const int offa = (4 * kh) * PS + ((2 * (d.ua >> 1)) * 24 + ((d.ua & 1) + dx) * 12 + 1 + dy) * 16;
-                const int offb = (4 * kh) * PS + ((2 * (d.ub >> 1)) * 24 + ((d.ub & 1) + dx) * 12 + 1 + dy) * 16;
-                xr[m % XD][0] = *reinterpret_cast<const f16x8*>(smem + rd_base + offa);
-                xr[m % XD][1] = *reinterpret_cast<const f16x8*>(smem + rd_base + offa + TERM);
-                xr[m % XD][2] = *reinterpret_cast<const f16x8*>(smem + rd_base + offb);
-                xr[m % XD][3] = *reinterpret_cast<const f16x8*>(smem + rd_base + offb + TERM);
+            auto kloop = [&](auto dx0c) {
+                constexpr bool DX0 = decltype(dx0c)::value;
+                constexpr int NS = (DX0 ? 3 : 9) * KH;
+                constexpr int NM = DX0 ? 3 * KH * (NU / 2) : micro_steps<W, NU, KH>();
+                auto step_of = [](int m) constexpr -> MicroStep {
+                    if constexpr (DX0) {                                 // K step s = (filter row, slice): tap 3 row + 1; units (2q, 2q + 1)
+                        const int s_ = m / (NU / 2), q = m % (NU / 2);
+                        return MicroStep{((3 * (s_ / KH) + 1) * KH + s_ % KH), 2 * q, 2 * q + 1, q == 0};
+                    } else {
+                        return micro_step<W, NU, KH>(m);
+                    }
+                };
+                // position of K step s in this loop's filter-ring order
+                auto ring_of = [](int s_) constexpr -> int { return DX0 ? ((s_ / KH) / 3) * KH + s_ % KH : s_; };
+                auto ldx = [&](int m) {
+                    const MicroStep d = step_of(m);
+                    const int tap = d.s / KH, kh = d.s % KH, r = tap / 3, dx = tap % 3 - 1;
+                    const int offa = (4 * kh) * PS + (((d.ua / W) * SPU) * SP + (d.ua % W + dx) * CP) * 16;
+                    const int offb = (4 * kh) * PS + (((d.ub / W) * SPU) * SP + (d.ub % W + dx) * CP) * 16;
+                    xr[m % XD][0] = *reinterpret_cast<const f16x8*>(smem + rb[r] + offa);
+                    xr[m % XD][1] = *reinterpret_cast<const f16x8*>(smem + rb[r] + offa + TERM);
+                    xr[m % XD][2] = *reinterpret_cast<const f16x8*>(smem + rb[r] + offb);
+                    xr[m % XD][3] = *reinterpret_cast<const f16x8*>(smem + rb[r] + offb + TERM);
+                };
+#pragma unroll
+                for (int m = 0; m < XD - 1; ++m) ldx(m);
+                static_for<0, NM>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    constexpr MicroStep d = step_of(m);
+                    constexpr int tap = d.s / KH, kh = d.s % KH;
+                    constexpr int rp = ring_of(d.s);                     // this K step's position in the ring order
+                    if constexpr (d.first_of_step && rp + WD - 1 < NS) {   // keep the filter ring full
+                        constexpr int nx = rp + WD - 1;
+                        constexpr int ntap = DX0 ? 3 * (nx / KH) + 1 : nx / KH;
+                        ldw(ntap, nx % KH, nx % WD);
+                    }
+                    if constexpr (m + XD - 1 < NM) ldx(m + XD - 1);
+                    const f16x8 wh = __builtin_bit_cast(f16x8, wr[rp % WD][0]);
+                    const f16x8 wl = __builtin_bit_cast(f16x8, wr[rp % WD][1]);
+                    const f16x8 ah = xr[m % XD][0], al = xr[m % XD][1], bh = xr[m % XD][2], bl = xr[m % XD][3];
+                    // a unit's first matrix instruction takes a literal zero addend: tap 0 (dx = -1) unless the unit is column 0, then
+                    // tap 1 (dilated: tap 1 for every unit)
+                    constexpr bool fa = kh == 0 && tap == ((d.ua % W) && !DX0 ? 0 : 1), fb = kh == 0 && tap == ((d.ub % W) && !DX0 ? 0 : 1);
+                    const f32x4v za = fa ? f32x4v{0.f, 0.f, 0.f, 0.f} : acc[d.ua], zb = fb ? f32x4v{0.f, 0.f, 0.f, 0.f} : acc[d.ub];
+                    acc[d.ua] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al, za, 0, 0, 0);
+                    acc[d.ub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl, zb, 0, 0, 0);
+                    acc[d.ua] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah, acc[d.ua], 0, 0, 0);
+                    acc[d.ub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh, acc[d.ub], 0, 0, 0);
+                    acc[d.ua] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah, acc[d.ua], 0, 0, 0);
+                    acc[d.ub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh, acc[d.ub], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
             };
-            constexpr int NM = micro_steps<NU, KH>();
+            if (W == 2 && dx0) kloop(std::integral_constant<bool, W == 2>{});
+            else kloop(std::false_type{});
+
+            // ---- what the result is for
+            if (kind == PH_R2 || kind == PH_P2) {
+                // the running sum takes it (descale is a power of two: one rounding, as an add)
 #pragma unroll
-            for (int m = 0; m < XD - 1; ++m) ldx(m);
-            static_for<0, NM>([&](auto mc) {
-                constexpr int m = decltype(mc)::value;
-                constexpr MicroStep d = micro_step<NU, KH>(m);
-                constexpr int tap = d.s / KH, kh = d.s % KH;
-                if constexpr (d.first_of_step && d.s + WD - 1 < NS) ldw(d.s + WD - 1);     // keep the filter ring full
-                if constexpr (m + XD - 1 < NM) ldx(m + XD - 1);
-                const f16x8 wh = __builtin_bit_cast(f16x8, wr[d.s % WD][0]);
-                const f16x8 wl = __builtin_bit_cast(f16x8, wr[d.s % WD][1]);
-                const f16x8 ah = xr[m % XD][0], al = xr[m % XD][1], bh = xr[m % XD][2], bl = xr[m % XD][3];
-                // a unit's first matrix instruction takes a literal zero addend: tap 0 for column 1, tap 1 for column 0
-                constexpr bool fa = kh == 0 && tap == ((d.ua & 1) ? 0 : 1), fb = kh == 0 && tap == ((d.ub & 1) ? 0 : 1);
-                const f32x4v za = fa ? f32x4v{0.f, 0.f, 0.f, 0.f} : acc[d.ua], zb = fb ? f32x4v{0.f, 0.f, 0.f, 0.f} : acc[d.ub];
-                acc[d.ua] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al, za, 0, 0, 0);
-                acc[d.ub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl, zb, 0, 0, 0);
-                acc[d.ua] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah, acc[d.ua], 0, 0, 0);
-                acc[d.ub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh, acc[d.ub], 0, 0, 0);
-                acc[d.ua] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah, acc[d.ua], 0, 0, 0);
-                acc[d.ub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh, acc[d.ub], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            // ---- second convolution of a block: the running sum takes it (descale is a power of two: one rounding, as an add)
-            if (cv == 1) {
-#pragma unroll
-                for (int i = 0; i < NU; ++i) {
+                for (int i = 0; i < NU; ++i)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) xs[i][e] = fmaf(acc[i][e], descale, xs[i][e]);
-                }
+            } else if (kind == PH_C2) {
+                // shortcut + (conv2 + bias2)  (layers.py:456)
+                const f32x4v b2 = *reinterpret_cast<const f32x4v*>(p.bias[blk][1] + ch0);
+#pragma unroll
+                for (int i = 0; i < NU; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xs[i][e] = xs[i][e] + fmaf(acc[i][e], descale, b2[e]);
             }
             prev_descale = descale;
         }
     }
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
-        const int s = s0 + 2 * (j0 + (i >> 1)) + sp;
-        if (s < p.B) st_out(p.out + ((size_t)(s * 8 + y) * 2 + (i & 1)) * C + ch0, to_f4(xs[i]));
+        const int s = s0 + w0 + (i / W) * SPU + sp;
+        if (s < p.B) st_out(p.out + ((size_t)(s * H + y) * W + (i % W)) * C + ch0, to_f4(xs[i]));
     }
     if (rbits && lane == 0) atomicOr(p.range_flag, rbits);
 }
 
-template <int C>
-static int launch_chain_w2(const ChainParams& p, hipStream_t stream, bool dry) {
-    constexpr int LDS = 2 * (C / 8) * 8 * 24 * 16;
-    auto kern = conv_chain_w2_kernel<C>;
+template <int C, int W>
+static int launch_chain_t(const ChainParams& p, hipStream_t stream, bool dry) {
+    constexpr int G = W == 2 ? 8 : 4, SP = W * (W == 2 ? 12 : 18);
+    constexpr int LDS = 2 * (C / 8) * G * SP * 16 + (G * C + 2 * G) * 4;       // operand planes + InstanceNorm++ scratch
+    auto kern = conv_chain_kernel<C, W>;
     { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), LDS); if (rc) return rc; }
     if (dry) return SBC_OK;
-    hipLaunchKernelGGL(kern, dim3((p.B + 7) / 8), dim3(512), LDS, stream, p);
+    hipLaunchKernelGGL(kern, dim3((p.B + G - 1) / G), dim3(512), LDS, stream, p);
     SBC_CHECK_HIP(hipGetLastError());
     return SBC_OK;
 }
 
 int launch_chain(const sbc_op& op, const sbc_chain& c, hipStream_t stream, bool dry) {
     SBC_REQUIRE(op.in && op.out && op.in != op.out, "chain: in / out must be set and distinct");
-    SBC_REQUIRE(op.H == 8 && op.W == 2 && op.cin == op.cout && (op.cin == 64 || op.cin == 128),
-                "chain: 8 x 2 samples of 64 or 128 channels (got %d x %d, %d -> %d)", op.H, op.W, op.cin, op.cout);
+    SBC_REQUIRE(op.cin == op.cout && ((op.H == 8 && op.W == 2 && (op.cin == 64 || op.cin == 128)) || (op.H == 16 && op.W == 4 && op.cin == 64)),
+                "chain: 8 x 2 samples of 64 or 128 channels, or 16 x 4 samples of 64 (got %d x %d, %d -> %d)", op.H, op.W, op.cin, op.cout);
     SBC_REQUIRE((op.flags & SBC_CONV_F16X2) && !(op.flags & SBC_CONV_F16W), "chain: SBC_CONV_F16X2 only (the weight forms it reads)");
     SBC_REQUIRE(c.n_blocks >= 1 && c.n_blocks <= SBC_CHAIN_MAX_BLOCKS, "chain: %d blocks (1 .. %d)", c.n_blocks, SBC_CHAIN_MAX_BLOCKS);
-    SBC_REQUIRE(op.B > 0 && (long)op.B * 16 * op.cin <= 0x7fffffffL, "chain: bad batch %d", op.B);
+    SBC_REQUIRE(op.B > 0 && (long)op.B * op.H * op.W * op.cin <= 0x7fffffffL, "chain: bad batch %d", op.B);
     ChainParams p;
     memset(&p, 0, sizeof(p));
     p.in = (const float*)op.in;
     p.out = (float*)op.out;
     p.n_blocks = c.n_blocks;
     for (int b = 0; b < c.n_blocks; ++b) {
-        SBC_REQUIRE(c.w1[b] && c.w2[b] && (c.type[b] == SBC_CHAIN_RCU || c.type[b] == SBC_CHAIN_CRP), "chain: block %d: weights / type", b);
+        SBC_REQUIRE(c.w1[b] && c.w2[b] && c.type[b] >= SBC_CHAIN_RCU && c.type[b] <= SBC_CHAIN_RES, "chain: block %d: weights / type", b);
         p.w[b][0] = (const uint4*)c.w1[b];
         p.w[b][1] = (const uint4*)c.w2[b];
         p.type[b] = c.type[b];
+        p.dil[b] = 1;
+        if (c.type[b] == SBC_CHAIN_RES) {
+            const int d = c.dil[b] > 1 ? c.dil[b] : 1;
+            SBC_REQUIRE(c.bias1[b] && c.bias2[b] && c.norm1[b] && c.norm2[b] && (!c.w3[b] || c.bias3[b]), "chain: RES block %d: biases / norms", b);
+            SBC_REQUIRE(d == 1 || (op.W == 2 && (d == 2 || d == 4)), "chain: RES block %d: dilation %d (1, or 2 / 4 at a width of two)", b, d);
+            p.dil[b] = d;
+            p.w[b][2] = (const uint4*)c.w3[b];
+            p.bias[b][0] = c.bias1[b]; p.bias[b][1] = c.bias2[b]; p.bias[b][2] = c.bias3[b];
+            p.norm[b][0] = c.norm1[b]; p.norm[b][1] = c.norm2[b];
+        }
     }
     p.calib = (float*)op.calib;
     p.B = op.B;
     unsigned* flag = nullptr;
     { const int rc = range_flag_ptr(&flag); if (rc) return rc; }
     p.range_flag = flag;
-    return op.cin == 128 ? launch_chain_w2<128>(p, stream, dry) : launch_chain_w2<64>(p, stream, dry);
+    if (op.W == 4) return launch_chain_t<64, 4>(p, stream, dry);
+    return op.cin == 128 ? launch_chain_t<128, 2>(p, stream, dry) : launch_chain_t<64, 2>(p, stream, dry);
 }
 
 }  // namespace sbc

@@ -27,7 +27,10 @@ struct POp {
     std::string norm_key;            // CONV with SBC_PRO_NORM_SELF: the norm whose (alpha | gamma | beta) `stats` points at (plan.py)
     std::string weight, bias, weight2;       // weight2: the second convolution of an SBC_OP_CONV_PAIR / SBC_OP_RES_BLOCK
     std::string bias2, norm2;                // SBC_OP_RES_BLOCK: the second convolution's bias, the second norm (plan.py)
-    struct Block { int type; std::string w1, w2; };
+    struct Block {                           // plan.py: Op.blocks; RES blocks carry the rest
+        int type; std::string w1, w2;
+        int dil = 1; std::string bias1, bias2, norm1, norm2, w3, bias3;
+    };
     std::vector<Block> blocks;               // SBC_OP_CHAIN: the RCU / CRP blocks in execution order (plan.py: Op.blocks)
 };
 
@@ -96,6 +99,12 @@ struct Builder {
         const int d = dilation ? dilation : 1;
         const bool pooled = down && !dilation;
         const int c1 = down ? t[x].c : cout;
+        if (chain_fusable(x) && t[x].c == cout && !pooled && (d == 1 || t[x].w == 2)) {       // plan.py: a RES block of a CHAIN record
+            POp::Block bl{SBC_CHAIN_RES, p + "conv1.weight", p + "conv2.weight"};
+            bl.dil = d; bl.bias1 = p + "conv1.bias"; bl.bias2 = p + "conv2.bias"; bl.norm1 = p + "normalize1"; bl.norm2 = p + "normalize2";
+            if (down) { bl.w3 = p + "shortcut.weight"; bl.bias3 = p + "shortcut.bias"; }
+            return chain(p + "chain", x, {bl});
+        }
         const int s1 = stats(p + "normalize1", x, p + "normalize1");
         if (fuse_res && t[x].c == 32 && cout == 32 && !down && !dilation && t[x].h == 64 && t[x].w == 16 && s1 != SELF_NORM) {   // plan.res_fusable
             const int out = tensor(p + "conv2", t[x].h, t[x].w, cout);
@@ -118,11 +127,13 @@ struct Builder {
         if (t[x].c != cout || down) sc = conv(p + "shortcut", x, p + "shortcut", cout, true, 0, -1, -1, -1, -1, 3, d);
         return conv(p + "conv2", a, p + "conv2", cout, true, SBC_PRO_NORM | SBC_PRO_ELU, s2, sc, -1, -1, 3, d);
     }
-    bool chain_fusable(int x) const { return fuse_chain && t[x].h == 8 && t[x].w == 2 && (t[x].c == 64 || t[x].c == 128); }
+    bool chain_fusable(int x) const {                                                          // plan.chain_fusable
+        return fuse_chain && ((t[x].h == 8 && t[x].w == 2 && (t[x].c == 64 || t[x].c == 128)) || (t[x].h == 16 && t[x].w == 4 && t[x].c == 64));
+    }
     static std::vector<POp::Block> rcu_blocks(const std::string& p, int n_blocks) {             // plan._Builder.rcu_blocks
         std::vector<POp::Block> v;
         for (int i = 1; i <= n_blocks; ++i)
-            v.push_back({SBC_CHAIN_RCU, p + std::to_string(i) + "_1_conv.weight", p + std::to_string(i) + "_2_conv.weight"});
+            v.push_back(POp::Block{SBC_CHAIN_RCU, p + std::to_string(i) + "_1_conv.weight", p + std::to_string(i) + "_2_conv.weight"});
         return v;
     }
     int chain(const std::string& name, int x, const std::vector<POp::Block>& blocks) {          // plan._Builder.chain
@@ -314,6 +325,21 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
     const int sn = b.stats("normalizer", ref5, "normalizer", false);
     const int o_t = b.tensor("score", nt, nr, d->channels);
     { POp o; o.kind = SBC_OP_END_CONV; o.src = ref5; o.dst = o_t; o.weight = "end_conv.weight"; o.bias = "end_conv.bias"; o.stats = sn; b.ops.push_back(o); }
+    // plan.merge_chains: adjacent CHAIN records, the second the only consumer of the first one's output, become one record
+    for (size_t k = 0; k + 1 < b.ops.size();) {
+        POp& a = b.ops[k];
+        const POp& c = b.ops[k + 1];
+        bool ok = a.kind == SBC_OP_CHAIN && c.kind == SBC_OP_CHAIN && c.src == a.dst && a.blocks.size() + c.blocks.size() <= SBC_CHAIN_MAX_BLOCKS;
+        for (size_t j = k + 2; ok && j < b.ops.size(); ++j)
+            for (int id : {b.ops[j].src, b.ops[j].stats, b.ops[j].res1, b.ops[j].res2, b.ops[j].up}) ok = ok && id != a.dst;
+        if (ok) {
+            a.blocks.insert(a.blocks.end(), c.blocks.begin(), c.blocks.end());
+            a.dst = c.dst;
+            b.ops.erase(b.ops.begin() + k + 1);
+        } else {
+            ++k;
+        }
+    }
     for (auto& o : b.ops)                   // plan.TAG_DIRECT_MID
         if (o.tag == 3 && !(o.flags & (SBC_PRO_NORM | SBC_EPI_UP | SBC_EPI_MOMENTS_OUT))) o.tag = 5;
     s->tensors = b.t; s->pops = b.ops; s->x_t = x; s->out_t = o_t;
@@ -361,12 +387,24 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
                 memcpy(host.data() + off[nkey] + (size_t)k * src.c, v, sizeof(float) * src.c);
             }
         }
+        for (const auto& bl : o.blocks)                      // the norms of the RES blocks of a CHAIN record
+            for (const std::string& nk : {bl.norm1, bl.norm2}) {
+                if (nk.empty() || off.count(nk)) continue;
+                for (int k = 0; k < 3; ++k) {
+                    const char* suffix[3] = {".alpha", ".gamma", ".beta"};
+                    const float* v = find(nk + suffix[k], src.c);
+                    if (!v) return fail();
+                    if (k == 0) reserve(nk, 3 * (size_t)src.c);
+                    v = rounded(v, src.c);
+                    memcpy(host.data() + off[nk] + (size_t)k * src.c, v, sizeof(float) * src.c);
+                }
+            }
         if (o.kind == SBC_OP_INORM_STATS) continue;
         if (o.weight.empty() && o.blocks.empty()) continue;   // max pooling has no parameters
         const int k = o.ksize, cin = src.c, cout = dst.c;
         const size_t wn = (size_t)cout * cin * k * k;
         std::vector<std::string> wkeys{o.weight, o.weight2};
-        for (const auto& bl : o.blocks) { wkeys.push_back(bl.w1); wkeys.push_back(bl.w2); }
+        for (const auto& bl : o.blocks) { wkeys.push_back(bl.w1); wkeys.push_back(bl.w2); wkeys.push_back(bl.w3); }
         for (const std::string& wkey : wkeys) {
         if (wkey.empty()) continue;
         if (!off.count(wkey) && !off.count(wkey + "#split")) {
@@ -399,7 +437,9 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
             }
         }
         }
-        for (const std::string& bkey : {o.bias, o.bias2}) {
+        std::vector<std::string> bkeys{o.bias, o.bias2};
+        for (const auto& bl : o.blocks) { bkeys.push_back(bl.bias1); bkeys.push_back(bl.bias2); bkeys.push_back(bl.bias3); }
+        for (const std::string& bkey : bkeys) {
             if (bkey.empty() || off.count(bkey)) continue;
             const float* bv = find(bkey, cout);
             if (!bv) return fail();
@@ -454,8 +494,15 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
             ch.n_blocks = (int32_t)o.blocks.size();
             for (size_t k = 0; k < o.blocks.size(); ++k) {
                 ch.type[k] = o.blocks[k].type;
-                ch.w1[k] = wp(o.blocks[k].w1 + "#split"); ch.w2[k] = wp(o.blocks[k].w2 + "#split");
-                ch.w1_wino[k] = wp(o.blocks[k].w1 + "#winograd_split"); ch.w2_wino[k] = wp(o.blocks[k].w2 + "#winograd_split");
+                const POp::Block& bl = o.blocks[k];
+                ch.w1[k] = wp(bl.w1 + "#split"); ch.w2[k] = wp(bl.w2 + "#split");
+                ch.w1_wino[k] = wp(bl.w1 + "#winograd_split"); ch.w2_wino[k] = wp(bl.w2 + "#winograd_split");
+                if (bl.type == SBC_CHAIN_RES) {
+                    ch.dil[k] = bl.dil;
+                    ch.bias1[k] = (const float*)wp(bl.bias1); ch.bias2[k] = (const float*)wp(bl.bias2);
+                    ch.norm1[k] = (const float*)wp(bl.norm1); ch.norm2[k] = (const float*)wp(bl.norm2);
+                    if (!bl.w3.empty()) { ch.w3[k] = wp(bl.w3 + "#split"); ch.bias3[k] = (const float*)wp(bl.bias3); }
+                }
             }
             s->chains.push_back(ch);
             r.ext = &s->chains.back();

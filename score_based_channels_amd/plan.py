@@ -39,7 +39,7 @@ CONV_PAIR = 21
 CONV_POOL = 22
 RES_BLOCK = 23
 CHAIN = 24               # a chain of RCU / CRP blocks at the 8 x 2 level in one launch (csrc/conv_chain.hip)
-CHAIN_RCU, CHAIN_CRP, CHAIN_MAX_BLOCKS = 0, 1, 4
+CHAIN_RCU, CHAIN_CRP, CHAIN_RES, CHAIN_MAX_BLOCKS = 0, 1, 2, 6
 BWD_ACCUM, PACK_ADJOINT, OP_SIDE, OP_JOIN, PACK_WINOGRAD = 0x200, 0x400, 0x800, 0x1000, 0x2000
 
 # profiling tags (sbc_op.tag; bench.py times each class by hipEvents in a single-stream segment after its timed region):
@@ -96,7 +96,8 @@ class Op:
     moments: Optional[Tensor] = None    # second output: tile moments of dst (EPI_MOMENTS_OUT), [HW/128][C][2] per sample
     geom: Optional[Tensor] = None       # INORM_STATS from tile moments: the tensor whose (H, W, C) the launch describes
     norm_key: Optional[str] = None      # CONV with PRO_NORM_SELF: state_dict prefix of the norm whose (alpha, gamma, beta) `stats` points at
-    blocks: Optional[list] = None       # CHAIN: [(CHAIN_RCU | CHAIN_CRP, weight key of conv 1, weight key of conv 2), ...]
+    blocks: Optional[list] = None       # CHAIN: [(CHAIN_RCU | CHAIN_CRP | CHAIN_RES, weight key of conv 1, of conv 2, extra), ...]; extra: None, or for
+                                        # a RES block {'bias1', 'bias2', 'norm1', 'norm2', 'dil', 'w3', 'bias3'} (w3 / bias3: shortcut conv or None)
 
     def inputs(self):
         return [t for t in (self.src, self.stats, self.res1, self.res2, self.up) if t is not None]
@@ -191,6 +192,13 @@ class _Builder:
         d = 1 if dilation is None else dilation
         pooled = resample == 'down' and dilation is None
         c1 = x.c if resample == 'down' else cout
+        if self.fuse_chain and chain_fusable(x.h, x.w, x.c) and x.c == cout and not pooled and (d == 1 or x.w == 2):
+            # the whole block as a RES block of a CHAIN record: the launch forms both norms' statistics itself (a workgroup holds
+            # whole samples), so neither statistics records nor the intermediate tensor exist
+            has_sc = resample is not None
+            extra = {'bias1': p + 'conv1.bias', 'bias2': p + 'conv2.bias', 'norm1': p + 'normalize1', 'norm2': p + 'normalize2', 'dil': d,
+                     'w3': p + 'shortcut.weight' if has_sc else None, 'bias3': p + 'shortcut.bias' if has_sc else None}
+            return self.chain(p + 'chain', x, [(CHAIN_RES, p + 'conv1.weight', p + 'conv2.weight', extra)])
         s1 = self.stats(p + 'normalize1', x, p + 'normalize1')
         if self.fuse_res and res_fusable(x.h, x.w, x.c, cout, resample, dilation) and not isinstance(s1, SelfNorm):
             # the whole block in one launch: a workgroup owns a sample and forms normalize2's statistics itself; the intermediate
@@ -234,7 +242,7 @@ class _Builder:
 
     @staticmethod
     def rcu_blocks(p, n_blocks):
-        return [(CHAIN_RCU, p + '%d_1_conv.weight' % i, p + '%d_2_conv.weight' % i) for i in range(1, n_blocks + 1)]
+        return [(CHAIN_RCU, p + '%d_1_conv.weight' % i, p + '%d_2_conv.weight' % i, None) for i in range(1, n_blocks + 1)]
 
     def rcu(self, p, x, n_blocks):
         """layers.py:126-134 (n_stages = 2, no bias)."""
@@ -280,7 +288,7 @@ class _Builder:
         if len(xs) == 1 and self.fuse_chain and chain_fusable(xs[0].h, xs[0].w, xs[0].c) and features == xs[0].c:
             # the whole RefineBlock is one chain: adapt RCU x 2, CRP, output RCU (layers.py:234-249 without the MSF of several inputs)
             return self.chain(p + 'chain', xs[0], self.rcu_blocks(p + 'adapt_convs.0.', 2)
-                              + [(CHAIN_CRP, p + 'crp.convs.0.weight', p + 'crp.convs.1.weight')]
+                              + [(CHAIN_CRP, p + 'crp.convs.0.weight', p + 'crp.convs.1.weight', None)]
                               + self.rcu_blocks(p + 'output_convs.', 3 if end else 1))
         if len(xs) == 1:
             h = self.rcu(p + 'adapt_convs.0.', xs[0], 2)
@@ -294,7 +302,7 @@ class _Builder:
             h = self.conv(p + 'msf.convs.0', h0, p + 'msf.convs.0', features, up=t1)
             self.ops[-1].join = joined
         if self.fuse_chain and chain_fusable(h.h, h.w, h.c):
-            return self.chain(p + 'tail', h, [(CHAIN_CRP, p + 'crp.convs.0.weight', p + 'crp.convs.1.weight')]
+            return self.chain(p + 'tail', h, [(CHAIN_CRP, p + 'crp.convs.0.weight', p + 'crp.convs.1.weight', None)]
                               + self.rcu_blocks(p + 'output_convs.', 3 if end else 1))
         h = self.crp(p + 'crp.', h)
         return self.rcu(p + 'output_convs.', h, 3 if end else 1)
@@ -307,10 +315,27 @@ PAIR_SHAPES = ((32, 16),)
 PAIR_SHAPES_F16W = ((32, 16), (32, 32), (32, 64), (64, 16), (64, 32))
 
 
+def merge_chains(ops):
+    """Adjacent CHAIN records where the second one is the only consumer of the first one's output become ONE record (up to
+    CHAIN_MAX_BLOCKS blocks): res5.0 + res5.1 + the whole of refine1, for instance.  In place."""
+    k = 0
+    while k + 1 < len(ops):
+        a, b = ops[k], ops[k + 1]
+        if (a.kind == CHAIN and b.kind == CHAIN and b.src is a.dst and not (a.side or b.side or a.join or b.join)
+                and len(a.blocks) + len(b.blocks) <= CHAIN_MAX_BLOCKS
+                and not any(a.dst in o.inputs() for o in ops[k + 2:])):
+            ops[k:k + 2] = [Op(CHAIN, a.name + '+' + b.name, src=a.src, dst=b.dst, blocks=a.blocks + b.blocks)]
+        else:
+            k += 1
+
+
 def chain_fusable(h, w, c):
-    """Shapes SBC_OP_CHAIN takes: 8 x 2 samples of 64 or 128 channels (the lowest level of a 64 x 16 array)."""
-    if os.environ.get('SBC_NO_CHAIN'):               # A/B aid: every convolution and max pool of the level as its own launch
+    """Shapes SBC_OP_CHAIN takes: 8 x 2 samples of 64 or 128 channels and 16 x 4 samples of 64 channels (the two lowest levels of a
+    64 x 16 array)."""
+    if os.environ.get('SBC_NO_CHAIN'):               # A/B aid: every convolution and max pool of those levels as its own launch
         return False
+    if h == 16 and w == 4 and c == 64:
+        return not os.environ.get('SBC_NO_CHAIN4')   # A/B aid: the 16 x 4 level unfused
     return h == 8 and w == 2 and c in (64, 128)
 
 
@@ -366,6 +391,7 @@ def build_score_plan(ngf=32, nt=64, nr=16, channels=2, share_slots=True, overlap
     sn = b.stats('normalizer', ref5, 'normalizer', consumer_is_conv=False)
     out = b.t('score', nt, nr, channels)
     b.ops.append(Op(END_CONV, 'end_conv', src=ref5, dst=out, weight='end_conv.weight', bias='end_conv.bias', stats=sn))
+    merge_chains(b.ops)
     for op in b.ops:                        # (after the statistics folding, which adds EPI_MOMENTS_OUT to producers)
         if op.tag == TAG_CONV_MID and not op.flags & (PRO_NORM | EPI_UP | EPI_MOMENTS_OUT):
             op.tag = TAG_DIRECT_MID
@@ -432,7 +458,7 @@ def count_conv_flops(plan):
         elif op.kind == CONV_POOL:
             total += 2 * op.src.h * op.src.w * op.src.c * op.dst.c * 9
         elif op.kind == CHAIN:
-            total += len(op.blocks) * 2 * 2 * op.src.h * op.src.w * op.src.c * op.dst.c * 9
+            total += sum(3 if (b[3] and b[3]['w3']) else 2 for b in op.blocks) * 2 * op.src.h * op.src.w * op.src.c * op.dst.c * 9
         elif op.kind in (BEGIN_CONV, END_CONV):
             total += 2 * op.src.h * op.src.w * op.src.c * op.dst.c * 9
     return total

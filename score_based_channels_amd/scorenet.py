@@ -299,10 +299,17 @@ class ScoreNet:
             elif op.kind == P.CHAIN:
                 o.ksize, o.dil = 3, 1
                 ch = _lib.sbc_chain(n_blocks=len(op.blocks))
-                for k, (typ, k1, k2) in enumerate(op.blocks):
+                for k, (typ, k1, k2, ex) in enumerate(op.blocks):
                     ch.type[k] = typ
                     ch.w1[k], ch.w2[k] = _ptr(self._wdev, self._woff[k1 + '#split']), _ptr(self._wdev, self._woff[k2 + '#split'])
-                    ch.w1_wino[k], ch.w2_wino[k] = wino(k1), wino(k2)
+                    if ex is None or ex['dil'] == 1:                # (dilated layers have no Winograd form)
+                        ch.w1_wino[k], ch.w2_wino[k] = wino(k1), wino(k2)
+                    if ex is not None:
+                        ch.dil[k] = ex['dil']
+                        ch.bias1[k], ch.bias2[k] = _ptr(self._wdev, self._woff[ex['bias1']]), _ptr(self._wdev, self._woff[ex['bias2']])
+                        ch.norm1[k], ch.norm2[k] = _ptr(self._wdev, self._woff[ex['norm1']]), _ptr(self._wdev, self._woff[ex['norm2']])
+                        if ex['w3'] is not None:
+                            ch.w3[k], ch.bias3[k] = _ptr(self._wdev, self._woff[ex['w3'] + '#split']), _ptr(self._wdev, self._woff[ex['bias3']])
                 keep.append(ch)
                 o.ext = C.cast(C.pointer(ch), C.c_void_p)
                 o.flags |= P.CONV_F16X2

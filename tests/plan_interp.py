@@ -99,8 +99,16 @@ def exec_op(op, sd, get, labels):
             out = src + _nhwc(O.conv2d(_nchw(u), sd[op.weight2], sd[op.bias2], 1))
         elif op.kind == P.CHAIN:                 # RCU / CRP blocks in sequence (layers.py:76-83, 126-134)
             out = src
-            for typ, k1, k2 in op.blocks:
-                if typ == P.CHAIN_RCU:
+            for typ, k1, k2, ex in op.blocks:
+                if typ == P.CHAIN_RES:           # a ResidualBlock without resampling or channel change (layers.py:443-456)
+                    st = inorm_stats(out, sd[ex['norm1'] + '.alpha'], sd[ex['norm1'] + '.gamma'], sd[ex['norm1'] + '.beta'])
+                    v = O.elu((out - st[:, None, None, 0]) * st[:, None, None, 1] + st[:, None, None, 2])
+                    t = _nhwc(O.conv2d(_nchw(v), sd[k1], sd[ex['bias1']], ex['dil']))
+                    st2 = inorm_stats(t, sd[ex['norm2'] + '.alpha'], sd[ex['norm2'] + '.gamma'], sd[ex['norm2'] + '.beta'])
+                    u = O.elu((t - st2[:, None, None, 0]) * st2[:, None, None, 1] + st2[:, None, None, 2])
+                    sc = out if ex['w3'] is None else _nhwc(O.conv2d(_nchw(out), sd[ex['w3']], sd[ex['bias3']], ex['dil']))
+                    out = sc + _nhwc(O.conv2d(_nchw(u), sd[k2], sd[ex['bias2']], ex['dil']))
+                elif typ == P.CHAIN_RCU:
                     t = O.conv2d(_nchw(O.elu(out)), sd[k1], None, 1)
                     out = out + _nhwc(O.conv2d(O.elu(t), sd[k2], None, 1))
                 else:

@@ -800,55 +800,91 @@ def test_f16x2_calibration_input_is_fixed():
 
 
 def _chain_reference(x, blocks, ws):
-    """RCU / CRP blocks in sequence with the oracle's primitives (layers.py:76-83, 126-134); x NHWC."""
+    """RCU / CRP / RES blocks in sequence with the oracle's primitives (layers.py:76-83, 126-134, 443-456); x NHWC.
+    ``blocks``: tokens 'R' (RCU), 'C' (CRP), 'S<d>' (ResidualBlock, identity shortcut, dilation d), 'X<d>' (ResidualBlock with a
+    shortcut convolution); ``ws``: per block (w1, w2, extra) with extra = dict(b1, b2, n1, n2[, w3, b3]) for the RES blocks."""
     out = x
-    for (typ, _, _), (w1, w2) in zip(blocks, ws):
-        if typ == 0:
+    for tok, (w1, w2, ex) in zip(blocks, ws):
+        if tok == 'R':
             t = O.conv2d(O.elu(out).transpose(0, 3, 1, 2), w1, None, 1)
             out = out + O.conv2d(O.elu(t), w2, None, 1).transpose(0, 2, 3, 1)
-        else:
+        elif tok == 'C':
             out = O.elu(out)
             path = O.conv2d(O.max_pool5(out.transpose(0, 3, 1, 2)), w1, None, 1)
             out = path.transpose(0, 2, 3, 1) + out
             path = O.conv2d(O.max_pool5(path), w2, None, 1)
             out = path.transpose(0, 2, 3, 1) + out
+        else:
+            d = int(tok[1:])
+            v = O.elu(O.instance_norm_plus(out.transpose(0, 3, 1, 2), *ex['n1']))
+            t = O.conv2d(v, w1, ex['b1'], d)
+            u = O.elu(O.instance_norm_plus(t, *ex['n2']))
+            sc = out if tok[0] == 'S' else O.conv2d(out.transpose(0, 3, 1, 2), ex['w3'], ex['b3'], d).transpose(0, 2, 3, 1)
+            out = sc + O.conv2d(u, w2, ex['b2'], d).transpose(0, 2, 3, 1)
     return out.astype(F32)
 
 
-@pytest.mark.parametrize('blocks', ['R', 'C', 'RR', 'CR', 'RRCR'])
+CHAIN_CASES = [('R',), ('C',), ('R', 'R'), ('C', 'R'), ('R', 'R', 'C', 'R'), ('S1',), ('S1', 'R'), ('X4', 'S4', 'R', 'R', 'C', 'R'), ('S2',), ('X2', 'C')]
+
+
+@pytest.mark.parametrize('blocks', CHAIN_CASES, ids=['-'.join(b) for b in CHAIN_CASES])
 @pytest.mark.parametrize('B', [1, 8, 13, 203])
-@pytest.mark.parametrize('Cc', [64, 128])
-def test_chain_matches_oracle(gpu, Cc, B, blocks):
-    """SBC_OP_CHAIN (csrc/conv_chain.hip): runs of RCU and CRP blocks at the 8 x 2 level in one launch -- eight samples per
-    workgroup, the running tensor in registers, operands in LDS, column-parity units that skip the taps which only read padding --
-    against the oracle's convolutions / max pools / ELUs block by block, with a different weight scale per convolution, ragged
-    last groups, and bit-identical results for a sample whatever batch it is part of."""
+@pytest.mark.parametrize('Cc,H,W', [(64, 8, 2), (128, 8, 2), (64, 16, 4)])
+def test_chain_matches_oracle(gpu, Cc, H, W, B, blocks):
+    """SBC_OP_CHAIN (csrc/conv_chain.hip): runs of RCU blocks, CRP blocks and ResidualBlocks at the 8 x 2 (and 16 x 4) level in one
+    launch -- eight (four) samples per workgroup, the running tensor in registers, operands in LDS, column units that skip the taps
+    which only read padding, InstanceNorm++ statistics formed in registers, dilated convolutions as their three live taps --
+    against the oracle's convolutions / max pools / norms / ELUs block by block, with a different weight scale per convolution,
+    ragged last groups, and bit-identical results for a sample whatever batch it is part of."""
     torch, _lib = gpu
     from score_based_channels_amd import plan as P
     from score_based_channels_amd.weights import pack_conv_weight_f16x2
-    rng = np.random.default_rng(B * 1000 + Cc + len(blocks))
-    x = (rng.standard_normal((B, 8, 2, Cc)) * 1.5 + 0.3).astype(F32)
-    spec = [(0 if b == 'R' else 1, None, None) for b in blocks]
-    ws = [((rng.standard_normal((Cc, Cc, 3, 3)) / np.sqrt(9 * Cc) * (0.6 if k % 2 else 1.3)).astype(F32),
-           (rng.standard_normal((Cc, Cc, 3, 3)) / np.sqrt(9 * Cc) * (0.05 if k % 2 else 0.4)).astype(F32)) for k in range(len(blocks))]
-    ref = _chain_reference(x, spec, ws)
+    if W == 4 and any(t[0] in 'SX' and int(t[1:]) > 1 for t in blocks):
+        pytest.skip('dilated ResidualBlocks exist at a width of two only (res4 / res5)')
+    rng = np.random.default_rng(B * 1000 + Cc + len(blocks) + W)
+    x = (rng.standard_normal((B, H, W, Cc)) * 1.5 + 0.3).astype(F32)
+
+    def conv_w(k, second):
+        return (rng.standard_normal((Cc, Cc, 3, 3)) / np.sqrt(9 * Cc) * ((0.05 if k % 2 else 0.4) if second else (0.6 if k % 2 else 1.3))).astype(F32)
+    ws = []
+    for k, tok in enumerate(blocks):
+        ex = None
+        if tok[0] in 'SX':
+            nrm = lambda: tuple((a + 0.1 * rng.standard_normal(Cc)).astype(F32) for a in (1.0, 1.0, 0.0))   # noqa: E731  alpha, gamma, beta
+            ex = dict(b1=(0.2 * rng.standard_normal(Cc)).astype(F32), b2=(0.2 * rng.standard_normal(Cc)).astype(F32), n1=nrm(), n2=nrm())
+            if tok[0] == 'X':
+                ex.update(w3=conv_w(k, False), b3=(0.2 * rng.standard_normal(Cc)).astype(F32))
+        ws.append((conv_w(k, False), conv_w(k, True), ex))
+    ref = _chain_reference(x, blocks, ws)
     dx = _dev(torch, x)
-    dws = [(_dev(torch, pack_conv_weight_f16x2(a).view(np.float32)), _dev(torch, pack_conv_weight_f16x2(b).view(np.float32))) for a, b in ws]
+    keep = []
+
+    def dev(a):
+        keep.append(_dev(torch, a))
+        return keep[-1].data_ptr()
     ch = _lib.sbc_chain(n_blocks=len(blocks))
-    for k, ((typ, _, _), (a, b)) in enumerate(zip(spec, dws)):
-        ch.type[k], ch.w1[k], ch.w2[k] = typ, a.data_ptr(), b.data_ptr()
+    for k, (tok, (w1, w2, ex)) in enumerate(zip(blocks, ws)):
+        ch.type[k] = {'R': 0, 'C': 1}.get(tok[0], 2)
+        ch.w1[k], ch.w2[k] = dev(pack_conv_weight_f16x2(w1).view(np.float32)), dev(pack_conv_weight_f16x2(w2).view(np.float32))
+        if ex is not None:
+            ch.dil[k] = int(tok[1:])
+            ch.bias1[k], ch.bias2[k] = dev(ex['b1']), dev(ex['b2'])
+            ch.norm1[k], ch.norm2[k] = dev(np.concatenate(ex['n1'])), dev(np.concatenate(ex['n2']))
+            if 'w3' in ex:
+                ch.w3[k], ch.bias3[k] = dev(pack_conv_weight_f16x2(ex['w3']).view(np.float32)), dev(ex['b3'])
 
     def run(xin):
         out = torch.full(tuple(xin.shape), float('nan'), dtype=torch.float32, device='cuda')
-        op = _lib.sbc_op(kind=P.CHAIN, flags=P.CONV_F16X2, B=xin.shape[0], H=8, W=2, cin=Cc, cout=Cc, ksize=3, dil=1, in_=_p(xin), out=_p(out),
+        op = _lib.sbc_op(kind=P.CHAIN, flags=P.CONV_F16X2, B=xin.shape[0], H=H, W=W, cin=Cc, cout=Cc, ksize=3, dil=1, in_=_p(xin), out=_p(out),
                          ext=C.cast(C.pointer(ch), C.c_void_p))
         _launch(gpu, op)
         return out.cpu().numpy()
     got = run(dx)
     assert np.isfinite(got).all()
-    base = O.elu(x) if blocks[0] == 'C' and len(blocks) == 1 else x     # what the convolutions' sum is added to
-    assert rel_err(got - base, ref - base) < TOL, rel_err(got - base, ref - base)
-    assert rel_err(got, ref) < TOL
+    if blocks[0] in 'RC':
+        base = O.elu(x) if blocks == ('C',) else x                      # what the convolutions' sum is added to
+        assert rel_err(got - base, ref - base) < TOL, rel_err(got - base, ref - base)
+    assert rel_err(got, ref) < TOL, rel_err(got, ref)
     assert _lib.range_flag() == 0
     if B >= 8:
         assert np.array_equal(run(dx[:5].contiguous()), got[:5])       # batch independence, bit for bit

@@ -122,21 +122,31 @@ def test_fused_pair_plan_matches_reference_forward(weights64):
 
 
 def test_chain_plan_matches_reference_forward(weights64):
-    """``build_score_plan(fuse_chain=True)``: the RCU / CRP runs of the 8 x 2 level are CHAIN records (csrc/conv_chain.hip) -- refine1
-    as ONE record of four blocks, the adapt convolutions and CRP + output convolutions of refine2 / refine31 and the low-resolution
-    adapt convolutions of refine3 as one record each: 34 records fewer, the same FLOPs, and interpreted on the CPU the same forward."""
+    """``build_score_plan(fuse_chain=True)``: the RCU / CRP runs and the ResidualBlocks without resampling or channel change of the
+    8 x 2 and 16 x 4 levels are CHAIN records (csrc/conv_chain.hip), adjacent ones merged -- res5.0 + res5.1 + the whole of refine1
+    is ONE record of six blocks: 56 records fewer than the plan it replaces, the same FLOPs, and interpreted on the CPU the same forward."""
     _, sd = weights64
     g = load_golden('forward_64x16.npz')
     base = P.build_score_plan(32, 64, 16, fold_stats=True, fuse_pairs=P.PAIR_SHAPES, fuse_res=True)
     pl = P.build_score_plan(32, 64, 16, fold_stats=True, fuse_pairs=P.PAIR_SHAPES, fuse_res=True, fuse_chain=True)
     chains = [op for op in pl.ops if op.kind == P.CHAIN]
-    assert len(base.ops) == 125 and len(pl.ops) == 91 and len(chains) == 8
-    assert [len(op.blocks) for op in chains] == [4, 2, 2, 2, 2, 2, 2, 2] and [op.src.c for op in chains] == [128, 128, 128, 64, 64, 64, 64, 64]
-    assert all(op.src.h == 8 and op.src.w == 2 and op.dst.c == op.src.c for op in chains)
-    assert sum(len(op.blocks) for op in chains) == 18              # 15 RCU blocks + 3 CRP blocks = 36 of the level's 53 convolutions
-    assert not any(op.kind == P.MAXPOOL5 and op.src.h == 8 for op in pl.ops)
+    low, mid = [op for op in chains if op.src.h == 8], [op for op in chains if op.src.h == 16]
+    assert len(base.ops) == 125 and len(pl.ops) == 69 and len(low) == 8 and len(mid) == 3
+    assert [len(op.blocks) for op in low] == [1, 1, 6, 2, 2, 4, 2, 4] and [op.src.c for op in low] == [64, 128, 128, 128, 128, 64, 64, 64]
+    assert [[b[0] for b in op.blocks] for op in low[:3]] == [[P.CHAIN_RES], [P.CHAIN_RES], [P.CHAIN_RES, P.CHAIN_RES, P.CHAIN_RCU, P.CHAIN_RCU, P.CHAIN_CRP, P.CHAIN_RCU]]
+    assert [b[3]['dil'] for op in low[:3] for b in op.blocks if b[3]] == [1, 2, 4, 4] and low[2].blocks[0][3]['w3'] == 'res5.0.shortcut.weight'
+    assert all(op.src.w == 2 and op.dst.c == op.src.c for op in low) and all(op.src.w == 4 and op.src.c == 64 for op in mid)
+    assert [len(op.blocks) for op in mid] == [1, 2, 4]
+    # of the 8 x 2 level's 53 convolutions only res4.0 (64 -> 128 channels: three launches) and the five MSF convolutions stay on their own
+    assert sum(3 if (b[3] and b[3]['w3']) else 2 for op in low for b in op.blocks) == 45
+    assert not any(op.kind == P.MAXPOOL5 and op.src.h in (8, 16) for op in pl.ops)
+    assert not any(op.kind == P.INORM_STATS and (op.geom or op.src).h * (op.geom or op.src).w <= 64 for op in pl.ops)
     assert P.count_conv_flops(pl) == 820772864
     assert not any(op.kind == P.CHAIN for op in P.build_score_plan(32, 256, 64, fuse_chain=True).ops)
+    # ... and without folded statistics (statistics records elsewhere) the chained blocks still need none
+    nf = P.build_score_plan(32, 64, 16, fuse_pairs=P.PAIR_SHAPES, fuse_chain=True)
+    assert sum(op.kind == P.INORM_STATS for op in nf.ops) == 25 - 2 * 5
     x = np.ascontiguousarray(g['x'][:2].transpose(0, 2, 3, 1))
-    out = run_plan(pl, sd, x, np.full((2,), 1155))
-    assert rel_err(out.transpose(0, 3, 1, 2), g['out'][1][:2]) < 2e-5
+    for plan in (pl, nf):
+        out = run_plan(plan, sd, x, np.full((2,), 1155))
+        assert rel_err(out.transpose(0, 3, 1, 2), g['out'][1][:2]) < 2e-5

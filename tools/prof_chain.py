@@ -20,15 +20,15 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 1700
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
     rng = np.random.default_rng(0)
-    for Cc, blocks in ((128, 'RRCR'), (128, 'RR'), (64, 'RR'), (64, 'CR')):
-        x = torch.from_numpy((rng.standard_normal((B, 8, 2, Cc)) * 1.5).astype(np.float32)).cuda()
+    for Cc, blocks, H, W in ((128, 'RRCR', 8, 2), (128, 'RR', 8, 2), (64, 'RR', 8, 2), (64, 'CR', 8, 2), (64, 'RR', 16, 4), (64, 'CR', 16, 4)):
+        x = torch.from_numpy((rng.standard_normal((B, H, W, Cc)) * 1.5).astype(np.float32)).cuda()
         out = torch.empty_like(x)
         ws = [[torch.from_numpy(pack_conv_weight_f16x2((rng.standard_normal((Cc, Cc, 3, 3)) / np.sqrt(9 * Cc)).astype(np.float32)).view(np.float32)).cuda()
                for _ in range(2)] for _ in blocks]
         ch = _lib.sbc_chain(n_blocks=len(blocks))
         for k, b in enumerate(blocks):
             ch.type[k], ch.w1[k], ch.w2[k] = (0 if b == 'R' else 1), ws[k][0].data_ptr(), ws[k][1].data_ptr()
-        op = _lib.sbc_op(kind=P.CHAIN, flags=P.CONV_F16X2, B=B, H=8, W=2, cin=Cc, cout=Cc, ksize=3, dil=1, in_=x.data_ptr(), out=out.data_ptr(),
+        op = _lib.sbc_op(kind=P.CHAIN, flags=P.CONV_F16X2, B=B, H=H, W=W, cin=Cc, cout=Cc, ksize=3, dil=1, in_=x.data_ptr(), out=out.data_ptr(),
                          ext=C.cast(C.pointer(ch), C.c_void_p))
         st = torch.cuda.current_stream().cuda_stream
         for _ in range(5):
@@ -42,8 +42,8 @@ def main():
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / reps * 1e3
         nconv = 2 * len(blocks)
-        flops = nconv * 2.0 * B * 16 * 9 * Cc * Cc
-        print('C=%d blocks=%s B=%d: %.1f us per launch, %.2f us per convolution, %.0f TFLOP/s algorithmic' % (Cc, blocks, B, us, us / nconv, flops / us / 1e6))
+        flops = nconv * 2.0 * B * H * W * 9 * Cc * Cc
+        print('%dx%d C=%d blocks=%s B=%d: %.1f us per launch, %.2f us per convolution, %.0f TFLOP/s algorithmic' % (H, W, Cc, blocks, B, us, us / nconv, flops / us / 1e6))
 
 
 if __name__ == '__main__':
