@@ -69,11 +69,11 @@ __device__ __forceinline__ void static_for(F&& f) {
 // x + dx lies inside the image (x = unit index mod W) are taken in pairs, in ascending order:
 //   W = 2:  dx = 0: all NU units;  dx = -1: the column-1 units;  dx = +1: the column-0 units (NU / 2 each)
 //   W = 4:  dx = 0: all NU units;  dx = -1: columns 1 .. 3;      dx = +1: columns 0 .. 2     (3 NU / 4 each)
-struct MicroStep { int s, ua, ub; bool first_of_step; };
+struct MicroStep { int s, ua, ub; bool first_of_step; };      // ub < 0: a single unit (odd number of live units: W = 8)
 template <int W, int NU>
 __host__ __device__ constexpr int valid_units(int dx) { return dx == 0 ? NU : NU * (W - 1) / W; }
 template <int W, int NU>
-__host__ __device__ constexpr int valid_unit(int dx, int k) {          // the k-th unit (ascending) with 0 <= x + dx < W
+__host__ __device__ constexpr int valid_unit(int dx, int k) {          // the k-th unit (ascending) with 0 <= x + dx < W, or -1
     int seen = 0;
     for (int i = 0; i < NU; ++i) {
         const int xx = i % W + dx;
@@ -84,11 +84,10 @@ __host__ __device__ constexpr int valid_unit(int dx, int k) {          // the k-
     return -1;
 }
 template <int W, int NU, int KH>
-__host__ __device__ constexpr int micro_steps() { return 3 * (valid_units<W, NU>(0) + 2 * valid_units<W, NU>(1)) / 2 * KH; }
+__host__ __device__ constexpr int micro_steps() { return 3 * ((valid_units<W, NU>(0) + 1) / 2 + 2 * ((valid_units<W, NU>(1) + 1) / 2)) * KH; }
 template <int W, int NU, int KH>
 __host__ __device__ constexpr MicroStep micro_step(int m) {
-    constexpr int M0 = valid_units<W, NU>(0) / 2, M1 = valid_units<W, NU>(1) / 2, ROW = (M0 + 2 * M1) * KH;
-    static_assert(valid_units<W, NU>(0) % 2 == 0 && valid_units<W, NU>(1) % 2 == 0, "units are taken in pairs");
+    constexpr int M0 = (valid_units<W, NU>(0) + 1) / 2, M1 = (valid_units<W, NU>(1) + 1) / 2, ROW = (M0 + 2 * M1) * KH;
     const int row = m / ROW;
     int r = m % ROW, tapc = 0, kh = 0, q = 0;
     if (r < M1 * KH) { tapc = 0; kh = r / M1; q = r % M1; }
@@ -100,29 +99,34 @@ __host__ __device__ constexpr MicroStep micro_step(int m) {
 // C channels in = out; 8 waves; unit i of a wave = (sample group i / W, column i % W):
 //   W = 2 (8 x 2 samples), G = 8 samples per workgroup, a unit = one column of TWO samples (lane n: sample n >> 3, row n & 7);
 //          C = 128: wave = 16-output-channel block cb, all 8 units;  C = 64: wave = (cb, half), the 4 units of two sample pairs;
-//   W = 4 (16 x 4 samples, C = 64), G = 4: a unit = one column of ONE sample (lane n: row n); wave = (cb, half), 8 units.
+//   W = 4 (16 x 4 samples, C = 64), G = 4: a unit = one column of ONE sample (lane n: row n); wave = (cb, half), 8 units;
+//   W = 8 (32 x 8 samples; RCU blocks only): a unit = one column of one HALF of a sample (lane n: row 16 half + n), 8 units = the
+//          eight columns;  C = 64, G = 1: wave = (cb, half);  C = 32, G = 2: wave = (cb, sample, half).
 template <int C, int W>
 __global__ __launch_bounds__(512, 2) void conv_chain_kernel(ChainParams p) {
-    constexpr int H = W == 2 ? 8 : 16;
-    constexpr int G = W == 2 ? 8 : 4;
-    constexpr int CG = C / 8, KH = C / 32, NCB = C / 16, NHALF = 8 / NCB;
+    constexpr int H = W == 2 ? 8 : W == 4 ? 16 : 32;
+    constexpr int G = W == 2 ? 8 : W == 4 ? 4 : (C == 32 ? 2 : 1);
+    constexpr int CG = C / 8, KH = C / 32, NCB = C / 16, NHALF = 8 / NCB;   // NHALF: unit groups among the waves
     constexpr int SPU = W == 2 ? 2 : 1;                   // samples per unit
-    constexpr int NSG = G / SPU / NHALF;                  // sample groups (pairs at W = 2, samples at W = 4) per wave
+    constexpr int NSG = W == 8 ? 1 : G / SPU / NHALF;     // sample groups (pairs at W = 2, samples at W = 4, half samples at W = 8) per wave
     constexpr int NU = NSG * W;                           // units per wave
     constexpr int CP = H + (W == 2 ? 4 : 2);              // row slots per column: H rows + a zero slot above and below (+ alignment)
     constexpr int SP = W * CP;                            // slots per sample
     constexpr int PS = G * SP * 16;                       // bytes of one (term, channel group) plane
     constexpr int TERM = CG * PS;                         // low-term planes behind the high-term planes
-    static_assert((C == 64 || C == 128) && (W == 2 || (W == 4 && C == 64)), "8 x 2 samples of 64 / 128 channels, 16 x 4 samples of 64");
+    static_assert((W == 2 && (C == 64 || C == 128)) || (W == 4 && C == 64) || (W == 8 && (C == 32 || C == 64)), "shapes of the header");
     static_assert(PS % 256 == 0 && (W != 2 || (SP % 16) == 8), "plane stride = whole bank rows; second sample of a W = 2 unit 8 slots (mod 16) on");
+    static_assert(NU == 8 || NU == 4, "accumulator budget: at most 8 units per wave");
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cb = wave % NCB, uh = wave / NCB;
-    const int w0 = uh * NSG * SPU;                        // first sample (within the workgroup's G) of this wave
+    // first sample (within the workgroup's G) of this wave, and the image row of its units' lane 0
+    const int w0 = W == 8 ? uh / 2 : uh * NSG * SPU;
+    const int yoff = W == 8 ? 16 * (uh & 1) : 0;
     const int kq = lane >> 4, n = lane & 15;
-    const int sp = W == 2 ? n >> 3 : 0, y = W == 2 ? n & 7 : n;   // sample of the unit, image row of this lane's pixel
+    const int sp = W == 2 ? n >> 3 : 0, y = yoff + (W == 2 ? n & 7 : n);   // sample of the unit, image row of this lane's pixel
     const int s0 = blockIdx.x * G;
 
     // ---- zero the planes once: the slots above and below every column are never written
@@ -383,11 +387,13 @@ __global__ __launch_bounds__(512, 2) void conv_chain_kernel(ChainParams p) {
                     const MicroStep d = step_of(m);
                     const int tap = d.s / KH, kh = d.s % KH, r = tap / 3, dx = tap % 3 - 1;
                     const int offa = (4 * kh) * PS + (((d.ua / W) * SPU) * SP + (d.ua % W + dx) * CP) * 16;
-                    const int offb = (4 * kh) * PS + (((d.ub / W) * SPU) * SP + (d.ub % W + dx) * CP) * 16;
                     xr[m % XD][0] = *reinterpret_cast<const f16x8*>(smem + rb[r] + offa);
                     xr[m % XD][1] = *reinterpret_cast<const f16x8*>(smem + rb[r] + offa + TERM);
-                    xr[m % XD][2] = *reinterpret_cast<const f16x8*>(smem + rb[r] + offb);
-                    xr[m % XD][3] = *reinterpret_cast<const f16x8*>(smem + rb[r] + offb + TERM);
+                    if (d.ub >= 0) {
+                        const int offb = (4 * kh) * PS + (((d.ub / W) * SPU) * SP + (d.ub % W + dx) * CP) * 16;
+                        xr[m % XD][2] = *reinterpret_cast<const f16x8*>(smem + rb[r] + offb);
+                        xr[m % XD][3] = *reinterpret_cast<const f16x8*>(smem + rb[r] + offb + TERM);
+                    }
                 };
 #pragma unroll
                 for (int m = 0; m < XD - 1; ++m) ldx(m);
@@ -404,17 +410,26 @@ __global__ __launch_bounds__(512, 2) void conv_chain_kernel(ChainParams p) {
                     if constexpr (m + XD - 1 < NM) ldx(m + XD - 1);
                     const f16x8 wh = __builtin_bit_cast(f16x8, wr[rp % WD][0]);
                     const f16x8 wl = __builtin_bit_cast(f16x8, wr[rp % WD][1]);
-                    const f16x8 ah = xr[m % XD][0], al = xr[m % XD][1], bh = xr[m % XD][2], bl = xr[m % XD][3];
+                    const f16x8 ah = xr[m % XD][0], al = xr[m % XD][1];
                     // a unit's first matrix instruction takes a literal zero addend: tap 0 (dx = -1) unless the unit is column 0, then
                     // tap 1 (dilated: tap 1 for every unit)
-                    constexpr bool fa = kh == 0 && tap == ((d.ua % W) && !DX0 ? 0 : 1), fb = kh == 0 && tap == ((d.ub % W) && !DX0 ? 0 : 1);
-                    const f32x4v za = fa ? f32x4v{0.f, 0.f, 0.f, 0.f} : acc[d.ua], zb = fb ? f32x4v{0.f, 0.f, 0.f, 0.f} : acc[d.ub];
-                    acc[d.ua] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al, za, 0, 0, 0);
-                    acc[d.ub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl, zb, 0, 0, 0);
-                    acc[d.ua] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah, acc[d.ua], 0, 0, 0);
-                    acc[d.ub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh, acc[d.ub], 0, 0, 0);
-                    acc[d.ua] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah, acc[d.ua], 0, 0, 0);
-                    acc[d.ub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh, acc[d.ub], 0, 0, 0);
+                    constexpr bool fa = kh == 0 && tap == ((d.ua % W) && !DX0 ? 0 : 1);
+                    const f32x4v za = fa ? f32x4v{0.f, 0.f, 0.f, 0.f} : acc[d.ua];
+                    if constexpr (d.ub >= 0) {
+                        const f16x8 bh = xr[m % XD][2], bl = xr[m % XD][3];
+                        constexpr bool fb = kh == 0 && tap == ((d.ub % W) && !DX0 ? 0 : 1);
+                        const f32x4v zb = fb ? f32x4v{0.f, 0.f, 0.f, 0.f} : acc[d.ub];
+                        acc[d.ua] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al, za, 0, 0, 0);
+                        acc[d.ub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl, zb, 0, 0, 0);
+                        acc[d.ua] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah, acc[d.ua], 0, 0, 0);
+                        acc[d.ub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh, acc[d.ub], 0, 0, 0);
+                        acc[d.ua] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah, acc[d.ua], 0, 0, 0);
+                        acc[d.ub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh, acc[d.ub], 0, 0, 0);
+                    } else {
+                        acc[d.ua] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al, za, 0, 0, 0);
+                        acc[d.ua] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah, acc[d.ua], 0, 0, 0);
+                        acc[d.ua] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah, acc[d.ua], 0, 0, 0);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 });
             };
@@ -449,7 +464,7 @@ __global__ __launch_bounds__(512, 2) void conv_chain_kernel(ChainParams p) {
 
 template <int C, int W>
 static int launch_chain_t(const ChainParams& p, hipStream_t stream, bool dry) {
-    constexpr int G = W == 2 ? 8 : 4, SP = W * (W == 2 ? 12 : 18);
+    constexpr int G = W == 2 ? 8 : W == 4 ? 4 : (C == 32 ? 2 : 1), SP = W * (W == 2 ? 12 : W == 4 ? 18 : 34);
     constexpr int LDS = 2 * (C / 8) * G * SP * 16 + (G * C + 2 * G) * 4;       // operand planes + InstanceNorm++ scratch
     auto kern = conv_chain_kernel<C, W>;
     { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), LDS); if (rc) return rc; }
@@ -461,8 +476,9 @@ static int launch_chain_t(const ChainParams& p, hipStream_t stream, bool dry) {
 
 int launch_chain(const sbc_op& op, const sbc_chain& c, hipStream_t stream, bool dry) {
     SBC_REQUIRE(op.in && op.out && op.in != op.out, "chain: in / out must be set and distinct");
-    SBC_REQUIRE(op.cin == op.cout && ((op.H == 8 && op.W == 2 && (op.cin == 64 || op.cin == 128)) || (op.H == 16 && op.W == 4 && op.cin == 64)),
-                "chain: 8 x 2 samples of 64 or 128 channels, or 16 x 4 samples of 64 (got %d x %d, %d -> %d)", op.H, op.W, op.cin, op.cout);
+    SBC_REQUIRE(op.cin == op.cout && ((op.H == 8 && op.W == 2 && (op.cin == 64 || op.cin == 128)) || (op.H == 16 && op.W == 4 && op.cin == 64) ||
+                                      (op.H == 32 && op.W == 8 && (op.cin == 32 || op.cin == 64))),
+                "chain: 8 x 2 samples of 64 / 128 channels, 16 x 4 samples of 64, 32 x 8 samples of 32 / 64 (got %d x %d, %d -> %d)", op.H, op.W, op.cin, op.cout);
     SBC_REQUIRE((op.flags & SBC_CONV_F16X2) && !(op.flags & SBC_CONV_F16W), "chain: SBC_CONV_F16X2 only (the weight forms it reads)");
     SBC_REQUIRE(c.n_blocks >= 1 && c.n_blocks <= SBC_CHAIN_MAX_BLOCKS, "chain: %d blocks (1 .. %d)", c.n_blocks, SBC_CHAIN_MAX_BLOCKS);
     SBC_REQUIRE(op.B > 0 && (long)op.B * op.H * op.W * op.cin <= 0x7fffffffL, "chain: bad batch %d", op.B);
@@ -475,6 +491,7 @@ int launch_chain(const sbc_op& op, const sbc_chain& c, hipStream_t stream, bool 
         SBC_REQUIRE(c.w1[b] && c.w2[b] && c.type[b] >= SBC_CHAIN_RCU && c.type[b] <= SBC_CHAIN_RES, "chain: block %d: weights / type", b);
         p.w[b][0] = (const uint4*)c.w1[b];
         p.w[b][1] = (const uint4*)c.w2[b];
+        SBC_REQUIRE(op.W != 8 || c.type[b] == SBC_CHAIN_RCU, "chain: block %d: 32 x 8 samples take RCU blocks only (a wave holds half a sample there)", b);
         p.type[b] = c.type[b];
         p.dil[b] = 1;
         if (c.type[b] == SBC_CHAIN_RES) {
@@ -492,6 +509,7 @@ int launch_chain(const sbc_op& op, const sbc_chain& c, hipStream_t stream, bool 
     unsigned* flag = nullptr;
     { const int rc = range_flag_ptr(&flag); if (rc) return rc; }
     p.range_flag = flag;
+    if (op.W == 8) return op.cin == 32 ? launch_chain_t<32, 8>(p, stream, dry) : launch_chain_t<64, 8>(p, stream, dry);
     if (op.W == 4) return launch_chain_t<64, 4>(p, stream, dry);
     return op.cin == 128 ? launch_chain_t<128, 2>(p, stream, dry) : launch_chain_t<64, 2>(p, stream, dry);
 }

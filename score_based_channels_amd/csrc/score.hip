@@ -99,7 +99,7 @@ struct Builder {
         const int d = dilation ? dilation : 1;
         const bool pooled = down && !dilation;
         const int c1 = down ? t[x].c : cout;
-        if (chain_fusable(x) && t[x].c == cout && !pooled && (d == 1 || t[x].w == 2)) {       // plan.py: a RES block of a CHAIN record
+        if (chain_fusable(x, SBC_CHAIN_RES) && t[x].c == cout && !pooled && (d == 1 || t[x].w == 2)) {       // plan.py: a RES block of a CHAIN record
             POp::Block bl{SBC_CHAIN_RES, p + "conv1.weight", p + "conv2.weight"};
             bl.dil = d; bl.bias1 = p + "conv1.bias"; bl.bias2 = p + "conv2.bias"; bl.norm1 = p + "normalize1"; bl.norm2 = p + "normalize2";
             if (down) { bl.w3 = p + "shortcut.weight"; bl.bias3 = p + "shortcut.bias"; }
@@ -127,8 +127,10 @@ struct Builder {
         if (t[x].c != cout || down) sc = conv(p + "shortcut", x, p + "shortcut", cout, true, 0, -1, -1, -1, -1, 3, d);
         return conv(p + "conv2", a, p + "conv2", cout, true, SBC_PRO_NORM | SBC_PRO_ELU, s2, sc, -1, -1, 3, d);
     }
-    bool chain_fusable(int x) const {                                                          // plan.chain_fusable
-        return fuse_chain && ((t[x].h == 8 && t[x].w == 2 && (t[x].c == 64 || t[x].c == 128)) || (t[x].h == 16 && t[x].w == 4 && t[x].c == 64));
+    bool chain_fusable(int x, int kind = SBC_CHAIN_RCU) const {                                // plan.chain_fusable
+        if (!fuse_chain) return false;
+        if (t[x].h == 32 && t[x].w == 8 && (t[x].c == 32 || t[x].c == 64)) return kind == SBC_CHAIN_RCU;
+        return (t[x].h == 8 && t[x].w == 2 && (t[x].c == 64 || t[x].c == 128)) || (t[x].h == 16 && t[x].w == 4 && t[x].c == 64);
     }
     static std::vector<POp::Block> rcu_blocks(const std::string& p, int n_blocks) {             // plan._Builder.rcu_blocks
         std::vector<POp::Block> v;
@@ -195,7 +197,7 @@ struct Builder {
     int refine(const std::string& p, const std::vector<int>& xs, int features, bool end = false) {
         int h;
         const POp::Block crp_block{SBC_CHAIN_CRP, p + "crp.convs.0.weight", p + "crp.convs.1.weight"};
-        if (xs.size() == 1 && chain_fusable(xs[0]) && features == t[xs[0]].c) {              // the whole RefineBlock is one chain
+        if (xs.size() == 1 && chain_fusable(xs[0], SBC_CHAIN_CRP) && features == t[xs[0]].c) {              // the whole RefineBlock is one chain
             std::vector<POp::Block> bl = rcu_blocks(p + "adapt_convs.0.", 2);
             bl.push_back(crp_block);
             for (const auto& r : rcu_blocks(p + "output_convs.", end ? 3 : 1)) bl.push_back(r);
@@ -209,7 +211,7 @@ struct Builder {
             const int h0 = rcu(p + "adapt_convs.0.", xs[0], 2);
             h = conv(p + "msf.convs.0", h0, p + "msf.convs.0", features, true, 0, -1, -1, -1, t1);
         }
-        if (chain_fusable(h)) {
+        if (chain_fusable(h, SBC_CHAIN_CRP)) {
             std::vector<POp::Block> bl{crp_block};
             for (const auto& r : rcu_blocks(p + "output_convs.", end ? 3 : 1)) bl.push_back(r);
             return chain(p + "tail", h, bl);

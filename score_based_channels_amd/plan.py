@@ -192,7 +192,7 @@ class _Builder:
         d = 1 if dilation is None else dilation
         pooled = resample == 'down' and dilation is None
         c1 = x.c if resample == 'down' else cout
-        if self.fuse_chain and chain_fusable(x.h, x.w, x.c) and x.c == cout and not pooled and (d == 1 or x.w == 2):
+        if self.fuse_chain and chain_fusable(x.h, x.w, x.c, CHAIN_RES) and x.c == cout and not pooled and (d == 1 or x.w == 2):
             # the whole block as a RES block of a CHAIN record: the launch forms both norms' statistics itself (a workgroup holds
             # whole samples), so neither statistics records nor the intermediate tensor exist
             has_sc = resample is not None
@@ -285,7 +285,7 @@ class _Builder:
         """layers.py:234-249; MSF (layers.py:178-184) for two inputs, the second may be at half resolution.  The second
         input's adapt convolutions and its MSF convolution do not depend on the first input's: with ``overlap`` they are
         issued first as side records and the first input's MSF convolution (which adds their result) joins them."""
-        if len(xs) == 1 and self.fuse_chain and chain_fusable(xs[0].h, xs[0].w, xs[0].c) and features == xs[0].c:
+        if len(xs) == 1 and self.fuse_chain and chain_fusable(xs[0].h, xs[0].w, xs[0].c, CHAIN_CRP) and features == xs[0].c:
             # the whole RefineBlock is one chain: adapt RCU x 2, CRP, output RCU (layers.py:234-249 without the MSF of several inputs)
             return self.chain(p + 'chain', xs[0], self.rcu_blocks(p + 'adapt_convs.0.', 2)
                               + [(CHAIN_CRP, p + 'crp.convs.0.weight', p + 'crp.convs.1.weight', None)]
@@ -301,7 +301,7 @@ class _Builder:
             h0 = self.rcu(p + 'adapt_convs.0.', xs[0], 2)
             h = self.conv(p + 'msf.convs.0', h0, p + 'msf.convs.0', features, up=t1)
             self.ops[-1].join = joined
-        if self.fuse_chain and chain_fusable(h.h, h.w, h.c):
+        if self.fuse_chain and chain_fusable(h.h, h.w, h.c, CHAIN_CRP):
             return self.chain(p + 'tail', h, [(CHAIN_CRP, p + 'crp.convs.0.weight', p + 'crp.convs.1.weight', None)]
                               + self.rcu_blocks(p + 'output_convs.', 3 if end else 1))
         h = self.crp(p + 'crp.', h)
@@ -329,13 +329,15 @@ def merge_chains(ops):
             k += 1
 
 
-def chain_fusable(h, w, c):
-    """Shapes SBC_OP_CHAIN takes: 8 x 2 samples of 64 or 128 channels and 16 x 4 samples of 64 channels (the two lowest levels of a
-    64 x 16 array)."""
+def chain_fusable(h, w, c, kind=CHAIN_RCU):
+    """Shapes SBC_OP_CHAIN takes: 8 x 2 samples of 64 or 128 channels, 16 x 4 samples of 64 channels (the two lowest levels of a
+    64 x 16 array), and -- RCU blocks only: a wave holds half a sample there -- 32 x 8 samples of 32 or 64 channels."""
     if os.environ.get('SBC_NO_CHAIN'):               # A/B aid: every convolution and max pool of those levels as its own launch
         return False
     if h == 16 and w == 4 and c == 64:
         return not os.environ.get('SBC_NO_CHAIN4')   # A/B aid: the 16 x 4 level unfused
+    if h == 32 and w == 8 and c in (32, 64):
+        return kind == CHAIN_RCU and not os.environ.get('SBC_NO_CHAIN8')   # A/B aid: the 32 x 8 level unfused
     return h == 8 and w == 2 and c in (64, 128)
 
 

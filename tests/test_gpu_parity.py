@@ -746,8 +746,11 @@ def test_folded_statistics_match_the_statistics_launches(weights64, mode):
     # f16x2: the last RCU block is a pair launch (no moments), and the two full-resolution ResidualBlocks are one launch each, which
     # forms the statistics of its intermediate itself
     assert n_fold == (10 if mode == 'bf16x3' else 7)
-    # ... and the fourteen norms of the 16x4 and 8x2 levels have no statistics launch at all (SBC_PRO_NORM_SELF)
-    assert sum(1 for op in ops if op.flags & P.PRO_NORM_SELF) == 14 and sum(1 for op in ops if op.kind == P.INORM_STATS) == (11 if mode == 'bf16x3' else 9)
+    # ... and the fourteen norms of the 16x4 and 8x2 levels have no statistics launch at all: SBC_PRO_NORM_SELF, or -- f16x2, where five of
+    # those ResidualBlocks are RES blocks of SBC_OP_CHAIN records -- formed inside the chain launch
+    n_res = sum(1 for op in ops if op.kind == P.CHAIN for b in op.blocks if b[0] == P.CHAIN_RES)
+    assert n_res == (0 if mode == 'bf16x3' else 5) and sum(1 for op in ops if op.flags & P.PRO_NORM_SELF) == 14 - 2 * n_res
+    assert sum(1 for op in ops if op.kind == P.INORM_STATS) == (11 if mode == 'bf16x3' else 9)
     for li, lev in enumerate([0, 1155, 2310]):
         labels = torch.full((x.shape[0],), lev)
         a = fold(x, labels)

@@ -20,7 +20,7 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 1700
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
     rng = np.random.default_rng(0)
-    for Cc, blocks, H, W in ((128, 'RRCR', 8, 2), (128, 'RR', 8, 2), (64, 'RR', 8, 2), (64, 'CR', 8, 2), (64, 'RR', 16, 4), (64, 'CR', 16, 4)):
+    for Cc, blocks, H, W in ((128, 'RRCR', 8, 2), (128, 'RR', 8, 2), (64, 'RR', 8, 2), (64, 'CR', 8, 2), (64, 'RR', 16, 4), (64, 'CR', 16, 4), (32, 'RRR', 32, 8), (64, 'RR', 32, 8)):
         x = torch.from_numpy((rng.standard_normal((B, H, W, Cc)) * 1.5).astype(np.float32)).cuda()
         out = torch.empty_like(x)
         ws = [[torch.from_numpy(pack_conv_weight_f16x2((rng.standard_normal((Cc, Cc, 3, 3)) / np.sqrt(9 * Cc)).astype(np.float32)).view(np.float32)).cuda()
