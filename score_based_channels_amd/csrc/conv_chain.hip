@@ -96,17 +96,26 @@ __host__ __device__ constexpr MicroStep micro_step(int m) {
     return MicroStep{(3 * row + tapc) * KH + kh, valid_unit<W, NU>(tapc - 1, 2 * q), valid_unit<W, NU>(tapc - 1, 2 * q + 1), q == 0};
 }
 
-// C channels in = out; 8 waves; unit i of a wave = (sample group i / W, column i % W):
+// samples per workgroup of NW waves (one 16-output-channel block per wave, 8 units per wave -- 4 at W = 2 with 64 channels)
+__host__ __device__ constexpr int chain_samples(int C, int W, int NW) {
+    const int groups = NW / (C / 16);                                   // unit groups among the waves
+    return W == 2 ? (C == 128 ? 8 : 4 * groups) : W == 4 ? 2 * groups : (groups + 1) / 2;
+}
+
+// C channels in = out; NW waves; unit i of a wave = (sample group i / W, column i % W):
 //   W = 2 (8 x 2 samples), G = 8 samples per workgroup, a unit = one column of TWO samples (lane n: sample n >> 3, row n & 7);
 //          C = 128: wave = 16-output-channel block cb, all 8 units;  C = 64: wave = (cb, half), the 4 units of two sample pairs;
 //   W = 4 (16 x 4 samples, C = 64), G = 4: a unit = one column of ONE sample (lane n: row n); wave = (cb, half), 8 units;
 //   W = 8 (32 x 8 samples; RCU blocks only): a unit = one column of one HALF of a sample (lane n: row 16 half + n), 8 units = the
 //          eight columns;  C = 64, G = 1: wave = (cb, half);  C = 32, G = 2: wave = (cb, sample, half).
-template <int C, int W>
-__global__ __launch_bounds__(512, 2) void conv_chain_kernel(ChainParams p) {
+template <int C, int W, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
     constexpr int H = W == 2 ? 8 : W == 4 ? 16 : 32;
-    constexpr int G = W == 2 ? 8 : W == 4 ? 4 : (C == 32 ? 2 : 1);
-    constexpr int CG = C / 8, KH = C / 32, NCB = C / 16, NHALF = 8 / NCB;   // NHALF: unit groups among the waves
+    constexpr int CG = C / 8, KH = C / 32, NCB = C / 16, NHALF = NW / NCB;   // NHALF: unit groups among the waves
+    static_assert(NW % NCB == 0 && NHALF >= 1, "a wave owns one 16-output-channel block");
+    // samples per workgroup: every unit group of waves takes 8 units (4 at W = 2, C = 64)
+    constexpr int G = chain_samples(C, W, NW);
+    constexpr int NTH = 64 * NW;
     constexpr int SPU = W == 2 ? 2 : 1;                   // samples per unit
     constexpr int NSG = W == 8 ? 1 : G / SPU / NHALF;     // sample groups (pairs at W = 2, samples at W = 4, half samples at W = 8) per wave
     constexpr int NU = NSG * W;                           // units per wave
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(512, 2) void conv_chain_kernel(ChainParams p) {
     const int s0 = blockIdx.x * G;
 
     // ---- zero the planes once: the slots above and below every column are never written
-    for (int i = tid; i < 2 * TERM / 16; i += 512) *reinterpret_cast<uint4*>(smem + i * 16) = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < 2 * TERM / 16; i += NTH) *reinterpret_cast<uint4*>(smem + i * 16) = make_uint4(0, 0, 0, 0);
 
     // ---- the running tensor, accumulator layout: lane (kq, n) holds channels 16 cb + 4 kq .. + 3 of pixel n of each unit
     f32x4v xs[NU];
@@ -462,14 +471,14 @@ __global__ __launch_bounds__(512, 2) void conv_chain_kernel(ChainParams p) {
     if (rbits && lane == 0) atomicOr(p.range_flag, rbits);
 }
 
-template <int C, int W>
+template <int C, int W, int NW>
 static int launch_chain_t(const ChainParams& p, hipStream_t stream, bool dry) {
-    constexpr int G = W == 2 ? 8 : W == 4 ? 4 : (C == 32 ? 2 : 1), SP = W * (W == 2 ? 12 : W == 4 ? 18 : 34);
+    constexpr int G = chain_samples(C, W, NW), SP = W * (W == 2 ? 12 : W == 4 ? 18 : 34);
     constexpr int LDS = 2 * (C / 8) * G * SP * 16 + (G * C + 2 * G) * 4;       // operand planes + InstanceNorm++ scratch
-    auto kern = conv_chain_kernel<C, W>;
+    auto kern = conv_chain_kernel<C, W, NW>;
     { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), LDS); if (rc) return rc; }
     if (dry) return SBC_OK;
-    hipLaunchKernelGGL(kern, dim3((p.B + G - 1) / G), dim3(512), LDS, stream, p);
+    hipLaunchKernelGGL(kern, dim3((p.B + G - 1) / G), dim3(64 * NW), LDS, stream, p);
     SBC_CHECK_HIP(hipGetLastError());
     return SBC_OK;
 }
@@ -509,9 +518,13 @@ int launch_chain(const sbc_op& op, const sbc_chain& c, hipStream_t stream, bool 
     unsigned* flag = nullptr;
     { const int rc = range_flag_ptr(&flag); if (rc) return rc; }
     p.range_flag = flag;
-    if (op.W == 8) return op.cin == 32 ? launch_chain_t<32, 8>(p, stream, dry) : launch_chain_t<64, 8>(p, stream, dry);
-    if (op.W == 4) return launch_chain_t<64, 4>(p, stream, dry);
-    return op.cin == 128 ? launch_chain_t<128, 2>(p, stream, dry) : launch_chain_t<64, 2>(p, stream, dry);
+    // Four-wave workgroups where a 16-output-channel block per wave allows it (64 channels at 8 x 2 / 16 x 4, 32 channels at 32 x 8):
+    // two of them share a CU and drift apart, so one converts operands while the other multiplies (A/B aid: SBC_CHAIN_NW8)
+    static const bool nw8 = getenv("SBC_CHAIN_NW8") != nullptr;
+    if (op.W == 8) return op.cin == 64 ? launch_chain_t<64, 8, 8>(p, stream, dry) : nw8 ? launch_chain_t<32, 8, 8>(p, stream, dry) : launch_chain_t<32, 8, 4>(p, stream, dry);
+    if (op.W == 4) return nw8 ? launch_chain_t<64, 4, 8>(p, stream, dry) : launch_chain_t<64, 4, 4>(p, stream, dry);
+    if (op.cin == 128) return launch_chain_t<128, 2, 8>(p, stream, dry);
+    return nw8 ? launch_chain_t<64, 2, 8>(p, stream, dry) : launch_chain_t<64, 2, 4>(p, stream, dry);
 }
 
 }  // namespace sbc
