@@ -405,7 +405,8 @@ def main():
         p_alds, p_streams = make_batches(H, Pm, idx, idx, ln, np.full(T, 3e-11), np.full(T, 0.01), rank * T + np.arange(T), init, 1)
         pa = p_alds[0]
         run_all(p_alds, p_streams, 2, False)
-        for tag in (P.TAG_CONV_TOP, P.TAG_PAIR_TOP, P.TAG_POOL_TOP, P.TAG_RES_TOP, P.TAG_CONV_MID, P.TAG_DIRECT_MID):
+        chain_tags = tuple(P.TAG_CHAIN + k for k in range(len(P.CHAIN_KERNELS)))
+        for tag in (P.TAG_CONV_TOP, P.TAG_PAIR_TOP, P.TAG_POOL_TOP, P.TAG_RES_TOP, P.TAG_CONV_MID, P.TAG_DIRECT_MID) + chain_tags:
             ops = [op for op in net.score_plan(nt, nr).ops if op.tag == tag]
             if not ops:
                 continue
@@ -417,8 +418,11 @@ def main():
             pa.plan.profile(-1)
             if n:
                 klass[tag] = {'ms_total': ms, 'launches': n, 'launches_per_step': len(ops), 'us_per_launch': ms / n * 1e3,
-                              'flops_per_step': float(sum((2 if op.kind in (P.CONV_PAIR, P.RES_BLOCK) else 1) * 2.0 * T * op.src.h * op.src.w * 9
-                                                          * op.src.c * op.dst.c for op in ops)),
+                              'flops_per_step': float(sum((2 if op.kind in (P.CONV_PAIR, P.RES_BLOCK) else P.chain_conv_count(op) if op.kind == P.CHAIN else 1)
+                                                          * 2.0 * T * op.src.h * op.src.w * 9 * op.src.c * op.dst.c for op in ops)),
+                              # CHAIN records: the fraction of the 9 taps their column units execute, FLOP-weighted over the class
+                              'live_taps': (sum(P.chain_live_tap_fraction(op) * P.chain_conv_count(op) for op in ops)
+                                            / sum(P.chain_conv_count(op) for op in ops)) if ops[0].kind == P.CHAIN else 1.0,
                               'bytes_per_step': float(sum(4.0 * T * op.src.h * op.src.w * (op.src.c + op.dst.c * (1 + (op.res1 is not None)
                                                                                                              + (op.res2 is not None)))
                                                           for op in ops))}
@@ -578,6 +582,8 @@ def main():
                      P.TAG_DIRECT_MID: ('conv_dp_kernel<64, 8, 8, 1, false, 4>' if conv_mode == 'f16x2' and nr == 16 else
                                         'conv_wx3_kernel<64, 64, 1, true, 2, false, 2, 1, %d>' % {'bf16x3': 0, 'f16w': 1, 'f16x2': 2}.get(conv_mode, 0))}
             direct_mid = names[P.TAG_DIRECT_MID].startswith('conv_dp')
+            for k, (cc, cw) in enumerate(P.CHAIN_KERNELS):
+                names[P.TAG_CHAIN + k] = 'conv_chain_kernel<%d, %d, %d>' % (cc, cw, 8 if (cc, cw) in ((128, 2), (64, 8)) else 4)
             what = {P.TAG_CONV_TOP: 'the unfused 3x3 32->32 convolutions at %dx%d (Winograd F(2x2,3x3))' % (nt, nr),
                     P.TAG_PAIR_TOP: 'the fused RCU blocks at %dx%d: two direct 3x3 32->32 convolutions per launch, intermediate in LDS' % (nt, nr),
                     P.TAG_POOL_TOP: 'the fused CRP stages at %dx%d: 5x5 max pool + direct 3x3 32->32 convolution + running sum per launch, pooled tensor in LDS' % (nt, nr),
@@ -587,13 +593,18 @@ def main():
                                     'a tile-moment output (Winograd F(2x2,3x3))' % (nt // 2, nr // 2),
                     P.TAG_DIRECT_MID: 'the other undilated 3x3 64->64 convolutions of the %dx%d level (%s)'
                                       % (nt // 2, nr // 2, 'direct, filter fragments in registers' if direct_mid else 'Winograd F(2x2,3x3)')}
+            for k, (cc, cw) in enumerate(P.CHAIN_KERNELS):
+                what[P.TAG_CHAIN + k] = ('the chains of RCU / CRP blocks and ResidualBlocks at %dx%d with %d channels: one launch per run of blocks, %d samples '
+                                         'per workgroup, the running tensor in registers, operands in LDS, direct 3x3 convolutions whose column units '
+                                         'skip the taps that only read padding (csrc/conv_chain.hip)'
+                                         % (nt * cw // nr, cw, cc, {2: 8 if cc == 128 else 4, 4: 2, 8: 1}[cw]))
             entries = {}
             for tag, kc in klass.items():
                 t_launch = kc['us_per_launch'] * 1e-6
                 fl = kc['flops_per_step'] / kc['launches_per_step']           # algorithmic FLOPs of an average launch of the class
                 by = kc['bytes_per_step'] / kc['launches_per_step']
                 ratio = (18.0 / 16.0 if tag == P.TAG_PAIR_TOP else 1.0 if tag in (P.TAG_POOL_TOP, P.TAG_RES_TOP) or (tag == P.TAG_DIRECT_MID and direct_mid)
-                         else 16.0 / 36.0) * (terms or 1.0)
+                         else kc['live_taps'] if tag >= P.TAG_CHAIN else 16.0 / 36.0) * (terms or 1.0)
                 ach = fl / t_launch / 1e12
                 e = {'kernel': names[tag], 'what': what[tag], 'launches_per_step': kc['launches_per_step'],
                      'us_per_launch': kc['us_per_launch'], 'share_of_one_stream_step': kc['us_per_launch'] * kc['launches_per_step'] / 1e3 / one_stream_ms,

@@ -69,7 +69,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // x + dx lies inside the image (x = unit index mod W) are taken in pairs, in ascending order:
 //   W = 2:  dx = 0: all NU units;  dx = -1: the column-1 units;  dx = +1: the column-0 units (NU / 2 each)
 //   W = 4:  dx = 0: all NU units;  dx = -1: columns 1 .. 3;      dx = +1: columns 0 .. 2     (3 NU / 4 each)
-struct MicroStep { int s, ua, ub; bool first_of_step; };      // ub < 0: a single unit (odd number of live units: W = 8)
+struct MicroStep { int s, u[4]; bool first_of_step; };        // up to four units per micro-step; u[k] < 0: unused slot
 template <int W, int NU>
 __host__ __device__ constexpr int valid_units(int dx) { return dx == 0 ? NU : NU * (W - 1) / W; }
 template <int W, int NU>
@@ -84,16 +84,18 @@ __host__ __device__ constexpr int valid_unit(int dx, int k) {          // the k-
     return -1;
 }
 template <int W, int NU, int KH>
-__host__ __device__ constexpr int micro_steps() { return 3 * ((valid_units<W, NU>(0) + 1) / 2 + 2 * ((valid_units<W, NU>(1) + 1) / 2)) * KH; }
+__host__ __device__ constexpr int micro_steps() { return 3 * ((valid_units<W, NU>(0) + 3) / 4 + 2 * ((valid_units<W, NU>(1) + 3) / 4)) * KH; }
 template <int W, int NU, int KH>
 __host__ __device__ constexpr MicroStep micro_step(int m) {
-    constexpr int M0 = (valid_units<W, NU>(0) + 1) / 2, M1 = (valid_units<W, NU>(1) + 1) / 2, ROW = (M0 + 2 * M1) * KH;
+    constexpr int M0 = (valid_units<W, NU>(0) + 3) / 4, M1 = (valid_units<W, NU>(1) + 3) / 4, ROW = (M0 + 2 * M1) * KH;
     const int row = m / ROW;
     int r = m % ROW, tapc = 0, kh = 0, q = 0;
     if (r < M1 * KH) { tapc = 0; kh = r / M1; q = r % M1; }
     else if (r < (M1 + M0) * KH) { r -= M1 * KH; tapc = 1; kh = r / M0; q = r % M0; }
     else { r -= (M1 + M0) * KH; tapc = 2; kh = r / M1; q = r % M1; }
-    return MicroStep{(3 * row + tapc) * KH + kh, valid_unit<W, NU>(tapc - 1, 2 * q), valid_unit<W, NU>(tapc - 1, 2 * q + 1), q == 0};
+    return MicroStep{(3 * row + tapc) * KH + kh,
+                     {valid_unit<W, NU>(tapc - 1, 4 * q), valid_unit<W, NU>(tapc - 1, 4 * q + 1), valid_unit<W, NU>(tapc - 1, 4 * q + 2),
+                      valid_unit<W, NU>(tapc - 1, 4 * q + 3)}, q == 0};
 }
 
 // samples per workgroup of NW waves (one 16-output-channel block per wave, 8 units per wave -- 4 at W = 2 with 64 channels)
@@ -257,6 +259,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
             constexpr int WD = 4;
             uint4 wr[WD][2];
             auto ldw = [&](int tap, int kh, int slot) {                 // compile-time constants at every call
+#ifdef SBC_CHAIN_NO_WLOAD   // timing probe (tools/): every K step re-uses the first fragment's registers -- wrong results
+                if (slot != 0) { wr[slot][0] = wr[0][0]; wr[slot][1] = wr[0][1]; return; }
+#endif
                 const int idx = wl_base + ((tap * (C / 16) + 2 * kh) * (C / 32) * 2) * 64;
                 wr[slot][0] = w[idx];
                 wr[slot][1] = w[idx + 64];
@@ -342,6 +347,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
             }
             float ta = 0.f;
             uint2 vh[NU], vl[NU];
+#ifdef SBC_CHAIN_NO_CONVERT   // timing probe: no ELU / pooling / norm / split (the values above are dead code then) -- wrong results
+#pragma unroll
+            for (int i = 0; i < NU; ++i) { vh[i] = make_uint2(blk, ph); vl[i] = make_uint2(ph, blk); }
+#else
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
                 StageScale ss{scale, ta};
@@ -350,6 +359,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
                 ta = ss.amax;
                 split_f16x2(f, scale, vh[i], vl[i]);
             }
+#endif
             pair_range_tile(ta, scale, rbits, p.calib ? p.calib + 3 * blk + wi : nullptr);
             if (dx0) { ldw(1, 0, 0); ldw(KH > 1 ? 1 : 4, KH > 1 ? 1 : 0, 1); ldw(KH > 2 ? 1 : 4, KH > 2 ? 2 : 0, 2); }
             else { ldw(0, 0, 0); ldw(1 / KH, 1 % KH, 1); ldw(2 / KH, 2 % KH, 2); }
@@ -376,16 +386,18 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
                 const int yy = y + (r - 1) * dil;
                 rb[r] = dil == 1 ? rd_base + r * 16 : ((unsigned)yy < (unsigned)H ? rd_base + (1 + (r - 1) * dil) * 16 : rd_base - y * 16);
             }
-            constexpr int XD = 4;
-            f16x8 xr[XD][4];
+            constexpr int XD = 2;                                       // micro-steps of up to four units: 8 fragments each
+            f16x8 xr[XD][8];
             auto kloop = [&](auto dx0c) {
                 constexpr bool DX0 = decltype(dx0c)::value;
                 constexpr int NS = (DX0 ? 3 : 9) * KH;
-                constexpr int NM = DX0 ? 3 * KH * (NU / 2) : micro_steps<W, NU, KH>();
+                constexpr int QD = (NU + 3) / 4;                         // micro-steps of a dilated K step (all units)
+                constexpr int NM = DX0 ? 3 * KH * QD : micro_steps<W, NU, KH>();
                 auto step_of = [](int m) constexpr -> MicroStep {
-                    if constexpr (DX0) {                                 // K step s = (filter row, slice): tap 3 row + 1; units (2q, 2q + 1)
-                        const int s_ = m / (NU / 2), q = m % (NU / 2);
-                        return MicroStep{((3 * (s_ / KH) + 1) * KH + s_ % KH), 2 * q, 2 * q + 1, q == 0};
+                    if constexpr (DX0) {                                 // K step s = (filter row, slice): tap 3 row + 1; units 4q .. 4q + 3
+                        const int s_ = m / QD, q = m % QD;
+                        return MicroStep{((3 * (s_ / KH) + 1) * KH + s_ % KH),
+                                         {4 * q, 4 * q + 1 < NU ? 4 * q + 1 : -1, 4 * q + 2 < NU ? 4 * q + 2 : -1, 4 * q + 3 < NU ? 4 * q + 3 : -1}, q == 0};
                     } else {
                         return micro_step<W, NU, KH>(m);
                     }
@@ -393,15 +405,17 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
                 // position of K step s in this loop's filter-ring order
                 auto ring_of = [](int s_) constexpr -> int { return DX0 ? ((s_ / KH) / 3) * KH + s_ % KH : s_; };
                 auto ldx = [&](int m) {
+#ifdef SBC_CHAIN_NO_XLOAD   // timing probe: the operand ring is loaded once -- wrong results
+                    if (m >= XD) return;
+#endif
                     const MicroStep d = step_of(m);
                     const int tap = d.s / KH, kh = d.s % KH, r = tap / 3, dx = tap % 3 - 1;
-                    const int offa = (4 * kh) * PS + (((d.ua / W) * SPU) * SP + (d.ua % W + dx) * CP) * 16;
-                    xr[m % XD][0] = *reinterpret_cast<const f16x8*>(smem + rb[r] + offa);
-                    xr[m % XD][1] = *reinterpret_cast<const f16x8*>(smem + rb[r] + offa + TERM);
-                    if (d.ub >= 0) {
-                        const int offb = (4 * kh) * PS + (((d.ub / W) * SPU) * SP + (d.ub % W + dx) * CP) * 16;
-                        xr[m % XD][2] = *reinterpret_cast<const f16x8*>(smem + rb[r] + offb);
-                        xr[m % XD][3] = *reinterpret_cast<const f16x8*>(smem + rb[r] + offb + TERM);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (d.u[k] < 0) continue;
+                        const int off = (4 * kh) * PS + (((d.u[k] / W) * SPU) * SP + (d.u[k] % W + dx) * CP) * 16;
+                        xr[m % XD][2 * k] = *reinterpret_cast<const f16x8*>(smem + rb[r] + off);
+                        xr[m % XD][2 * k + 1] = *reinterpret_cast<const f16x8*>(smem + rb[r] + off + TERM);
                     }
                 };
 #pragma unroll
@@ -419,26 +433,25 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
                     if constexpr (m + XD - 1 < NM) ldx(m + XD - 1);
                     const f16x8 wh = __builtin_bit_cast(f16x8, wr[rp % WD][0]);
                     const f16x8 wl = __builtin_bit_cast(f16x8, wr[rp % WD][1]);
-                    const f16x8 ah = xr[m % XD][0], al = xr[m % XD][1];
-                    // a unit's first matrix instruction takes a literal zero addend: tap 0 (dx = -1) unless the unit is column 0, then
-                    // tap 1 (dilated: tap 1 for every unit)
-                    constexpr bool fa = kh == 0 && tap == ((d.ua % W) && !DX0 ? 0 : 1);
-                    const f32x4v za = fa ? f32x4v{0.f, 0.f, 0.f, 0.f} : acc[d.ua];
-                    if constexpr (d.ub >= 0) {
-                        const f16x8 bh = xr[m % XD][2], bl = xr[m % XD][3];
-                        constexpr bool fb = kh == 0 && tap == ((d.ub % W) && !DX0 ? 0 : 1);
-                        const f32x4v zb = fb ? f32x4v{0.f, 0.f, 0.f, 0.f} : acc[d.ub];
-                        acc[d.ua] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al, za, 0, 0, 0);
-                        acc[d.ub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl, zb, 0, 0, 0);
-                        acc[d.ua] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah, acc[d.ua], 0, 0, 0);
-                        acc[d.ub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh, acc[d.ub], 0, 0, 0);
-                        acc[d.ua] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah, acc[d.ua], 0, 0, 0);
-                        acc[d.ub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh, acc[d.ub], 0, 0, 0);
-                    } else {
-                        acc[d.ua] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al, za, 0, 0, 0);
-                        acc[d.ua] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah, acc[d.ua], 0, 0, 0);
-                        acc[d.ua] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah, acc[d.ua], 0, 0, 0);
-                    }
+                    // term-major over the micro-step's units: an accumulator's next matrix instruction is up to four instructions on.
+                    // A unit's first one takes a literal zero addend: tap 0 (dx = -1) unless the unit is column 0, then tap 1
+                    // (dilated: tap 1 for every unit)
+                    static_for<0, 4>([&](auto kc) {
+                        constexpr int k = decltype(kc)::value;
+                        if constexpr (d.u[k] >= 0) {
+                            constexpr bool first = kh == 0 && tap == ((d.u[k] % W) && !DX0 ? 0 : 1);
+                            const f32x4v z = first ? f32x4v{0.f, 0.f, 0.f, 0.f} : acc[d.u[k]];
+                            acc[d.u[k]] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xr[m % XD][2 * k + 1], z, 0, 0, 0);
+                        }
+                    });
+                    static_for<0, 4>([&](auto kc) {
+                        constexpr int k = decltype(kc)::value;
+                        if constexpr (d.u[k] >= 0) acc[d.u[k]] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xr[m % XD][2 * k], acc[d.u[k]], 0, 0, 0);
+                    });
+                    static_for<0, 4>([&](auto kc) {
+                        constexpr int k = decltype(kc)::value;
+                        if constexpr (d.u[k] >= 0) acc[d.u[k]] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xr[m % XD][2 * k], acc[d.u[k]], 0, 0, 0);
+                    });
                     __builtin_amdgcn_sched_barrier(0);
                 });
             };

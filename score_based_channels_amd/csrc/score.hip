@@ -143,6 +143,8 @@ struct Builder {
             const int dst = tensor(name + "." + std::to_string(k / SBC_CHAIN_MAX_BLOCKS), t[x].h, t[x].w, t[x].c);
             POp o;
             o.kind = SBC_OP_CHAIN; o.src = x; o.dst = dst;
+            // plan.TAG_CHAIN + index in plan.CHAIN_KERNELS: (128, 2), (64, 2), (64, 4), (64, 8), (32, 8)
+            o.tag = 7 + (t[x].c == 128 ? 0 : t[x].w == 2 ? 1 : t[x].w == 4 ? 2 : t[x].c == 64 ? 3 : 4);
             o.blocks.assign(blocks.begin() + k, blocks.begin() + std::min(blocks.size(), k + (size_t)SBC_CHAIN_MAX_BLOCKS));
             producer[dst] = (int)ops.size();
             ops.push_back(o);

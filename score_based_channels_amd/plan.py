@@ -48,6 +48,8 @@ TAG_PAIR_TOP = 2        # fused RCU blocks (CONV_PAIR) at full resolution
 TAG_CONV_MID = 3        # undilated 3x3 convs 2 ngf -> 2 ngf at half resolution (the 32x8 level of a 64x16 array)
 TAG_POOL_TOP = 4        # fused CRP stages (CONV_POOL) at full resolution
 TAG_RES_TOP = 6         # fused ResidualBlocks (RES_BLOCK) at full resolution
+TAG_CHAIN = 7           # CHAIN records (csrc/conv_chain.hip): 7 + the index of their kernel instantiation in CHAIN_KERNELS
+CHAIN_KERNELS = ((128, 2), (64, 2), (64, 4), (64, 8), (32, 8))       # (channels, width)
 TAG_DIRECT_MID = 5      # the TAG_CONV_MID layers without a norm prologue / resize / tile-moment output: in conv_mode f16x2 the direct
                         # persistent kernel (csrc/conv_dp.hip) takes them, the Winograd kernel the rest
 
@@ -235,7 +237,8 @@ class _Builder:
         for k in range(0, len(blocks), CHAIN_MAX_BLOCKS):
             part = blocks[k:k + CHAIN_MAX_BLOCKS]
             dst = self.t('%s.%d' % (name, k // CHAIN_MAX_BLOCKS), x.h, x.w, x.c)
-            self.ops.append(Op(CHAIN, dst.name, src=x, dst=dst, blocks=part, side=self.side_now))
+            self.ops.append(Op(CHAIN, dst.name, src=x, dst=dst, blocks=part, side=self.side_now,
+                               tag=TAG_CHAIN + CHAIN_KERNELS.index((x.c, x.w))))
             self.producer[id(dst)] = self.ops[-1]
             x = dst
         return x
@@ -324,7 +327,7 @@ def merge_chains(ops):
         if (a.kind == CHAIN and b.kind == CHAIN and b.src is a.dst and not (a.side or b.side or a.join or b.join)
                 and len(a.blocks) + len(b.blocks) <= CHAIN_MAX_BLOCKS
                 and not any(a.dst in o.inputs() for o in ops[k + 2:])):
-            ops[k:k + 2] = [Op(CHAIN, a.name + '+' + b.name, src=a.src, dst=b.dst, blocks=a.blocks + b.blocks)]
+            ops[k:k + 2] = [Op(CHAIN, a.name + '+' + b.name, src=a.src, dst=b.dst, blocks=a.blocks + b.blocks, tag=a.tag)]
         else:
             k += 1
 
@@ -449,6 +452,24 @@ def assign_slots(plan):
     return plan
 
 
+def chain_conv_count(op):
+    """Convolutions of a CHAIN record (two per block, three for a RES block with a shortcut convolution)."""
+    return sum(3 if (b[3] and b[3]['w3']) else 2 for b in op.blocks)
+
+
+def chain_live_tap_fraction(op):
+    """Fraction of the 9 W products per output the chain kernel executes (csrc/conv_chain.hip): column units skip the taps that
+    only read padding -- dx != 0 for the border columns; a dilated convolution at a width of two keeps its three dx = 0 taps."""
+    w = op.src.w
+    full = (3 * w + 6 * (w - 1)) / (9.0 * w)
+    n = live = 0.0
+    for b in op.blocks:
+        k = 3 if (b[3] and b[3]['w3']) else 2
+        n += k
+        live += k * (3.0 / 9.0 if (b[3] and b[3]['dil'] > 1) else full)
+    return live / n
+
+
 def count_conv_flops(plan):
     """2 * MACs of every convolution record, per sample (820 772 864 at 64x16)."""
     total = 0
@@ -460,7 +481,7 @@ def count_conv_flops(plan):
         elif op.kind == CONV_POOL:
             total += 2 * op.src.h * op.src.w * op.src.c * op.dst.c * 9
         elif op.kind == CHAIN:
-            total += sum(3 if (b[3] and b[3]['w3']) else 2 for b in op.blocks) * 2 * op.src.h * op.src.w * op.src.c * op.dst.c * 9
+            total += chain_conv_count(op) * 2 * op.src.h * op.src.w * op.src.c * op.dst.c * 9
         elif op.kind in (BEGIN_CONV, END_CONV):
             total += 2 * op.src.h * op.src.w * op.src.c * op.dst.c * 9
     return total

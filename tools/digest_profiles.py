@@ -3,7 +3,7 @@ usage: digest_profiles.py [cdlc|big] [round tag, default r03]"""
 import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 W = sys.argv[1] if len(sys.argv) > 1 else 'cdlc'
-TAG = sys.argv[2] if len(sys.argv) > 2 else 'r04'
+TAG = sys.argv[2] if len(sys.argv) > 2 else 'r05'
 R = os.path.join(ROOT, 'gpurun_out', 'profile_passes_' + W) + '/'
 P = os.path.join(ROOT, 'profiles') + '/'
 BIG = W == 'big'
@@ -12,12 +12,13 @@ CANDIDATES = (['conv_wx3_kernel<32, 32, 1, true, 3, true, 1, 1, 1>', 'conv_pair_
                'conv_wx3_kernel<64, 64, 1, true, 2, false, 2, 1, 1>'] if BIG else
               ['conv_wx3_kernel<32, 32, 1, true, 4, true, 1, 1, 2>', 'conv_pair_p3_kernel<16, 8, 2, 4, 32>',
                'conv_pool_kernel<16, 8, 2, 4, 32>', 'conv_wx3_kernel<64, 64, 1, true, 2, false, 2, 1, 2>',
-               'conv_dp_kernel<64, 8, 8, 1, false, 4>', 'conv_res_kernel'])
+               'conv_dp_kernel<64, 8, 8, 1, false, 4>', 'conv_res_kernel', 'conv_chain_kernel<128, 2, 8>', 'conv_chain_kernel<64, 2, 4>',
+               'conv_chain_kernel<64, 4, 4>', 'conv_chain_kernel<64, 8, 8>', 'conv_chain_kernel<32, 8, 4>'])
 PX = (256 * 64) if BIG else (64 * 16)
 T = 1024 if BIG else 1700
 CMD = '--workload %s --streams 1 --no-cpu-baseline --no-strong --no-other-mode --no-exact-mode --sustained 0' % W
 DESC = ('conv_mode f16w + fused RCU pairs + folded statistics, one stream, T=1024 (256x64 arrays)' if BIG else
-        'conv_mode f16x2 (calibrated activation scales) + fused RCU pairs and CRP stages + folded statistics, one stream, T=1700')
+        'conv_mode f16x2 (calibrated activation scales) + fused RCU pairs, CRP stages, ResidualBlocks and low-resolution chains + folded statistics, one stream, T=1700')
 
 
 def find(d, suffix):
