@@ -11,6 +11,7 @@ single ``plan.run(n_steps)``: per-step scalars come from device tables indexed b
 NMSE log stays on the device until it is read.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -195,6 +196,7 @@ class AldBatch:
         if self._lag_plan is None:
             names = [op.name for op in self.net.score_plan(self.nt, self.nr).ops]
             k = next((i for i, nm in enumerate(names) if nm.startswith('refine31.')), len(names) // 2)
+            k = int(os.environ.get('SBC_LAG_RECORDS', k))        # (A/B aid: where the throw-away prefix ends)
             self._lag_plan = _lib.Plan(list(self.bound.ops)[:k], keepalive=self)
             self._lag_plan.set_persistent_cus(getattr(self, '_persist', 0))
         self._lag_plan.run(self._stream(), 1, False)
