@@ -77,6 +77,12 @@ typedef enum sbc_op_kind {
                                 out = x + conv2(ELU(norm2(conv1(ELU(norm1(x))))))   layers.py:443-456, normalization.py:150-176;
                                 32 channels, 64 x 16 samples: a workgroup owns a whole sample, so it forms the InstanceNorm++
                                 statistics of the intermediate itself (csrc/conv_res.hip)                                    */
+    SBC_OP_CONV_DOWN = 25,   /* (ABI 13) the tail of a downsampling ResidualBlock in one launch (layers.py:443-456 with ConvMeanPool :309-313):
+                                out = meanpool2(conv3x3(ELU(norm(in))) + bias) + meanpool2(conv1x1(res1) + bias2), as a 4x4 stride-2 and a
+                                2x2 stride-2 direct convolution with the pooled filters (weight_split = sbc_pack_conv_weight_pooled_f16x2 of the
+                                3x3 weight, weight2_split = the same of the 1x1 shortcut weight); in = conv1's output, res1 = the block's input,
+                                both [B][H][W][cin], stats = the norm's (mu, scale, shift); 32 -> 64 channels at W = 16, 64 -> 64 at W = 8,
+                                H a multiple of 16; SBC_CONV_F16X2 only (csrc/conv_down.hip)                                           */
     SBC_OP_CHAIN = 24        /* (ABI 13) a CHAIN of RCU blocks, CRP blocks and ResidualBlocks in ONE launch, for the two lowest
                                 resolution levels (8 x 2 samples of 64 or 128 channels, 16 x 4 samples of 64; layers.py:76-83,
                                 126-134,234-249,443-456): a workgroup owns eight (four) samples, the running tensor x stays in
@@ -436,6 +442,8 @@ typedef struct sbc_score_desc {
                                     what the Python host does by default next to SBC_SCORE_FUSE_PAIRS (scorenet.DEFAULT_FUSE_RES) */
 #define SBC_SCORE_FUSE_CHAIN 0x8 /* (ABI 13) the RCU / CRP runs of the 8 x 2 level as SBC_OP_CHAIN records (conv_mode 3); what the Python host does by
                                     default next to SBC_SCORE_FUSE_PAIRS (scorenet.DEFAULT_FUSE_CHAIN) */
+#define SBC_SCORE_FUSE_DOWN 0x10 /* (ABI 13) pooled conv2 + pooled 1x1 shortcut of the downsampling ResidualBlocks res2.0 / res3.0 as one SBC_OP_CONV_DOWN
+                                    record (conv_mode 3); what the Python host does by default (scorenet.DEFAULT_FUSE_DOWN) */
 typedef struct sbc_score sbc_score;
 int sbc_score_create(const sbc_score_desc* desc, const sbc_tensor_ref* tensors, int32_t n_tensors, sbc_score** out);
 int sbc_score_buffers(sbc_score* score, float** x, float** out, int64_t** labels);
@@ -458,6 +466,10 @@ int sbc_pack_conv_weight_winograd_f16(const float* src, int32_t cout, int32_t ci
  * host that knows its activations may write the first two words itself).  dst holds sbc_f16x2_elems(...) uint16. */
 #define SBC_F16X2_ACT_SHIFT 0
 #define sbc_f16x2_elems(taps, cin, cout) ((size_t)(taps) * (cin) * (cout) * 2 + 8)
+/* (ABI 13) The filter of `meanpool2(conv(x))` as ONE stride-2 convolution, in the sbc_pack_conv_weight_f16x2 form with ksize + 1 taps per side:
+ * src [cout][cin][ksize][ksize] (ksize 3 -> a 4x4 filter, ksize 1 -> 2x2), W'[p][q] = 1/4 sum_{a,b in {0,1}} W[p - a][q - b] formed in double.
+ * dst: sbc_f16x2_elems((ksize + 1)^2, cin, cout) uint16. */
+int sbc_pack_conv_weight_pooled_f16x2(const float* src, int32_t cout, int32_t cin, int32_t ksize, uint16_t* dst);
 int sbc_pack_conv_weight_f16x2(const float* src, int32_t cout, int32_t cin, int32_t ksize, uint16_t* dst);
 int sbc_pack_conv_weight_winograd_f16x2(const float* src, int32_t cout, int32_t cin, uint16_t* dst);
 /* Range flag of the f16x2 kernels on the CURRENT device, a bit set collected since the last reset:

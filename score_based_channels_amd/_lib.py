@@ -15,7 +15,7 @@ EXPORTS = ('sbc_abi_version', 'sbc_set_persistent_cus', 'sbc_last_error', 'sbc_d
            'sbc_pack_conv_weight', 'sbc_pack_conv_weight_winograd',
            'sbc_pack_conv_weight_split', 'sbc_pack_conv_weight_winograd_split',
            'sbc_pack_conv_weight_f16', 'sbc_pack_conv_weight_winograd_f16',
-           'sbc_pack_conv_weight_f16x2', 'sbc_pack_conv_weight_winograd_f16x2', 'sbc_range_flag',
+           'sbc_pack_conv_weight_f16x2', 'sbc_pack_conv_weight_winograd_f16x2', 'sbc_pack_conv_weight_pooled_f16x2', 'sbc_range_flag',
            'sbc_f16x2_calibration_input', 'sbc_f16x2_calibrate', 'sbc_debug_philox4x32', 'sbc_debug_complex_normal',
            'sbc_score_create', 'sbc_score_buffers', 'sbc_score_ops', 'sbc_score_level_source', 'sbc_score_forward',
            'sbc_score_destroy', 'sbc_wgrad_scratch_floats')
@@ -112,6 +112,7 @@ def lib():
     h.sbc_pack_conv_weight_winograd_f16.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     h.sbc_pack_conv_weight_f16x2.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     h.sbc_pack_conv_weight_winograd_f16x2.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    h.sbc_pack_conv_weight_pooled_f16x2.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     h.sbc_range_flag.argtypes = [C.POINTER(C.c_int32), C.c_int32]
     h.sbc_f16x2_calibration_input.argtypes = [C.c_void_p, C.c_int64]
     h.sbc_f16x2_calibrate.argtypes = [C.POINTER(sbc_op), C.c_int32, C.c_void_p]

@@ -103,6 +103,7 @@ static int dispatch(const sbc_op& op, const void* ext, hipStream_t s) {
         case SBC_OP_CONV_POOL: return launch_conv_pool(op, s);
         case SBC_OP_RES_BLOCK: return launch_res_block(op, s);
         case SBC_OP_CHAIN: return launch_chain(op, *(const sbc_chain*)ext, s);
+        case SBC_OP_CONV_DOWN: return launch_conv_down(op, s);
         case SBC_OP_MAXPOOL5: return launch_maxpool5(op, s);
         case SBC_OP_END_CONV:
             SBC_REQUIRE(endc, "end_conv: ext (sbc_endconv) must be set");
@@ -288,7 +289,7 @@ int sbc_f16x2_calibrate(const sbc_op* ops, int32_t n_ops, void* stream) {
         run[i].B = 1;                                       // the first sample of every buffer
         run[i].flags &= ~(SBC_OP_SIDE | SBC_OP_JOIN);
         if ((run[i].flags & SBC_CONV_F16X2) && (run[i].kind == SBC_OP_CONV || run[i].kind == SBC_OP_CONV_PAIR || run[i].kind == SBC_OP_CONV_POOL ||
-                                                  run[i].kind == SBC_OP_RES_BLOCK)) {
+                                                  run[i].kind == SBC_OP_RES_BLOCK || run[i].kind == SBC_OP_CONV_DOWN)) {
             slot_of[i] = n_slots;
             n_slots += 2;
         } else if ((run[i].flags & SBC_CONV_F16X2) && run[i].kind == SBC_OP_CHAIN && run[i].ext) {
@@ -349,6 +350,9 @@ int sbc_f16x2_calibrate(const sbc_op* ops, int32_t n_ops, void* stream) {
                 if (!rc) rc = set_trailer(c.w2_wino[b], 16, o.cin, o.cout, scale_for(a2), a2);
                 if (!rc && c.type[b] == SBC_CHAIN_RES) rc = set_trailer(c.w3[b], 9, o.cin, o.cout, scale_for(a3), a3);
             }
+        } else if (o.kind == SBC_OP_CONV_DOWN) {
+            rc = set_trailer(o.weight_split, 16, o.cin, o.cout, s1, amax[slot_of[i]]);              // the pooled 3x3 filter (4x4 taps)
+            if (!rc) rc = set_trailer(o.weight2_split, 4, o.cin, o.cout, s2, amax[slot_of[i] + 1]);   // the pooled 1x1 shortcut (2x2 taps)
         } else if (o.kind == SBC_OP_CONV_PAIR || o.kind == SBC_OP_RES_BLOCK) {
             rc = set_trailer(o.weight_split, 9, o.cin, o.cout, s1, amax[slot_of[i]]);
             if (!rc) rc = set_trailer(o.weight_wino_split, 16, o.cin, o.cout, s1, amax[slot_of[i]]);
@@ -395,6 +399,7 @@ int sbc_plan_create(const sbc_op* ops, int32_t n_ops, sbc_plan** out_plan) {
         else if (po.op.kind == SBC_OP_CONV_POOL) rc = launch_conv_pool(po.op, nullptr, true);
         else if (po.op.kind == SBC_OP_RES_BLOCK) rc = launch_res_block(po.op, nullptr, true);
         else if (po.op.kind == SBC_OP_CHAIN) rc = launch_chain(po.op, po.ext.chain, nullptr, true);
+        else if (po.op.kind == SBC_OP_CONV_DOWN) rc = launch_conv_down(po.op, nullptr, true);
         else if (po.op.kind == SBC_OP_END_CONV) rc = launch_end_conv(po.op, po.ext.endc, nullptr, true);
         else if (po.op.kind == SBC_OP_LANGEVIN) rc = launch_langevin(po.op, po.ext.lang, nullptr, true);
         if (rc) { delete plan; return rc; }
@@ -664,11 +669,9 @@ static void f16x2_trailer_write(uint16_t* dst, size_t n16, int s) {
     memcpy(dst + n16, tr, sizeof(tr));
 }
 
-int sbc_pack_conv_weight_f16x2(const float* src, int32_t cout, int32_t cin, int32_t ksize, uint16_t* dst) {
-    SBC_REQUIRE(src && dst, "sbc_pack_conv_weight_f16x2: NULL pointer");
-    SBC_REQUIRE(cin % 16 == 0 && cout % 32 == 0 && (ksize == 1 || ksize == 3),
-                "sbc_pack_conv_weight_f16x2: cin %% 16, cout %% 32, ksize in {1,3} required (got %d, %d, %d)", cin, cout, ksize);
-    const int taps = ksize * ksize, KG = cin / 16, NB = cout / 32;
+// [cout][cin][taps] float32 -> the two-term fp16 fragment order (+ trailer); shared by the plain and the pooled packer
+static void pack_f16x2_taps(const float* src, int cout, int cin, int taps, uint16_t* dst) {
+    const int KG = cin / 16, NB = cout / 32;
     const int s = f16x2_shift(src, (size_t)cout * cin * taps);
     for (int tap = 0; tap < taps; ++tap)
         for (int g = 0; g < KG; ++g)
@@ -681,6 +684,33 @@ int sbc_pack_conv_weight_f16x2(const float* src, int32_t cout, int32_t cin, int3
                                     &dst[((base + 1) * 64 + lane) * 8 + j]);
                     }
     f16x2_trailer_write(dst, (size_t)taps * KG * NB * 2 * 512, s);
+}
+
+int sbc_pack_conv_weight_f16x2(const float* src, int32_t cout, int32_t cin, int32_t ksize, uint16_t* dst) {
+    SBC_REQUIRE(src && dst, "sbc_pack_conv_weight_f16x2: NULL pointer");
+    SBC_REQUIRE(cin % 16 == 0 && cout % 32 == 0 && (ksize == 1 || ksize == 3),
+                "sbc_pack_conv_weight_f16x2: cin %% 16, cout %% 32, ksize in {1,3} required (got %d, %d, %d)", cin, cout, ksize);
+    pack_f16x2_taps(src, cout, cin, ksize * ksize, dst);
+    return SBC_OK;
+}
+
+int sbc_pack_conv_weight_pooled_f16x2(const float* src, int32_t cout, int32_t cin, int32_t ksize, uint16_t* dst) {
+    SBC_REQUIRE(src && dst, "sbc_pack_conv_weight_pooled_f16x2: NULL pointer");
+    SBC_REQUIRE(cin % 16 == 0 && cout % 32 == 0 && (ksize == 1 || ksize == 3),
+                "sbc_pack_conv_weight_pooled_f16x2: cin %% 16, cout %% 32, ksize in {1,3} required (got %d, %d, %d)", cin, cout, ksize);
+    // meanpool2(conv_k(x)) = conv_{k+1, stride 2}(x) with W'[p][q] = 1/4 sum_{a,b in {0,1}} W[p - a][q - b]   (layers.py:309-313)
+    const int k = ksize, k1 = ksize + 1;
+    std::vector<float> wp((size_t)cout * cin * k1 * k1);
+    for (size_t oc = 0; oc < (size_t)cout * cin; ++oc)
+        for (int p = 0; p < k1; ++p)
+            for (int q = 0; q < k1; ++q) {
+                double v = 0;
+                for (int a = 0; a < 2; ++a)
+                    for (int b = 0; b < 2; ++b)
+                        if (p - a >= 0 && p - a < k && q - b >= 0 && q - b < k) v += (double)src[oc * k * k + (p - a) * k + (q - b)];
+                wp[oc * k1 * k1 + p * k1 + q] = (float)(0.25 * v);
+            }
+    pack_f16x2_taps(wp.data(), cout, cin, k1 * k1, dst);
     return SBC_OK;
 }
 

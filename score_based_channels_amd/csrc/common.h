@@ -46,6 +46,7 @@ int launch_conv_pair(const sbc_op& op, hipStream_t stream, bool dry = false);
 int launch_conv_pool(const sbc_op& op, hipStream_t stream, bool dry = false);
 int launch_res_block(const sbc_op& op, hipStream_t stream, bool dry = false);   // conv_res.hip
 int launch_chain(const sbc_op& op, const sbc_chain& ext, hipStream_t stream, bool dry = false);   // conv_chain.hip
+int launch_conv_down(const sbc_op& op, hipStream_t stream, bool dry = false);                    // conv_down.hip
 int launch_begin_conv(const sbc_op& op, hipStream_t stream);
 int launch_inorm_stats(const sbc_op& op, hipStream_t stream);
 int launch_maxpool5(const sbc_op& op, hipStream_t stream);

@@ -386,7 +386,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
                 const int yy = y + (r - 1) * dil;
                 rb[r] = dil == 1 ? rd_base + r * 16 : ((unsigned)yy < (unsigned)H ? rd_base + (1 + (r - 1) * dil) * 16 : rd_base - y * 16);
             }
-            constexpr int XD = 2;                                       // micro-steps of up to four units: 8 fragments each
+#ifndef SBC_CHAIN_XD
+#define SBC_CHAIN_XD 2
+#endif
+            constexpr int XD = SBC_CHAIN_XD;                            // micro-steps of up to four units: 8 fragments each
             f16x8 xr[XD][8];
             auto kloop = [&](auto dx0c) {
                 constexpr bool DX0 = decltype(dx0c)::value;
@@ -455,8 +458,14 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
                     __builtin_amdgcn_sched_barrier(0);
                 });
             };
+#ifdef SBC_CHAIN_PRIO
+            __builtin_amdgcn_s_setprio(SBC_CHAIN_PRIO);
+#endif
             if (W == 2 && dx0) kloop(std::integral_constant<bool, W == 2>{});
             else kloop(std::false_type{});
+#ifdef SBC_CHAIN_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
 
             // ---- what the result is for
             if (kind == PH_R2 || kind == PH_P2) {

@@ -41,6 +41,7 @@ struct Builder {
     bool fuse_res = false;           // plan.py: fuse_res / res_fusable (SBC_OP_RES_BLOCK; conv_mode f16x2 with fused pairs)
     bool f16w = false;               // ... the fp16-weight mode also fuses 64-pixel rows (plan.PAIR_WIDTHS_F16W)
     bool fold_stats = false;         // plan.py: fold_stats (statistics of full-resolution tensors from their producers' tile moments)
+    bool fuse_down = false;          // plan.py: fuse_down / down_fusable (SBC_OP_CONV_DOWN; conv_mode f16x2)
     bool fuse_chain = false;         // plan.py: fuse_chain / chain_fusable (SBC_OP_CHAIN at the 8 x 2 level; conv_mode f16x2)
     std::map<int, int> producer;     // tensor -> index of the record that writes it
     std::vector<Tn> t;
@@ -119,6 +120,17 @@ struct Builder {
         }
         const int a = conv(p + "conv1", x, p + "conv1", c1, true, SBC_PRO_NORM | SBC_PRO_ELU, s1, -1, -1, -1, 3, d);
         const int s2 = stats(p + "normalize2", a, p + "normalize2");
+        if (pooled && fuse_down && s2 != SELF_NORM && t[x].h % 16 == 0 &&
+            ((t[x].w == 16 && t[x].c == 32 && cout == 64) || (t[x].w == 8 && t[x].c == 64 && cout == 64))) {        // plan.down_fusable
+            const int out = tensor(p + "conv2", t[x].h / 2, t[x].w / 2, cout);
+            POp o;
+            o.kind = SBC_OP_CONV_DOWN; o.src = a; o.dst = out; o.stats = s2; o.res1 = x;
+            o.weight = p + "conv2.conv.weight"; o.weight2 = p + "shortcut.conv.weight";
+            o.bias = p + "conv2.conv.bias"; o.bias2 = p + "shortcut.conv.bias";
+            producer[out] = (int)ops.size();
+            ops.push_back(o);
+            return out;
+        }
         if (pooled) {
             const int sc = conv(p + "shortcut", x, p + "shortcut.conv", cout, true, SBC_EPI_POOL, -1, -1, -1, -1, 1, 1);
             return conv(p + "conv2", a, p + "conv2.conv", cout, true, SBC_PRO_NORM | SBC_PRO_ELU | SBC_EPI_POOL, s2, sc);
@@ -291,6 +303,7 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
                 "sbc_score_create: batch, conv_mode in {0 bf16x3, 1 f32, 2 f16w, 3 f16x2}, sigmas required");
     SBC_REQUIRE(!(d->flags & SBC_SCORE_FUSE_RES) || d->conv_mode == 3, "sbc_score_create: SBC_SCORE_FUSE_RES needs conv_mode 3 (f16x2)");
     SBC_REQUIRE(!(d->flags & SBC_SCORE_FUSE_CHAIN) || d->conv_mode == 3, "sbc_score_create: SBC_SCORE_FUSE_CHAIN needs conv_mode 3 (f16x2)");
+    SBC_REQUIRE(!(d->flags & SBC_SCORE_FUSE_DOWN) || d->conv_mode == 3, "sbc_score_create: SBC_SCORE_FUSE_DOWN needs conv_mode 3 (f16x2)");
     SBC_REQUIRE(!(d->flags & SBC_SCORE_FUSE_PAIRS) || d->conv_mode >= 2,
                 "sbc_score_create: SBC_SCORE_FUSE_PAIRS needs the fp16 weight forms (conv_mode 2 or 3)");
     std::map<std::string, const sbc_tensor_ref*> sd;
@@ -307,6 +320,7 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
     b.f16w = d->conv_mode == 2;
     b.fuse_res = (d->flags & SBC_SCORE_FUSE_RES) != 0;
     b.fuse_chain = (d->flags & SBC_SCORE_FUSE_CHAIN) != 0;
+    b.fuse_down = (d->flags & SBC_SCORE_FUSE_DOWN) != 0;
     b.fold_stats = (d->flags & SBC_SCORE_FOLD_STATS) != 0 && d->conv_mode != 1 && !(nt & (nt - 1)) && !(nr & (nr - 1));
     const int x = b.tensor("x", nt, nr, d->channels);
     int h = b.tensor("begin_conv", nt, nr, ngf);
@@ -411,6 +425,15 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
         for (const auto& bl : o.blocks) { wkeys.push_back(bl.w1); wkeys.push_back(bl.w2); wkeys.push_back(bl.w3); }
         for (const std::string& wkey : wkeys) {
         if (wkey.empty()) continue;
+        if (o.kind == SBC_OP_CONV_DOWN) {
+            // the pooled stride-2 filters: 3x3 -> 4x4 (conv2), 1x1 -> 2x2 (shortcut)   (scorenet.load_state_dict: '#pool')
+            if (off.count(wkey + "#pool")) continue;
+            const int kk = wkey == o.weight2 ? 1 : 3;
+            const float* w2 = find(wkey, (int64_t)cout * cin * kk * kk);
+            if (!w2) return fail();
+            sbc_pack_conv_weight_pooled_f16x2(w2, cout, cin, kk, (uint16_t*)reserve(wkey + "#pool", sbc_f16x2_elems((kk + 1) * (kk + 1), cin, cout) / 2));
+            continue;
+        }
         if (!off.count(wkey) && !off.count(wkey + "#split")) {
             const float* w = find(wkey, (int64_t)wn);
             if (!w) return fail();
@@ -492,6 +515,11 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
             r.weight_split = wp(o.weight + "#split");
             if (f16x2) r.weight_wino_split = wp(o.weight + "#winograd_split");
             r.flags |= f16w ? SBC_CONV_F16W : SBC_CONV_F16X2;
+        } else if (o.kind == SBC_OP_CONV_DOWN) {
+            r.weight_split = wp(o.weight + "#pool");
+            r.weight2_split = wp(o.weight2 + "#pool");
+            r.bias2 = wp(o.bias2);
+            r.flags |= SBC_CONV_F16X2;
         } else if (o.kind == SBC_OP_CHAIN) {
             sbc_chain ch;
             memset(&ch, 0, sizeof(ch));

@@ -38,6 +38,7 @@ PRO_ELU_ACC = 0x20000         # ELU with fp32's relative accuracy for small nega
 CONV_PAIR = 21
 CONV_POOL = 22
 RES_BLOCK = 23
+CONV_DOWN = 25           # the tail of a downsampling ResidualBlock (pooled conv2 + pooled 1x1 shortcut) in one launch (csrc/conv_down.hip)
 CHAIN = 24               # a chain of RCU / CRP blocks at the 8 x 2 level in one launch (csrc/conv_chain.hip)
 CHAIN_RCU, CHAIN_CRP, CHAIN_RES, CHAIN_MAX_BLOCKS = 0, 1, 2, 6
 BWD_ACCUM, PACK_ADJOINT, OP_SIDE, OP_JOIN, PACK_WINOGRAD = 0x200, 0x400, 0x800, 0x1000, 0x2000
@@ -120,6 +121,7 @@ class ScorePlan:
 class _Builder:
     def __init__(self, ngf, nt, nr, overlap=False, fold_stats=False, fuse_pairs=False):
         self.ngf, self.nt, self.nr = ngf, nt, nr
+        self.fuse_down = False          # pooled conv2 + pooled shortcut of a downsampling ResidualBlock as one CONV_DOWN record
         self.fuse_chain = False         # RCU / CRP runs of the 8 x 2 level as CHAIN records (csrc/conv_chain.hip)
         self.fuse_res = False           # ResidualBlocks without resampling at 64x16, 32 channels as one RES_BLOCK record (csrc/conv_res.hip)
         self.fuse_pairs = fuse_pairs    # RCU blocks as one CONV_PAIR record (csrc/conv_pair.hip): True / a tuple of (channels, width)
@@ -214,6 +216,14 @@ class _Builder:
         a = self.conv(p + 'conv1', x, p + 'conv1', c1, flags=PRO_NORM | PRO_ELU, stats=s1, dil=d)
         s2 = self.stats(p + 'normalize2', a, p + 'normalize2')
         has_sc = pooled or x.c != cout or resample is not None
+        if pooled and self.fuse_down and down_fusable(x.h, x.w, x.c, cout) and not isinstance(s2, SelfNorm):
+            # pooled conv2 + pooled 1x1 shortcut as ONE launch of stride-2 convolutions with the pooled filters: both inputs read once,
+            # the pooled shortcut tensor never exists
+            out = self.t(p + 'conv2', x.h // 2, x.w // 2, cout)
+            self.ops.append(Op(CONV_DOWN, p + 'down', src=a, dst=out, weight=p + 'conv2.conv.weight', weight2=p + 'shortcut.conv.weight',
+                               bias=p + 'conv2.conv.bias', bias2=p + 'shortcut.conv.bias', stats=s2, res1=x))
+            self.producer[id(out)] = self.ops[-1]
+            return out
         if has_sc:
             # the shortcut convolution only meets the main branch again at conv2's residual add
             self.side_now = self.low_res(x)
@@ -318,6 +328,14 @@ PAIR_SHAPES = ((32, 16),)
 PAIR_SHAPES_F16W = ((32, 16), (32, 32), (32, 64), (64, 16), (64, 32))
 
 
+def down_fusable(h, w, cin, cout):
+    """Downsampling ResidualBlocks SBC_OP_CONV_DOWN takes: 32 -> 64 channels at 16-pixel rows, 64 -> 64 at 8 (res2.0 / res3.0 of a
+    64 x 16 array), heights that are multiples of 16."""
+    if os.environ.get('SBC_NO_CONV_DOWN'):           # A/B aid: pooled Winograd convolution + 1x1 shortcut launch
+        return False
+    return h % 16 == 0 and ((w == 16 and cin == 32 and cout == 64) or (w == 8 and cin == 64 and cout == 64))
+
+
 def merge_chains(ops):
     """Adjacent CHAIN records where the second one is the only consumer of the first one's output become ONE record (up to
     CHAIN_MAX_BLOCKS blocks): res5.0 + res5.1 + the whole of refine1, for instance.  In place."""
@@ -366,7 +384,7 @@ def pair_fusable(h, w, c, shapes=PAIR_SHAPES):
 
 
 def build_score_plan(ngf=32, nt=64, nr=16, channels=2, share_slots=True, overlap=False, fold_stats=False, fuse_pairs=False, fuse_res=False,
-                     fuse_chain=False):
+                     fuse_chain=False, fuse_down=False):
     """Op list of one ``NCSNv2Deepest.forward`` for ``[B, 2, nt, nr]`` inputs (ncsnv2.py:269-300).
     ``share_slots=False`` gives every logical tensor its own storage (a training step reads every activation again on
     the way back, ``train.py``)."""
@@ -375,6 +393,7 @@ def build_score_plan(ngf=32, nt=64, nr=16, channels=2, share_slots=True, overlap
     b = _Builder(ngf, nt, nr, overlap, fold_stats, fuse_pairs)
     b.fuse_res = bool(fuse_res)
     b.fuse_chain = bool(fuse_chain)
+    b.fuse_down = bool(fuse_down)
     x = b.t('x', nt, nr, channels)
     h = b.t('begin_conv', nt, nr, ngf)
     b.ops.append(Op(BEGIN_CONV, 'begin_conv', src=x, dst=h, weight='begin_conv.weight', bias='begin_conv.bias'))
@@ -480,6 +499,8 @@ def count_conv_flops(plan):
             total += 2 * 2 * op.src.h * op.src.w * op.src.c * op.dst.c * 9
         elif op.kind == CONV_POOL:
             total += 2 * op.src.h * op.src.w * op.src.c * op.dst.c * 9
+        elif op.kind == CONV_DOWN:               # (counted as the reference runs it: 3x3 + 1x1 at full resolution)
+            total += 2 * op.src.h * op.src.w * op.src.c * op.dst.c * (9 + 1)
         elif op.kind == CHAIN:
             total += chain_conv_count(op) * 2 * op.src.h * op.src.w * op.src.c * op.dst.c * 9
         elif op.kind in (BEGIN_CONV, END_CONV):

@@ -16,7 +16,7 @@ from . import _lib
 from . import plan as P
 from .config import CONV_MODES, DEFAULT_CONV_MODE
 from .weights import (check_state_dict, fp16_state_dict, get_sigmas, pack_conv_weight, pack_conv_weight_f16,
-                      pack_conv_weight_f16x2, pack_conv_weight_split, pack_conv_weight_winograd,
+                      pack_conv_weight_f16x2, pack_conv_weight_pooled_f16x2, pack_conv_weight_split, pack_conv_weight_winograd,
                       pack_conv_weight_winograd_f16, pack_conv_weight_winograd_f16x2, pack_conv_weight_winograd_split)
 
 
@@ -46,6 +46,8 @@ DEFAULT_FUSE_RES = True
 # RCU / CRP runs of the 8 x 2 level as SBC_OP_CHAIN records (csrc/conv_chain.hip: eight samples resident per workgroup, only the
 # filters stream): conv_mode f16x2 with fused pairs
 DEFAULT_FUSE_CHAIN = True
+# pooled conv2 + pooled 1x1 shortcut of the downsampling ResidualBlocks res2.0 / res3.0 as one SBC_OP_CONV_DOWN record (csrc/conv_down.hip)
+DEFAULT_FUSE_DOWN = True
 
 
 class ScoreNet:
@@ -75,7 +77,7 @@ class ScoreNet:
                             ``.half()``, layers.py:179); tolerance stated in tests/test_gpu_parity.py.
     """
 
-    def __init__(self, config, device=None, conv_mode=None, overlap=None, fold_stats=None, fuse_pairs=None, fuse_res=None, fuse_chain=None):
+    def __init__(self, config, device=None, conv_mode=None, overlap=None, fold_stats=None, fuse_pairs=None, fuse_res=None, fuse_chain=None, fuse_down=None):
         conv_mode = DEFAULT_CONV_MODE if conv_mode is None else conv_mode
         if conv_mode not in CONV_MODES:
             raise ValueError('conv_mode must be one of %s, got %r' % (CONV_MODES, conv_mode))
@@ -95,6 +97,7 @@ class ScoreNet:
         self.fuse_pairs = (DEFAULT_FUSE_PAIRS if fuse_pairs is None else bool(fuse_pairs)) and conv_mode in ('f16x2', 'f16w')
         self.fuse_res = ((DEFAULT_FUSE_RES and self.fuse_pairs) if fuse_res is None else bool(fuse_res)) and conv_mode == 'f16x2'
         self.fuse_chain = ((DEFAULT_FUSE_CHAIN and self.fuse_pairs) if fuse_chain is None else bool(fuse_chain)) and conv_mode == 'f16x2'
+        self.fuse_down = ((DEFAULT_FUSE_DOWN and self.fuse_pairs) if fuse_down is None else bool(fuse_down)) and conv_mode == 'f16x2'
         self.config = config
         m, d = config.model, config.data
         if str(m.normalization) != 'InstanceNorm++' or str(m.nonlinearity).lower() != 'elu':
@@ -182,6 +185,9 @@ class ScoreNet:
                     add(name + '#split', pack_conv_weight_f16x2(w).view(np.float32))      # 2 fp16 terms + scale trailer
                     if w.shape[2:] == (3, 3):
                         add(name + '#winograd_split', pack_conv_weight_winograd_f16x2(w).view(np.float32))
+                    if name.endswith('.conv.weight'):
+                        # a ConvMeanPool layer (layers.py:291-313): also the pooled stride-2 filter SBC_OP_CONV_DOWN reads
+                        add(name + '#pool', pack_conv_weight_pooled_f16x2(w).view(np.float32))
                 else:
                     add(name + '#split', pack_conv_weight_f16(w).view(np.float32))        # fp16 bit patterns
                     if w.shape[2:] == (3, 3):
@@ -251,7 +257,8 @@ class ScoreNet:
             fold = self.fold_stats and not (nt & (nt - 1)) and not (nr & (nr - 1))     # conv_wx3 takes power-of-two images
             self._plans[key] = P.build_score_plan(self.ngf, nt, nr, self.channels, overlap=self.overlap, fold_stats=fold,
                                                   fuse_pairs=(P.PAIR_SHAPES_F16W if self.conv_mode == 'f16w' else P.PAIR_SHAPES) if self.fuse_pairs else False,
-                                                  fuse_res=self.fuse_res, fuse_chain=self.fuse_chain and not self.overlap)
+                                                  fuse_res=self.fuse_res, fuse_chain=self.fuse_chain and not self.overlap,
+                                                  fuse_down=self.fuse_down and not self.overlap)
         return self._plans[key]
 
     def bind(self, B, nt, nr, *, step=None, sigma_of_step=None, use_labels=True):
@@ -296,6 +303,12 @@ class ScoreNet:
                 o.weight_split = _ptr(self._wdev, self._woff[op.weight + '#split'])
                 o.weight_wino_split = wino(op.weight)
                 o.flags |= P.CONV_F16W if self.conv_mode == 'f16w' else P.CONV_F16X2
+            elif op.kind == P.CONV_DOWN:
+                o.ksize, o.dil = 3, 1
+                o.weight_split = _ptr(self._wdev, self._woff[op.weight + '#pool'])
+                o.weight2_split = _ptr(self._wdev, self._woff[op.weight2 + '#pool'])
+                o.bias2 = _ptr(self._wdev, self._woff[op.bias2])
+                o.flags |= P.CONV_F16X2
             elif op.kind == P.CHAIN:
                 o.ksize, o.dil = 3, 1
                 ch = _lib.sbc_chain(n_blocks=len(op.blocks))

@@ -292,6 +292,23 @@ def pack_conv_weight_f16x2(w, act_scale=1.0):
     return _pack_f16x2(w.reshape(o, c, kh * kw), act_scale)
 
 
+def pooled_filter(w):
+    """The filter of ``meanpool2(conv_k(x))`` as ONE stride-2 convolution (ConvMeanPool, layers.py:309-313): ``[O, C, k, k]`` ->
+    ``[O, C, k + 1, k + 1]`` with ``W'[p][q] = 1/4 sum_{a,b in {0,1}} W[p - a][q - b]``, formed in float64, rounded once."""
+    w = np.asarray(w, np.float64)
+    o, c, k, _ = w.shape
+    out = np.zeros((o, c, k + 1, k + 1), np.float64)
+    for a in range(2):
+        for b in range(2):
+            out[:, :, a:a + k, b:b + k] += w
+    return (0.25 * out).astype(np.float32)
+
+
+def pack_conv_weight_pooled_f16x2(w, act_scale=1.0):
+    """``pack_conv_weight_f16x2`` of ``pooled_filter(w)`` (``csrc/conv_down.hip``; identical to ``sbc_pack_conv_weight_pooled_f16x2``)."""
+    return pack_conv_weight_f16x2(pooled_filter(w), act_scale)
+
+
 def pack_conv_weight_winograd_f16x2(w, act_scale=1.0):
     """Winograd F(2x2, 3x3) weights ``U = G g G^T`` (float64, rounded once to float32) in the ``pack_conv_weight_f16x2``
     form with the 16 transform positions in place of the taps (``csrc/conv_wx3.hip``, ``MODE = 2``)."""

@@ -97,6 +97,12 @@ def exec_op(op, sd, get, labels):
             st2 = inorm_stats(t, sd[k + '.alpha'], sd[k + '.gamma'], sd[k + '.beta'])
             u = O.elu((t - st2[:, None, None, 0]) * st2[:, None, None, 1] + st2[:, None, None, 2])
             out = src + _nhwc(O.conv2d(_nchw(u), sd[op.weight2], sd[op.bias2], 1))
+        elif op.kind == P.CONV_DOWN:             # pooled conv2 + pooled 1x1 shortcut of a downsampling ResidualBlock (layers.py:443-456, 309-313)
+            st = get(op.stats)[:, 0]
+            v = O.elu((src - st[:, None, None, 0]) * st[:, None, None, 1] + st[:, None, None, 2])
+            main = O.mean_pool2(O.conv2d(_nchw(v), sd[op.weight], sd[op.bias], 1))
+            sc = O.mean_pool2(O.conv2d(_nchw(get(op.res1)), sd[op.weight2], sd[op.bias2], 1))
+            out = _nhwc(sc + main)
         elif op.kind == P.CHAIN:                 # RCU / CRP blocks in sequence (layers.py:76-83, 126-134)
             out = src
             for typ, k1, k2, ex in op.blocks:

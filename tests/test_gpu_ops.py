@@ -892,3 +892,42 @@ def test_chain_matches_oracle(gpu, Cc, H, W, B, blocks):
     assert _lib.range_flag() == 0
     if B >= 8:
         assert np.array_equal(run(dx[:5].contiguous()), got[:5])       # batch independence, bit for bit
+
+
+@pytest.mark.parametrize('B', [1, 3, 40])
+@pytest.mark.parametrize('cin,cout,H,W', [(32, 64, 64, 16), (32, 64, 16, 16), (64, 64, 32, 8), (64, 64, 16, 8)])
+def test_conv_down_matches_oracle(gpu, cin, cout, H, W, B):
+    """SBC_OP_CONV_DOWN (csrc/conv_down.hip): the tail of a downsampling ResidualBlock,
+    meanpool2(conv3x3(ELU(norm(a))) + b) + meanpool2(conv1x1(x) + bs) (layers.py:443-456, 309-313), as a 4x4 and a 2x2 stride-2
+    convolution with the pooled filters -- against the oracle's full-resolution convolutions followed by its mean pool, and bit for
+    bit independent of the batch a sample is part of."""
+    torch, _lib = gpu
+    from score_based_channels_amd import plan as P
+    from score_based_channels_amd.weights import pack_conv_weight_pooled_f16x2
+    rng = np.random.default_rng(B * 100 + H + W + cin)
+    a = (rng.standard_normal((B, H, W, cin)) * 1.5 + 0.3).astype(F32)
+    x = (rng.standard_normal((B, H, W, cin)) * 0.8 - 0.2).astype(F32)
+    w3 = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(9 * cin)).astype(F32)
+    w1 = (rng.standard_normal((cout, cin, 1, 1)) / np.sqrt(cin) * 0.3).astype(F32)
+    b3, b1 = (0.2 * rng.standard_normal(cout)).astype(F32), (0.2 * rng.standard_normal(cout)).astype(F32)
+    al, ga, be = ((v + 0.1 * rng.standard_normal(cin)).astype(F32) for v in (1.0, 1.0, 0.0))
+    st = inorm_stats(a, al, ga, be)                                              # [B, 3, C]: (mu, scale, shift)
+    v = O.elu((a - st[:, None, None, 0]) * st[:, None, None, 1] + st[:, None, None, 2])
+    ref = (O.mean_pool2(O.conv2d(v.transpose(0, 3, 1, 2), w3, b3, 1)) + O.mean_pool2(O.conv2d(x.transpose(0, 3, 1, 2), w1, b1, 1))).transpose(0, 2, 3, 1)
+    da, dx, dst = _dev(torch, a), _dev(torch, x), _dev(torch, st)
+    d3, d1 = _dev(torch, pack_conv_weight_pooled_f16x2(w3).view(np.float32)), _dev(torch, pack_conv_weight_pooled_f16x2(w1).view(np.float32))
+    db3, db1 = _dev(torch, b3), _dev(torch, b1)
+
+    def run(n):
+        out = torch.full((n, H // 2, W // 2, cout), float('nan'), dtype=torch.float32, device='cuda')
+        op = _lib.sbc_op(kind=P.CONV_DOWN, flags=P.CONV_F16X2, B=n, H=H, W=W, cin=cin, cout=cout, ksize=3, dil=1, in_=_p(da), out=_p(out),
+                         res1=_p(dx), stats=_p(dst), weight_split=_p(d3), weight2_split=_p(d1), bias=_p(db3), bias2=_p(db1))
+        _launch(gpu, op)
+        return out.cpu().numpy()
+    got = run(B)
+    assert np.isfinite(got).all()
+    assert rel_err(got, ref) < TOL, rel_err(got, ref)
+    assert rel_err_elementwise(got, ref, floor=0.05) < 1e-4
+    assert _lib.range_flag() == 0
+    if B >= 3:
+        assert np.array_equal(run(2), got[:2])

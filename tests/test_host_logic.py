@@ -329,6 +329,11 @@ def test_pack_conv_weight_f16x2_c_matches_python():
         assert np.max(np.abs(back - w)) <= 2.0 ** -22 * np.abs(w).max()
         big = np.abs(w) >= np.abs(w).max() * 2.0 ** -10
         assert np.max(np.abs(back[big] / w[big] - 1)) <= 2.0 ** -22
+        from score_based_channels_amd.weights import pack_conv_weight_pooled_f16x2
+        refp = pack_conv_weight_pooled_f16x2(w)                     # the pooled (stride-2) filter of csrc/conv_down.hip: 3x3 -> 4x4, 1x1 -> 2x2
+        dstp = np.zeros(refp.size, np.uint16)
+        _lib.check(_lib.lib().sbc_pack_conv_weight_pooled_f16x2(w.ctypes.data, o, c, k, dstp.ctypes.data))
+        assert np.array_equal(dstp, refp) and refp.size == (k + 1) ** 2 * o * c * 2 + 8
         if k == 3:
             refw = pack_conv_weight_winograd_f16x2(w)
             dstw = np.zeros_like(refw)

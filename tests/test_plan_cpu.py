@@ -154,3 +154,21 @@ def test_chain_plan_matches_reference_forward(weights64):
     for plan in (pl, nf):
         out = run_plan(plan, sd, x, np.full((2,), 1155))
         assert rel_err(out.transpose(0, 3, 1, 2), g['out'][1][:2]) < 2e-5
+
+
+def test_conv_down_plan_matches_reference_forward(weights64):
+    """``build_score_plan(fuse_down=True)``: the pooled conv2 and the pooled 1x1 shortcut of res2.0 and res3.0 are ONE CONV_DOWN
+    record each (csrc/conv_down.hip); res31.0 -- whose norm the consumer computes itself at 16x4 -- stays as it is.  Same FLOPs as
+    the reference counts them, and interpreted on the CPU the same forward."""
+    _, sd = weights64
+    g = load_golden('forward_64x16.npz')
+    base = P.build_score_plan(32, 64, 16, fold_stats=True, fuse_pairs=P.PAIR_SHAPES, fuse_res=True, fuse_chain=True)
+    pl = P.build_score_plan(32, 64, 16, fold_stats=True, fuse_pairs=P.PAIR_SHAPES, fuse_res=True, fuse_chain=True, fuse_down=True)
+    down = [op for op in pl.ops if op.kind == P.CONV_DOWN]
+    assert len(base.ops) == 61 and len(pl.ops) == 59 and [op.name for op in down] == ['res2.0.down', 'res3.0.down']
+    assert [(op.src.w, op.src.c, op.dst.c, op.dst.h) for op in down] == [(16, 32, 64, 32), (8, 64, 64, 16)]
+    assert all(op.res1 is not None and op.stats is not None and op.weight.endswith('conv2.conv.weight') and op.weight2.endswith('shortcut.conv.weight') for op in down)
+    assert P.count_conv_flops(pl) == 820772864
+    x = np.ascontiguousarray(g['x'][:2].transpose(0, 2, 3, 1))
+    out = run_plan(pl, sd, x, np.full((2,), 1155))
+    assert rel_err(out.transpose(0, 3, 1, 2), g['out'][1][:2]) < 2e-5
