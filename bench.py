@@ -406,7 +406,7 @@ def main():
         pa = p_alds[0]
         run_all(p_alds, p_streams, 2, False)
         chain_tags = tuple(P.TAG_CHAIN + k for k in range(len(P.CHAIN_KERNELS)))
-        for tag in (P.TAG_CONV_TOP, P.TAG_PAIR_TOP, P.TAG_POOL_TOP, P.TAG_RES_TOP, P.TAG_CONV_MID, P.TAG_DIRECT_MID) + chain_tags:
+        for tag in (P.TAG_CONV_TOP, P.TAG_PAIR_TOP, P.TAG_POOL_TOP, P.TAG_RES_TOP, P.TAG_CONV_MID, P.TAG_DIRECT_MID) + chain_tags + (P.TAG_DOWN, P.TAG_DOWN + 1):
             ops = [op for op in net.score_plan(nt, nr).ops if op.tag == tag]
             if not ops:
                 continue
@@ -418,13 +418,15 @@ def main():
             pa.plan.profile(-1)
             if n:
                 klass[tag] = {'ms_total': ms, 'launches': n, 'launches_per_step': len(ops), 'us_per_launch': ms / n * 1e3,
-                              'flops_per_step': float(sum((2 if op.kind in (P.CONV_PAIR, P.RES_BLOCK) else P.chain_conv_count(op) if op.kind == P.CHAIN else 1)
+                              # (CONV_DOWN: 3x3 + 1x1 at full resolution, as the reference runs them: 10 / 9 of a 3x3 convolution)
+                              'flops_per_step': float(sum((2 if op.kind in (P.CONV_PAIR, P.RES_BLOCK) else P.chain_conv_count(op) if op.kind == P.CHAIN
+                                                           else 10.0 / 9.0 if op.kind == P.CONV_DOWN else 1)
                                                           * 2.0 * T * op.src.h * op.src.w * 9 * op.src.c * op.dst.c for op in ops)),
                               # CHAIN records: the fraction of the 9 taps their column units execute, FLOP-weighted over the class
                               'live_taps': (sum(P.chain_live_tap_fraction(op) * P.chain_conv_count(op) for op in ops)
                                             / sum(P.chain_conv_count(op) for op in ops)) if ops[0].kind == P.CHAIN else 1.0,
-                              'bytes_per_step': float(sum(4.0 * T * op.src.h * op.src.w * (op.src.c + op.dst.c * (1 + (op.res1 is not None)
-                                                                                                             + (op.res2 is not None)))
+                              'bytes_per_step': float(sum(4.0 * T * (2 * op.src.h * op.src.w * op.src.c + op.dst.h * op.dst.w * op.dst.c) if op.kind == P.CONV_DOWN
+                                                          else 4.0 * T * op.src.h * op.src.w * (op.src.c + op.dst.c * (1 + (op.res1 is not None) + (op.res2 is not None)))
                                                           for op in ops))}
         pa.rewind()
         t0 = time.perf_counter()
@@ -582,6 +584,7 @@ def main():
                      P.TAG_DIRECT_MID: ('conv_dp_kernel<64, 8, 8, 1, false, 4>' if conv_mode == 'f16x2' and nr == 16 else
                                         'conv_wx3_kernel<64, 64, 1, true, 2, false, 2, 1, %d>' % {'bf16x3': 0, 'f16w': 1, 'f16x2': 2}.get(conv_mode, 0))}
             direct_mid = names[P.TAG_DIRECT_MID].startswith('conv_dp')
+            names[P.TAG_DOWN], names[P.TAG_DOWN + 1] = 'conv_down_kernel<32, 64, 16>', 'conv_down_kernel<64, 64, 8>'
             for k, (cc, cw) in enumerate(P.CHAIN_KERNELS):
                 names[P.TAG_CHAIN + k] = 'conv_chain_kernel<%d, %d, %d>' % (cc, cw, 8 if (cc, cw) in ((128, 2), (64, 8)) else 4)
             what = {P.TAG_CONV_TOP: 'the unfused 3x3 32->32 convolutions at %dx%d (Winograd F(2x2,3x3))' % (nt, nr),
@@ -598,13 +601,16 @@ def main():
                                          'per workgroup, the running tensor in registers, operands in LDS, direct 3x3 convolutions whose column units '
                                          'skip the taps that only read padding (csrc/conv_chain.hip)'
                                          % (nt * cw // nr, cw, cc, {2: 8 if cc == 128 else 4, 4: 2, 8: 1}[cw]))
+            for k in (0, 1):
+                what[P.TAG_DOWN + k] = ('the pooled 3x3 convolution + pooled 1x1 shortcut of the downsampling ResidualBlock at %dx%d: 4x4 and 2x2 stride-2 direct '
+                                        'convolutions with the pooled filters, both inputs read once (csrc/conv_down.hip)' % (nt >> k, nr >> k))
             entries = {}
             for tag, kc in klass.items():
                 t_launch = kc['us_per_launch'] * 1e-6
                 fl = kc['flops_per_step'] / kc['launches_per_step']           # algorithmic FLOPs of an average launch of the class
                 by = kc['bytes_per_step'] / kc['launches_per_step']
                 ratio = (18.0 / 16.0 if tag == P.TAG_PAIR_TOP else 1.0 if tag in (P.TAG_POOL_TOP, P.TAG_RES_TOP) or (tag == P.TAG_DIRECT_MID and direct_mid)
-                         else kc['live_taps'] if tag >= P.TAG_CHAIN else 16.0 / 36.0) * (terms or 1.0)
+                         else 0.5 if tag >= P.TAG_DOWN else kc['live_taps'] if tag >= P.TAG_CHAIN else 16.0 / 36.0) * (terms or 1.0)
                 ach = fl / t_launch / 1e12
                 e = {'kernel': names[tag], 'what': what[tag], 'launches_per_step': kc['launches_per_step'],
                      'us_per_launch': kc['us_per_launch'], 'share_of_one_stream_step': kc['us_per_launch'] * kc['launches_per_step'] / 1e3 / one_stream_ms,

@@ -127,6 +127,7 @@ struct Builder {
             o.kind = SBC_OP_CONV_DOWN; o.src = a; o.dst = out; o.stats = s2; o.res1 = x;
             o.weight = p + "conv2.conv.weight"; o.weight2 = p + "shortcut.conv.weight";
             o.bias = p + "conv2.conv.bias"; o.bias2 = p + "shortcut.conv.bias";
+            o.tag = 12 + (t[x].w == 16 ? 0 : 1);                                                // plan.TAG_DOWN
             producer[out] = (int)ops.size();
             ops.push_back(o);
             return out;

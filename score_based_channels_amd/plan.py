@@ -51,6 +51,7 @@ TAG_POOL_TOP = 4        # fused CRP stages (CONV_POOL) at full resolution
 TAG_RES_TOP = 6         # fused ResidualBlocks (RES_BLOCK) at full resolution
 TAG_CHAIN = 7           # CHAIN records (csrc/conv_chain.hip): 7 + the index of their kernel instantiation in CHAIN_KERNELS
 CHAIN_KERNELS = ((128, 2), (64, 2), (64, 4), (64, 8), (32, 8))       # (channels, width)
+TAG_DOWN = 12           # CONV_DOWN records: 12 at 16-pixel rows (res2.0), 13 at 8 (res3.0)
 TAG_DIRECT_MID = 5      # the TAG_CONV_MID layers without a norm prologue / resize / tile-moment output: in conv_mode f16x2 the direct
                         # persistent kernel (csrc/conv_dp.hip) takes them, the Winograd kernel the rest
 
@@ -221,7 +222,8 @@ class _Builder:
             # the pooled shortcut tensor never exists
             out = self.t(p + 'conv2', x.h // 2, x.w // 2, cout)
             self.ops.append(Op(CONV_DOWN, p + 'down', src=a, dst=out, weight=p + 'conv2.conv.weight', weight2=p + 'shortcut.conv.weight',
-                               bias=p + 'conv2.conv.bias', bias2=p + 'shortcut.conv.bias', stats=s2, res1=x))
+                               bias=p + 'conv2.conv.bias', bias2=p + 'shortcut.conv.bias', stats=s2, res1=x,
+                               tag=TAG_DOWN + (0 if x.w == 16 else 1)))
             self.producer[id(out)] = self.ops[-1]
             return out
         if has_sc:

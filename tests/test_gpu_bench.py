@@ -31,8 +31,9 @@ def test_bench_line_contract_single_gpu():
     assert 'workload' in d['config'] and 'model' not in d['config'] and d['config']['nmse_finite']
     r = d['roofline']
     assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
-    # five full-/half-resolution classes (the direct 64 -> 64 class of round 4 became chain records) + the five chain kernels
-    assert len(r['kernels']) == 10 and sum(k.startswith('conv_chain_kernel') for k in r['kernels']) == 5 and 'conv_res_kernel' in r['kernels']
+    # five full-/half-resolution classes (the direct 64 -> 64 class of round 4 became chain records), the five chain kernels, the two conv_down kernels
+    assert len(r['kernels']) == 12 and sum(k.startswith('conv_chain_kernel') for k in r['kernels']) == 5 and 'conv_res_kernel' in r['kernels']
+    assert sum(k.startswith('conv_down_kernel') for k in r['kernels']) == 2
     assert d['config']['streams_is_cli_default'] and d['config']['f16x2_range_flag'] == 0
     # frac is the ALGORITHMIC fraction of the dense fp16 MFMA peak; the matrix pipe's busy fraction is a separate field
     assert r['peak'] == 2516.6 and 0 < r['frac'] < r['mfma_busy'] < 1 and 0 < r['frac_step'] < 1

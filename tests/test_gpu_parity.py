@@ -718,8 +718,8 @@ def test_overlapped_branches_do_not_change_results(weights64):
     x = torch.from_numpy(rng.standard_normal((96, 2, 64, 16)).astype(np.float32))
     labels = torch.from_numpy(rng.integers(0, 2311, 96))
     # (the overlapped plan keeps the low-resolution levels as separate records -- side records must stay individual launches -- so the
-    # sequential plan it is compared with is built without SBC_OP_CHAIN records too: same kernels on the same data)
-    seq = ScoreNet(cfg, overlap=False, fuse_chain=False).cuda().load_state_dict(sd)
+    # sequential plan it is compared with is built without SBC_OP_CHAIN / SBC_OP_CONV_DOWN records too: same kernels on the same data)
+    seq = ScoreNet(cfg, overlap=False, fuse_chain=False, fuse_down=False).cuda().load_state_dict(sd)
     ovl = ScoreNet(cfg, overlap=True).cuda().load_state_dict(sd)
     ref = seq(x, labels)
     assert sum(o.side for o in ovl.score_plan(64, 16).ops) == 24
