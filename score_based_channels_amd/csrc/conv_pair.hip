@@ -601,6 +601,277 @@ __global__ __launch_bounds__(192 * NW, 3) void conv_pair_p3_kernel(PairParams p)
 
 
 
+// The pipeline of conv_pair_p3_kernel WITHOUT THE HALO WORK (W = 16, 32 channels): a workgroup owns a contiguous run of tiles, so
+// the rows two vertically adjacent tiles share are converted and convolved once.  The operand planes are rings over rows:
+//   X (conv1's input, fp16 terms): 24 rows in three slots of 8 + a 4-row copy of rows 20..23 in front of row 0;
+//   M (the intermediate):          24 rows in three slots of 8 + a 2-row copy of rows 22, 23 in front of row 0.
+// Item k of the run uses slot k % 3.  A TILE item (output rows r0 .. r0+7 of sample n) converts the EIGHT input rows r0+2 .. r0+9
+// into its X slot, computes the EIGHT intermediate rows r0+1 .. r0+8 into its M slot (conv1 reads X rows slot-4 .. slot+7: the four
+// rows before the slot are the previous item's last four) and the eight output rows (conv2 reads M rows slot-2 .. slot+7).  Where no
+// previous tile of the same sample precedes it in the run -- the run's first tile, the first tile of every sample -- a PRE item
+// comes first: it fills only the last four X rows (input rows r0-2 .. r0+1; zeros outside the image) and the last two M rows (r0-1,
+// r0) of its slot and stores nothing.  Against conv_pair_p3_kernel a sample of 64 rows converts 68 rows instead of 96, evaluates
+// conv1 on 66 rows instead of 80 and reads every input row from memory once (+ the PRE rows of a run that starts mid-sample).
+// The copies in front of row 0 make every window contiguous: a value written to rows 20..23 (X) / 22, 23 (M) is written twice.
+// Each role advances its own cursor over the run (scalar registers); one workgroup barrier per item as before -- the writer of
+// iteration `it` (X slot it % 3, M slot (it - 1) % 3) never touches the rows the readers of that iteration use (X: slot (it - 1) % 3
+// and the four rows before it; M: slot (it - 2) % 3 and the two rows before it).
+// Every output is the same sum in the same order as in the two kernels above: identical bit for bit.
+template <int MODE>
+__global__ __launch_bounds__(768, 3) void conv_pair_roll_kernel(PairParams p) {
+    constexpr int W = 16, R = 8, C = 32, NW = 4, NTH = 64 * NW;
+    constexpr int KGS = C / 8, C4 = C / 4;
+    constexpr int NT = MODE == 2 ? 2 : 1;
+    constexpr int WP = W + 2, ROWB = WP * 16;          // bytes of one plane row
+    constexpr int RING = 24, XMIR = 4, MMIR = 2;       // ring rows; rows copied in front of row 0
+    constexpr int XPS = ((RING + XMIR) * ROWB + 255) / 256 * 256;
+    constexpr int MPS = ((RING + MMIR) * ROWB + 255) / 256 * 256;
+    constexpr int RAW_BYTES = R * W * C * 4;
+    constexpr int X_OFF = 2 * RAW_BYTES, M_OFF = X_OFF + NT * KGS * XPS;
+    constexpr int NK = R * W * C4 / NTH;               // 16-byte chunks per thread and TILE item (4); a PRE item: the last two
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+
+    const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x / NTH);      // 0: conv1 waves, 1: conv2 waves, 2: conversion waves
+    const int tid = threadIdx.x - role * NTH, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hf = wave & 1, sub = wave >> 1;          // 16-output-channel half; row parity of this wave's units
+    const int kq = lane >> 4, c = lane & 15;
+    const int H = p.H;
+
+    uint4 wf[9][NT];
+    if (role < 2) {
+        const int lsrc = (16 * hf + c) + 32 * (kq & 1);
+        const uint4* w = role == 0 ? p.w1 : p.w2;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) wf[tap][t] = w[((tap * (C / 16) + (kq >> 1)) * NT + t) * 64 + lsrc];
+    }
+    float scale1 = 1.f, descale1 = 1.f, scale2 = 1.f, descale2 = 1.f;
+    unsigned rbits = 0;
+    if constexpr (MODE == 2) {
+        const float4 t1 = f16x2_trailer(reinterpret_cast<const float4*>(p.w1), 9 * (C / 16) * (C / 32) * NT);
+        const float4 t2 = f16x2_trailer(reinterpret_cast<const float4*>(p.w2), 9 * (C / 16) * (C / 32) * NT);
+        scale1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t1.x)));
+        scale2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t2.x)));
+        descale1 = t1.y; descale2 = t2.y;
+        if (t1.w != 0.f || t2.w != 0.f) rbits |= 4u;     // (conv_pair_kernel: the four-instruction ELU only)
+    }
+
+    // ---- zero the padding columns of every plane row once
+    for (int i = threadIdx.x; i < NT * KGS * (RING + XMIR) * 2; i += 3 * NTH) {
+        const int side = i & 1, row = (i >> 1) % (RING + XMIR), pl = (i >> 1) / (RING + XMIR);
+        *reinterpret_cast<uint4*>(smem + X_OFF + pl * XPS + row * ROWB + side * (W + 1) * 16) = make_uint4(0, 0, 0, 0);
+    }
+    for (int i = threadIdx.x; i < NT * KGS * (RING + MMIR) * 2; i += 3 * NTH) {
+        const int side = i & 1, row = (i >> 1) % (RING + MMIR), pl = (i >> 1) / (RING + MMIR);
+        *reinterpret_cast<uint4*>(smem + M_OFF + pl * MPS + row * ROWB + side * (W + 1) * 16) = make_uint4(0, 0, 0, 0);
+    }
+
+    // ---- this workgroup's run: XCD x owns tiles [t_begin, t_end), its workgroups take equal contiguous pieces [a, b) of it
+    const int xcd = blockIdx.x & 7, jw = blockIdx.x >> 3;
+    const int t_begin = xcd * p.tiles_per_xcd;
+    const int cnt = max(min(t_begin + p.tiles_per_xcd, p.ntiles) - t_begin, 0);
+    const int a = t_begin + jw * cnt / p.wgs_per_xcd, b = t_begin + (jw + 1) * cnt / p.wgs_per_xcd;
+    if (a >= b) return;                                               // (whole workgroup)
+    const int tps = p.tiles_per_sample;
+    const int n_items = (b - a) + 1 + ((b - 1) / tps - a / tps);    // tiles + the run's PRE + one PRE per sample that starts inside
+    // cursor over the run: the next item is PRE (pre != 0) or TILE of tile j of sample n
+    struct Cur { int n, j, pre; };
+    auto cur_first = [&]() { Cur q; q.n = a / tps; q.j = a - q.n * tps; q.pre = 1; return q; };
+    auto cur_next = [&](Cur& q) {
+        if (q.pre) { q.pre = 0; return; }
+        if (++q.j == tps) { q.j = 0; ++q.n; q.pre = 1; }
+    };
+    auto next_slot = [](int s) { return s == 16 ? 0 : s + 8; };
+
+    if (role == 2) {
+        // ================================================================= conversion: LDS-DMA one item ahead, raw -> X slot
+        auto issue_dma = [&](const Cur& q, int buf) {
+            const int rb = R * q.j - (q.pre ? R : 0) + 2;            // image row of the slot's row 0
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                if (k < NK / 2 && q.pre) continue;                   // (uniform)
+                const int j = k * NW + wave;                          // piece: 64 chunks = half a row
+                const int ri = j >> 1;
+                const int grow = min(max(rb + ri, 0), H - 1);         // rows outside the image: any row inside (converted to zeros)
+                const char* sbase = reinterpret_cast<const char*>(p.in) + ((size_t)(q.n * H + grow) * W * C) * 4 + (size_t)(j & 1) * 1024;
+                const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem + buf * RAW_BYTES + j * 1024;
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(lane * 16), "s"(dst), "s"(sbase) : "memory");
+            }
+        };
+        auto convert = [&](const Cur& q, int buf, int slot) {
+            const int rb = R * q.j - (q.pre ? R : 0) + 2;
+            float ta = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk) {
+                if (kk < NK / 2 && q.pre) continue;
+                const int qi = kk * NTH + tid;
+                const int px = qi / C4, c4 = qi % C4;
+                const int ri = px / W, col = px - ri * W;
+                const int grow = rb + ri;
+                float4 v = *reinterpret_cast<const float4*>(smem + buf * RAW_BYTES + qi * 16);
+                if (grow < 0 || grow >= H) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                v = elu4(v);
+                unsigned char* dst = smem + X_OFF + (c4 >> 1) * XPS + ((slot + ri + XMIR) * WP + col + 1) * 16 + (c4 & 1) * 8;
+                if constexpr (MODE == 2) {
+                    StageScale ss{scale1, ta};
+                    scale_track(v, &ss);
+                    ta = ss.amax;
+                    uint2 h, l;
+                    split_f16x2(v, scale1, h, l);
+                    *reinterpret_cast<uint2*>(dst) = h;
+                    *reinterpret_cast<uint2*>(dst + KGS * XPS) = l;
+                    if (kk >= NK / 2 && slot == 16) {                 // rows 20..23: the copy in front of row 0
+                        *reinterpret_cast<uint2*>(dst - RING * ROWB) = h;
+                        *reinterpret_cast<uint2*>(dst - RING * ROWB + KGS * XPS) = l;
+                    }
+                } else {
+                    f16x4 h;
+                    h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+                    *reinterpret_cast<f16x4*>(dst) = h;
+                    if (kk >= NK / 2 && slot == 16) *reinterpret_cast<f16x4*>(dst - RING * ROWB) = h;
+                }
+            }
+            if constexpr (MODE == 2) pair_range_tile(ta, scale1, rbits, p.calib);
+        };
+        Cur qd = cur_first(), qc = qd;
+        issue_dma(qd, 0);
+        cur_next(qd);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int slot = 0;
+        for (int it = 0; it < n_items + 2; ++it) {
+            lds_barrier();
+            if (it + 1 < n_items) { issue_dma(qd, (it + 1) & 1); cur_next(qd); }
+            if (it < n_items) { convert(qc, it & 1, slot); cur_next(qc); slot = next_slot(slot); }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // item it + 1 has landed before the next barrier publishes it
+        }
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // filter fragments
+        // one convolution over NU units two plane rows apart, the first one's tap (0, 0) source at byte ub0 of term 0
+        auto conv = [&](auto nuc, const int ub0, const int PS, f32x4v* acc) {
+            constexpr int NU = decltype(nuc)::value;
+            constexpr int DU = 2 * ROWB;
+            constexpr int NS = 9 * NU, D = NT == 2 ? 3 : 6;
+            f16x8 ring[D][NT];
+            auto ld = [&](int s) {
+                const int tap = s / NU, i = s % NU;
+                const int off = i * DU + ((tap / 3) * WP + (tap % 3)) * 16;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) ring[s % D][t] = *reinterpret_cast<const f16x8*>(smem + ub0 + (off + t * KGS * PS));
+            };
+#pragma unroll
+            for (int s = 0; s < D - 1 && s < NS; ++s) ld(s);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int tap = s / NU, i = s % NU;
+                if (s + D - 1 < NS) ld(s + D - 1);
+                const f16x8 xh = ring[s % D][0];
+                const f16x8 wh = __builtin_bit_cast(f16x8, wf[tap][0]);
+                const f32x4v c0 = tap == 0 ? f32x4v{0.f, 0.f, 0.f, 0.f} : acc[i];
+                if constexpr (NT == 2) {
+                    const f16x8 xl = ring[s % D][NT - 1];
+                    const f16x8 wl = __builtin_bit_cast(f16x8, wf[tap][NT - 1]);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, c0, 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[i], 0, 0, 0);
+                } else {
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, c0, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        const int cq = 4 * hf + kq;                                    // channel quad of this lane's four outputs
+        if (role == 0) {
+            // ============================================================= conv1: X window -> ELU -> split -> M slot
+            // intermediate row m of the slot (image row r0 + 1 + m) reads X rows slot + m - 2 .. slot + m
+            auto conv1_item = [&](const Cur& q, int slot, auto nuc) {
+                constexpr int NU = decltype(nuc)::value, I0 = 4 - NU;   // a PRE item: the wave's last unit only (m = 6 + sub)
+                const int r0 = R * q.j - (q.pre ? R : 0);
+                f32x4v acc[NU];
+                conv(nuc, X_OFF + kq * XPS + ((slot + sub + 2 * I0 - 2 + XMIR) * WP + c) * 16, XPS, acc);
+                // A PRE item's single accumulator is read right behind its last matrix instruction.  hipcc inserts the wait states a
+                // vector instruction needs behind v_mfma (11 for this shape) in front of its own instructions but does not look
+                // inside inline assembly -- and in the fp16-weight mode (descale1 == 1 folds away) elu4's asm block is the first reader.
+                if constexpr (NU == 1) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+                float tb = 0.f;
+#pragma unroll
+                for (int i = 0; i < NU; ++i) {
+                    const int m = sub + 2 * (I0 + i);
+                    const int grow = r0 + 1 + m;
+                    float4 v = make_float4(acc[i][0] * descale1, acc[i][1] * descale1, acc[i][2] * descale1, acc[i][3] * descale1);
+                    v = elu4(v);
+                    if (grow < 0 || grow >= H) v = make_float4(0.f, 0.f, 0.f, 0.f);    // zero padding of conv2, not conv1 of padding
+                    unsigned char* dst = smem + M_OFF + (cq >> 1) * MPS + ((slot + m + MMIR) * WP + c + 1) * 16 + (cq & 1) * 8;
+                    if constexpr (MODE == 2) {
+                        StageScale ss{scale2, tb};
+                        scale_track(v, &ss);
+                        tb = ss.amax;
+                        uint2 h, l;
+                        split_f16x2(v, scale2, h, l);
+                        *reinterpret_cast<uint2*>(dst) = h;
+                        *reinterpret_cast<uint2*>(dst + KGS * MPS) = l;
+                        if (I0 + i == 3 && slot == 16) {               // rows 22, 23: the copy in front of row 0
+                            *reinterpret_cast<uint2*>(dst - RING * ROWB) = h;
+                            *reinterpret_cast<uint2*>(dst - RING * ROWB + KGS * MPS) = l;
+                        }
+                    } else {
+                        f16x4 h;
+                        h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+                        *reinterpret_cast<f16x4*>(dst) = h;
+                        if (I0 + i == 3 && slot == 16) *reinterpret_cast<f16x4*>(dst - RING * ROWB) = h;
+                    }
+                }
+                if constexpr (MODE == 2) pair_range_tile(tb, scale2, rbits, p.calib ? p.calib + 1 : nullptr);
+            };
+            Cur q = cur_first();
+            int slot = 0;
+            for (int it = 0; it < n_items + 2; ++it) {
+                lds_barrier();
+                if (it < 1 || it - 1 >= n_items) continue;
+                if (q.pre) conv1_item(q, slot, std::integral_constant<int, 1>{});
+                else conv1_item(q, slot, std::integral_constant<int, 4>{});
+                cur_next(q);
+                slot = next_slot(slot);
+            }
+        } else {
+            // ============================================================= conv2: M window, + x, store (TILE items only)
+            // output row o of the tile (image row r0 + o) reads M rows slot + o - 2 .. slot + o
+            Cur q = cur_first();
+            int slot = 0;
+            for (int it = 0; it < n_items + 2; ++it) {
+                lds_barrier();
+                if (it < 2) continue;
+                if (!q.pre) {
+                    constexpr int NU = 4, DO = 2 * W * C;
+                    const int r0 = R * q.j;
+                    f32x4v acc[NU];
+                    float4 xr[NU];
+                    const unsigned o0 = (unsigned)(((q.n * H + r0 + sub) * W + c) * C + cq * 4);
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) xr[i] = *reinterpret_cast<const float4*>(p.in + o0 + i * DO);
+                    conv(std::integral_constant<int, NU>{}, M_OFF + kq * MPS + ((slot + sub - 2 + MMIR) * WP + c) * 16, MPS, acc);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) {
+                        float4 y;
+                        y.x = fmaf(acc[i][0], descale2, xr[i].x); y.y = fmaf(acc[i][1], descale2, xr[i].y);
+                        y.z = fmaf(acc[i][2], descale2, xr[i].z); y.w = fmaf(acc[i][3], descale2, xr[i].w);
+                        st_out(p.out + o0 + i * DO, y);
+                    }
+                }
+                cur_next(q);
+                slot = next_slot(slot);
+            }
+        }
+    }
+    if constexpr (MODE == 2) {
+        if (rbits && (threadIdx.x & 63) == 0) atomicOr(p.range_flag, rbits);
+    }
+}
+
 // One stage of a CRP block in ONE launch (SBC_OP_CONV_POOL):
 //       out = conv3x3(ELU?(MaxPool5x5(x))) [+ (res2 + ELU(res1))]            ncsnv2/models/layers.py:76-83
 // for 32-channel NHWC fp32 tensors, 16 pixels wide.  Unfused, a stage is a max-pool launch (one tensor read, one written) and a
@@ -925,6 +1196,28 @@ static int launch_pair_p3(const PairParams& p0, hipStream_t stream, bool dry) {
 }
 
 template <int MODE>
+static int launch_pair_roll(const PairParams& p0, hipStream_t stream, bool dry) {
+    constexpr int NT = MODE == 2 ? 2 : 1, ROWB = 18 * 16;
+    constexpr int XPS = (28 * ROWB + 255) / 256 * 256, MPS = (26 * ROWB + 255) / 256 * 256;
+    constexpr size_t lds = (size_t)2 * 8 * 16 * 32 * 4 + (size_t)NT * 4 * (XPS + MPS);
+    static_assert(lds <= 160 * 1024, "LDS of the one resident workgroup");
+    auto kern = conv_pair_roll_kernel<MODE>;
+    { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds); if (rc) return rc; }
+    if (dry) return SBC_OK;
+    PairParams p = p0;
+    p.tiles_per_sample = p.H / 8;
+    p.ntiles = p.B * p.tiles_per_sample;
+    int dev = 0, cus = 256;
+    SBC_CHECK_HIP(hipGetDevice(&dev));
+    SBC_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    p.tiles_per_xcd = (p.ntiles + 7) / 8;
+    p.wgs_per_xcd = max(1, min(persistent_cus(cus) / 8, p.tiles_per_xcd));
+    hipLaunchKernelGGL(kern, dim3(8 * p.wgs_per_xcd), dim3(768), lds, stream, p);
+    SBC_CHECK_HIP(hipGetLastError());
+    return SBC_OK;
+}
+
+template <int MODE>
 static int launch_pool(const PairParams& p0, hipStream_t stream, bool dry) {
     constexpr int W = 16, R = 8, C = 32, NT = MODE == 2 ? 2 : 1;
     constexpr int RI = R + 6, RP = R + 2, WP = W + 2;
@@ -1010,6 +1303,9 @@ int launch_conv_pair(const sbc_op& op, hipStream_t stream, bool dry) {
     // many tiles per CU: the three-stage pipeline (identical results; below ~16 tiles per workgroup its fill and drain cost more
     // than it gains: 1040 tiles 21.8 us against 21.3, 6800 tiles 112 against 122, 13600 tiles 230 against 242)
     static const bool no_p3 = getenv("SBC_NO_PAIR_P3") != nullptr;           // A/B aid
+    static const bool no_roll = getenv("SBC_NO_PAIR_ROLL") != nullptr;       // A/B aid: the pipeline with per-tile halos
+    if (!no_p3 && !no_roll && op.W == 16 && op.H % 8 == 0 && (long)op.B * (op.H / 8) >= 4096)
+        return x2 ? launch_pair_roll<2>(p, stream, dry) : launch_pair_roll<1>(p, stream, dry);
     if (!no_p3 && op.W == 16 && op.H % 8 == 0 && (long)op.B * (op.H / 8) >= 4096)
         return x2 ? launch_pair_p3<16, 8, 2>(p, stream, dry) : launch_pair_p3<16, 8, 1>(p, stream, dry);
     if (op.W == 16 && op.H % 8 == 0) return x2 ? launch_pair<16, 8, 2>(p, stream, dry) : launch_pair<16, 8, 1>(p, stream, dry);

@@ -1,51 +1,55 @@
-"""Performance triage helper (not part of the product): time one SBC_OP_CONV_PAIR launch against the two launches it replaces.
-usage: prof_pair.py [B H W] [--mode f16x2|f16w]"""
-import argparse, ctypes as C, os, sys
+#!/usr/bin/env python3
+"""Stand-alone timing of SBC_OP_CONV_PAIR / SBC_OP_CONV_POOL at the full-resolution level (64x16, 32 channels) on the GPU box:
+hipEvent average over back-to-back launches.  A/B switches of csrc/conv_pair.hip are read from the environment by the library
+(SBC_NO_PAIR_ROLL, SBC_NO_PAIR_P3).
+
+    python tools/prof_pair.py [B=1700] [reps=50]
+"""
+import ctypes as C
+import os
+import sys
+
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-from score_based_channels_amd import _lib, plan as P
-from score_based_channels_amd.weights import (pack_conv_weight_f16, pack_conv_weight_f16x2, pack_conv_weight_winograd_f16,
-                                              pack_conv_weight_winograd_f16x2)
-ap = argparse.ArgumentParser()
-ap.add_argument('shape', nargs='*', type=int, default=[1700, 64, 16])
-ap.add_argument('--mode', default='f16x2')
-ap.add_argument('--iters', type=int, default=30)
-a = ap.parse_args()
-B, H, W = a.shape
-torch.manual_seed(3); np.random.seed(3)
-x = torch.randn(B, H, W, 32, device='cuda')
-mid, out, out2 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
-w1, w2 = (np.random.randn(32, 32, 3, 3).astype(np.float32) / 17 for _ in range(2))
-pk, pkw, flag = ((pack_conv_weight_f16x2, pack_conv_weight_winograd_f16x2, P.CONV_F16X2) if a.mode == 'f16x2' else
-                 (pack_conv_weight_f16, pack_conv_weight_winograd_f16, P.CONV_F16W))
-d = [torch.from_numpy(f(w).view(np.float32)).cuda() for w in (w1, w2) for f in (pk, pkw)]
-pair = _lib.sbc_op(kind=P.CONV_PAIR, flags=flag, B=B, H=H, W=W, cin=32, cout=32, ksize=3, dil=1, in_=x.data_ptr(),
-                   out=out.data_ptr(), weight_split=d[0].data_ptr(), weight2_split=d[2].data_ptr())
-c1 = _lib.sbc_op(kind=P.CONV, flags=flag | P.PRO_ELU, B=B, H=H, W=W, cin=32, cout=32, ksize=3, dil=1, in_=x.data_ptr(),
-                 out=mid.data_ptr(), weight_split=d[0].data_ptr(), weight_wino_split=d[1].data_ptr())
-c2 = _lib.sbc_op(kind=P.CONV, flags=flag | P.PRO_ELU, B=B, H=H, W=W, cin=32, cout=32, ksize=3, dil=1, in_=mid.data_ptr(),
-                 out=out2.data_ptr(), weight_split=d[2].data_ptr(), weight_wino_split=d[3].data_ptr(), res1=x.data_ptr())
-h = _lib.lib()
-def run(ops, n):
-    for _ in range(n):
-        for o in ops:
-            _lib.check(h.sbc_op_launch(C.byref(o), None))
-def timeit(ops):
-    run(ops, 3); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); run(ops, a.iters); e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / a.iters * 1e3
-tp, tu = timeit([pair]), timeit([c1, c2])
-if 'pt' in os.environ.get('SBC_LIB_PATH', ''):
-    dbg = torch.zeros(10, dtype=torch.int64, device='cuda'); pair.aux = dbg.data_ptr()
-    run([pair], 1); torch.cuda.synchronize()
-    names = ['conv2 epilogue -> loop top', 'barrier 1', 'convert', 'barrier 2', 'mid write', 'barrier 3', 'residual issue + conv2', 'wait + store', 'dma issue', 'conv1']
-    tot = dbg.sum().item()
-    print('wave-0 cycles per phase (sum over %d workgroups): ' % 512 + ', '.join('%s %.1f%%' % (n, 100.0 * v / tot) for n, v in zip(names, dbg.tolist())), '| cycles per WG %.0f' % (tot / 512))
-if os.environ.get('DUMP'):
-    np.save(os.environ['DUMP'], out.cpu().numpy())
-err = float((out - out2).abs().max() / (out2 - x).abs().max())
-by = 4.0 * B * H * W * 32
-print('%s %s: pair %.1f us (%.2f TB/s of 2 tensors), two launches %.1f us (%.2f TB/s of 5 tensors); max deviation %.2e of the conv part'
-      % (a.mode, a.shape, tp, 2 * by / tp / 1e6, tu, 5 * by / tu / 1e6, err))
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    from score_based_channels_amd import _lib, plan as P
+    from score_based_channels_amd.weights import pack_conv_weight_f16x2
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 1700
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+    rng = np.random.default_rng(0)
+    H, W, Cc = 64, 16, 32
+    x = torch.from_numpy((rng.standard_normal((B, H, W, Cc)) * 1.5).astype(np.float32)).cuda()
+    out = torch.empty_like(x)
+    w = [torch.from_numpy(pack_conv_weight_f16x2((rng.standard_normal((Cc, Cc, 3, 3)) / np.sqrt(9 * Cc)).astype(np.float32)).view(np.float32)).cuda()
+         for _ in range(2)]
+    ops = {
+        'pair': _lib.sbc_op(kind=P.CONV_PAIR, flags=P.CONV_F16X2, B=B, H=H, W=W, cin=Cc, cout=Cc, ksize=3, dil=1, in_=x.data_ptr(),
+                            out=out.data_ptr(), weight_split=w[0].data_ptr(), weight2_split=w[1].data_ptr()),
+        'pool': _lib.sbc_op(kind=P.CONV_POOL, flags=P.CONV_F16X2 | P.PRO_ELU, B=B, H=H, W=W, cin=Cc, cout=Cc, ksize=3, dil=1, in_=x.data_ptr(),
+                            out=out.data_ptr(), weight_split=w[0].data_ptr()),
+    }
+    st = torch.cuda.current_stream().cuda_stream
+    for name, op in ops.items():
+        for _ in range(5):
+            _lib.check(_lib.lib().sbc_op_launch(C.byref(op), C.c_void_p(st)))
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            _lib.check(_lib.lib().sbc_op_launch(C.byref(op), C.c_void_p(st)))
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / reps * 1e3
+        nconv = 2 if name == 'pair' else 1
+        flops = nconv * 2.0 * B * H * W * 9 * Cc * Cc
+        print('%s 64x16 C=32 B=%d [%s]: %.1f us per launch, %.0f TFLOP/s algorithmic' % (
+            name, B, ' '.join(k for k in ('SBC_NO_PAIR_ROLL', 'SBC_NO_PAIR_P3') if os.environ.get(k)) or 'default', us, flops / us / 1e6))
+
+
+if __name__ == '__main__':
+    main()
