@@ -124,9 +124,11 @@ class AldBatch:
             Np=self.np_)
         lang = _lib.sbc_op(kind=P.LANGEVIN, B=T, ext=C.cast(C.pointer(self._lang), C.c_void_p))
         inc = _lib.sbc_op(kind=P.STEP_INC, B=1, out=_ptr(self.d_step))
-        self.plan = _lib.Plan(list(self.bound.ops) + [lang, inc], keepalive=self)
+        self._step_ops = list(self.bound.ops) + [lang, inc]
+        self.plan = _lib.Plan(self._step_ops, keepalive=self)
         self.score_plan = _lib.Plan(list(self.bound.ops), keepalive=self)
-        self._lag_plan = None           # run_lagged: the records of the first ~45 % of a score evaluation
+        # run_leading / run_following: ONE Langevin step's records cut at ~45 % of a score evaluation -- [:k] and [k:]
+        self._lag_plan = self._rest_plan = None
 
     def _stream(self):
         return torch.cuda.current_stream(self.net.device).cuda_stream
@@ -135,7 +137,7 @@ class AldBatch:
         """Destroy the two plans and drop their back-references: ``AldBatch`` <-> ``Plan(keepalive=self)`` is a reference
         cycle, so without this the slot buffers of a finished chunk (GBs) live until the cyclic collector runs.  The
         tensors already handed out (``X``, ``nmse_log()``) stay valid; the batch cannot run again."""
-        for pl in (self.plan, self.score_plan, self._lag_plan):
+        for pl in (self.plan, self.score_plan, self._lag_plan, self._rest_plan):
             if pl is not None:
                 pl.close()
                 pl._keep = None
@@ -184,29 +186,71 @@ class AldBatch:
             self.plan.run(self._stream(), n, False)
         self._done = done + n
 
-    def run_lagged(self, n_steps=None):
-        """``run(n_steps)`` for the SECOND of two concurrent sub-batch streams (``driver.run_concurrently``): before its first step the
-        stream evaluates the first part of the score network once for nothing (the records up to the middle of the low-resolution
-        stretch: they write activation slots only, which the real step rewrites), so it walks the schedule ~0.45 of a step behind the
-        first stream -- one stream is in the high-resolution, issue-bound part of a step while the other is in the dozens of small
-        low-resolution launches.  No event, no timer: the lag is made of the work itself, whatever the array size.  Measured
-        (DESIGN.md section 13.5): sustained two-stream step 5.47 -> 5.38 ms for lags of 0.38-0.52 of a step, nothing outside."""
-        if self.net.overlap:                       # (side-stream records must stay inside one plan)
-            return self.run(n_steps)
+    # --- two concurrent sub-batch streams, the second ~0.45 of a step behind the first (driver.run_concurrently) ------------------
+    # One stream is in the high-resolution, issue-bound part of a step while the other is in the dozens of small low-resolution
+    # launches: ~4 % per step (sustained two-stream step 5.47 -> 5.38 ms for lags of 0.38-0.52 of a step in round 4, nothing outside).
+    # The lag is made of the work itself, whatever the array size: the records of one step are cut at the first record of refine31
+    # (the middle of the low-resolution stretch) into a head [:k] and a rest [k:]; the LEADING stream runs the head of its first step
+    # alone on the chip (full-width grids), then lets the FOLLOWING stream start; the following stream ends with the rest of its last
+    # step alone (full width again) once the leader is done.  Every stream runs exactly its own n steps, record for record -- no
+    # throw-away evaluation (round 4 ran 0.45 of a score evaluation for nothing per call, 2 % of a 20-step call).
+    def _cut_step(self):
         if self._lag_plan is None:
             names = [op.name for op in self.net.score_plan(self.nt, self.nr).ops]
             k = next((i for i, nm in enumerate(names) if nm.startswith('refine31.')), len(names) // 2)
-            k = int(os.environ.get('SBC_LAG_RECORDS', k))        # (A/B aid: where the throw-away prefix ends)
-            self._lag_plan = _lib.Plan(list(self.bound.ops)[:k], keepalive=self)
-            self._lag_plan.set_persistent_cus(getattr(self, '_persist', 0))
-        self._lag_plan.run(self._stream(), 1, False)
-        self.run(n_steps)
+            k = int(os.environ.get('SBC_LAG_RECORDS', k))        # (A/B aid: where the cut is)
+            k = min(max(k, 1), len(self._step_ops) - 1)
+            self._lag_plan = _lib.Plan(self._step_ops[:k], keepalive=self)
+            self._rest_plan = _lib.Plan(self._step_ops[k:], keepalive=self)
+        return self._lag_plan, self._rest_plan
+
+    def _check_steps(self, n_steps):
+        done = self._done
+        n = self.n_steps - done if n_steps is None else int(n_steps)
+        if n < 1 or done + n > self.n_steps:
+            raise ValueError('schedule has %d steps, %d already done, %d requested' % (self.n_steps, done, n))
+        if self.step_noise is not None and done + n > self.step_noise.shape[0]:
+            raise ValueError('replayed noise covers %d steps, %d requested' % (self.step_noise.shape[0], done + n))
+        return n
+
+    def run_leading(self, n_steps, head_done, width=0):
+        """``run(n_steps)`` for the FIRST of two concurrent sub-batch streams: the head of the first step at full grid width, then
+        ``head_done()`` (the caller records the event the following stream waits for), then everything else at ``width`` CUs."""
+        n = self._check_steps(n_steps)
+        head, rest = self._cut_step()
+        st = self._stream()
+        try:
+            head.set_persistent_cus(0)
+            head.run(st, 1, False)
+        finally:
+            head_done()
+        rest.set_persistent_cus(width)
+        rest.run(st, 1, False)
+        if n > 1:
+            self.plan.run(st, n - 1, False)
+        self._done += n
+
+    def run_following(self, n_steps, wait_head, wait_leader, width=0):
+        """``run(n_steps)`` for the SECOND stream: starts behind ``wait_head()`` (the caller makes this stream wait for the leader's
+        event), runs its steps at ``width`` CUs, and the rest of its last step at full width behind ``wait_leader()``."""
+        n = self._check_steps(n_steps)
+        head, rest = self._cut_step()
+        st = self._stream()
+        wait_head()
+        if n > 1:
+            self.plan.run(st, n - 1, False)
+        head.set_persistent_cus(width)
+        head.run(st, 1, False)
+        wait_leader()
+        rest.set_persistent_cus(0)
+        rest.run(st, 1, False)
+        self._done += n
 
     def set_persistent_cus(self, n):
         """Grid width (CUs) of the persistent kernels of THIS batch's launches, 0 = all CUs (``sbc_plan_set_persistent_cus``: a
         field of the batch's plans, not process state -- batches on other threads / streams / devices are unaffected)."""
         self._persist = int(n)
-        for pl in (self.plan, self.score_plan, self._lag_plan):
+        for pl in (self.plan, self.score_plan, self._lag_plan, self._rest_plan):
             if pl is not None:
                 pl.set_persistent_cus(n)
 

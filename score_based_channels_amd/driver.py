@@ -91,20 +91,43 @@ def run_concurrently(batches, streams, n_steps, use_graph=False):
     # threads or devices do not see it, and it is reset in the `finally` below whatever happens in between)
     half = torch.cuda.get_device_properties(dev).multi_processor_count // 2 if (not use_graph and small) else 0
 
-    # ... and every second stream walks the schedule ~0.45 of a step behind (AldBatch.run_lagged: the lag is a throw-away evaluation of
-    # the first part of the network, 0.45 of a step once per call, and buys ~4 % of every step after it: even, or better, from ~12
-    # steps on; the schedule of test_score is 6933 steps)
-    lag = (not use_graph and small and n_steps >= int(os.environ.get('SBC_STREAM_LAG_MIN_STEPS', '16'))       # (the variable: tests)
-           and not os.environ.get('SBC_NO_STREAM_LAG'))
+    # ... and every second stream walks the schedule ~0.45 of a step behind its neighbour (AldBatch.run_leading / run_following: the
+    # lag is the head of the leader's first step, run alone; ~4 % of every step after it)
+    lag = (not use_graph and small and n_steps >= int(os.environ.get('SBC_STREAM_LAG_MIN_STEPS', '2'))       # (the variable: tests)
+           and not os.environ.get('SBC_NO_STREAM_LAG') and not any(b.net.overlap for b in batches))
+    # pair (2j, 2j + 1): two device events (leader's head done; leader done) and the host flags that say they have been RECORDED --
+    # a stream that waits for an event nobody has recorded yet does not wait at all
+    class _Pair:
+        def __init__(self):
+            self.head_evt, self.done_evt = torch.cuda.Event(), torch.cuda.Event()
+            self.head_flag, self.done_flag = threading.Event(), threading.Event()
+    pairs = [_Pair() for _ in range(len(batches) // 2)] if lag else []
 
     def work(b, st, k):
         try:
             torch.cuda.set_device(b.net.device)
             with torch.cuda.stream(st):
-                if lag and k % 2:
-                    b.run_lagged(n_steps)
-                else:
+                pr = pairs[k // 2] if k // 2 < len(pairs) else None
+                if pr is None:
                     b.run(n_steps, use_graph=use_graph)
+                elif k % 2 == 0:
+                    def head_done():
+                        pr.head_evt.record(st)
+                        pr.head_flag.set()
+                    try:
+                        b.run_leading(n_steps, head_done, half)
+                        pr.done_evt.record(st)
+                    finally:
+                        pr.head_flag.set()
+                        pr.done_flag.set()
+                else:
+                    def wait_head():
+                        pr.head_flag.wait()
+                        st.wait_event(pr.head_evt)
+                    def wait_leader():
+                        pr.done_flag.wait()
+                        st.wait_event(pr.done_evt)
+                    b.run_following(n_steps, wait_head, wait_leader, half)
         except BaseException as e:                        # surfaced in the caller's thread
             errors.append(e)
     threads = [threading.Thread(target=work, args=(b, st, k)) for k, (b, st) in enumerate(zip(batches, streams))]

@@ -536,10 +536,10 @@ def test_concurrent_sub_batch_streams_do_not_change_results(net64):
 
 
 def test_lagging_second_stream_does_not_change_results(net64, monkeypatch):
-    """In runs of 200+ steps the second sub-batch stream starts with a throw-away evaluation of the first half of the network, so that
-    it walks the schedule behind the first one (``AldBatch.run_lagged``, driver.run_concurrently).  The throw-away records write
-    activation slots only: logs and estimates equal the one-stream run bit for bit (the threshold is lowered so that a 9-step run
-    takes the path)."""
+    """The second of two sub-batch streams walks the schedule ~0.45 of a step behind the first: the leader runs the head of its first
+    step alone, the follower the rest of its last step (``AldBatch.run_leading`` / ``run_following``, driver.run_concurrently: one
+    step's records cut in two plans, two device events).  Every stream still runs exactly its own records in order: logs and
+    estimates equal the one-stream run bit for bit."""
     import torch
     from score_based_channels_amd import synth
     from score_based_channels_amd.ald import snr_to_noise

@@ -50,7 +50,7 @@ def main():
             with torch.cuda.stream(streams[k]):
                 evs[k][0].record()
                 if use_lag and k == 1:
-                    alds[k]._lag_plan or alds[k].run_lagged(0)
+                    alds[k]._cut_step()
                     alds[k]._lag_plan.run(streams[k].cuda_stream, 1, False)
                 for s in range(n):
                     alds[k].plan.run(streams[k].cuda_stream, 1, False)
