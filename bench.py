@@ -572,11 +572,12 @@ def main():
             #   Winograd F(2x2,3x3) kernels execute 16/36 of the direct products; the fused pair is a direct convolution whose
             #   first stage also computes the 2 halo rows of its 8-row tile: (10 + 8) / (2 * 8)
             terms = {'bf16x3': 6.0, 'f16x2': 3.0, 'f16w': 1.0}.get(conv_mode)
+            pair_roll = nr == 16 and T * (nt // 8) >= 4096 and conv_mode in ('f16x2', 'f16w')
             names = {P.TAG_CONV_TOP: 'conv_wx3_kernel<32, 32, 1, true, %s, true, 1, 1, %d>' % ({'bf16x3': '3', 'f16x2': '4', 'f16w': '3'}.get(conv_mode, '3'),
                                                                                               {'bf16x3': 0, 'f16w': 1, 'f16x2': 2}.get(conv_mode, 0)),
-                     # (16-pixel rows, at least 4096 tiles in the launch: the three-stage pipelined kernel, csrc/conv_pair.hip)
-                     P.TAG_PAIR_TOP: '%s<%d, %d, %d, %d, 32>' % ('conv_pair_p3_kernel' if nr == 16 and T * (nt // 8) >= 4096 else 'conv_pair_kernel',
-                                                                   nr, 4 if nr == 64 else 8, 2 if conv_mode == 'f16x2' else 1, 8 if nr == 64 else 4),
+                     # (16-pixel rows, at least 4096 tiles in the launch: the three-role pipeline over row rings, csrc/conv_pair.hip)
+                     P.TAG_PAIR_TOP: ('conv_pair_roll_kernel<%d>' % (2 if conv_mode == 'f16x2' else 1) if pair_roll else
+                                      'conv_pair_kernel<%d, %d, %d, %d, 32>' % (nr, 4 if nr == 64 else 8, 2 if conv_mode == 'f16x2' else 1, 8 if nr == 64 else 4)),
                      P.TAG_POOL_TOP: 'conv_pool_kernel<%d, 8, %d, 4, 32>' % (nr, 2 if conv_mode == 'f16x2' else 1),
                      P.TAG_RES_TOP: 'conv_res_kernel',
                      P.TAG_CONV_MID: 'conv_wx3_kernel<64, 64, 1, true, 2, false, 2, 1, %d>' % {'bf16x3': 0, 'f16w': 1, 'f16x2': 2}.get(conv_mode, 0),
@@ -588,7 +589,9 @@ def main():
             for k, (cc, cw) in enumerate(P.CHAIN_KERNELS):
                 names[P.TAG_CHAIN + k] = 'conv_chain_kernel<%d, %d, %d>' % (cc, cw, 8 if (cc, cw) in ((128, 2), (64, 8)) else 4)
             what = {P.TAG_CONV_TOP: 'the unfused 3x3 32->32 convolutions at %dx%d (Winograd F(2x2,3x3))' % (nt, nr),
-                    P.TAG_PAIR_TOP: 'the fused RCU blocks at %dx%d: two direct 3x3 32->32 convolutions per launch, intermediate in LDS' % (nt, nr),
+                    P.TAG_PAIR_TOP: 'the fused RCU blocks at %dx%d: two direct 3x3 32->32 convolutions per launch, intermediate in LDS%s'
+                                    % (nt, nr, '; a workgroup walks a contiguous run of 8-row tiles and keeps the rows adjacent tiles share in LDS rings '
+                                               '(no halo recomputation: round 5)' if pair_roll else ''),
                     P.TAG_POOL_TOP: 'the fused CRP stages at %dx%d: 5x5 max pool + direct 3x3 32->32 convolution + running sum per launch, pooled tensor in LDS' % (nt, nr),
                     P.TAG_RES_TOP: 'the fused ResidualBlocks at %dx%d: norm, ELU, direct 3x3 32->32 convolution, InstanceNorm++ statistics of the whole '
                                    'intermediate sample, norm, ELU, second convolution, + x per launch; one workgroup per sample' % (nt, nr),
@@ -609,7 +612,7 @@ def main():
                 t_launch = kc['us_per_launch'] * 1e-6
                 fl = kc['flops_per_step'] / kc['launches_per_step']           # algorithmic FLOPs of an average launch of the class
                 by = kc['bytes_per_step'] / kc['launches_per_step']
-                ratio = (18.0 / 16.0 if tag == P.TAG_PAIR_TOP else 1.0 if tag in (P.TAG_POOL_TOP, P.TAG_RES_TOP) or (tag == P.TAG_DIRECT_MID and direct_mid)
+                ratio = (((nt + 1.0) / nt if pair_roll else 18.0 / 16.0) if tag == P.TAG_PAIR_TOP else 1.0 if tag in (P.TAG_POOL_TOP, P.TAG_RES_TOP) or (tag == P.TAG_DIRECT_MID and direct_mid)
                          else 0.5 if tag >= P.TAG_DOWN else kc['live_taps'] if tag >= P.TAG_CHAIN else 16.0 / 36.0) * (terms or 1.0)
                 ach = fl / t_launch / 1e12
                 e = {'kernel': names[tag], 'what': what[tag], 'launches_per_step': kc['launches_per_step'],
@@ -664,7 +667,9 @@ def main():
                       'kernel': note + 'achieved = algorithmic (direct-convolution, 2 x MACs) FLOPs of one launch / its average duration; '
                                        'peak = dense f16 MFMA peak; frac = achieved / peak (SURVEY section 8(d)).  mfma_busy = EXECUTED '
                                        'matrix-instruction FLOPs / time / peak: in f16x2 every product is 3 fp16 MFMAs (hh + hl + lh), a direct '
-                                       'fused pair also computes its halo rows (x 18/16), Winograd F(2x2,3x3) executes 16/36 of the products'}
+                                       'fused pair evaluates its first convolution on two extra rows per sample (x 130/128 at 64 rows; the '
+                                       'tile-at-a-time kernels of small batches: two extra rows per 8-row tile, x 18/16), Winograd F(2x2,3x3) '
+                                       'executes 16/36 of the products'}
             # the whole Langevin step the headline times, by the same definition (= channels/s x 5.6904e12 / (n_gpus x peak))
             rf['frac_step'] = flops_fwd / (ms_per_step * 1e-3) / 1e12 / mpeak
             rf['frac_note'] = ('frac, frac_step and kernels[*].frac_algorithmic: direct-convolution FLOPs / time / %.1f TFLOP/s; mfma_busy: '

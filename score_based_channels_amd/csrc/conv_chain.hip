@@ -108,7 +108,7 @@ __host__ __device__ constexpr int chain_samples(int C, int W, int NW) {
 //   W = 2 (8 x 2 samples), G = 8 samples per workgroup, a unit = one column of TWO samples (lane n: sample n >> 3, row n & 7);
 //          C = 128: wave = 16-output-channel block cb, all 8 units;  C = 64: wave = (cb, half), the 4 units of two sample pairs;
 //   W = 4 (16 x 4 samples, C = 64), G = 4: a unit = one column of ONE sample (lane n: row n); wave = (cb, half), 8 units;
-//   W = 8 (32 x 8 samples; RCU blocks only): a unit = one column of one HALF of a sample (lane n: row 16 half + n), 8 units = the
+//   W = 8 (32 x 8 samples; RCU and RES blocks): a unit = one column of one HALF of a sample (lane n: row 16 half + n), 8 units = the
 //          eight columns;  C = 64, G = 1: wave = (cb, half);  C = 32, G = 2: wave = (cb, sample, half).
 template <int C, int W, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
@@ -165,6 +165,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
     float prev_descale = 1.f;
     unsigned rbits = 0;
     float* const nscr = reinterpret_cast<float*>(smem + 2 * TERM);       // InstanceNorm++ scratch: mu [G][C], then (m, 1 / sqrt(v + eps)) [G][2]
+    float* const hscr = nscr + G * C + 2 * G;                            // W = 8: half-sample sums, two buffers of [NW][16]
     __syncthreads();
 
     // ---- InstanceNorm2dPlus (normalization.py:163-176) + ELU of a tensor held in the accumulator layout, for the RES blocks: every
@@ -177,6 +178,16 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
         constexpr int RL = W == 2 ? 8 : 16;                           // lanes (rows) of one sample in a 16-lane group
         const float inv_hw = 1.f / (float)(H * W);
         f32x4v mu[NSG], rs[NSG];
+        // W = 8: the rows of a sample are split over two waves (uh, uh ^ 1, same channel block): the two half sums meet in LDS and
+        // both waves add them in the same order (rows 0..15 first), one workgroup barrier per statistic
+        auto join_halves = [&](f32x4v& t, float* buf) {
+            if constexpr (W == 8) {
+                if (n == 0) *reinterpret_cast<f32x4v*>(buf + wave * 16 + 4 * kq) = t;
+                lds_barrier();
+                const f32x4v o = *reinterpret_cast<const f32x4v*>(buf + (wave ^ NCB) * 16 + 4 * kq);
+                t = (uh & 1) ? vadd4(o, t) : vadd4(t, o);
+            }
+        };
 #pragma unroll
         for (int g = 0; g < NSG; ++g) {
             f32x4v sum = v[g * W];
@@ -186,6 +197,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
             for (int m = 1; m < RL; m <<= 1)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) sum[e] += __shfl_xor(sum[e], m);
+            join_halves(sum, hscr);
             mu[g] = vscale4(sum, inv_hw);
             f32x4v m2 = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -196,6 +208,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
             for (int m = 1; m < RL; m <<= 1)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) m2[e] += __shfl_xor(m2[e], m);
+            join_halves(m2, hscr + NW * 16);
 #pragma unroll
             for (int e = 0; e < 4; ++e) rs[g][e] = 1.f / sqrtf(m2[e] * inv_hw + 1e-5f);
             if (y == 0) *reinterpret_cast<f32x4v*>(nscr + (w0 + g * SPU + sp) * C + ch0) = mu[g];
@@ -496,7 +509,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
 template <int C, int W, int NW>
 static int launch_chain_t(const ChainParams& p, hipStream_t stream, bool dry) {
     constexpr int G = chain_samples(C, W, NW), SP = W * (W == 2 ? 12 : W == 4 ? 18 : 34);
-    constexpr int LDS = 2 * (C / 8) * G * SP * 16 + (G * C + 2 * G) * 4;       // operand planes + InstanceNorm++ scratch
+    constexpr int LDS = 2 * (C / 8) * G * SP * 16 + (G * C + 2 * G) * 4 + (W == 8 ? 2 * NW * 16 * 4 : 0);   // operand planes + InstanceNorm++ scratch
     auto kern = conv_chain_kernel<C, W, NW>;
     { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), LDS); if (rc) return rc; }
     if (dry) return SBC_OK;
@@ -522,7 +535,7 @@ int launch_chain(const sbc_op& op, const sbc_chain& c, hipStream_t stream, bool 
         SBC_REQUIRE(c.w1[b] && c.w2[b] && c.type[b] >= SBC_CHAIN_RCU && c.type[b] <= SBC_CHAIN_RES, "chain: block %d: weights / type", b);
         p.w[b][0] = (const uint4*)c.w1[b];
         p.w[b][1] = (const uint4*)c.w2[b];
-        SBC_REQUIRE(op.W != 8 || c.type[b] == SBC_CHAIN_RCU, "chain: block %d: 32 x 8 samples take RCU blocks only (a wave holds half a sample there)", b);
+        SBC_REQUIRE(op.W != 8 || c.type[b] != SBC_CHAIN_CRP, "chain: block %d: 32 x 8 samples take RCU and RES blocks only (a wave holds half a sample there: no max pool)", b);
         p.type[b] = c.type[b];
         p.dil[b] = 1;
         if (c.type[b] == SBC_CHAIN_RES) {

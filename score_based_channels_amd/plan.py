@@ -360,6 +360,10 @@ def chain_fusable(h, w, c, kind=CHAIN_RCU):
     if h == 16 and w == 4 and c == 64:
         return not os.environ.get('SBC_NO_CHAIN4')   # A/B aid: the 16 x 4 level unfused
     if h == 32 and w == 8 and c in (32, 64):
+        # (the kernel also takes ResidualBlocks there -- res2.1 -- but measured no gain over its two Winograd launches with folded
+        # statistics: 4.26-4.32 against 4.24-4.25 ms per two-stream step; SBC_CHAIN8_RES=1 plans it, Python plans only)
+        if kind == CHAIN_RES:
+            return bool(os.environ.get('SBC_CHAIN8_RES')) and not os.environ.get('SBC_NO_CHAIN8')
         return kind == CHAIN_RCU and not os.environ.get('SBC_NO_CHAIN8')   # A/B aid: the 32 x 8 level unfused
     return h == 8 and w == 2 and c in (64, 128)
 

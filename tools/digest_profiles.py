@@ -10,7 +10,7 @@ BIG = W == 'big'
 # the kernel classes bench.py tags; the dominant one = largest total time in the --stats pass
 CANDIDATES = (['conv_wx3_kernel<32, 32, 1, true, 3, true, 1, 1, 1>', 'conv_pair_kernel<64, 4, 1, 8, 32>',
                'conv_wx3_kernel<64, 64, 1, true, 2, false, 2, 1, 1>'] if BIG else
-              ['conv_wx3_kernel<32, 32, 1, true, 4, true, 1, 1, 2>', 'conv_pair_p3_kernel<16, 8, 2, 4, 32>',
+              ['conv_wx3_kernel<32, 32, 1, true, 4, true, 1, 1, 2>', 'conv_pair_roll_kernel<2>', 'conv_pair_p3_kernel<16, 8, 2, 4, 32>', 'conv_down_kernel<32, 64, 16>', 'conv_down_kernel<64, 64, 8>',
                'conv_pool_kernel<16, 8, 2, 4, 32>', 'conv_wx3_kernel<64, 64, 1, true, 2, false, 2, 1, 2>',
                'conv_dp_kernel<64, 8, 8, 1, false, 4>', 'conv_res_kernel', 'conv_chain_kernel<128, 2, 8>', 'conv_chain_kernel<64, 2, 4>',
                'conv_chain_kernel<64, 4, 4>', 'conv_chain_kernel<64, 8, 8>', 'conv_chain_kernel<32, 8, 4>'])
