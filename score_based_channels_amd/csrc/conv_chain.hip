@@ -108,8 +108,8 @@ __host__ __device__ constexpr int chain_samples(int C, int W, int NW) {
 //   W = 2 (8 x 2 samples), G = 8 samples per workgroup, a unit = one column of TWO samples (lane n: sample n >> 3, row n & 7);
 //          C = 128: wave = 16-output-channel block cb, all 8 units;  C = 64: wave = (cb, half), the 4 units of two sample pairs;
 //   W = 4 (16 x 4 samples, C = 64), G = 4: a unit = one column of ONE sample (lane n: row n); wave = (cb, half), 8 units;
-//   W = 8 (32 x 8 samples; RCU and RES blocks): a unit = one column of one HALF of a sample (lane n: row 16 half + n), 8 units = the
-//          eight columns;  C = 64, G = 1: wave = (cb, half);  C = 32, G = 2: wave = (cb, sample, half).
+//   W = 8 (32 x 8 samples): a unit = one column of one HALF of a sample (lane n: row 16 half + n), 8 units = the eight columns --
+//          statistics and the max pool's boundary rows cross the two waves of a sample through LDS;  C = 64, G = 1: wave = (cb, half);  C = 32, G = 2: wave = (cb, sample, half).
 template <int C, int W, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
     constexpr int H = W == 2 ? 8 : W == 4 ? 16 : 32;
@@ -166,6 +166,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
     unsigned rbits = 0;
     float* const nscr = reinterpret_cast<float*>(smem + 2 * TERM);       // InstanceNorm++ scratch: mu [G][C], then (m, 1 / sqrt(v + eps)) [G][2]
     float* const hscr = nscr + G * C + 2 * G;                            // W = 8: half-sample sums, two buffers of [NW][16]
+    float* const pscr = hscr + 2 * NW * 16;                              // W = 8: boundary rows of the max pool, [NW][2 rows][NU][4 kq] float4
     __syncthreads();
 
     // ---- InstanceNorm2dPlus (normalization.py:163-176) + ELU of a tensor held in the accumulator layout, for the RES blocks: every
@@ -328,6 +329,17 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
                 }
                 // nn.MaxPool2d(5, 1, 2), separable: rows y - 2 .. y + 2 of the lane's own column (lanes n - 2 .. n + 2 of the same
                 // sample; -inf outside, as PyTorch pads), then columns x - 2 .. x + 2: the same lane of the sample group's other units
+                // (W = 8: the two rows on the other side of the half-sample boundary belong to the partner wave (uh ^ 1, same channel
+                // block): both publish their two boundary rows in LDS first -- [wave][row][unit][kq] float4 -- one more barrier per pool)
+                const bool lower = (uh & 1) == 0;
+                if constexpr (W == 8) {
+                    const int slot = lower ? n - 14 : n;                 // rows 14, 15 of the upper half / rows 0, 1 of the lower one
+                    if ((unsigned)slot < 2u) {
+#pragma unroll
+                        for (int i = 0; i < NU; ++i) *reinterpret_cast<f32x4v*>(pscr + (((wave * 2 + slot) * NU + i) * 4 + kq) * 4) = v[i];
+                    }
+                    lds_barrier();
+                }
 #pragma unroll
                 for (int i = 0; i < NU; ++i) {
                     const f32x4v m = v[i];
@@ -339,6 +351,12 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
                         f32x4v o;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = __shfl(m[e], lane + d);
+                        if constexpr (W == 8) {
+                            const int nd = n + d;
+                            const int slot = lower ? nd - 16 : nd + 2;     // the partner's published row, when nd is outside this wave's 16
+                            const f32x4v po = *reinterpret_cast<const f32x4v*>(pscr + ((((wave ^ NCB) * 2 + (slot & 1)) * NU + i) * 4 + kq) * 4);
+                            if ((unsigned)nd >= 16u) o = po;
+                        }
                         if (ok) r = vmax4(r, o);
                     }
                     v[i] = r;
@@ -509,7 +527,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
 template <int C, int W, int NW>
 static int launch_chain_t(const ChainParams& p, hipStream_t stream, bool dry) {
     constexpr int G = chain_samples(C, W, NW), SP = W * (W == 2 ? 12 : W == 4 ? 18 : 34);
-    constexpr int LDS = 2 * (C / 8) * G * SP * 16 + (G * C + 2 * G) * 4 + (W == 8 ? 2 * NW * 16 * 4 : 0);   // operand planes + InstanceNorm++ scratch
+    // operand planes + InstanceNorm++ scratch (+ at W = 8 the half-sample sums and the max pool's boundary rows)
+    constexpr int LDS = 2 * (C / 8) * G * SP * 16 + (G * C + 2 * G) * 4 + (W == 8 ? 2 * NW * 16 * 4 + NW * 2 * 8 * 4 * 16 : 0);
     auto kern = conv_chain_kernel<C, W, NW>;
     { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), LDS); if (rc) return rc; }
     if (dry) return SBC_OK;
@@ -535,7 +554,6 @@ int launch_chain(const sbc_op& op, const sbc_chain& c, hipStream_t stream, bool 
         SBC_REQUIRE(c.w1[b] && c.w2[b] && c.type[b] >= SBC_CHAIN_RCU && c.type[b] <= SBC_CHAIN_RES, "chain: block %d: weights / type", b);
         p.w[b][0] = (const uint4*)c.w1[b];
         p.w[b][1] = (const uint4*)c.w2[b];
-        SBC_REQUIRE(op.W != 8 || c.type[b] != SBC_CHAIN_CRP, "chain: block %d: 32 x 8 samples take RCU and RES blocks only (a wave holds half a sample there: no max pool)", b);
         p.type[b] = c.type[b];
         p.dil[b] = 1;
         if (c.type[b] == SBC_CHAIN_RES) {

@@ -142,7 +142,7 @@ struct Builder {
     }
     bool chain_fusable(int x, int kind = SBC_CHAIN_RCU) const {                                // plan.chain_fusable
         if (!fuse_chain) return false;
-        if (t[x].h == 32 && t[x].w == 8 && (t[x].c == 32 || t[x].c == 64)) return kind == SBC_CHAIN_RCU;
+        if (t[x].h == 32 && t[x].w == 8 && (t[x].c == 32 || t[x].c == 64)) return kind != SBC_CHAIN_RES;
         return (t[x].h == 8 && t[x].w == 2 && (t[x].c == 64 || t[x].c == 128)) || (t[x].h == 16 && t[x].w == 4 && t[x].c == 64);
     }
     static std::vector<POp::Block> rcu_blocks(const std::string& p, int n_blocks) {             // plan._Builder.rcu_blocks

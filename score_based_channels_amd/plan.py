@@ -354,7 +354,8 @@ def merge_chains(ops):
 
 def chain_fusable(h, w, c, kind=CHAIN_RCU):
     """Shapes SBC_OP_CHAIN takes: 8 x 2 samples of 64 or 128 channels, 16 x 4 samples of 64 channels (the two lowest levels of a
-    64 x 16 array), and -- RCU blocks only: a wave holds half a sample there -- 32 x 8 samples of 32 or 64 channels."""
+    64 x 16 array), and 32 x 8 samples of 32 or 64 channels (a wave holds half a sample there; ResidualBlocks are left to their own
+    launches at that size: no gain measured)."""
     if os.environ.get('SBC_NO_CHAIN'):               # A/B aid: every convolution and max pool of those levels as its own launch
         return False
     if h == 16 and w == 4 and c == 64:
@@ -364,7 +365,9 @@ def chain_fusable(h, w, c, kind=CHAIN_RCU):
         # statistics: 4.26-4.32 against 4.24-4.25 ms per two-stream step; SBC_CHAIN8_RES=1 plans it, Python plans only)
         if kind == CHAIN_RES:
             return bool(os.environ.get('SBC_CHAIN8_RES')) and not os.environ.get('SBC_NO_CHAIN8')
-        return kind == CHAIN_RCU and not os.environ.get('SBC_NO_CHAIN8')   # A/B aid: the 32 x 8 level unfused
+        if kind == CHAIN_CRP and os.environ.get('SBC_NO_CHAIN8_CRP'):      # A/B aid: refine4's CRP as max pool + convolution launches
+            return False
+        return not os.environ.get('SBC_NO_CHAIN8')                         # A/B aid: the 32 x 8 level unfused
     return h == 8 and w == 2 and c in (64, 128)
 
 
