@@ -83,11 +83,11 @@ typedef enum sbc_op_kind {
                                 3x3 weight, weight2_split = the same of the 1x1 shortcut weight); in = conv1's output, res1 = the block's input,
                                 both [B][H][W][cin], stats = the norm's (mu, scale, shift); 32 -> 64 channels at W = 16, 64 -> 64 at W = 8,
                                 H a multiple of 16; SBC_CONV_F16X2 only (csrc/conv_down.hip)                                           */
-    SBC_OP_CHAIN = 24        /* (ABI 13) a CHAIN of RCU blocks, CRP blocks and ResidualBlocks in ONE launch, for the two lowest
-                                resolution levels (8 x 2 samples of 64 or 128 channels, 16 x 4 samples of 64; layers.py:76-83,
-                                126-134,234-249,443-456): a workgroup owns eight (four) samples, the running tensor x stays in
-                                registers between the blocks and the convolution operands in LDS; only the filters stream
-                                (csrc/conv_chain.hip).  ext = sbc_chain                                                       */
+    SBC_OP_CHAIN = 24        /* (ABI 13) a CHAIN of RCU blocks, CRP blocks and ResidualBlocks in ONE launch, for the low
+                                resolution levels (8 x 2 samples of 64 or 128 channels, 16 x 4 samples of 64, 32 x 8 samples of 32 or
+                                64; layers.py:76-83,126-134,234-249,443-456): a workgroup owns eight (four, one or two) samples, the
+                                running tensor x stays in registers between the blocks and the convolution operands in LDS; only
+                                the filters stream (csrc/conv_chain.hip).  ext = sbc_chain                                    */
 } sbc_op_kind;
 
 /* sbc_op.flags for SBC_OP_CONV / SBC_OP_MAXPOOL5 */
