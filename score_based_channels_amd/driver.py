@@ -104,32 +104,35 @@ def run_concurrently(batches, streams, n_steps, use_graph=False):
     pairs = [_Pair() for _ in range(len(batches) // 2)] if lag else []
 
     def work(b, st, k):
+        pr = pairs[k // 2] if k // 2 < len(pairs) else None
         try:
             torch.cuda.set_device(b.net.device)
             with torch.cuda.stream(st):
-                pr = pairs[k // 2] if k // 2 < len(pairs) else None
                 if pr is None:
                     b.run(n_steps, use_graph=use_graph)
                 elif k % 2 == 0:
                     def head_done():
                         pr.head_evt.record(st)
                         pr.head_flag.set()
-                    try:
-                        b.run_leading(n_steps, head_done, half)
-                        pr.done_evt.record(st)
-                    finally:
-                        pr.head_flag.set()
-                        pr.done_flag.set()
+                    b.run_leading(n_steps, head_done, half)
+                    pr.done_evt.record(st)
                 else:
                     def wait_head():
                         pr.head_flag.wait()
                         st.wait_event(pr.head_evt)
+
                     def wait_leader():
                         pr.done_flag.wait()
                         st.wait_event(pr.done_evt)
                     b.run_following(n_steps, wait_head, wait_leader, half)
         except BaseException as e:                        # surfaced in the caller's thread
             errors.append(e)
+        finally:
+            # whatever happened to the leader (even before its first launch), its follower must not wait on the host for ever: a
+            # stream that waits for an event nobody recorded does not wait
+            if pr is not None and k % 2 == 0:
+                pr.head_flag.set()
+                pr.done_flag.set()
     threads = [threading.Thread(target=work, args=(b, st, k)) for k, (b, st) in enumerate(zip(batches, streams))]
     started = []
     try:

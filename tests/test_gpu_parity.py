@@ -560,6 +560,30 @@ def test_lagging_second_stream_does_not_change_results(net64, monkeypatch):
         assert np.array_equal(two[0], one[0]) and np.array_equal(two[1], one[1])
 
 
+@pytest.mark.timeout(300)
+def test_failing_leader_stream_does_not_hang_its_follower(net64, monkeypatch):
+    """The following stream waits on the HOST until its leader has recorded the event it is to wait for on the device
+    (driver.run_concurrently).  A leader that fails -- here before its first launch -- releases it all the same: the call raises the
+    leader's error instead of hanging."""
+    import torch
+    from score_based_channels_amd import synth
+    from score_based_channels_amd.ald import AldBatch, snr_to_noise
+    from score_based_channels_amd.driver import run_trajectories
+    nch, nt, nr, npil = 8, 64, 16, 38
+    raw = synth.generate_channels('CDL-C', nch, nt, nr, 0.5, seed=45)
+    H = np.conj(np.transpose(raw / np.std(raw), (0, 2, 1))).astype(np.complex64)
+    Pm = np.conj(np.transpose(synth.qpsk_pilots(np.random.default_rng(46), nch, nt, npil), (0, 2, 1)))
+    idx = np.arange(nch)
+    ln = np.repeat(snr_to_noise(np.array([10.0]), nt), nch)
+    init = torch.randn(nch, nt, nr, dtype=torch.complex64, generator=torch.Generator().manual_seed(9))
+
+    def boom(self, *a, **k):
+        raise RuntimeError('leader failed')
+    monkeypatch.setattr(AldBatch, 'run_leading', boom)
+    with pytest.raises(RuntimeError, match='leader failed'):
+        run_trajectories(net64, H, Pm, idx, idx, ln, 3e-11, 0.01, [0, 1155, 2310], 3, 13, init, n_streams=2)
+
+
 @pytest.mark.parametrize('nt,nr', [(16, 64), (32, 32), (128, 8)])
 def test_forward_other_geometries_match_oracle(nt, nr, weights64):
     """Array shapes the reference goldens do not cover (wide images, square images, 8-column images): every level still
