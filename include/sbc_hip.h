@@ -444,6 +444,9 @@ typedef struct sbc_score_desc {
                                     default next to SBC_SCORE_FUSE_PAIRS (scorenet.DEFAULT_FUSE_CHAIN) */
 #define SBC_SCORE_FUSE_DOWN 0x10 /* (ABI 13) pooled conv2 + pooled 1x1 shortcut of the downsampling ResidualBlocks res2.0 / res3.0 as one SBC_OP_CONV_DOWN
                                     record (conv_mode 3); what the Python host does by default (scorenet.DEFAULT_FUSE_DOWN) */
+#define SBC_SCORE_FUSE_END  0x20 /* (ABI 13) the normalizer's statistics inside the SBC_OP_END_CONV launch (SBC_PRO_NORM_SELF on that record: 32 channels,
+                                    1024 pixels; any conv_mode); what the Python host does by default next to SBC_SCORE_FUSE_PAIRS
+                                    (scorenet.DEFAULT_FUSE_END) */
 typedef struct sbc_score sbc_score;
 int sbc_score_create(const sbc_score_desc* desc, const sbc_tensor_ref* tensors, int32_t n_tensors, sbc_score** out);
 int sbc_score_buffers(sbc_score* score, float** x, float** out, int64_t** labels);

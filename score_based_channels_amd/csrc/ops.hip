@@ -459,10 +459,180 @@ __global__ __launch_bounds__(256) void end_conv_kernel(const float* __restrict__
     *reinterpret_cast<float2*>(out + (size_t)px * 2) = o;
 }
 
+// The same tail with the normalizer's statistics formed IN the launch (SBC_PRO_NORM_SELF; round 5): a persistent 8-wave workgroup per
+// CU owns whole samples.  The statistics launch read the 223 MB tensor once (40 us at 1700 x 64 x 16) and this kernel read it again;
+// here a sample is read ONCE into registers (16 float4 a thread, requested while the previous sample's convolution runs), its
+// InstanceNorm++ statistics (normalization.py:163-176: per-channel mean and biased variance over the pixels, two passes; mean and
+// UNBIASED variance of the channel means) are formed from the registers -- in-thread, three xor shuffles over the lanes that share a
+// channel quad, the eight waves through LDS, all in a fixed order --, the normalised + ELU'd sample goes to LDS ([pixel][CIN + 4]
+// floats: 16 consecutive pixels hit 16 different 16-byte slots), and every thread convolves its two output pixels from there with the
+// weights as scalar operands (end_conv_kernel's inner loop, two pixels sharing each scalar).
+template <int CIN, int NTH>
+__global__ __launch_bounds__(NTH) void end_conv_self_kernel(const float* __restrict__ in, const float* __restrict__ agb,
+                                                             const float* __restrict__ w, const float* __restrict__ bias,
+                                                             float* __restrict__ out, sbc_endconv e, int B, int H, int W) {
+    constexpr int C4 = CIN / 4, S = CIN + 4, NWV = NTH / 64, PJ = NTH / C4;      // waves; pixels per round of chunks
+    constexpr int NQ = 1024 * C4 / NTH, NPX = 1024 / NTH;                       // chunks / output pixels per thread at HW = 1024
+    static_assert(CIN == 32, "eight channel quads: a thread keeps one quad for all its chunks");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int HW = H * W;
+    const int nq = HW * C4 / NTH, npx = HW / NTH;                             // (<= NQ, <= NPX: checked by the launcher)
+    float* const act = lds;                                                   // [HW + 1][S]: the activated sample + one zero pixel
+    float* const red = lds + (HW + 1) * S;                                    // two buffers of [waves][CIN] partial sums
+    float* const mean_s = red + 2 * NWV * CIN;                                // [CIN] channel means
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c4 = tid & (C4 - 1), j = tid >> 3;                              // channel quad; pixel k * PJ + j for chunk k
+    const float inv_hw = 1.f / (float)HW;
+    if (tid < S) act[HW * S + tid] = 0.f;                                     // the zero pixel (taps outside the image)
+    const float4 al = *reinterpret_cast<const float4*>(agb + c4 * 4), ga = *reinterpret_cast<const float4*>(agb + CIN + c4 * 4),
+                 be = *reinterpret_cast<const float4*>(agb + 2 * CIN + c4 * 4);
+    const float b0 = bias[0], b1 = bias[1];
+    float4 xv[NQ];
+    auto request = [&](int n) {
+        const float* base = in + ((size_t)n * HW + j) * CIN + c4 * 4;
+#pragma unroll
+        for (int k = 0; k < NQ; ++k)
+            if (k < nq) xv[k] = *reinterpret_cast<const float4*>(base + (size_t)k * PJ * CIN);
+    };
+    // sum over the threads that share a channel quad: lanes (bits 3..5), then the waves through `buf` -- every thread adds the
+    // eight wave sums in the same order
+    auto quad_total = [&](float4 t, float* buf) {
+#pragma unroll
+        for (int m = 8; m < 64; m <<= 1) {
+            t.x += __shfl_xor(t.x, m); t.y += __shfl_xor(t.y, m); t.z += __shfl_xor(t.z, m); t.w += __shfl_xor(t.w, m);
+        }
+        if (lane < C4) *reinterpret_cast<float4*>(buf + wave * CIN + c4 * 4) = t;
+        __syncthreads();
+        float4 a = *reinterpret_cast<const float4*>(buf + c4 * 4);
+#pragma unroll
+        for (int wv = 1; wv < NWV; ++wv) {
+            const float4 o = *reinterpret_cast<const float4*>(buf + wv * CIN + c4 * 4);
+            a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+        }
+        return a;
+    };
+    int n = blockIdx.x;
+    if (n < B) request(n);
+    for (; n < B; n += gridDim.x) {
+        // ---- statistics of the sample in the registers
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < NQ; ++k)
+            if (k < nq) { sum.x += xv[k].x; sum.y += xv[k].y; sum.z += xv[k].z; sum.w += xv[k].w; }
+        sum = quad_total(sum, red);
+        const float4 mu = make_float4(sum.x * inv_hw, sum.y * inv_hw, sum.z * inv_hw, sum.w * inv_hw);
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < NQ; ++k)
+            if (k < nq) {
+                float d;
+                d = xv[k].x - mu.x; q.x = fmaf(d, d, q.x); d = xv[k].y - mu.y; q.y = fmaf(d, d, q.y);
+                d = xv[k].z - mu.z; q.z = fmaf(d, d, q.z); d = xv[k].w - mu.w; q.w = fmaf(d, d, q.w);
+            }
+        if (tid < C4) *reinterpret_cast<float4*>(mean_s + c4 * 4) = mu;
+        q = quad_total(q, red + NWV * CIN);                                   // (its barrier also publishes mean_s)
+        float m = 0.f;
+#pragma unroll 8
+        for (int c = 0; c < CIN; ++c) m += mean_s[c];
+        m *= 1.f / (float)CIN;
+        float v = 0.f;
+#pragma unroll 8
+        for (int c = 0; c < CIN; ++c) { const float d = mean_s[c] - m; v = fmaf(d, d, v); }
+        const float rv = 1.f / sqrtf(v * (1.f / (float)(CIN - 1)) + 1e-5f);
+        float4 sc, sh;                                                        // out = (x - mu) * sc + sh   (ops.hip: inorm_stats_kernel)
+        sc.x = ga.x / sqrtf(fmaxf(q.x * inv_hw, 0.f) + 1e-5f); sh.x = fmaf(ga.x, (mu.x - m) * rv * al.x, be.x);
+        sc.y = ga.y / sqrtf(fmaxf(q.y * inv_hw, 0.f) + 1e-5f); sh.y = fmaf(ga.y, (mu.y - m) * rv * al.y, be.y);
+        sc.z = ga.z / sqrtf(fmaxf(q.z * inv_hw, 0.f) + 1e-5f); sh.z = fmaf(ga.z, (mu.z - m) * rv * al.z, be.z);
+        sc.w = ga.w / sqrtf(fmaxf(q.w * inv_hw, 0.f) + 1e-5f); sh.w = fmaf(ga.w, (mu.w - m) * rv * al.w, be.w);
+        // ---- normalise, ELU, to LDS; then the registers take the next sample
+#pragma unroll
+        for (int k = 0; k < NQ; ++k)
+            if (k < nq) {
+                float4 y;
+                y.x = (xv[k].x - mu.x) * sc.x + sh.x; y.y = (xv[k].y - mu.y) * sc.y + sh.y;
+                y.z = (xv[k].z - mu.z) * sc.z + sh.z; y.w = (xv[k].w - mu.w) * sc.w + sh.w;
+                *reinterpret_cast<float4*>(act + (k * PJ + j) * S + c4 * 4) = elu4(y);
+            }
+        if (n + (int)gridDim.x < B) request(n + gridDim.x);
+        __syncthreads();
+        // ---- end_conv: thread = output pixels tid, tid + NTH, ...
+        int toff[NPX][9];
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) {
+            const int px = min(tid + i * NTH, HW - 1), h = px / W, wq = px - h * W;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int hh = h + tap / 3 - 1, ww = wq + tap % 3 - 1;
+                toff[i][tap] = ((hh >= 0 && hh < H && ww >= 0 && ww < W) ? hh * W + ww : HW) * S;
+            }
+        }
+        float a0[NPX], a1[NPX];
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) { a0[i] = 0.f; a1[i] = 0.f; }
+#pragma unroll 1
+        for (int cb = 0; cb < CIN; cb += 4) {
+            const float* w0 = w + cb * 9;                   // output 0, channels cb .. cb + 3 (uniform: scalar loads)
+            const float* w1 = w + (CIN + cb) * 9;           // output 1
+            // (the reads of a filter row first: left to itself hipcc waits for each one in front of its eight FMAs, and the LDS round trip
+            // per read is not hidden)
+#pragma unroll
+            for (int tr = 0; tr < 3; ++tr) {
+                float4 x4[NPX][3];
+#pragma unroll
+                for (int tq = 0; tq < 3; ++tq)
+#pragma unroll
+                    for (int i = 0; i < NPX; ++i) x4[i][tq] = *reinterpret_cast<const float4*>(act + toff[i][3 * tr + tq] + cb);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tq = 0; tq < 3; ++tq) {
+                    const int tap = 3 * tr + tq;
+#pragma unroll
+                    for (int i = 0; i < NPX; ++i) {
+                        a0[i] = fmaf(x4[i][tq].x, w0[tap], a0[i]);      a1[i] = fmaf(x4[i][tq].x, w1[tap], a1[i]);
+                        a0[i] = fmaf(x4[i][tq].y, w0[9 + tap], a0[i]);  a1[i] = fmaf(x4[i][tq].y, w1[9 + tap], a1[i]);
+                        a0[i] = fmaf(x4[i][tq].z, w0[18 + tap], a0[i]); a1[i] = fmaf(x4[i][tq].z, w1[18 + tap], a1[i]);
+                        a0[i] = fmaf(x4[i][tq].w, w0[27 + tap], a0[i]); a1[i] = fmaf(x4[i][tq].w, w1[27 + tap], a1[i]);
+                    }
+                }
+            }
+        }
+        const float sigma = e.labels ? e.sigmas[e.labels[n]] : e.sigma_of_step[*e.step];
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) {
+            if (i < npx) {
+                float2 o;
+                o.x = (a0[i] + b0) / sigma;
+                o.y = (a1[i] + b1) / sigma;
+                *reinterpret_cast<float2*>(out + ((size_t)n * HW + tid + i * NTH) * 2) = o;
+            }
+        }
+        // (the next sample's first statistics barrier keeps anyone from rewriting `act` before every thread is through here)
+    }
+}
+
 int launch_end_conv(const sbc_op& op, const sbc_endconv& e, hipStream_t stream, bool dry) {
     SBC_REQUIRE(op.in && op.out && op.weight && op.bias && op.stats, "end_conv: in/out/weight/bias/stats must be set");
     SBC_REQUIRE(op.cout == 2, "end_conv: cout=%d", op.cout);
     SBC_REQUIRE((e.labels && e.sigmas) || (e.sigma_of_step && e.step), "end_conv: no noise-level source");
+    if (op.flags & SBC_PRO_NORM_SELF) {
+        // stats = the normalizer's (alpha | gamma | beta): the launch forms the statistics itself, a workgroup holds whole samples
+        const int hw = op.H * op.W;
+        SBC_REQUIRE(op.cin == 32 && hw == 1024,
+                    "end_conv: SBC_PRO_NORM_SELF takes 32 channels and images of 1024 pixels (got %d channels, %dx%d)", op.cin, op.H, op.W);
+        constexpr int NTH = 512;            // (1024 threads, one output pixel each: 128 registers a thread spill -- 212 us against 98)
+        const size_t lds = ((size_t)(hw + 1) * (op.cin + 4) + 2 * (NTH / 64) * op.cin + op.cin) * sizeof(float);
+        { auto k0 = end_conv_self_kernel<32, NTH>; const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(k0), lds); if (rc) return rc; }
+        if (dry) return SBC_OK;
+        int dev = 0, cus = 256;
+        SBC_CHECK_HIP(hipGetDevice(&dev));
+        SBC_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        const int grid = max(1, min(persistent_cus(cus), op.B));
+        auto kern = end_conv_self_kernel<32, NTH>;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NTH), lds, stream, (const float*)op.in, (const float*)op.stats,
+                           (const float*)op.weight, (const float*)op.bias, (float*)op.out, e, op.B, op.H, op.W);
+        SBC_CHECK_HIP(hipGetLastError());
+        return SBC_OK;
+    }
     const int HW = op.H * op.W, TM = 256;
     SBC_REQUIRE(TM % op.W == 0 && (HW % TM == 0 || TM % HW == 0), "end_conv: image %dx%d does not tile", op.H, op.W);
     const int total = op.B * HW;

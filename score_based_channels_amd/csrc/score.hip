@@ -341,9 +341,14 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
     const int ref3 = b.refine("refine3.", {layers[2], ref31}, 2 * ngf);
     const int ref4 = b.refine("refine4.", {layers[1], ref3}, ngf);
     const int ref5 = b.refine("refine5.", {layers[0], ref4}, ngf, true);
-    const int sn = b.stats("normalizer", ref5, "normalizer", false);
     const int o_t = b.tensor("score", nt, nr, d->channels);
-    { POp o; o.kind = SBC_OP_END_CONV; o.src = ref5; o.dst = o_t; o.weight = "end_conv.weight"; o.bias = "end_conv.bias"; o.stats = sn; b.ops.push_back(o); }
+    if ((d->flags & SBC_SCORE_FUSE_END) && ngf == 32 && nt * nr == 1024) {       // plan.end_fusable
+        POp o; o.kind = SBC_OP_END_CONV; o.src = ref5; o.dst = o_t; o.weight = "end_conv.weight"; o.bias = "end_conv.bias";
+        o.flags = SBC_PRO_NORM_SELF; o.norm_key = "normalizer"; b.ops.push_back(o);
+    } else {
+        const int sn = b.stats("normalizer", ref5, "normalizer", false);
+        POp o; o.kind = SBC_OP_END_CONV; o.src = ref5; o.dst = o_t; o.weight = "end_conv.weight"; o.bias = "end_conv.bias"; o.stats = sn; b.ops.push_back(o);
+    }
     // plan.merge_chains: adjacent CHAIN records, the second the only consumer of the first one's output, become one record
     for (size_t k = 0; k + 1 < b.ops.size();) {
         POp& a = b.ops[k];

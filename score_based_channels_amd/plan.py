@@ -371,6 +371,14 @@ def chain_fusable(h, w, c, kind=CHAIN_RCU):
     return h == 8 and w == 2 and c in (64, 128)
 
 
+def end_fusable(h, w, c):
+    """Shapes whose normalizer statistics the END_CONV launch forms itself (PRO_NORM_SELF): 32 channels, 1024 pixels (the
+    normalised sample of a 64 x 16 array fills the LDS of a CU)."""
+    if os.environ.get('SBC_NO_END_SELF'):            # A/B aid: statistics record + end convolution as separate launches
+        return False
+    return c == 32 and h * w == 1024
+
+
 def res_fusable(h, w, cin, cout, resample, dilation):
     """ResidualBlocks SBC_OP_RES_BLOCK takes: 32 -> 32 channels, no resampling or dilation, 64 x 16 samples (two fp16 operand planes
     of a whole sample fill the LDS of a CU)."""
@@ -393,7 +401,7 @@ def pair_fusable(h, w, c, shapes=PAIR_SHAPES):
 
 
 def build_score_plan(ngf=32, nt=64, nr=16, channels=2, share_slots=True, overlap=False, fold_stats=False, fuse_pairs=False, fuse_res=False,
-                     fuse_chain=False, fuse_down=False):
+                     fuse_chain=False, fuse_down=False, fuse_end=False):
     """Op list of one ``NCSNv2Deepest.forward`` for ``[B, 2, nt, nr]`` inputs (ncsnv2.py:269-300).
     ``share_slots=False`` gives every logical tensor its own storage (a training step reads every activation again on
     the way back, ``train.py``)."""
@@ -421,9 +429,15 @@ def build_score_plan(ngf=32, nt=64, nr=16, channels=2, share_slots=True, overlap
     ref3 = b.refine('refine3.', [l3, ref31], 2 * ngf)
     ref4 = b.refine('refine4.', [l2, ref3], ngf)
     ref5 = b.refine('refine5.', [l1, ref4], ngf, end=True)
-    sn = b.stats('normalizer', ref5, 'normalizer', consumer_is_conv=False)
     out = b.t('score', nt, nr, channels)
-    b.ops.append(Op(END_CONV, 'end_conv', src=ref5, dst=out, weight='end_conv.weight', bias='end_conv.bias', stats=sn))
+    if fuse_end and end_fusable(nt, nr, ngf):
+        # the normalizer's statistics are formed inside the end-convolution launch (a workgroup holds whole samples: the tensor is
+        # read once instead of twice, and there is no statistics record)
+        b.ops.append(Op(END_CONV, 'end_conv', src=ref5, dst=out, weight='end_conv.weight', bias='end_conv.bias', flags=PRO_NORM_SELF,
+                        norm_key='normalizer'))
+    else:
+        sn = b.stats('normalizer', ref5, 'normalizer', consumer_is_conv=False)
+        b.ops.append(Op(END_CONV, 'end_conv', src=ref5, dst=out, weight='end_conv.weight', bias='end_conv.bias', stats=sn))
     merge_chains(b.ops)
     for op in b.ops:                        # (after the statistics folding, which adds EPI_MOMENTS_OUT to producers)
         if op.tag == TAG_CONV_MID and not op.flags & (PRO_NORM | EPI_UP | EPI_MOMENTS_OUT):

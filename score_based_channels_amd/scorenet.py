@@ -48,6 +48,8 @@ DEFAULT_FUSE_RES = True
 DEFAULT_FUSE_CHAIN = True
 # pooled conv2 + pooled 1x1 shortcut of the downsampling ResidualBlocks res2.0 / res3.0 as one SBC_OP_CONV_DOWN record (csrc/conv_down.hip)
 DEFAULT_FUSE_DOWN = True
+# the normalizer's statistics inside the end-convolution launch (SBC_PRO_NORM_SELF on the END_CONV record; csrc/ops.hip: end_conv_self_kernel)
+DEFAULT_FUSE_END = True
 
 
 class ScoreNet:
@@ -77,7 +79,7 @@ class ScoreNet:
                             ``.half()``, layers.py:179); tolerance stated in tests/test_gpu_parity.py.
     """
 
-    def __init__(self, config, device=None, conv_mode=None, overlap=None, fold_stats=None, fuse_pairs=None, fuse_res=None, fuse_chain=None, fuse_down=None):
+    def __init__(self, config, device=None, conv_mode=None, overlap=None, fold_stats=None, fuse_pairs=None, fuse_res=None, fuse_chain=None, fuse_down=None, fuse_end=None):
         conv_mode = DEFAULT_CONV_MODE if conv_mode is None else conv_mode
         if conv_mode not in CONV_MODES:
             raise ValueError('conv_mode must be one of %s, got %r' % (CONV_MODES, conv_mode))
@@ -98,6 +100,9 @@ class ScoreNet:
         self.fuse_res = ((DEFAULT_FUSE_RES and self.fuse_pairs) if fuse_res is None else bool(fuse_res)) and conv_mode == 'f16x2'
         self.fuse_chain = ((DEFAULT_FUSE_CHAIN and self.fuse_pairs) if fuse_chain is None else bool(fuse_chain)) and conv_mode == 'f16x2'
         self.fuse_down = ((DEFAULT_FUSE_DOWN and self.fuse_pairs) if fuse_down is None else bool(fuse_down)) and conv_mode == 'f16x2'
+        # fuse_end: the normalizer's statistics inside the end-convolution launch (fp32 vector arithmetic in every conv_mode; part of the
+        # fused default plan, so tied to fuse_pairs like the others: the unfused plan stays what the bf16x3 re-run of a flagged batch uses)
+        self.fuse_end = (DEFAULT_FUSE_END and self.fuse_pairs) if fuse_end is None else bool(fuse_end)
         self.config = config
         m, d = config.model, config.data
         if str(m.normalization) != 'InstanceNorm++' or str(m.nonlinearity).lower() != 'elu':
@@ -258,7 +263,7 @@ class ScoreNet:
             self._plans[key] = P.build_score_plan(self.ngf, nt, nr, self.channels, overlap=self.overlap, fold_stats=fold,
                                                   fuse_pairs=(P.PAIR_SHAPES_F16W if self.conv_mode == 'f16w' else P.PAIR_SHAPES) if self.fuse_pairs else False,
                                                   fuse_res=self.fuse_res, fuse_chain=self.fuse_chain and not self.overlap,
-                                                  fuse_down=self.fuse_down and not self.overlap)
+                                                  fuse_down=self.fuse_down and not self.overlap, fuse_end=self.fuse_end)
         return self._plans[key]
 
     def bind(self, B, nt, nr, *, step=None, sigma_of_step=None, use_labels=True):

@@ -13,21 +13,22 @@ pytestmark = pytest.mark.gpu
 MODES = {'bf16x3': 0, 'f32': 1, 'f16w': 2, 'f16x2': 3}
 
 
-def _create(sd, cfg, B, nt, nr, mode, pairs=False, fold=False, res=False, chain=False, down=False):
+def _create(sd, cfg, B, nt, nr, mode, pairs=False, fold=False, res=False, chain=False, down=False, end=False):
     from score_based_channels_amd import _lib
     keep = {k: np.ascontiguousarray(v, np.float32) for k, v in sd.items() if k != 'sigmas'}
     refs = (_lib.sbc_tensor_ref * len(keep))(*[
         _lib.sbc_tensor_ref(name=k.encode(), data=v.ctypes.data, numel=v.size) for k, v in keep.items()])
     sig = np.ascontiguousarray(sd['sigmas'], np.float32)
     desc = _lib.sbc_score_desc(ngf=32, channels=2, nt=nt, nr=nr, batch=B, conv_mode=MODES[mode], sigmas=sig.ctypes.data,
-                               num_classes=sig.size, flags=(1 if pairs else 0) | (2 if fold else 0) | (4 if res else 0) | (8 if chain else 0) | (16 if down else 0))
+                               num_classes=sig.size, flags=(1 if pairs else 0) | (2 if fold else 0) | (4 if res else 0) | (8 if chain else 0) | (16 if down else 0) | (32 if end else 0))
     h = C.c_void_p()
     _lib.check(_lib.lib().sbc_score_create(C.byref(desc), refs, len(keep), C.byref(h)))
     return h
 
 
 @pytest.mark.parametrize('mode', ['bf16x3', 'f32', 'f16w', 'f16x2', 'f16x2+pairs', 'f16w+pairs', 'f16x2+pairs+fold', 'bf16x3+fold',
-                                  'f16x2+pairs+fold+res', 'f16x2+pairs+fold+res+chain', 'f16x2+pairs+fold+res+chain+down'])
+                                  'f16x2+pairs+fold+res', 'f16x2+pairs+fold+res+chain', 'f16x2+pairs+fold+res+chain+down', 'f16x2+pairs+fold+res+chain+down+end',
+                                  'bf16x3+end'])
 def test_c_built_score_network_equals_python_host(weights64, mode):
     import torch
     from score_based_channels_amd import _lib
@@ -36,12 +37,12 @@ def test_c_built_score_network_equals_python_host(weights64, mode):
     L = _lib.lib()
     B, nt, nr = 3, 64, 16
     mode, *opts = mode.split('+')
-    pairs, fold, res, chain, down = 'pairs' in opts, 'fold' in opts, 'res' in opts, 'chain' in opts, 'down' in opts
-    h = _create(sd, cfg, B, nt, nr, mode, pairs, fold, res, chain, down)
+    pairs, fold, res, chain, down, end = 'pairs' in opts, 'fold' in opts, 'res' in opts, 'chain' in opts, 'down' in opts, 'end' in opts
+    h = _create(sd, cfg, B, nt, nr, mode, pairs, fold, res, chain, down, end)
     try:
         ops_p, n = C.POINTER(_lib.sbc_op)(), C.c_int32()
         _lib.check(L.sbc_score_ops(h, C.byref(ops_p), C.byref(n)))
-        net = ScoreNet(cfg, conv_mode=mode, fuse_pairs=pairs, fold_stats=fold, fuse_res=res, fuse_chain=chain, fuse_down=down).cuda().load_state_dict(sd)
+        net = ScoreNet(cfg, conv_mode=mode, fuse_pairs=pairs, fold_stats=fold, fuse_res=res, fuse_chain=chain, fuse_down=down, fuse_end=end).cuda().load_state_dict(sd)
         bound = net.bind(B, nt, nr)
         assert n.value == len(bound.ops)
         assert chain == any(o.kind == 24 for o in bound.ops) and down == any(o.kind == 25 for o in bound.ops)
@@ -107,7 +108,7 @@ def test_langevin_plan_composed_from_c_records(weights64, mode, pairs, fold, cha
     ln = float(snr_to_noise(g['snr_db'], nt)[0])
     steps = noise.step_block(0, H.shape, n_steps)
     # reference run through the Python host
-    net = ScoreNet(cfg, conv_mode=mode, fold_stats=fold, fuse_pairs=pairs, fuse_res=False, fuse_chain=chain, fuse_down=False).cuda().load_state_dict(sd)
+    net = ScoreNet(cfg, conv_mode=mode, fold_stats=fold, fuse_pairs=pairs, fuse_res=False, fuse_chain=chain, fuse_down=False, fuse_end=False).cuda().load_state_dict(sd)
     ald = AldBatch(net, H, Pm, np.arange(B), np.arange(B), ln, levels=levels, step_noise=torch.from_numpy(steps))
     ald.set_init(torch.from_numpy(noise.init(H.shape)))
     Y = ald.synthesize_measurements(torch.from_numpy(noise.measurement(0, (B, npil, nr)))).clone()

@@ -344,6 +344,43 @@ def test_end_conv_matches_oracle(gpu, B, H, W):
     assert rel_err(out.cpu().numpy(), ref) < 1e-5
 
 
+@pytest.mark.parametrize('B,H,W', [(5, 64, 16), (1, 64, 16), (300, 64, 16), (4, 32, 32), (3, 16, 64), (2, 128, 8)])
+def test_end_conv_with_its_own_statistics_matches_oracle(gpu, B, H, W):
+    """SBC_OP_END_CONV with SBC_PRO_NORM_SELF (csrc/ops.hip: end_conv_self_kernel): `stats` is the normalizer's (alpha | gamma | beta) and
+    the launch forms the InstanceNorm++ statistics itself -- persistent workgroups that hold whole samples, the tensor read once --
+    against the oracle's normalisation + ELU + convolution + division by sigma (ncsnv2.py:291-298), with per-channel offsets and scales,
+    more samples than workgroups, and results that do not depend on the batch."""
+    torch, _lib = gpu
+    from score_based_channels_amd import plan as P
+    rng = np.random.default_rng(B + H)
+    # (offsets of a few standard deviations: the fp32 oracle's own mean subtraction is good to ~1e-6 of the normalised values there)
+    x = (rng.standard_normal((B, H, W, 32)) * (0.3 + rng.random(32) * 3) + 2 * rng.standard_normal(32)).astype(F32)
+    agb = np.stack(((1 + 0.1 * rng.standard_normal(32)), (1 + 0.1 * rng.standard_normal(32)), 0.1 * rng.standard_normal(32))).astype(F32)
+    w = (rng.standard_normal((2, 32, 3, 3)) / 17).astype(F32)
+    b = rng.standard_normal(2).astype(F32)
+    sigmas = np.exp(np.linspace(np.log(39.15), np.log(3.6e-4), 50)).astype(F32)
+    labels = rng.integers(0, 50, B)
+    d = [_dev(torch, a) for a in (x, agb, w, b, sigmas, labels.astype(np.int64))]
+
+    def run(lo, hi):
+        out = torch.full((hi - lo, H, W, 2), float('nan'), device='cuda')
+        ext = _lib.sbc_endconv(sigmas=_p(d[4]), labels=_p(d[5][lo:hi]))
+        _launch(gpu, _lib.sbc_op(kind=P.END_CONV, flags=P.PRO_NORM_SELF, B=hi - lo, H=H, W=W, cin=32, cout=2, ksize=3, dil=1, in_=_p(d[0][lo:hi]),
+                                 out=_p(out), weight=_p(d[2]), bias=_p(d[3]), stats=_p(d[1]), ext=C.cast(C.pointer(ext), C.c_void_p)))
+        return out.cpu().numpy()
+    got = run(0, B)
+    v = O.elu(O.instance_norm_plus(x.transpose(0, 3, 1, 2), agb[0], agb[1], agb[2]))
+    ref = O.conv2d(v, w, b).transpose(0, 2, 3, 1) / sigmas[labels][:, None, None, None]
+    assert np.isfinite(got).all() and rel_err(got, ref) < 1e-5
+    if B > 1:
+        assert np.array_equal(run(B // 2, B), got[B // 2:])                    # a sample's numbers do not depend on its neighbours
+    with pytest.raises(_lib.SbcError):                                           # shapes the kernel does not take are refused, not mangled
+        out = torch.zeros(2, 8, 8, 2, device='cuda')
+        ext = _lib.sbc_endconv(sigmas=_p(d[4]), labels=_p(d[5]))
+        _launch(gpu, _lib.sbc_op(kind=P.END_CONV, flags=P.PRO_NORM_SELF, B=2, H=8, W=8, cin=32, cout=2, ksize=3, dil=1, in_=_p(d[0]), out=_p(out),
+                                 weight=_p(d[2]), bias=_p(d[3]), stats=_p(d[1]), ext=C.cast(C.pointer(ext), C.c_void_p)))
+
+
 @pytest.mark.parametrize('wino', [False, True])
 def test_f16x2_range_flag(gpu, wino):
     """conv_mode f16x2 stages activations as two fp16 terms: an activation beyond 16000 could overflow the

@@ -157,6 +157,26 @@ def test_chain_plan_matches_reference_forward(weights64):
         assert rel_err(out.transpose(0, 3, 1, 2), g['out'][1][:2]) < 2e-5
 
 
+def test_end_statistics_in_the_end_convolution_plan_matches_reference_forward(weights64):
+    """``build_score_plan(fuse_end=True)``: no statistics record for the normalizer -- the END_CONV record carries PRO_NORM_SELF and the
+    norm's key (csrc/ops.hip: end_conv_self_kernel forms the statistics from the sample it holds); arrays whose sample does not fit a
+    CU's LDS keep the record.  Interpreted on the CPU: the same forward."""
+    _, sd = weights64
+    g = load_golden('forward_64x16.npz')
+    kw = dict(fold_stats=True, fuse_pairs=P.PAIR_SHAPES, fuse_res=True, fuse_chain=True, fuse_down=True)
+    base, pl = P.build_score_plan(32, 64, 16, **kw), P.build_score_plan(32, 64, 16, fuse_end=True, **kw)
+    assert len(base.ops) == 55 and len(pl.ops) == 54 and [op.name for op in base.ops[-2:]] == ['normalizer', 'end_conv']
+    end = pl.ops[-1]
+    assert end.kind == P.END_CONV and end.flags == P.PRO_NORM_SELF and end.norm_key == 'normalizer' and end.stats is None
+    assert pl.ops[-2].kind == P.CONV_PAIR and P.count_conv_flops(pl) == 820772864
+    big = P.build_score_plan(32, 256, 64, fuse_end=True)
+    assert big.ops[-1].stats is not None and big.ops[-2].name == 'normalizer'
+    assert P.build_score_plan(32, 32, 32, fuse_end=True).ops[-1].flags == P.PRO_NORM_SELF and P.build_score_plan(32, 32, 16, fuse_end=True).ops[-1].stats is not None
+    x = np.ascontiguousarray(g['x'][:2].transpose(0, 2, 3, 1))
+    out = run_plan(pl, sd, x, np.full((2,), 1155))
+    assert rel_err(out.transpose(0, 3, 1, 2), g['out'][1][:2]) < 2e-5
+
+
 def test_conv_down_plan_matches_reference_forward(weights64):
     """``build_score_plan(fuse_down=True)``: the pooled conv2 and the pooled 1x1 shortcut of res2.0 and res3.0 are ONE CONV_DOWN
     record each (csrc/conv_down.hip); res31.0 -- whose norm the consumer computes itself at 16x4 -- stays as it is.  Same FLOPs as
