@@ -110,13 +110,16 @@ __host__ __device__ constexpr int chain_samples(int C, int W, int NW) {
 //   W = 4 (16 x 4 samples, C = 64), G = 4: a unit = one column of ONE sample (lane n: row n); wave = (cb, half), 8 units;
 //   W = 8 (32 x 8 samples): a unit = one column of one HALF of a sample (lane n: row 16 half + n), 8 units = the eight columns --
 //          statistics and the max pool's boundary rows cross the two waves of a sample through LDS;  C = 64, G = 1: wave = (cb, half);  C = 32, G = 2: wave = (cb, sample, half).
-template <int C, int W, int NW>
+// GD = 2 (W = 2 only): HALF the samples per workgroup (four at 128 channels, two at 64) -- twice the workgroups for batches that would
+// leave most of the chip idle otherwise (a launch of 425 samples is 54 workgroups of eight); the same sums in the same order.
+template <int C, int W, int NW, int GD = 1>
 __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
     constexpr int H = W == 2 ? 8 : W == 4 ? 16 : 32;
     constexpr int CG = C / 8, KH = C / 32, NCB = C / 16, NHALF = NW / NCB;   // NHALF: unit groups among the waves
     static_assert(NW % NCB == 0 && NHALF >= 1, "a wave owns one 16-output-channel block");
     // samples per workgroup: every unit group of waves takes 8 units (4 at W = 2, C = 64)
-    constexpr int G = chain_samples(C, W, NW);
+    constexpr int G = chain_samples(C, W, NW) / GD;
+    static_assert(GD == 1 || (GD == 2 && W == 2), "half groups exist at a width of two");
     constexpr int NTH = 64 * NW;
     constexpr int SPU = W == 2 ? 2 : 1;                   // samples per unit
     constexpr int NSG = W == 8 ? 1 : G / SPU / NHALF;     // sample groups (pairs at W = 2, samples at W = 4, half samples at W = 8) per wave
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
     constexpr int TERM = CG * PS;                         // low-term planes behind the high-term planes
     static_assert((W == 2 && (C == 64 || C == 128)) || (W == 4 && C == 64) || (W == 8 && (C == 32 || C == 64)), "shapes of the header");
     static_assert(PS % 256 == 0 && (W != 2 || (SP % 16) == 8), "plane stride = whole bank rows; second sample of a W = 2 unit 8 slots (mod 16) on");
-    static_assert(NU == 8 || NU == 4, "accumulator budget: at most 8 units per wave");
+    static_assert(NU == 8 || NU == 4 || NU == 2, "accumulator budget: at most 8 units per wave");
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -524,12 +527,12 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
     if (rbits && lane == 0) atomicOr(p.range_flag, rbits);
 }
 
-template <int C, int W, int NW>
+template <int C, int W, int NW, int GD = 1>
 static int launch_chain_t(const ChainParams& p, hipStream_t stream, bool dry) {
-    constexpr int G = chain_samples(C, W, NW), SP = W * (W == 2 ? 12 : W == 4 ? 18 : 34);
+    constexpr int G = chain_samples(C, W, NW) / GD, SP = W * (W == 2 ? 12 : W == 4 ? 18 : 34);
     // operand planes + InstanceNorm++ scratch (+ at W = 8 the half-sample sums and the max pool's boundary rows)
     constexpr int LDS = 2 * (C / 8) * G * SP * 16 + (G * C + 2 * G) * 4 + (W == 8 ? 2 * NW * 16 * 4 + NW * 2 * 8 * 4 * 16 : 0);
-    auto kern = conv_chain_kernel<C, W, NW>;
+    auto kern = conv_chain_kernel<C, W, NW, GD>;
     { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), LDS); if (rc) return rc; }
     if (dry) return SBC_OK;
     hipLaunchKernelGGL(kern, dim3((p.B + G - 1) / G), dim3(64 * NW), LDS, stream, p);
@@ -576,8 +579,22 @@ int launch_chain(const sbc_op& op, const sbc_chain& c, hipStream_t stream, bool 
     static const bool nw8 = getenv("SBC_CHAIN_NW8") != nullptr;
     if (op.W == 8) return op.cin == 64 ? launch_chain_t<64, 8, 8>(p, stream, dry) : nw8 ? launch_chain_t<32, 8, 8>(p, stream, dry) : launch_chain_t<32, 8, 4>(p, stream, dry);
     if (op.W == 4) return nw8 ? launch_chain_t<64, 4, 8>(p, stream, dry) : launch_chain_t<64, 4, 4>(p, stream, dry);
-    if (op.cin == 128) return launch_chain_t<128, 2, 8>(p, stream, dry);
-    return nw8 ? launch_chain_t<64, 2, 8>(p, stream, dry) : launch_chain_t<64, 2, 4>(p, stream, dry);
+    // 8 x 2 samples, small batches: half groups when the full groups would occupy at most half of the CUs this launch may count on
+    // (the plan's persistent-grid width: all CUs, or half of them when two sub-batch streams share the chip).  (A/B aid: SBC_CHAIN_GD=1 / 2)
+    int dev = 0, cus = 256;
+    SBC_CHECK_HIP(hipGetDevice(&dev));
+    SBC_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    static const int force_gd = getenv("SBC_CHAIN_GD") ? atoi(getenv("SBC_CHAIN_GD")) : 0;
+    const int avail = persistent_cus(cus);
+    if (op.cin == 128) {
+        const bool half = force_gd ? force_gd == 2 : 2 * ((op.B + 7) / 8) <= avail;
+        if (dry) { const int rc = launch_chain_t<128, 2, 8, 2>(p, stream, true); if (rc) return rc; return launch_chain_t<128, 2, 8>(p, stream, true); }
+        return half ? launch_chain_t<128, 2, 8, 2>(p, stream, dry) : launch_chain_t<128, 2, 8>(p, stream, dry);
+    }
+    if (nw8) return launch_chain_t<64, 2, 8>(p, stream, dry);
+    const bool half = force_gd ? force_gd == 2 : 2 * ((op.B + 3) / 4) <= 2 * avail;      // (two 4-wave workgroups per CU)
+    if (dry) { const int rc = launch_chain_t<64, 2, 4, 2>(p, stream, true); if (rc) return rc; return launch_chain_t<64, 2, 4>(p, stream, true); }
+    return half ? launch_chain_t<64, 2, 4, 2>(p, stream, dry) : launch_chain_t<64, 2, 4>(p, stream, dry);
 }
 
 }  // namespace sbc

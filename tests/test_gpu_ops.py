@@ -942,6 +942,55 @@ def test_chain_matches_oracle(gpu, Cc, H, W, B, blocks):
         assert np.array_equal(run(dx[:5].contiguous()), got[:5])       # batch independence, bit for bit
 
 
+@pytest.mark.parametrize('Cc,blocks', [(128, ('R', 'C')), (128, ('X2', 'S2')), (64, ('C', 'R')), (64, ('S1',))])
+def test_chain_full_and_half_groups_agree(gpu, Cc, blocks):
+    """At 8 x 2 the chain kernel exists with eight (four) samples per workgroup and, for batches that would leave most of the chip
+    idle, with half of that (csrc/conv_chain.hip: GD = 2; launch_chain picks by batch size).  2100 samples take the full groups, pieces of
+    300 the half groups: the same sums in the same order -- identical bit for bit -- and the oracle's numbers."""
+    torch, _lib = gpu
+    from score_based_channels_amd import plan as P
+    from score_based_channels_amd.weights import pack_conv_weight_f16x2
+    B, H, W = 2100, 8, 2
+    rng = np.random.default_rng(Cc + len(blocks))
+    x = (rng.standard_normal((B, H, W, Cc)) * 1.5 + 0.3).astype(F32)
+    keep, ws = [], []
+
+    def dev(a):
+        keep.append(_dev(torch, a))
+        return keep[-1].data_ptr()
+    ch = _lib.sbc_chain(n_blocks=len(blocks))
+    for k, tok in enumerate(blocks):
+        w1 = (rng.standard_normal((Cc, Cc, 3, 3)) / np.sqrt(9 * Cc)).astype(F32)
+        w2 = (rng.standard_normal((Cc, Cc, 3, 3)) / np.sqrt(9 * Cc) * 0.3).astype(F32)
+        ex = None
+        ch.type[k] = {'R': 0, 'C': 1}.get(tok[0], 2)
+        ch.w1[k], ch.w2[k] = dev(pack_conv_weight_f16x2(w1).view(np.float32)), dev(pack_conv_weight_f16x2(w2).view(np.float32))
+        if tok[0] in 'SX':
+            nrm = lambda: tuple((a + 0.1 * rng.standard_normal(Cc)).astype(F32) for a in (1.0, 1.0, 0.0))   # noqa: E731
+            ex = dict(b1=(0.2 * rng.standard_normal(Cc)).astype(F32), b2=(0.2 * rng.standard_normal(Cc)).astype(F32), n1=nrm(), n2=nrm())
+            ch.dil[k] = int(tok[1:])
+            ch.bias1[k], ch.bias2[k] = dev(ex['b1']), dev(ex['b2'])
+            ch.norm1[k], ch.norm2[k] = dev(np.concatenate(ex['n1'])), dev(np.concatenate(ex['n2']))
+            if tok[0] == 'X':
+                ex.update(w3=(rng.standard_normal((Cc, Cc, 3, 3)) / np.sqrt(9 * Cc)).astype(F32), b3=(0.2 * rng.standard_normal(Cc)).astype(F32))
+                ch.w3[k], ch.bias3[k] = dev(pack_conv_weight_f16x2(ex['w3']).view(np.float32)), dev(ex['b3'])
+        ws.append((w1, w2, ex))
+    dx = _dev(torch, x)
+
+    def run(xin):
+        out = torch.full(tuple(xin.shape), float('nan'), dtype=torch.float32, device='cuda')
+        op = _lib.sbc_op(kind=P.CHAIN, flags=P.CONV_F16X2, B=xin.shape[0], H=H, W=W, cin=Cc, cout=Cc, ksize=3, dil=1, in_=_p(xin), out=_p(out),
+                         ext=C.cast(C.pointer(ch), C.c_void_p))
+        _launch(gpu, op)
+        return out.cpu().numpy()
+    full = run(dx)
+    assert np.isfinite(full).all() and _lib.range_flag() == 0
+    for lo in range(0, B, 300):
+        assert np.array_equal(run(dx[lo:lo + 300].contiguous()), full[lo:lo + 300]), lo
+    ref = _chain_reference(x[:64], blocks, ws)
+    assert rel_err(full[:64], ref) < 3 * TOL
+
+
 @pytest.mark.parametrize('B', [1, 3, 40])
 @pytest.mark.parametrize('cin,cout,H,W', [(32, 64, 64, 16), (32, 64, 16, 16), (64, 64, 32, 8), (64, 64, 16, 8)])
 def test_conv_down_matches_oracle(gpu, cin, cout, H, W, B):
