@@ -572,12 +572,12 @@ def main():
             #   Winograd F(2x2,3x3) kernels execute 16/36 of the direct products; the fused pair is a direct convolution whose
             #   first stage also computes the 2 halo rows of its 8-row tile: (10 + 8) / (2 * 8)
             terms = {'bf16x3': 6.0, 'f16x2': 3.0, 'f16w': 1.0}.get(conv_mode)
-            pair_roll = nr == 16 and T * (nt // 8) >= 4096 and conv_mode in ('f16x2', 'f16w')
+            pair_roll = nr == 16 and T * (nt // 8) >= 1024 and conv_mode in ('f16x2', 'f16w')
             row = False                                                   # (tools/experiments/conv_row.hip: not built in)
             names = {P.TAG_CONV_TOP: 'conv_row_kernel' if row else
                                      'conv_wx3_kernel<32, 32, 1, true, %s, true, 1, 1, %d>' % ({'bf16x3': '3', 'f16x2': '4', 'f16w': '3'}.get(conv_mode, '3'),
                                                                                               {'bf16x3': 0, 'f16w': 1, 'f16x2': 2}.get(conv_mode, 0)),
-                     # (16-pixel rows, at least 4096 tiles in the launch: the three-role pipeline over row rings, csrc/conv_pair.hip)
+                     # (16-pixel rows, at least 1024 tiles in the launch: the three-role pipeline over row rings, csrc/conv_pair.hip)
                      P.TAG_PAIR_TOP: ('conv_pair_roll_kernel<%d>' % (2 if conv_mode == 'f16x2' else 1) if pair_roll else
                                       'conv_pair_kernel<%d, %d, %d, %d, 32>' % (nr, 4 if nr == 64 else 8, 2 if conv_mode == 'f16x2' else 1, 8 if nr == 64 else 4)),
                      P.TAG_POOL_TOP: 'conv_pool_kernel<%d, 8, %d, 4, 32>' % (nr, 2 if conv_mode == 'f16x2' else 1),

@@ -1304,7 +1304,10 @@ int launch_conv_pair(const sbc_op& op, hipStream_t stream, bool dry) {
     // than it gains: 1040 tiles 21.8 us against 21.3, 6800 tiles 112 against 122, 13600 tiles 230 against 242)
     static const bool no_p3 = getenv("SBC_NO_PAIR_P3") != nullptr;           // A/B aid
     static const bool no_roll = getenv("SBC_NO_PAIR_ROLL") != nullptr;       // A/B aid: the pipeline with per-tile halos
-    if (!no_p3 && !no_roll && op.W == 16 && op.H % 8 == 0 && (long)op.B * (op.H / 8) >= 4096)
+    // (from 1024 tiles: a workgroup's run is then at least four tiles at full grid width, eight at half width -- 850 trajectories per
+    // GPU 2.51 -> 2.44 ms per step, 425: 1.57 -> 1.53 against the tile-at-a-time kernel; round 4's pipeline wanted 4096)
+    static const long roll_min = getenv("SBC_PAIR_ROLL_MIN_TILES") ? atol(getenv("SBC_PAIR_ROLL_MIN_TILES")) : 1024;   // (the variable: A/B aid)
+    if (!no_p3 && !no_roll && op.W == 16 && op.H % 8 == 0 && (long)op.B * (op.H / 8) >= roll_min)
         return x2 ? launch_pair_roll<2>(p, stream, dry) : launch_pair_roll<1>(p, stream, dry);
     if (!no_p3 && op.W == 16 && op.H % 8 == 0 && (long)op.B * (op.H / 8) >= 4096)
         return x2 ? launch_pair_p3<16, 8, 2>(p, stream, dry) : launch_pair_p3<16, 8, 1>(p, stream, dry);
