@@ -128,6 +128,18 @@ int persistent_cus(int cus) {
     const int n = env > 0 ? env : tls_persistent_cus > 0 ? tls_persistent_cus : g_persistent_cus.load(std::memory_order_relaxed);
     return n > 0 && n < cus ? n : cus;
 }
+// Grid of a persistent kernel whose workgroups take WHOLE samples, one workgroup per CU (conv_res, end_conv_self): the rounds a
+// workgroup makes are an integer, so no more workgroups than that round count needs -- 213 samples on a width of 128 are two
+// rounds either way, 107 workgroups do them and leave 21 CUs to the other stream (425 trajectories per GPU: 1.55 -> 1.47 ms per step).
+// (Taking up to a quarter MORE workgroups than the plan's width where that saves a round -- 850 samples: 142 workgroups, 6 rounds
+// instead of 7 -- was measured too: it costs the other stream what it gains, 4.26 -> 4.29 ms at 1700.)  (A/B aid: SBC_NO_BALANCED_GRID)
+int balanced_sample_grid(int samples, int cus) {
+    static const bool off = getenv("SBC_NO_BALANCED_GRID") != nullptr;
+    const int w = persistent_cus(cus);
+    if (off || samples <= 0) return samples < w ? (samples > 0 ? samples : 1) : w;
+    const int rounds = (samples + w - 1) / w;
+    return (samples + rounds - 1) / rounds;
+}
 struct PersistentCusScope {                              // RAII: a plan's width for the duration of its launches on this thread
     int saved;
     explicit PersistentCusScope(int n) : saved(tls_persistent_cus) { if (n > 0) tls_persistent_cus = n; }

@@ -34,6 +34,7 @@ void set_error(const char* fmt, ...);
 // A/B probe: SBC_PERSIST_CUS=<n> makes the persistent kernels (conv_pair, conv_pool, conv_dp, conv_res) size their grids for n CUs
 // instead of all of them, so that two streams' launches can be resident side by side.
 int persistent_cus(int cus);
+int balanced_sample_grid(int samples, int cus);   // grid of the sample-per-workgroup persistent kernels (api.hip)
 int ensure_dyn_lds(const void* kernel, size_t bytes);
 
 // conv_mode f16x2: the current device's range-flag word (allocated and zeroed on first use; api.hip)

@@ -379,7 +379,7 @@ int launch_res_block(const sbc_op& op, hipStream_t stream, bool dry) {
     int dev = 0, cus = 256;
     SBC_CHECK_HIP(hipGetDevice(&dev));
     SBC_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    hipLaunchKernelGGL(conv_res_kernel, dim3(min(op.B, persistent_cus(cus))), dim3(512), lds, stream, p);
+    hipLaunchKernelGGL(conv_res_kernel, dim3(balanced_sample_grid(op.B, cus)), dim3(512), lds, stream, p);
     SBC_CHECK_HIP(hipGetLastError());
     return SBC_OK;
 }

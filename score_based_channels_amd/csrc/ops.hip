@@ -626,7 +626,7 @@ int launch_end_conv(const sbc_op& op, const sbc_endconv& e, hipStream_t stream, 
         int dev = 0, cus = 256;
         SBC_CHECK_HIP(hipGetDevice(&dev));
         SBC_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        const int grid = max(1, min(persistent_cus(cus), op.B));
+        const int grid = balanced_sample_grid(op.B, cus);
         auto kern = end_conv_self_kernel<32, NTH>;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NTH), lds, stream, (const float*)op.in, (const float*)op.stats,
                            (const float*)op.weight, (const float*)op.bias, (float*)op.out, e, op.B, op.H, op.W);
