@@ -573,7 +573,7 @@ def main():
             #   first stage also computes the 2 halo rows of its 8-row tile: (10 + 8) / (2 * 8)
             terms = {'bf16x3': 6.0, 'f16x2': 3.0, 'f16w': 1.0}.get(conv_mode)
             pair_roll = nr == 16 and T * (nt // 8) >= 1024 and conv_mode in ('f16x2', 'f16w')
-            row = False                                                   # (tools/experiments/conv_row.hip: not built in)
+            row = False                                                   # (a direct kernel for these two layers: measured, not built in -- DESIGN.md section 9)
             names = {P.TAG_CONV_TOP: 'conv_row_kernel' if row else
                                      'conv_wx3_kernel<32, 32, 1, true, %s, true, 1, 1, %d>' % ({'bf16x3': '3', 'f16x2': '4', 'f16w': '3'}.get(conv_mode, '3'),
                                                                                               {'bf16x3': 0, 'f16w': 1, 'f16x2': 2}.get(conv_mode, 0)),

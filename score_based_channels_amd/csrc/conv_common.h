@@ -51,7 +51,6 @@ int launch_conv_wx3(const ConvParams& p, int cin, int cout, hipStream_t stream, 
 // 64 -> 64 channels, 3x3, images 8 / 4 / 2 pixels wide, conv_mode f16x2 (conv_dp.hip: direct persistent kernel with the filter
 // fragments resident in registers): SBC_OK after launching, 1 when the layer is not eligible (-> conv_wx3), < 0 on error.
 int launch_conv_dp(const sbc_op& op, unsigned* range_flag, hipStream_t stream, bool dry);
-int launch_conv_row(const sbc_op& op, unsigned* range_flag, hipStream_t stream, bool dry);   // tools/experiments/conv_row.hip (-DSBC_WITH_CONV_ROW)
 
 // Experiment (tools/experiments/conv_wp.hip, built only with -DSBC_WITH_WP): Winograd F(2x2,3x3) 64 -> 64 with the transformed
 // filter resident in registers (conv_mode f16x2): SBC_OK after launching, 1 when the layer is not eligible (-> conv_wx3).

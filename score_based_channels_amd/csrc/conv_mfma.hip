@@ -276,12 +276,8 @@ int launch_conv(const sbc_op& op, hipStream_t stream, bool dry) {
     static const bool no_wx3 = getenv("SBC_NO_WX3") != nullptr;                    // A/B aid: direct split-bf16 kernel everywhere
     const bool direct_only = (op.flags & SBC_EPI_ELUGRAD) != 0;       // the fp32 Winograd kernel's epilogue does not know the flag
     if ((op.flags & SBC_CONV_F16X2) && !f32_only) {
-        int rc = launch_conv_dp(op, p.range_flag, stream, dry);
+        const int rc = launch_conv_dp(op, p.range_flag, stream, dry);
         if (rc <= 0) return rc;                                                    // launched (0) or failed (< 0)
-#ifdef SBC_WITH_CONV_ROW   // tools/experiments/conv_row.hip (round 5: the two unfused 32 -> 32 layers at 64x16 as a direct pipeline over row rings; measured no faster)
-        rc = launch_conv_row(op, p.range_flag, stream, dry);
-        if (rc <= 0) return rc;
-#endif
     }
     if (op.weight_wino_split && !f32_only && !no_wx3 && op.ksize == 3 && op.dil == 1) {
         ConvParams pw = p;

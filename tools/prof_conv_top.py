@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Stand-alone timing of one 3x3 32 -> 32 SBC_OP_CONV at 64x16 (conv_mode f16x2) on the GPU box, whichever kernel the dispatcher picks
-(csrc/conv_mfma.hip: launch_conv; A/B switches of the library come from the environment, e.g. SBC_NO_CONV_DP32, SBC_NO_CONV_ROW).
+(csrc/conv_mfma.hip: launch_conv; A/B switches of the library come from the environment, e.g. SBC_NO_CONV_DP32).
 
     python tools/prof_conv_top.py [B=1700] [reps=50] [H=64] [W=16] [C=32]
 """
@@ -53,7 +53,7 @@ def main():
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / reps * 1e3
         flops = 2.0 * B * H * W * 9 * Cc * Cc
-        env = ' '.join(k for k in ('SBC_NO_CONV_DP32', 'SBC_NO_CONV_ROW') if os.environ.get(k)) or 'default'
+        env = ' '.join(k for k in ('SBC_NO_CONV_DP32',) if os.environ.get(k)) or 'default'
         print('%-50s %dx%d C=%d B=%d [%s]: %.1f us per launch, %.0f TFLOP/s algorithmic, %.2f TB/s' % (name, H, W, Cc, B, env, us, flops / us / 1e6, 2 * x.numel() * 4 / us / 1e6))
 
 
