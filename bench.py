@@ -573,9 +573,7 @@ def main():
             #   first stage also computes the 2 halo rows of its 8-row tile: (10 + 8) / (2 * 8)
             terms = {'bf16x3': 6.0, 'f16x2': 3.0, 'f16w': 1.0}.get(conv_mode)
             pair_roll = nr == 16 and T * (nt // 8) >= 1024 and conv_mode in ('f16x2', 'f16w')
-            row = False                                                   # (a direct kernel for these two layers: measured, not built in -- DESIGN.md section 9)
-            names = {P.TAG_CONV_TOP: 'conv_row_kernel' if row else
-                                     'conv_wx3_kernel<32, 32, 1, true, %s, true, 1, 1, %d>' % ({'bf16x3': '3', 'f16x2': '4', 'f16w': '3'}.get(conv_mode, '3'),
+            names = {P.TAG_CONV_TOP: 'conv_wx3_kernel<32, 32, 1, true, %s, true, 1, 1, %d>' % ({'bf16x3': '3', 'f16x2': '4', 'f16w': '3'}.get(conv_mode, '3'),
                                                                                               {'bf16x3': 0, 'f16w': 1, 'f16x2': 2}.get(conv_mode, 0)),
                      # (16-pixel rows, at least 1024 tiles in the launch: the three-role pipeline over row rings, csrc/conv_pair.hip)
                      P.TAG_PAIR_TOP: ('conv_pair_roll_kernel<%d>' % (2 if conv_mode == 'f16x2' else 1) if pair_roll else
@@ -590,9 +588,7 @@ def main():
             names[P.TAG_DOWN], names[P.TAG_DOWN + 1] = 'conv_down_kernel<32, 64, 16>', 'conv_down_kernel<64, 64, 8>'
             for k, (cc, cw) in enumerate(P.CHAIN_KERNELS):
                 names[P.TAG_CHAIN + k] = 'conv_chain_kernel<%d, %d, %d>' % (cc, cw, 8 if (cc, cw) in ((128, 2), (64, 8)) else 4)
-            what = {P.TAG_CONV_TOP: 'the unfused 3x3 32->32 convolutions at %dx%d (%s)'
-                                    % (nt, nr, 'direct, persistent workgroups over contiguous runs of 8-row tiles, operand rows in an LDS ring: round 5'
-                                               if row else 'Winograd F(2x2,3x3)'),
+            what = {P.TAG_CONV_TOP: 'the unfused 3x3 32->32 convolutions at %dx%d (Winograd F(2x2,3x3))' % (nt, nr),
                     P.TAG_PAIR_TOP: 'the fused RCU blocks at %dx%d: two direct 3x3 32->32 convolutions per launch, intermediate in LDS%s'
                                     % (nt, nr, '; a workgroup walks a contiguous run of 8-row tiles and keeps the rows adjacent tiles share in LDS rings '
                                                '(no halo recomputation: round 5)' if pair_roll else ''),
@@ -617,7 +613,7 @@ def main():
                 fl = kc['flops_per_step'] / kc['launches_per_step']           # algorithmic FLOPs of an average launch of the class
                 by = kc['bytes_per_step'] / kc['launches_per_step']
                 ratio = (((nt + 1.0) / nt if pair_roll else 18.0 / 16.0) if tag == P.TAG_PAIR_TOP else
-                         1.0 if tag in (P.TAG_POOL_TOP, P.TAG_RES_TOP) or (tag == P.TAG_DIRECT_MID and direct_mid) or (tag == P.TAG_CONV_TOP and row)
+                         1.0 if tag in (P.TAG_POOL_TOP, P.TAG_RES_TOP) or (tag == P.TAG_DIRECT_MID and direct_mid)
                          else 0.5 if tag >= P.TAG_DOWN else kc['live_taps'] if tag >= P.TAG_CHAIN else 16.0 / 36.0) * (terms or 1.0)
                 ach = fl / t_launch / 1e12
                 e = {'kernel': names[tag], 'what': what[tag], 'launches_per_step': kc['launches_per_step'],
