@@ -82,7 +82,11 @@ typedef enum sbc_op_kind {
                                 2x2 stride-2 direct convolution with the pooled filters (weight_split = sbc_pack_conv_weight_pooled_f16x2 of the
                                 3x3 weight, weight2_split = the same of the 1x1 shortcut weight); in = conv1's output, res1 = the block's input,
                                 both [B][H][W][cin], stats = the norm's (mu, scale, shift); 32 -> 64 channels at W = 16, 64 -> 64 at W = 8,
-                                H a multiple of 16; SBC_CONV_F16X2 only (csrc/conv_down.hip)                                           */
+                                H a multiple of 16; SBC_CONV_F16X2 only (csrc/conv_down.hip).  Calibration only (no kernel reads them, NULL is
+                                fine): weight / weight_wino_split = the UNPOOLED direct (sbc_pack_conv_weight_f16x2) and Winograd f16x2 forms of the
+                                3x3 layer, weight_wino = the unpooled direct f16x2 form of the 1x1 shortcut -- sbc_f16x2_calibrate writes the two
+                                layers' activation scales into those trailers too (a host that binds the same weight buffer at a size where the
+                                block is not down-fusable runs the unfused launches with the same scales)                                  */
     SBC_OP_CHAIN = 24        /* (ABI 13) a CHAIN of RCU blocks, CRP blocks and ResidualBlocks in ONE launch, for the low
                                 resolution levels (8 x 2 samples of 64 or 128 channels, 16 x 4 samples of 64, 32 x 8 samples of 32 or
                                 64; layers.py:76-83,126-134,234-249,443-456): a workgroup owns eight (four, one or two) samples, the
@@ -513,6 +517,26 @@ int sbc_debug_complex_normal(uint64_t seed, int64_t traj, int32_t step, int32_t 
 
 /* scratch floats SBC_OP_CONV_WGRAD / END_CONV_BWD / BEGIN_CONV_BWD need in `aux` for this shape */
 int64_t sbc_wgrad_scratch_floats(int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t ksize);
+
+/* ---- Environment variables -------------------------------------------------------------------------------------------------
+ * Everything the library (csrc/) and the Python host (score_based_channels_amd/) read from the environment, in ONE place.  None of them
+ * changes a result: they select between launch plans / kernel variants that compute the same sums (A/B timing aids, each verified
+ * bit-identical or within the stated tolerance by tests/), or configure the process (library path, distributed backend).  The
+ * torchrun variables RANK / WORLD_SIZE / LOCAL_RANK are read by shard.py.  tests/test_host_logic.py::test_documented_environment_variables
+ * holds this list to the getenv / os.environ sites of the tree.
+ *
+ *   process:    SBC_LIB_PATH (another build of this library), SBC_DIST_BACKEND (nccl | gloo; gloo lets several ranks share one GPU),
+ *               SBC_DIST_TIMEOUT_S (bench.py: process-group timeout), SBC_CPU_BASELINE_WORKERS (bench.py: worker count of the cpu_baseline leg)
+ *   streams:    SBC_PERSIST_CUS (grid width of the persistent kernels, overrides sbc_plan_set_persistent_cus), SBC_NO_BALANCED_GRID,
+ *               SBC_STREAM_SMALL_PX, SBC_STREAM_LAG_MIN_STEPS, SBC_NO_STREAM_LAG, SBC_LAG_RECORDS (driver.run_concurrently / ald.py),
+ *               SBC_NO_SKIP_OVERLAP, SBC_SKIP_OVERLAP_MAX_T (scorenet.py: the small-batch plan with the skip branches on a side stream)
+ *   plan:       SBC_NO_CONV_DOWN, SBC_NO_CHAIN, SBC_NO_CHAIN4, SBC_NO_CHAIN8, SBC_NO_CHAIN8_CRP, SBC_CHAIN8_RES, SBC_NO_END_SELF,
+ *               SBC_NO_RES_BLOCK, SBC_NO_CONV_POOL (plan.py: the unfused record sequence instead of the named fused record),
+ *               SBC_NO_CALIB (scorenet.py: f16x2 activation scales stay 1)
+ *   kernels:    SBC_NO_PAIR_P3, SBC_NO_PAIR_ROLL, SBC_PAIR_ROLL_MIN_TILES (conv_pair.hip), SBC_DP_WGS, SBC_NO_CONV_DP, SBC_NO_CONV_DP32
+ *               (conv_dp.hip), SBC_TILE (conv_x3.hip, conv_mfma.hip), SBC_WX3_MB2 (conv_wx3.hip), SBC_WINO_MB1, SBC_NO_WINO (conv_wino.hip,
+ *               conv_mfma.hip), SBC_CONV_MODE=f32, SBC_NO_WX3 (conv_mfma.hip), SBC_CHAIN_NW8, SBC_CHAIN_GD (conv_chain.hip)
+ */
 
 #ifdef __cplusplus
 }

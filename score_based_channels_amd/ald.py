@@ -214,7 +214,8 @@ class AldBatch:
         return n
 
     def run_leading(self, n_steps, head_done, width=0):
-        """``run(n_steps)`` for the FIRST of two concurrent sub-batch streams: the head of the first step at full grid width, then
+        """``run(n_steps)`` for the FIRST of two concurrent sub-batch streams: the head of the first step at the process-default grid width
+        (``set_persistent_cus(0)``: every CU unless ``sbc_set_persistent_cus`` / ``SBC_PERSIST_CUS`` say otherwise), then
         ``head_done()`` (the caller records the event the following stream waits for), then everything else at ``width`` CUs."""
         n = self._check_steps(n_steps)
         head, rest = self._cut_step()
@@ -247,7 +248,8 @@ class AldBatch:
         self._done += n
 
     def set_persistent_cus(self, n):
-        """Grid width (CUs) of the persistent kernels of THIS batch's launches, 0 = all CUs (``sbc_plan_set_persistent_cus``: a
+        """Grid width (CUs) of the persistent kernels of THIS batch's launches, 0 = the process default -- all CUs unless
+        ``sbc_set_persistent_cus`` / ``SBC_PERSIST_CUS`` narrowed it (``sbc_plan_set_persistent_cus``: a
         field of the batch's plans, not process state -- batches on other threads / streams / devices are unaffected)."""
         self._persist = int(n)
         for pl in (self.plan, self.score_plan, self._lag_plan, self._rest_plan):

@@ -365,6 +365,10 @@ int sbc_f16x2_calibrate(const sbc_op* ops, int32_t n_ops, void* stream) {
         } else if (o.kind == SBC_OP_CONV_DOWN) {
             rc = set_trailer(o.weight_split, 16, o.cin, o.cout, s1, amax[slot_of[i]]);              // the pooled 3x3 filter (4x4 taps)
             if (!rc) rc = set_trailer(o.weight2_split, 4, o.cin, o.cout, s2, amax[slot_of[i] + 1]);   // the pooled 1x1 shortcut (2x2 taps)
+            // ... and the layers' UNPOOLED forms, which the unfused launches of another array size read (include/sbc_hip.h: SBC_OP_CONV_DOWN)
+            if (!rc) rc = set_trailer(o.weight, 9, o.cin, o.cout, s1, amax[slot_of[i]]);
+            if (!rc) rc = set_trailer(o.weight_wino_split, 16, o.cin, o.cout, s1, amax[slot_of[i]]);
+            if (!rc) rc = set_trailer(o.weight_wino, 1, o.cin, o.cout, s2, amax[slot_of[i] + 1]);
         } else if (o.kind == SBC_OP_CONV_PAIR || o.kind == SBC_OP_RES_BLOCK) {
             rc = set_trailer(o.weight_split, 9, o.cin, o.cout, s1, amax[slot_of[i]]);
             if (!rc) rc = set_trailer(o.weight_wino_split, 16, o.cin, o.cout, s1, amax[slot_of[i]]);

@@ -283,12 +283,9 @@ class ScoreNet:
                                step=_ptr(step) if step is not None else None)
         ops = []
         keep = []                                                            # ext structs the records point at
-        skip_h = int(os.environ.get('SBC_EXP_SKIP_H', '0'))                  # timing experiment only (wrong results): drop a level's records
         for op in pl.ops:
             o = _lib.sbc_op()
             shape = op.geom if op.geom is not None else op.src              # (statistics from tile moments: the image's dims)
-            if skip_h and shape.h == skip_h and op.dst.h == skip_h:
-                continue
             o.kind, o.flags, o.B, o.H, o.W = op.kind, op.flags, B, shape.h, shape.w
             o.flags |= (P.OP_SIDE if op.side else 0) | (P.OP_JOIN if op.join else 0)
             o.cin, o.cout, o.ksize, o.dil, o.tag = shape.c, op.dst.c, op.ksize, op.dil, op.tag
@@ -312,6 +309,11 @@ class ScoreNet:
                 o.ksize, o.dil = 3, 1
                 o.weight_split = _ptr(self._wdev, self._woff[op.weight + '#pool'])
                 o.weight2_split = _ptr(self._wdev, self._woff[op.weight2 + '#pool'])
+                # calibration only (include/sbc_hip.h: SBC_OP_CONV_DOWN): the two layers' unpooled forms, read by the unfused launches
+                # of an array size at which the block is not down-fusable
+                o.weight = _ptr(self._wdev, self._woff[op.weight + '#split'])
+                o.weight_wino_split = wino(op.weight)
+                o.weight_wino = _ptr(self._wdev, self._woff[op.weight2 + '#split'])
                 o.bias2 = _ptr(self._wdev, self._woff[op.bias2])
                 o.flags |= P.CONV_F16X2
             elif op.kind == P.CHAIN:

@@ -30,6 +30,7 @@ def init_distributed(backend=None):
                 backend = os.environ.get('SBC_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
             kw = {'device_id': torch.device('cuda', local)} if backend == 'nccl' else {}
             dist.init_process_group(backend, **kw)
+            _agreement[0] = 0                          # a fresh group, a fresh store: every rank starts the sequence of agreement points anew
         if torch.cuda.is_available() and local >= torch.cuda.device_count():
             if os.environ.get('SBC_DIST_BACKEND') != 'gloo':
                 raise RuntimeError('LOCAL_RANK %d but only %d visible device(s): launch one rank per GPU (or set '
@@ -43,32 +44,56 @@ class PeerFailure(RuntimeError):
     collective until the process-group timeout."""
 
 
-def _flag_all_reduce(value):
-    import torch
-    import torch.distributed as dist
-    dev = 'cpu'
-    if dist.get_backend() == 'nccl':
-        dev = torch.device('cuda', torch.cuda.current_device())
-    t = torch.tensor([int(value)], dtype=torch.int32, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return int(t.item())
+# Agreement points without a collective (ADVICE r5): the process group's key-value store (the TCPStore every torchrun job has)
+# carries one arrival counter per agreement point and one failure key.  A failing rank only WRITES -- it never waits for anybody,
+# wherever it failed (before the first agreement point, between the last one and the gathers, while rank 0 writes its result file)
+# -- and a healthy rank polls: everybody arrived -> go on; failure key present -> PeerFailure.  No all-reduce that a dead peer
+# leaves unmatched, nothing for the RCCL watchdog to time out on.
+_POLL_S = 0.005
+_agreement = [0]          # index of this rank's next agreement point (every rank walks the same sequence)
+
+
+def _store():
+    from torch.distributed import distributed_c10d as c10d
+    return c10d._get_default_store()
+
+
+def _peer_timeout_s():
+    return float(os.environ.get('SBC_DIST_TIMEOUT_S', '300'))
 
 
 def check_peers(world, where=''):
-    """Agreement point in front of every collective of the CLIs: an all-reduce (MAX) of an error flag.  A rank that failed since
-    the last agreement point does not arrive here -- its handler (``report_failure``) contributes 1 to this very all-reduce instead
-    -- and every healthy rank raises ``PeerFailure`` rather than entering a gather the failed rank will never join."""
-    if world > 1 and _flag_all_reduce(0):
-        raise PeerFailure('another rank failed before %s; stopping this rank too' % (where or 'the next collective'))
+    """Agreement point in front of every collective of the CLIs.  A rank that failed since the last agreement point does not arrive
+    here -- its handler (``report_failure``) sets the failure key instead -- and every healthy rank raises ``PeerFailure`` rather than
+    entering a gather the failed rank will never join.  A peer that neither arrives nor reports within ``SBC_DIST_TIMEOUT_S``
+    (default 300 s) counts as failed."""
+    if world <= 1:
+        return
+    import time
+    st = _store()
+    k = _agreement[0]
+    _agreement[0] += 1
+    key = 'sbc/arrived/%d' % k
+    st.add(key, 1)
+    deadline = time.monotonic() + _peer_timeout_s()
+    while True:
+        if st.check(['sbc/failed']):
+            raise PeerFailure('another rank failed before %s; stopping this rank too' % (where or 'the next collective'))
+        if int(st.add(key, 0)) >= world:
+            return
+        if time.monotonic() > deadline:
+            raise PeerFailure('a peer did not reach the agreement point before %s within %.0f s' % (where or 'the next collective', _peer_timeout_s()))
+        time.sleep(_POLL_S)
 
 
 def report_failure(world):
-    """The failing rank's half of ``check_peers``: contributes 1 to the agreement all-reduce its peers are waiting in (or will
-    reach).  Call once, from the handler of whatever exception ended this rank's work; never for a ``PeerFailure``."""
+    """The failing rank's half of ``check_peers``: sets the failure key its peers poll at their next agreement point.  Never blocks,
+    so it is safe wherever the failure happened (also after the last collective).  Call once, from the handler of whatever
+    exception ended this rank's work; never for a ``PeerFailure``."""
     if world > 1:
         try:
-            _flag_all_reduce(1)
-        except Exception:                                  # the group itself is gone: nothing more to tell anybody
+            _store().set('sbc/failed', '1')
+        except Exception:                                  # the store itself is gone: nothing more to tell anybody
             pass
 
 

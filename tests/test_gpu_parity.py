@@ -906,23 +906,24 @@ def test_cli_several_test_profiles_are_one_sharded_list(tmp_path, monkeypatch):
 
 def test_cli_rank_failure_ends_every_rank_quickly(tmp_path):
     """A rank that raises before the final gather must not leave the others in the all_gather until the 300 s collective timeout
-    (shard.run_guarded / check_peers): SBC_TEST_FAIL_RANK makes rank 1 raise inside its run; the job exits non-zero within seconds."""
+    (shard.run_guarded / check_peers): tests/failing_rank_cli.py wraps the CLI so that rank 1 raises inside its run (no hook in the
+    product for this); the job exits non-zero within seconds."""
     import os
     import subprocess
     import sys
     import time
     from conftest import ROOT
-    env = dict(os.environ, PYTHONPATH=ROOT, SBC_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', SBC_TEST_FAIL_RANK='1')
+    env = dict(os.environ, PYTHONPATH=ROOT, SBC_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
         env.pop(k, None)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29761', '-m', 'score_based_channels_amd.test_score', '--synthetic', '--synthetic_weights', '2024',
+           '--master-port', '29761', os.path.join(ROOT, 'tests', 'failing_rank_cli.py'), '1', '--synthetic', '--synthetic_weights', '2024',
            '--num_channels', '2', '--levels_stride', '2310', '--seed', '1', '--no_plot']
     t0 = time.time()
     r = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
     assert time.time() - t0 < 150, 'the healthy rank waited for the collective timeout'
-    assert 'SBC_TEST_FAIL_RANK' in r.stderr and 'PeerFailure' in r.stderr
+    assert 'fails before the gather, on request' in r.stderr and 'PeerFailure' in r.stderr
 
 
 @pytest.mark.parametrize('mode', ['f16x2', 'bf16x3'])
@@ -969,6 +970,18 @@ def test_f16x2_scales_do_not_depend_on_which_size_is_bound_first(weights64):
         if form == '#split':
             first = tr
         assert tr[0] == first[0] and tr[0] != 1.0, (form, tr)
+    # the two layers of a CONV_DOWN record (res2.0 / res3.0: pooled 3x3 + pooled 1x1 shortcut) carry their scale in the
+    # pooled forms the fused launch reads AND in the unpooled forms the unfused launches of a non-down-fusable size (128 x 8) read
+    for blk in ('res2.0.', 'res3.0.'):
+        for key, forms in ((blk + 'conv2.conv.weight', (('#pool', 16), ('#split', 9), ('#winograd_split', 16))),
+                           (blk + 'shortcut.conv.weight', (('#pool', 4), ('#split', 1)))):
+            w = sd[key]
+            scales = []
+            for form, taps in forms:
+                off = n1._woff[key + form] + taps * w.shape[0] * w.shape[1]
+                scales.append(float(n1._wdev[off].item()))
+                assert float(n2._wdev[n2._woff[key + form] + taps * w.shape[0] * w.shape[1]].item()) == scales[-1], (key, form)
+            assert len(set(scales)) == 1 and scales[0] != 1.0, (key, scales)
 
 
 def test_persistent_grid_width_is_a_property_of_the_plan(weights64):

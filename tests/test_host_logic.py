@@ -388,3 +388,24 @@ def test_training_plan_covers_every_parameter_exactly_once():
     assert kinds.count(P.INORM_BWD) == 25 and kinds.count(P.MAXPOOL5_BWD) == 12
     assert kinds.count(P.END_CONV_BWD) == 1 and kinds.count(P.BEGIN_CONV_BWD) == 1 and kinds.count(P.UPSAMPLE_BWD) == 5
     assert kinds.count(P.POOL_BWD) == 6
+
+
+def test_documented_environment_variables():
+    """every SBC_* variable the library, the Python host or bench.py reads is listed in ONE place -- the
+    "Environment variables" section of include/sbc_hip.h -- and nothing is listed that nobody reads; the experiment switch that
+    produced wrong results (SBC_EXP_*) and the test hook (SBC_TEST_*) are gone from the product."""
+    import glob
+    import re
+    from conftest import ROOT
+    hdr = open(os.path.join(ROOT, 'include', 'sbc_hip.h')).read()
+    sec = hdr[hdr.index('---- Environment variables'):]
+    documented = set(re.findall(r'\bSBC_[A-Z0-9_]+\b', sec[:sec.index('*/')]))
+    read = set()
+    files = (glob.glob(os.path.join(ROOT, 'score_based_channels_amd', '*.py')) + glob.glob(os.path.join(ROOT, 'score_based_channels_amd', 'csrc', '*.hip'))
+             + glob.glob(os.path.join(ROOT, 'score_based_channels_amd', 'csrc', '*.h')) + [os.path.join(ROOT, 'bench.py')])
+    for f in files:
+        for line in open(f):
+            if 'getenv' in line or 'environ' in line:
+                read.update(re.findall(r'["\'](SBC_[A-Z0-9_]+)["\']', line))
+    assert read == documented, (sorted(read - documented), sorted(documented - read))
+    assert not [v for v in read if v.startswith(('SBC_EXP', 'SBC_TEST'))]

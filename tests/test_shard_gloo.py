@@ -79,3 +79,40 @@ def test_a_failing_rank_stops_the_others_at_the_agreement_point():
     assert res[1][1].startswith('own failure')
     assert max(r[2] for r in res) < 60                       # seconds, not the 300 s collective timeout
     assert not res[0][3] and not res[1][3]                   # both tore their process group down
+
+
+def _late_failing_worker(rank, world, port, q):
+    """rank 0 fails AFTER the last collective (say, while it writes its result file).  Its failure report must not be a
+    collective nobody matches: it returns at once, and the healthy rank -- which has no agreement point left -- finishes normally."""
+    import time
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), SBC_DIST_TIMEOUT_S='60')
+    from score_based_channels_amd import shard
+    r, w, _ = shard.init_distributed('gloo')
+    t0 = time.time()
+
+    def body():
+        shard.check_peers(w, 'the gather of the NMSE logs')
+        got = shard.gather_trajectory_logs(torch.full((2, 3), float(r)), 6, r, w)
+        assert got.shape == (2, 6)
+        if r == 0:
+            raise OSError('rank 0 could not write results.pt')
+        return 'done'
+
+    try:
+        out = shard.run_guarded(w, body)
+    except OSError as e:
+        out = 'own failure: %s' % e
+    q.put((rank, out, time.time() - t0))
+
+
+def test_a_rank_failing_after_the_last_collective_hangs_nobody():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 28600 + os.getpid() % 500
+    procs = [ctx.Process(target=_late_failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=120) for _ in procs)
+    [p.join(60) for p in procs]
+    assert res[0][1].startswith('own failure') and res[1][1] == 'done'
+    assert max(r[2] for r in res) < 30

@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """Fail if the device code of libsbc_hip.so contains packed-fp32 vector arithmetic (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32).
 
-Why: see the CXXFLAGS comment in score_based_channels_amd/csrc/Makefile and DESIGN.md section 9 -- on MI355X two different kernels
-that both issue these instructions corrupt each other's results when they share a SIMD.  The library is built with
--fno-slp-vectorize; this script checks the result instead of trusting the flag: it pulls every gfx950 code object out of the
+Why: a reproducibility precaution, not a measured hardware fault.  The round-2 library lost bit-reproducibility under concurrent
+streams and regained it when it was built without packed-fp32 instructions; a stand-alone reproducer written in round 5
+(tools/experiments/pk_fma_hazard.hip, profiles/r05_pk_fma_hazard.txt: 0 of 1200 concurrent launches differ) did NOT reproduce a
+hardware hazard, so the claim is withdrawn as a statement about MI355X.  -fno-slp-vectorize stays because it
+costs nothing measurable and keeps the one property that was observed; this script checks the build instead of trusting the flag: it
+pulls every gfx950 code object out of the
 clang offload bundles embedded in the shared library and disassembles it with llvm-objdump."""
 import os
 import re
