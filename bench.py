@@ -38,7 +38,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3       # v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2516.6     # v_mfma_f32_32x32x16_bf16 / _f16 dense ("~2.5 PF"), 16x the fp32 MFMA rate
 PEAK_HBM_TBS = 8.0                 # HBM3E spec (6.3 TB/s achievable by a float4 copy)
 STEPS_PER_CHANNEL = 2311 * 3
-PROFILE_ROUND = 'r05'
+PROFILE_ROUND = 'r06'
 REFERENCE_CPU_FILE = os.path.join(ROOT, 'profiles', PROFILE_ROUND + '_reference_cpu.json')   # written by tools/time_reference_cpu.py
 
 
@@ -163,6 +163,9 @@ def parse_args():
     ap.add_argument('--streams', type=int, default=None,
                     help='split the trajectories into this many concurrent sub-batch streams; default: what the CLIs default '
                          'to (config.DEFAULT_STREAMS)')
+    ap.add_argument('--skip-spec', default=None,
+                    help='JSON list of [branch prefix, anchor record prefix, lane] (plan.hoist_skip_branches) for the small-batch plan; '
+                         '"0" = no launch lanes; default: plan.DEFAULT_SKIP_SPEC for batches of at most scorenet.SKIP_OVERLAP_MAX_T trajectories')
     return ap.parse_args()
 
 
@@ -275,7 +278,7 @@ def main():
     from score_based_channels_amd.config import default_config
     from score_based_channels_amd import _lib
     from score_based_channels_amd.config import DEFAULT_CONV_MODE, DEFAULT_STREAMS
-    from score_based_channels_amd.driver import DEFAULT_USE_GRAPH, run_concurrently
+    from score_based_channels_amd.driver import DEFAULT_USE_GRAPH, run_concurrently, stream_count
     from score_based_channels_amd.scorenet import ScoreNet
     from score_based_channels_amd.weights import seeded_state_dict
 
@@ -293,7 +296,8 @@ def main():
                    overlap=None if args.overlap is None else bool(args.overlap),
                    fold_stats=None if args.fold_stats is None else bool(args.fold_stats),
                    fuse_pairs=None if args.fuse_pairs is None else bool(args.fuse_pairs),
-                   fuse_res=None if args.fuse_res is None else bool(args.fuse_res)).load_state_dict(sd)
+                   fuse_res=None if args.fuse_res is None else bool(args.fuse_res),
+                   skip_overlap=None if args.skip_spec is None else False if args.skip_spec == '0' else tuple(tuple(e) for e in json.loads(args.skip_spec))).load_state_dict(sd)
     use_graph = DEFAULT_USE_GRAPH if args.graph is None else bool(args.graph)
     snr = np.arange(-10, 32.5, 2.5)[:nsnr]
 
@@ -313,9 +317,10 @@ def main():
     def make_batches(H, Pm, h_idx, p_idx, ln, a0, be, traj, init, n_streams=1):
         """The trajectory list as `n_streams` AldBatch objects (independent sub-batches on their own HIP streams)."""
         alds, streams = [], []
+        n_streams = stream_count(net, len(h_idx), nt, nr, n_streams)      # (small chunks: one batch with launch lanes, as the CLIs run them)
         for part in np.array_split(np.arange(len(h_idx)), n_streams):
             a = AldBatch(net, H, Pm, h_idx[part], p_idx[part], ln[part], alpha_step=a0[part], beta_noise=be[part],
-                         seed=1234, traj_id=traj[part])
+                         seed=1234, traj_id=traj[part], lanes=None if n_streams == 1 else False)
             a.set_init(init[torch.from_numpy(h_idx[part])])
             a.synthesize_measurements()
             alds.append(a)
@@ -407,7 +412,7 @@ def main():
         run_all(p_alds, p_streams, 2, False)
         chain_tags = tuple(P.TAG_CHAIN + k for k in range(len(P.CHAIN_KERNELS)))
         for tag in (P.TAG_CONV_TOP, P.TAG_PAIR_TOP, P.TAG_POOL_TOP, P.TAG_RES_TOP, P.TAG_CONV_MID, P.TAG_DIRECT_MID) + chain_tags + (P.TAG_DOWN, P.TAG_DOWN + 1):
-            ops = [op for op in net.score_plan(nt, nr).ops if op.tag == tag]
+            ops = [op for op in net.score_plan(nt, nr, T).ops if op.tag == tag]
             if not ops:
                 continue
             pa.rewind()
@@ -495,7 +500,8 @@ def main():
     if world == 1 and not args.no_strong and not big and not args.full_schedule:
         strong_small = {'what': 'ms per Langevin step of rank 0\'s block when the %d trajectories of the default test_score run '
                                 '(BASELINE configs[1]) are sharded over W ranks (shard.my_block), timed on this ONE GPU with the CLI '
-                                'defaults; channels_per_s_if_all_ranks_alike = %d / (6933 x s_per_step): a projection, not a '
+                                'defaults (blocks of at most scorenet.SKIP_OVERLAP_MAX_T trajectories: one batch, skip branches on a launch lane); '
+                                'projection.channels_per_s_if_all_ranks_alike = %d / (6933 x s_per_step) is a PROJECTION, not a '
                                 'multi-GPU measurement' % (T, T), 'by_world_size': {}}
         for w in (2, 4, 8):
             lo, hi = shard.my_block(T, 0, w)
@@ -504,14 +510,33 @@ def main():
                                              sel, init, n_streams)
             Kq = max(5, min(K, 30))
             dtq = timed(q_alds, q_streams, Kq, use_graph, 3)
+            lanes = bool(q_alds[0].uses_lanes)
             for a in q_alds:
                 a.close()
             del q_alds
             strong_small['by_world_size'][str(w)] = {
-                'trajectories_per_gpu': int(hi - lo), 'ms_per_step': dtq / Kq * 1e3, 'steps': Kq,
+                'trajectories_per_gpu': int(hi - lo), 'ms_per_step': dtq / Kq * 1e3, 'steps': Kq, 'streams': len(q_streams), 'launch_lanes': lanes,
                 'channels_per_s_this_gpu': (hi - lo) / (STEPS_PER_CHANNEL * dtq / Kq),
-                'channels_per_s_if_all_ranks_alike': T / (STEPS_PER_CHANNEL * dtq / Kq),
-                'efficiency_vs_one_gpu': (dt / K) / (w * dtq / Kq)}
+                'projection': {'channels_per_s_if_all_ranks_alike': T / (STEPS_PER_CHANNEL * dtq / Kq),
+                               'efficiency_vs_one_gpu': (dt / K) / (w * dtq / Kq)}}
+
+    # ---------------------------------------------------------------- N > 1: BASELINE configs[1] itself STRONG-sharded over the ranks of this
+    # job -- the 1700 trajectories of one default test_score run, shard.my_block per rank, barrier + max over ranks like the headline: a
+    # MEASUREMENT of what `torchrun ... test_score` does with its trajectories on N GPUs (the weak line above gives every rank its own 1700)
+    strong_cfg2 = None
+    if world > 1 and not args.no_strong and not big and not args.full_schedule:
+        lo, hi = shard.my_block(T, rank, world)
+        sel = np.arange(lo, hi)
+        q_alds, q_streams = make_batches(H, Pm, idx[sel], idx[sel], ln[sel], np.full(len(sel), 3e-11), np.full(len(sel), 0.01), sel, init, n_streams)
+        Kq = max(5, min(K, 30))
+        dtq = timed(q_alds, q_streams, Kq, use_graph, 3)
+        strong_cfg2 = {'scaling': 'strong', 'value': T / (STEPS_PER_CHANNEL * dtq / Kq), 'unit': 'channels/s', 'ms_per_step': dtq / Kq * 1e3, 'steps': Kq,
+                       'trajectories_total': T, 'trajectories_per_gpu': int(hi - lo), 'streams': len(q_streams), 'launch_lanes': bool(q_alds[0].uses_lanes),
+                       'workload': 'BASELINE configs[1]: the %d trajectories of ONE default test_score run (100 channels x 17 SNR points), contiguous blocks '
+                                   'per rank (shard.my_block); time = max over ranks between barriers' % T}
+        for a in q_alds:
+            a.close()
+        del q_alds
 
     if rank == 0:
         ms_per_step = dt / K * 1e3
@@ -553,6 +578,7 @@ def main():
             out['sustained_ms_per_step'] = dt_sus / n_sus * 1e3
             out['sustained_value'] = world * T / (STEPS_PER_CHANNEL * dt_sus / n_sus)
             out['sustained_steps'] = n_sus
+            out['config']['sustained_channels_per_s'] = round(out['sustained_value'], 3)
         if other is not None:
             out['other_launch_mode'] = {'mode': 'eager launches' if use_graph else 'hipGraph replay',
                                         'ms_per_step': other / K * 1e3,
@@ -561,8 +587,15 @@ def main():
             out['strong'] = strong
         if strong_small is not None:
             out['strong_small'] = strong_small
+            for w, e in strong_small['by_world_size'].items():          # plain numbers in `config`: what the driver's record keeps
+                out['config']['rank_share_ms_per_step_T%d' % e['trajectories_per_gpu']] = round(e['ms_per_step'], 4)
+        if strong_cfg2 is not None:
+            out['strong_cfg2'] = strong_cfg2
+            out['config']['strong_cfg2_channels_per_s'] = round(strong_cfg2['value'], 3)
+            out['config']['strong_cfg2_ms_per_step'] = round(strong_cfg2['ms_per_step'], 4)
         if exact is not None:
             out['exact_mode'] = exact
+            out['config']['exact_mode_bf16x3_channels_per_s'] = round(exact['value'], 3)
         out['per_rank'] = rank_times
         out['config']['one_stream_ms_per_step'] = one_stream_ms
         if conv_mode == 'f16x2':
@@ -637,7 +670,7 @@ def main():
             fl_cls = klass[dom]['flops_per_step'] / klass[dom]['launches_per_step']
             by_cls = klass[dom]['bytes_per_step'] / klass[dom]['launches_per_step']
             traffic, tsrc = None, None
-            for rnd in (PROFILE_ROUND, 'r04'):
+            for rnd in (PROFILE_ROUND,):       # (a byte count of another round's kernels is not this build's: no fallback)
                 tfile = os.path.join(ROOT, 'profiles', '%s_traffic_%s.json' % (rnd, args.workload))
                 if not os.path.exists(tfile):
                     continue

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SBC_ABI_VERSION 13
+#define SBC_ABI_VERSION 14
 
 typedef enum sbc_status {
     SBC_OK = 0,
@@ -223,7 +223,17 @@ typedef struct sbc_op {
                                     record reads it (nor `weight_wino_split` there): sbc_f16x2_calibrate writes the layer's activation
                                     scale into the trailer of EVERY form it is handed, so that a host which shares one weight buffer
                                     between array sizes -- fused at one, unfused Winograd at another -- finds the same scale in both */
+    /* --- ABI 14: launch lanes of a plan (all zero: the record runs on the run stream in list order, as before) --- */
+    int32_t lane;                /* 0 = the stream handed to sbc_plan_run; 1 .. SBC_MAX_LANES-1 = a stream the plan owns.  Records of one
+                                    lane run in list order; records of different lanes are ordered ONLY by the events below (and by the
+                                    start and the end of an sbc_plan_run call, which every lane is forked from / joined into) */
+    int32_t signal;              /* 0, or an event id 1 .. SBC_MAX_EVENTS: recorded on this record's lane right behind it */
+    int32_t wait[2];             /* 0, or event ids this record's lane waits for in front of it; the id must be signalled by a record
+                                    EARLIER in the list (of the same iteration).  The host that builds the list owns the hazards: a
+                                    record must not write what a concurrently running lane reads or writes (plan.assign_slots) */
 } sbc_op;
+#define SBC_MAX_LANES 4
+#define SBC_MAX_EVENTS 64
 
 /* Training operators.  The reverse of a forward record `y = epi(conv(pro(x)))` is built by the host
  * (score_based_channels_amd/train.py) from these pieces; every tensor is NHWC float32 like its forward counterpart, `grad`
@@ -376,7 +386,9 @@ int sbc_op_launch(const sbc_op* op, void* stream);
 
 /* --- plans ---------------------------------------------------------------------------------------
  * sbc_plan_create copies `ops` (and their `ext` structs); the device buffers they point to must outlive the
- * plan.  sbc_plan_run executes the whole op list `n_iters` times in order on `stream`.  With
+ * plan.  sbc_plan_run executes the whole op list `n_iters` times in order on `stream` -- records with a `lane` (ABI 14) on the
+ * plan's own streams: every lane is forked from `stream` at the start of the call and joined into it at its end (not between
+ * the iterations, where the records' own events order the lanes), so that a caller sees ONE asynchronous unit of work.  With
  * use_graph != 0 the op list is captured once into a hipGraph (on first use for that stream) and replayed;
  * this is legal because nothing in a plan depends on host state -- step-dependent scalars are read from
  * device tables through the device step counter. */

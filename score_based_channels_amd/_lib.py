@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SBC_LIB_PATH') or os.path.join(_HERE, 'libsbc_hip.so')   # env override: A/B builds (tools/)
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 EXPORTS = ('sbc_abi_version', 'sbc_set_persistent_cus', 'sbc_last_error', 'sbc_device_count', 'sbc_op_launch', 'sbc_plan_create',
            'sbc_plan_run', 'sbc_plan_set_persistent_cus', 'sbc_plan_destroy', 'sbc_plan_profile', 'sbc_plan_profile_read',
@@ -39,7 +39,9 @@ class sbc_op(C.Structure):
                 ('weight2_split', C.c_void_p),
                 ('calib', C.c_void_p),                # ABI 11: NULL (set by sbc_f16x2_calibrate on its own copies)
                 ('bias2', C.c_void_p), ('norm2', C.c_void_p),   # ABI 12: RES_BLOCK (second convolution's bias, second norm's alpha|gamma|beta)
-                ('weight2_wino_split', C.c_void_p)]             # ABI 13: calibration only (every form of a layer gets the same scale)
+                ('weight2_wino_split', C.c_void_p),             # ABI 13: calibration only (every form of a layer gets the same scale)
+                # ABI 14: launch lanes of a plan (0 = the run stream), event ids recorded behind / waited for in front of the record
+                ('lane', C.c_int32), ('signal', C.c_int32), ('wait', C.c_int32 * 2)]
 
 
 class sbc_endconv(C.Structure):

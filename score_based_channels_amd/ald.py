@@ -62,10 +62,11 @@ class AldBatch:
     level (test_score.py:56).  Noise: ``seed`` keys the in-kernel Philox stream of trajectory ``traj_id[t]``
     (independent of batching / world size); pass ``step_noise`` ``[n_steps, T, Nt, Nr]`` complex64 to replay
     externally drawn noise instead (parity runs; fewer rows than ``n_steps`` are allowed when the run stops early).
+    ``lanes``: the score plan with launch lanes (small batches; ``ScoreNet.bind``), default by batch size.
     """
 
     def __init__(self, net, Htrue, P_pilots, h_index, p_index, local_noise, alpha_step=3e-11, beta_noise=0.01,
-                 levels=None, steps_each=3, seed=0, traj_id=None, step_noise=None, dc_boost=1.0):
+                 levels=None, steps_each=3, seed=0, traj_id=None, step_noise=None, dc_boost=1.0, lanes=None):
         dev = net.device
         self.net = net
         self.H = _as_c64(Htrue, dev)
@@ -111,9 +112,11 @@ class AldBatch:
                 raise ValueError('step_noise must be [k <= n_steps=%d, T=%d, Nt, Nr] (rows = steps that will be run)'
                                  % (self.n_steps, T))
         # score network bound to this batch: its input buffer IS the current estimate X (complex64 view)
+        # (lanes: None = by batch size; a driver that splits a chunk into concurrent sub-batches passes False for them)
         self.bound = net.bind(T, self.nt, self.nr, step=self.d_step, sigma_of_step=self.d_sigma_of_step,
-                              use_labels=False)
+                              use_labels=False, lanes=lanes)
         self.X = torch.view_as_complex(self.bound.x)                    # [T, Nt, Nr] complex64, in place
+        self.uses_lanes = any(op.lane or op.signal for op in self.bound.plan.ops)     # small batches: skip branches on launch lanes
         self._lang = _lib.sbc_langevin(
             X=_ptr(self.bound.x), score=_ptr(self.bound.out), P=_ptr(torch.view_as_real(self.P)),
             p_index=_ptr(self.d_pidx), Y=_ptr(torch.view_as_real(self.Y)), Htrue=_ptr(torch.view_as_real(self.H)),
@@ -196,7 +199,9 @@ class AldBatch:
     # throw-away evaluation (round 4 ran 0.45 of a score evaluation for nothing per call, 2 % of a 20-step call).
     def _cut_step(self):
         if self._lag_plan is None:
-            names = [op.name for op in self.net.score_plan(self.nt, self.nr).ops]
+            if self.uses_lanes:
+                raise RuntimeError('a plan with launch lanes is not cut into a leading and a following part (events would cross the cut)')
+            names = [op.name for op in self.bound.plan.ops]
             k = next((i for i, nm in enumerate(names) if nm.startswith('refine31.')), len(names) // 2)
             k = int(os.environ.get('SBC_LAG_RECORDS', k))        # (A/B aid: where the cut is)
             k = min(max(k, 1), len(self._step_ops) - 1)

@@ -156,6 +156,11 @@ struct sbc_plan {
     // side stream for ops flagged SBC_OP_SIDE (created on first use; forked from / joined into the run stream by events)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // launch lanes (sbc_op.lane / signal / wait, ABI 14): streams and events the plan owns, created by sbc_plan_create when a record asks
+    hipStream_t lanes[SBC_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t lane_evt[SBC_MAX_EVENTS + 1] = {};
+    hipEvent_t ev_begin = nullptr, ev_lane_end[SBC_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    bool uses_lanes = false;
     // per-tag timing
     int prof_tag = -1;
     std::vector<hipEvent_t> ev_pool;     // pairs
@@ -185,11 +190,33 @@ static int join_side(sbc_plan* plan, hipStream_t s) {
     return SBC_OK;
 }
 
+// Lanes: every lane of the plan starts behind what `s` holds at the start of an sbc_plan_run call ...
+static int fork_lanes(sbc_plan* plan, hipStream_t s) {
+    if (!plan->uses_lanes) return SBC_OK;
+    SBC_CHECK_HIP(hipEventRecord(plan->ev_begin, s));
+    for (int l = 1; l < SBC_MAX_LANES; ++l)
+        if (plan->lanes[l]) SBC_CHECK_HIP(hipStreamWaitEvent(plan->lanes[l], plan->ev_begin, 0));
+    return SBC_OK;
+}
+// ... and `s` continues behind every lane at its end
+static int join_lanes(sbc_plan* plan, hipStream_t s) {
+    if (!plan->uses_lanes) return SBC_OK;
+    for (int l = 1; l < SBC_MAX_LANES; ++l)
+        if (plan->lanes[l]) {
+            SBC_CHECK_HIP(hipEventRecord(plan->ev_lane_end[l], plan->lanes[l]));
+            SBC_CHECK_HIP(hipStreamWaitEvent(s, plan->ev_lane_end[l], 0));
+        }
+    return SBC_OK;
+}
+
 static int run_eager(sbc_plan* plan, hipStream_t s) {
     bool side_busy = false;
     bool main_moved = true;          // the run stream has had work queued since the side stream last forked from it
     for (auto& po : plan->ops) {
         hipStream_t os = s;                              // the stream this op runs on
+        if (po.op.lane > 0) os = plan->lanes[po.op.lane];
+        for (int w = 0; w < 2; ++w)
+            if (po.op.wait[w] > 0) SBC_CHECK_HIP(hipStreamWaitEvent(os, plan->lane_evt[po.op.wait[w]], 0));
         if (po.op.flags & SBC_OP_SIDE) {
             if (!plan->side) {
                 SBC_CHECK_HIP(hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking));
@@ -236,6 +263,7 @@ static int run_eager(sbc_plan* plan, hipStream_t s) {
             SBC_CHECK_HIP(hipEventRecord(plan->ev_pool[plan->ev_used + 1], os));
             plan->ev_used += 2;
         }
+        if (po.op.signal > 0) SBC_CHECK_HIP(hipEventRecord(plan->lane_evt[po.op.signal], os));
     }
     if (side_busy) return join_side(plan, s);            // never return with side work the run stream does not wait for
     return SBC_OK;
@@ -300,6 +328,7 @@ int sbc_f16x2_calibrate(const sbc_op* ops, int32_t n_ops, void* stream) {
     for (int i = 0; i < n_ops; ++i) {
         run[i].B = 1;                                       // the first sample of every buffer
         run[i].flags &= ~(SBC_OP_SIDE | SBC_OP_JOIN);
+        run[i].lane = run[i].signal = run[i].wait[0] = run[i].wait[1] = 0;        // the pass runs every record in list order on `stream`
         if ((run[i].flags & SBC_CONV_F16X2) && (run[i].kind == SBC_OP_CONV || run[i].kind == SBC_OP_CONV_PAIR || run[i].kind == SBC_OP_CONV_POOL ||
                                                   run[i].kind == SBC_OP_RES_BLOCK || run[i].kind == SBC_OP_CONV_DOWN)) {
             slot_of[i] = n_slots;
@@ -420,6 +449,41 @@ int sbc_plan_create(const sbc_op* ops, int32_t n_ops, sbc_plan** out_plan) {
         else if (po.op.kind == SBC_OP_LANGEVIN) rc = launch_langevin(po.op, po.ext.lang, nullptr, true);
         if (rc) { delete plan; return rc; }
     }
+    // launch lanes (ABI 14): validate the records' lane / event fields, create the streams and events they name
+    {
+        bool signalled[SBC_MAX_EVENTS + 1] = {};
+        auto bad = [&](const char* what, int i, int v) { set_error("sbc_plan_create: op %d: %s %d", i, what, v); sbc_plan_destroy(plan); return SBC_ERR_INVALID; };
+        for (int i = 0; i < n_ops; ++i) {
+            const sbc_op& o = plan->ops[i].op;
+            if (o.lane < 0 || o.lane >= SBC_MAX_LANES) return bad("lane out of range:", i, o.lane);
+            if (o.signal < 0 || o.signal > SBC_MAX_EVENTS) return bad("signal id out of range:", i, o.signal);
+            if ((o.flags & (SBC_OP_SIDE | SBC_OP_JOIN)) && (o.lane || o.signal || o.wait[0] || o.wait[1])) return bad("SBC_OP_SIDE / SBC_OP_JOIN and lanes do not mix, lane", i, o.lane);
+            for (int w = 0; w < 2; ++w) {
+                if (o.wait[w] < 0 || o.wait[w] > SBC_MAX_EVENTS) return bad("wait id out of range:", i, o.wait[w]);
+                if (o.wait[w] > 0 && !signalled[o.wait[w]]) return bad("waits for an event no earlier record signals:", i, o.wait[w]);
+            }
+            if (o.signal > 0) signalled[o.signal] = true;
+            if (o.lane > 0 || o.signal > 0) plan->uses_lanes = true;
+        }
+        if (plan->uses_lanes) {
+            auto hip_fail = [&](hipError_t e) { set_error("sbc_plan_create: lanes: %s", hipGetErrorString(e)); sbc_plan_destroy(plan); return SBC_ERR_HIP; };
+            // (no timing, no system-scope fence: the events order launches of ONE device; its kernels' own agent-scope release / acquire
+            // make their results visible to each other.  Measured: the same step time with plain hipEventDisableTiming events)
+            const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
+            hipError_t e = hipEventCreateWithFlags(&plan->ev_begin, evf);
+            if (e != hipSuccess) return hip_fail(e);
+            for (int i = 0; i < n_ops; ++i) {
+                const sbc_op& o = plan->ops[i].op;
+                if (o.lane > 0 && !plan->lanes[o.lane]) {
+                    // (stream priorities -1 / +1 for the lane and persistent-grid widths of 64 - 192 CUs for its launches were measured:
+                    // no effect on the step -- profiles/r06_skip_lanes.txt)
+                    if ((e = hipStreamCreateWithFlags(&plan->lanes[o.lane], hipStreamNonBlocking)) != hipSuccess) return hip_fail(e);
+                    if ((e = hipEventCreateWithFlags(&plan->ev_lane_end[o.lane], evf)) != hipSuccess) return hip_fail(e);
+                }
+                if (o.signal > 0 && !plan->lane_evt[o.signal] && (e = hipEventCreateWithFlags(&plan->lane_evt[o.signal], evf)) != hipSuccess) return hip_fail(e);
+            }
+        }
+    }
     *out_plan = plan;
     return SBC_OK;
 }
@@ -429,18 +493,20 @@ int sbc_plan_run(sbc_plan* plan, void* stream, int32_t n_iters, int32_t use_grap
     hipStream_t s = (hipStream_t)stream;
     PersistentCusScope width(plan->persistent_cus);
     if (!use_graph || plan->prof_tag >= 0) {
-        for (int it = 0; it < n_iters; ++it) {
-            const int rc = run_eager(plan, s);
-            if (rc) return rc;
-        }
-        return SBC_OK;
+        if (n_iters == 0) return SBC_OK;
+        int rc = fork_lanes(plan, s);
+        for (int it = 0; it < n_iters && !rc; ++it) rc = run_eager(plan, s);
+        const int rj = join_lanes(plan, s);              // also after a failed launch: never return with lane work `s` does not wait for
+        return rc ? rc : rj;
     }
     SBC_REQUIRE(s != nullptr, "sbc_plan_run: graph replay needs a non-default stream");
     if (!plan->exec || plan->graph_stream != s) {
         if (plan->exec) { (void)hipGraphExecDestroy(plan->exec); plan->exec = nullptr; }
         hipGraph_t graph = nullptr;
         SBC_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-        const int rc = run_eager(plan, s);
+        int rc = fork_lanes(plan, s);                    // (lanes join the capture through the events they wait for)
+        if (!rc) rc = run_eager(plan, s);
+        { const int rj = join_lanes(plan, s); if (!rc) rc = rj; }
         const hipError_t e = hipStreamEndCapture(s, &graph);
         if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
         SBC_CHECK_HIP(e);
@@ -469,6 +535,12 @@ void sbc_plan_destroy(sbc_plan* plan) {
     if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
     if (plan->ev_join) (void)hipEventDestroy(plan->ev_join);
     if (plan->side) (void)hipStreamDestroy(plan->side);
+    if (plan->ev_begin) (void)hipEventDestroy(plan->ev_begin);
+    for (int l = 1; l < SBC_MAX_LANES; ++l) {
+        if (plan->ev_lane_end[l]) (void)hipEventDestroy(plan->ev_lane_end[l]);
+        if (plan->lanes[l]) { (void)hipStreamSynchronize(plan->lanes[l]); (void)hipStreamDestroy(plan->lanes[l]); }
+    }
+    for (hipEvent_t e : plan->lane_evt) if (e) (void)hipEventDestroy(e);
     delete plan;
 }
 

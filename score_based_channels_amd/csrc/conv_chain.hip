@@ -112,6 +112,8 @@ __host__ __device__ constexpr int chain_samples(int C, int W, int NW) {
 //          statistics and the max pool's boundary rows cross the two waves of a sample through LDS;  C = 64, G = 1: wave = (cb, half);  C = 32, G = 2: wave = (cb, sample, half).
 // GD = 2 (W = 2 only): HALF the samples per workgroup (four at 128 channels, two at 64) -- twice the workgroups for batches that would
 // leave most of the chip idle otherwise (a launch of 425 samples is 54 workgroups of eight); the same sums in the same order.
+// GD = 4 (128 channels): a QUARTER -- two samples, one unit pair per wave -- for a rank's share of a sharded run (213 samples: 107
+// workgroups instead of 54; a convolution's time is its filter stream + barriers either way, half the matrix work per workgroup).
 template <int C, int W, int NW, int GD = 1>
 __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
     constexpr int H = W == 2 ? 8 : W == 4 ? 16 : 32;
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
     static_assert(NW % NCB == 0 && NHALF >= 1, "a wave owns one 16-output-channel block");
     // samples per workgroup: every unit group of waves takes 8 units (4 at W = 2, C = 64)
     constexpr int G = chain_samples(C, W, NW) / GD;
-    static_assert(GD == 1 || (GD == 2 && W == 2), "half groups exist at a width of two");
+    static_assert(GD == 1 || (GD == 2 && W == 2) || (GD == 4 && W == 2 && C == 128), "half groups exist at a width of two, quarter groups at 128 channels");
     constexpr int NTH = 64 * NW;
     constexpr int SPU = W == 2 ? 2 : 1;                   // samples per unit
     constexpr int NSG = W == 8 ? 1 : G / SPU / NHALF;     // sample groups (pairs at W = 2, samples at W = 4, half samples at W = 8) per wave
@@ -588,8 +590,14 @@ int launch_chain(const sbc_op& op, const sbc_chain& c, hipStream_t stream, bool 
     const int avail = persistent_cus(cus);
     if (op.cin == 128) {
         const bool half = force_gd ? force_gd == 2 : 2 * ((op.B + 7) / 8) <= avail;
-        if (dry) { const int rc = launch_chain_t<128, 2, 8, 2>(p, stream, true); if (rc) return rc; return launch_chain_t<128, 2, 8>(p, stream, true); }
-        return half ? launch_chain_t<128, 2, 8, 2>(p, stream, dry) : launch_chain_t<128, 2, 8>(p, stream, dry);
+        // quarter groups while they occupy at most half of the CUs (213 samples: 107 workgroups, -2 % per step; 425 samples: 213 workgroups, +3 %: half groups)
+        const bool quarter = force_gd ? force_gd == 4 : (op.B + 1) / 2 <= avail / 2;
+        if (dry) {
+            int rc = launch_chain_t<128, 2, 8, 4>(p, stream, true);
+            if (!rc) rc = launch_chain_t<128, 2, 8, 2>(p, stream, true);
+            return rc ? rc : launch_chain_t<128, 2, 8>(p, stream, true);
+        }
+        return quarter ? launch_chain_t<128, 2, 8, 4>(p, stream, dry) : half ? launch_chain_t<128, 2, 8, 2>(p, stream, dry) : launch_chain_t<128, 2, 8>(p, stream, dry);
     }
     if (nw8) return launch_chain_t<64, 2, 8>(p, stream, dry);
     const bool half = force_gd ? force_gd == 2 : 2 * ((op.B + 3) / 4) <= 2 * avail;      // (two 4-wave workgroups per CU)

@@ -69,6 +69,18 @@ def batch_limit(net, nt, nr, requested, reserve=0.25):
     return max(1, min(int(requested), by_mem, by_index))
 
 
+def stream_count(net, T, nt, nr, requested=None):
+    """Sub-batch streams for a lock-step chunk of ``T`` trajectories: the requested count (default ``config.DEFAULT_STREAMS``), except
+    that a chunk small enough for the plan with launch lanes (``ScoreNet.skip_overlap_for``: a rank's share of a sharded test_score
+    run) stays ONE batch -- its low-resolution launches are latency-bound, halving the batch does not shorten them, and the skip
+    branches already fill the idle CUs from a lane of the same plan (213 trajectories: 1.06 ms per step sequential, 1.15 as two
+    sub-batches, 0.98 with lanes; 425: 1.60 / 1.55 / 1.47)."""
+    n = DEFAULT_STREAMS if requested is None else max(1, int(requested))
+    if n > 1 and getattr(net, 'skip_overlap_for', None) is not None and net.skip_overlap_for(int(T), nt, nr):
+        return 1
+    return n
+
+
 def run_concurrently(batches, streams, n_steps, use_graph=False):
     """Advance several ``AldBatch`` objects by ``n_steps`` each, every one on its own HIP stream and fed by its own host
     thread.  A Langevin step is ~150 dependent launches, many of them (the 8x2 / 16x4 levels) with fewer workgroups than the
@@ -97,7 +109,7 @@ def run_concurrently(batches, streams, n_steps, use_graph=False):
     # ... and every second stream walks the schedule ~0.45 of a step behind its neighbour (AldBatch.run_leading / run_following: the
     # lag is the head of the leader's first step, run alone; ~4 % of every step after it)
     lag = (not use_graph and small and n_steps >= int(os.environ.get('SBC_STREAM_LAG_MIN_STEPS', '2'))       # (the variable: tests)
-           and not os.environ.get('SBC_NO_STREAM_LAG') and not any(b.net.overlap for b in batches))
+           and not os.environ.get('SBC_NO_STREAM_LAG') and not any(b.net.overlap or b.uses_lanes for b in batches))
     # pair (2j, 2j + 1): two device events (leader's head done; leader done) and the host flags that say they have been RECORDED --
     # a stream that waits for an event nobody has recorded yet does not wait at all
     class _Pair:
@@ -214,8 +226,9 @@ def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, b
     nt, nr = init.shape[-2], init.shape[-1]
     final = torch.zeros(hi - lo, nt, nr, dtype=torch.complex64, device=net.device) if return_final else None
     cur = torch.cuda.current_stream(net.device)
-    streams = [torch.cuda.Stream(net.device) for _ in range(max(1, int(n_streams)))]
     max_batch = batch_limit(net, nt, nr, max_batch)
+    # (a chunk small enough for the launch-lane plan runs as one batch: stream_count)
+    streams = [torch.cuda.Stream(net.device) for _ in range(stream_count(net, min(max_batch, hi - lo), nt, nr, n_streams))]
 
     def run_chunk(use_net, c0, c1):
         running = []
@@ -227,7 +240,7 @@ def run_trajectories(net, Htrue, P, h_index, p_index, local_noise, alpha_step, b
                 sn = None if step_noise is None else torch.from_numpy(np.ascontiguousarray(step_noise[:n_steps, part]))
                 ald = AldBatch(use_net, Htrue, P, h_index[part], p_index[part], local_noise[part], alpha_step[part],
                                beta_noise[part], levels=levels, steps_each=steps_each, seed=seed,
-                               traj_id=traj_id[part], dc_boost=dc_boost, step_noise=sn)
+                               traj_id=traj_id[part], dc_boost=dc_boost, step_noise=sn, lanes=None if len(streams) == 1 else False)
                 ald.set_init(init[torch.from_numpy(init_index[part])])
                 if Y is None:
                     ald.synthesize_measurements(None if meas_noise is None else torch.from_numpy(meas_noise[part]))

@@ -102,6 +102,10 @@ class Op:
     norm_key: Optional[str] = None      # CONV with PRO_NORM_SELF: state_dict prefix of the norm whose (alpha, gamma, beta) `stats` points at
     blocks: Optional[list] = None       # CHAIN: [(CHAIN_RCU | CHAIN_CRP | CHAIN_RES, weight key of conv 1, of conv 2, extra), ...]; extra: None, or for
                                         # a RES block {'bias1', 'bias2', 'norm1', 'norm2', 'dil', 'w3', 'bias3'} (w3 / bias3: shortcut conv or None)
+    # launch lanes (sbc_op.lane / signal / wait, include/sbc_hip.h ABI 14; `hoist_skip_branches`)
+    lane: int = 0                       # 0: the run stream; 1 .. MAX_LANES-1: a stream of the plan
+    signal: int = 0                     # event id recorded behind the record (0: none)
+    wait: tuple = ()                    # event ids the record's lane waits for in front of it (at most two)
 
     def inputs(self):
         return [t for t in (self.src, self.stats, self.res1, self.res2, self.up) if t is not None]
@@ -338,6 +342,69 @@ def down_fusable(h, w, cin, cout):
     return h % 16 == 0 and ((w == 16 and cin == 32 and cout == 64) or (w == 8 and cin == 64 and cout == 64))
 
 
+MAX_LANES, MAX_EVENTS = 4, 64
+
+# The skip branches of the decoder: refineK's adapt convolutions of its FIRST input (the encoder output layerK, layers.py:234-249,
+# ncsnv2.py:284-289) depend on nothing the decoder computes before refineK's MSF convolution adds them.  For small batches -- what a
+# rank holds when the 1700 trajectories of a test_score run are sharded over 4 - 8 GPUs -- the low-resolution launches between the
+# encoder output and that MSF convolution are latency-bound and leave most of the chip idle (213 trajectories: 54 workgroups of the
+# 8 x 2 chain kernel on 256 CUs); the skip branches then run beside them on lanes of their own.  (branch name prefix, the record the
+# branch is issued behind, lane): high-resolution branches start when the main path enters the low-resolution levels, in the order of
+# their lanes' list positions; every record is the same launch with the same arguments as in the sequential plan -- results are
+# identical bit for bit (tests/test_gpu_parity.py::test_skip_overlap_plan_equals_sequential_plan).
+# ONE lane: measured (profiles/r06_skip_lanes.txt) -- two or three lanes are slower than none (every further HIP stream costs more in
+# cross-queue dependencies than its concurrency returns), one lane -8 % per step at 213 and 425 trajectories.
+DEFAULT_SKIP_SPEC = (('refine5.adapt_convs.0.', 'res3.1.', 1), ('refine4.adapt_convs.0.', 'res3.1.', 1), ('refine3.adapt_convs.0.', 'res3.1.', 1),
+                     ('refine31.adapt_convs.0.', 'res31.1.', 1), ('refine2.adapt_convs.0.', 'res4.1.', 1))
+
+
+def hoist_skip_branches(ops, spec=DEFAULT_SKIP_SPEC):
+    """Move every branch of ``spec`` -- the contiguous run of records whose names start with the prefix -- behind the LAST record whose
+    name starts with its anchor, onto its lane: the branch's first record waits for an event the anchor record signals, its last
+    record signals the event its consumer (the first later record that reads the branch's result) waits for.  In place; branches that
+    do not exist in this plan (other fusion settings) are skipped."""
+    next_evt = [max([o.signal for o in ops] + [0]) + 1]
+
+    def signal_of(op):
+        if not op.signal:
+            if next_evt[0] > MAX_EVENTS:
+                raise ValueError('more than %d lane events' % MAX_EVENTS)
+            op.signal = next_evt[0]
+            next_evt[0] += 1
+        return op.signal
+
+    for prefix, anchor, lane in spec:
+        idx = [i for i, o in enumerate(ops) if o.name.startswith(prefix)]
+        if not idx:
+            continue
+        if idx != list(range(idx[0], idx[-1] + 1)) or not 0 < lane < MAX_LANES:
+            raise ValueError('skip branch %r is not one contiguous run of records (or bad lane %d)' % (prefix, lane))
+        branch = ops[idx[0]:idx[-1] + 1]
+        result = branch[-1].dst
+        if any(o.lane or o.side or o.join for o in branch):
+            raise ValueError('skip branch %r is already on a lane' % prefix)
+        anchors = [i for i, o in enumerate(ops) if o.name.startswith(anchor) and i < idx[0]]
+        if not anchors:
+            raise ValueError('anchor %r of skip branch %r not found in front of it' % (anchor, prefix))
+        a = anchors[-1]
+        # the branch reads only tensors that exist at the anchor (its own intermediates aside)
+        made = {id(t) for o in branch for t in o.outputs()}
+        ready = {id(t) for o in ops[:a + 1] for t in o.outputs()} | {id(ops[0].src)}
+        for o in branch:
+            for t in o.inputs():
+                if id(t) not in made and id(t) not in ready:
+                    raise ValueError('skip branch %r reads %s, which record %r does not have yet' % (prefix, t.name, ops[a].name))
+        del ops[idx[0]:idx[-1] + 1]
+        consumer = next(o for o in ops[idx[0]:] if any(t is result for t in o.inputs()))
+        if len(consumer.wait) >= 2:
+            raise ValueError('record %r already waits for two events' % consumer.name)
+        for o in branch:
+            o.lane = lane
+        branch[0].wait = tuple(branch[0].wait) + (signal_of(ops[a]),)
+        consumer.wait = tuple(consumer.wait) + (signal_of(branch[-1]),)
+        ops[a + 1:a + 1] = branch
+
+
 def merge_chains(ops):
     """Adjacent CHAIN records where the second one is the only consumer of the first one's output become ONE record (up to
     CHAIN_MAX_BLOCKS blocks): res5.0 + res5.1 + the whole of refine1, for instance.  In place."""
@@ -401,7 +468,7 @@ def pair_fusable(h, w, c, shapes=PAIR_SHAPES):
 
 
 def build_score_plan(ngf=32, nt=64, nr=16, channels=2, share_slots=True, overlap=False, fold_stats=False, fuse_pairs=False, fuse_res=False,
-                     fuse_chain=False, fuse_down=False, fuse_end=False):
+                     fuse_chain=False, fuse_down=False, fuse_end=False, skip_overlap=None):
     """Op list of one ``NCSNv2Deepest.forward`` for ``[B, 2, nt, nr]`` inputs (ncsnv2.py:269-300).
     ``share_slots=False`` gives every logical tensor its own storage (a training step reads every activation again on
     the way back, ``train.py``)."""
@@ -439,6 +506,10 @@ def build_score_plan(ngf=32, nt=64, nr=16, channels=2, share_slots=True, overlap
         sn = b.stats('normalizer', ref5, 'normalizer', consumer_is_conv=False)
         b.ops.append(Op(END_CONV, 'end_conv', src=ref5, dst=out, weight='end_conv.weight', bias='end_conv.bias', stats=sn))
     merge_chains(b.ops)
+    if skip_overlap:
+        if overlap:
+            raise ValueError('skip_overlap and overlap (SBC_OP_SIDE records) do not mix')
+        hoist_skip_branches(b.ops, DEFAULT_SKIP_SPEC if skip_overlap is True else skip_overlap)
     for op in b.ops:                        # (after the statistics folding, which adds EPI_MOMENTS_OUT to producers)
         if op.tag == TAG_CONV_MID and not op.flags & (PRO_NORM | EPI_UP | EPI_MOMENTS_OUT):
             op.tag = TAG_DIRECT_MID
@@ -461,6 +532,17 @@ def assign_slots(plan):
         if plan.ops[i].join:
             nxt = i
         done_at[i] = nxt if plan.ops[i].side else i
+    # a record on a lane is known to be complete at the first run-stream record that waits for an event which its lane signals at or
+    # behind it (records of one lane run in list order); without one, at the end of the list (sbc_plan_run joins every lane there)
+    for i, op in enumerate(plan.ops):
+        if op.lane:
+            done_at[i] = len(plan.ops) - 1
+            for k in range(i, len(plan.ops)):
+                if plan.ops[k].lane == op.lane and plan.ops[k].signal:
+                    waiters = [m for m in range(k + 1, len(plan.ops)) if plan.ops[m].lane == 0 and plan.ops[k].signal in plan.ops[m].wait]
+                    if waiters:
+                        done_at[i] = waiters[0]
+                        break
     last_use = {}
     for i, op in enumerate(plan.ops):
         for t in op.inputs():

@@ -27,7 +27,8 @@ def _ptr(t, offset_elems=0):
 class BoundScore:
     """A score plan bound to device buffers for a fixed batch size."""
 
-    def __init__(self, ops, x, out, slots, labels, extra_keep):
+    def __init__(self, ops, x, out, slots, labels, extra_keep, plan=None):
+        self.plan = plan            # the plan.ScorePlan the records were made from (record k of ``ops`` is ``plan.ops[k]``)
         self.ops = ops              # list of _lib.sbc_op (ctypes); END_CONV.ext points into ``extra_keep``
         self.x = x                  # float32 [B, Nt, Nr, 2]  (view as complex64 [B, Nt, Nr])
         self.out = out              # float32 [B, Nt, Nr, 2]
@@ -50,6 +51,11 @@ DEFAULT_FUSE_CHAIN = True
 DEFAULT_FUSE_DOWN = True
 # the normalizer's statistics inside the end-convolution launch (SBC_PRO_NORM_SELF on the END_CONV record; csrc/ops.hip: end_conv_self_kernel)
 DEFAULT_FUSE_END = True
+# Small batches (a rank's share when a test_score run is sharded over several GPUs): the decoder's skip branches on launch lanes of
+# their own beside the latency-bound low-resolution launches (plan.hoist_skip_branches; identical results).  Batches of at most this
+# many 64 x 16-equivalent trajectories (B Nt Nr / 1024) take that plan; SBC_SKIP_OVERLAP_MAX_T overrides the number, SBC_NO_SKIP_OVERLAP=1
+# turns the plan off (A/B aids)
+SKIP_OVERLAP_MAX_T = 600
 
 
 class ScoreNet:
@@ -79,7 +85,8 @@ class ScoreNet:
                             ``.half()``, layers.py:179); tolerance stated in tests/test_gpu_parity.py.
     """
 
-    def __init__(self, config, device=None, conv_mode=None, overlap=None, fold_stats=None, fuse_pairs=None, fuse_res=None, fuse_chain=None, fuse_down=None, fuse_end=None):
+    def __init__(self, config, device=None, conv_mode=None, overlap=None, fold_stats=None, fuse_pairs=None, fuse_res=None, fuse_chain=None, fuse_down=None, fuse_end=None,
+                 skip_overlap=None):
         conv_mode = DEFAULT_CONV_MODE if conv_mode is None else conv_mode
         if conv_mode not in CONV_MODES:
             raise ValueError('conv_mode must be one of %s, got %r' % (CONV_MODES, conv_mode))
@@ -103,6 +110,8 @@ class ScoreNet:
         # fuse_end: the normalizer's statistics inside the end-convolution launch (fp32 vector arithmetic in every conv_mode; part of the
         # fused default plan, so tied to fuse_pairs like the others: the unfused plan stays what the bf16x3 re-run of a flagged batch uses)
         self.fuse_end = (DEFAULT_FUSE_END and self.fuse_pairs) if fuse_end is None else bool(fuse_end)
+        # skip_overlap: True (default; plan.DEFAULT_SKIP_SPEC), False, or a spec of plan.hoist_skip_branches -- applied to small batches only
+        self.skip_overlap = True if skip_overlap is None else skip_overlap
         self.config = config
         m, d = config.model, config.data
         if str(m.normalization) != 'InstanceNorm++' or str(m.nonlinearity).lower() != 'elu':
@@ -256,24 +265,36 @@ class ScoreNet:
         return self._plans[key]
 
     # --- binding ----------------------------------------------------------------------------------
-    def score_plan(self, nt, nr):
-        key = (nt, nr)
+    def skip_overlap_for(self, B, nt, nr):
+        """Does a batch of ``B`` ``nt x nr`` arrays take the plan with the skip branches on their own launch lanes?  (``B`` None: no.)"""
+        if B is None or self.overlap or not self.skip_overlap or os.environ.get('SBC_NO_SKIP_OVERLAP'):
+            return False
+        return B * nt * nr <= 1024 * int(os.environ.get('SBC_SKIP_OVERLAP_MAX_T', SKIP_OVERLAP_MAX_T))
+
+    def score_plan(self, nt, nr, B=None, lanes=None):
+        """The launch plan of one score evaluation at ``nt x nr``; ``B`` (the batch it will be bound for) selects the small-batch
+        variant with launch lanes (same records, other order; ``skip_overlap_for``) unless ``lanes`` says so explicitly."""
+        skip = self.skip_overlap_for(B, nt, nr) if lanes is None else (bool(lanes) and bool(self.skip_overlap) and not self.overlap)
+        key = (nt, nr, skip)
         if key not in self._plans:
             fold = self.fold_stats and not (nt & (nt - 1)) and not (nr & (nr - 1))     # conv_wx3 takes power-of-two images
             self._plans[key] = P.build_score_plan(self.ngf, nt, nr, self.channels, overlap=self.overlap, fold_stats=fold,
                                                   fuse_pairs=(P.PAIR_SHAPES_F16W if self.conv_mode == 'f16w' else P.PAIR_SHAPES) if self.fuse_pairs else False,
                                                   fuse_res=self.fuse_res, fuse_chain=self.fuse_chain and not self.overlap,
-                                                  fuse_down=self.fuse_down and not self.overlap, fuse_end=self.fuse_end)
+                                                  fuse_down=self.fuse_down and not self.overlap, fuse_end=self.fuse_end,
+                                                  skip_overlap=(self.skip_overlap if skip else None))
         return self._plans[key]
 
-    def bind(self, B, nt, nr, *, step=None, sigma_of_step=None, use_labels=True):
-        """Allocate buffers for batch ``B`` and translate the plan into ``sbc_op`` records.
+    def bind(self, B, nt, nr, *, step=None, sigma_of_step=None, use_labels=True, lanes=None):
+        """Allocate buffers for batch ``B`` and translate the plan into ``sbc_op`` records.  ``lanes``: take the plan with launch
+        lanes (True) or the sequential one (False); default: by batch size (``skip_overlap_for``) -- a caller that runs several
+        sub-batches side by side passes False (``driver.stream_count``).
         Noise level source of the end conv: per-sample ``labels`` (module-call semantics) or the device step
         counter + ``sigma_of_step`` table (inside an ALD plan)."""
         if self._wdev is None:
             raise RuntimeError('load_state_dict() must be called before the network is used')
         self._ensure_calibrated(nt, nr)
-        pl = self.score_plan(nt, nr)
+        pl = self.score_plan(nt, nr, None if self._calibrating else B, lanes=False if self._calibrating else lanes)
         dev = self.device
         slots = [torch.empty(B * e, dtype=torch.float32, device=dev) for e in pl.slot_elems]
         labels = torch.zeros(B, dtype=torch.int64, device=dev) if use_labels else None
@@ -289,6 +310,9 @@ class ScoreNet:
             o.kind, o.flags, o.B, o.H, o.W = op.kind, op.flags, B, shape.h, shape.w
             o.flags |= (P.OP_SIDE if op.side else 0) | (P.OP_JOIN if op.join else 0)
             o.cin, o.cout, o.ksize, o.dil, o.tag = shape.c, op.dst.c, op.ksize, op.dil, op.tag
+            o.lane, o.signal = op.lane, op.signal
+            for k, e in enumerate(op.wait):
+                o.wait[k] = e
             o.in_ = _ptr(slots[op.src.slot])
             o.out = _ptr(slots[op.dst.slot])
             # (fused records in f16x2 also carry the layers' Winograd forms: no fused kernel reads them, sbc_f16x2_calibrate writes the
@@ -376,7 +400,7 @@ class ScoreNet:
             ops.append(o)
         x = slots[pl.x.slot].view(B, nt, nr, self.channels)
         out = slots[pl.out.slot].view(B, nt, nr, self.channels)
-        return BoundScore(ops, x, out, slots, labels, [ext, self._wdev, self.sigmas, sigma_of_step, step, keep])
+        return BoundScore(ops, x, out, slots, labels, [ext, self._wdev, self.sigmas, sigma_of_step, step, keep], plan=pl)
 
     # --- module call --------------------------------------------------------------------------------
     def __call__(self, x, labels):

@@ -947,8 +947,9 @@ def test_chain_matches_oracle(gpu, Cc, H, W, B, blocks):
 @pytest.mark.parametrize('Cc,blocks', [(128, ('R', 'C')), (128, ('X2', 'S2')), (64, ('C', 'R')), (64, ('S1',))])
 def test_chain_full_and_half_groups_agree(gpu, Cc, blocks):
     """At 8 x 2 the chain kernel exists with eight (four) samples per workgroup and, for batches that would leave most of the chip
-    idle, with half of that (csrc/conv_chain.hip: GD = 2; launch_chain picks by batch size).  2100 samples take the full groups, pieces of
-    300 the half groups: the same sums in the same order -- identical bit for bit -- and the oracle's numbers."""
+    idle, with half of that (csrc/conv_chain.hip: GD = 2; launch_chain picks by batch size) and, at 128 channels, a quarter (GD = 4: two
+    samples).  2100 samples take the full groups, pieces of 700 the half groups, pieces of 300 the quarter (128 channels) / half (64)
+    groups: the same sums in the same order -- identical bit for bit -- and the oracle's numbers."""
     torch, _lib = gpu
     from score_based_channels_amd import plan as P
     from score_based_channels_amd.weights import pack_conv_weight_f16x2
@@ -987,8 +988,10 @@ def test_chain_full_and_half_groups_agree(gpu, Cc, blocks):
         return out.cpu().numpy()
     full = run(dx)
     assert np.isfinite(full).all() and _lib.range_flag() == 0
-    for lo in range(0, B, 300):
+    for lo in range(0, B, 300):                                  # (128 channels: quarter groups since round 6; 64: half groups)
         assert np.array_equal(run(dx[lo:lo + 300].contiguous()), full[lo:lo + 300]), lo
+    for lo in range(0, B, 700):                                  # (half groups at both channel counts)
+        assert np.array_equal(run(dx[lo:lo + 700].contiguous()), full[lo:lo + 700]), lo
     ref = _chain_reference(x[:64], blocks, ws)
     assert rel_err(full[:64], ref) < 3 * TOL
 

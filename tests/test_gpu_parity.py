@@ -751,6 +751,61 @@ def test_overlapped_branches_do_not_change_results(weights64):
         assert torch.equal(ovl(x, labels), ref), rep
 
 
+def test_skip_overlap_plan_equals_sequential_plan(weights64):
+    """Round 6: batches of at most scorenet.SKIP_OVERLAP_MAX_T trajectories run the decoder's skip branches (refineK.adapt_convs.0) on
+    launch lanes of their own (sbc_op.lane / signal / wait, plan.hoist_skip_branches) beside the latency-bound low-resolution launches.
+    Same records, same arguments, other order and streams: bit-identical to the sequential plan -- module call, eager Langevin steps and
+    hipGraph replay -- also when two sub-batches with lanes share the chip, and repeatedly (a race would show as a flicker)."""
+    import torch
+    from score_based_channels_amd import synth
+    from score_based_channels_amd.ald import AldBatch
+    from score_based_channels_amd.driver import run_concurrently
+    from score_based_channels_amd.scorenet import ScoreNet
+    cfg, sd = weights64
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.standard_normal((96, 2, 64, 16)).astype(np.float32))
+    labels = torch.from_numpy(rng.integers(0, 2311, 96))
+    seq = ScoreNet(cfg, skip_overlap=False).cuda().load_state_dict(sd)
+    ovl = ScoreNet(cfg).cuda().load_state_dict(sd)
+    assert not any(o.lane for o in seq.score_plan(64, 16, 96).ops) and not any(o.lane for o in ovl.score_plan(64, 16, 4096).ops)
+    lanes = [o for o in ovl.score_plan(64, 16, 96).ops if o.lane]
+    assert len(lanes) == 6 and {o.name.split('.')[0] for o in lanes} == {'refine2', 'refine31', 'refine3', 'refine4', 'refine5'}
+    ref = seq(x, labels)
+    for rep in range(6):
+        assert torch.equal(ovl(x, labels), ref), rep
+    # Langevin steps: one stream, two sub-batch streams, graph replay
+    T = 192
+    raw = synth.generate_channels('CDL-C', 16, 64, 16, 0.5, 3)
+    H = np.conj(np.transpose(raw / np.std(raw), (0, 2, 1))).astype(np.complex64)
+    Pm = np.conj(np.transpose(synth.qpsk_pilots(np.random.default_rng(1), 16, 64, 38), (0, 2, 1)))
+    idx = np.arange(T) % 16
+    ln = np.repeat(64.0 * 10 ** (-np.arange(-10, 20, 2.5) / 10.), 16)[:T]
+    init = torch.randn(16, 64, 16, dtype=torch.complex64, generator=torch.Generator().manual_seed(2))
+
+    def run(net, parts, graph):
+        alds = []
+        for part in np.array_split(np.arange(T), parts):
+            a = AldBatch(net, H, Pm, idx[part], idx[part], ln[part], levels=[0, 700, 2310], steps_each=3, seed=11, traj_id=part)
+            a.set_init(init[torch.from_numpy(idx[part])])
+            a.synthesize_measurements()
+            alds.append(a)
+        streams = [torch.cuda.Stream() for _ in alds] if parts > 1 else [torch.cuda.current_stream()]
+        run_concurrently(alds, streams, 9, graph)
+        torch.cuda.synchronize()
+        X = torch.cat([a.X for a in alds]).cpu().numpy()
+        L = torch.cat([a.nmse_log() for a in alds], dim=1).cpu().numpy()
+        lanes_used = [a.uses_lanes for a in alds]
+        for a in alds:
+            a.close()
+        return X, L, lanes_used
+    X0, L0, u0 = run(seq, 1, False)
+    assert u0 == [False]
+    for parts, graph in ((1, False), (2, False), (1, True), (2, True), (1, False)):
+        X1, L1, u1 = run(ovl, parts, graph)
+        assert all(u1), (parts, graph)
+        assert np.array_equal(X0, X1) and np.array_equal(L0, L1), (parts, graph)
+
+
 @pytest.mark.parametrize('mode', ['bf16x3', 'f16x2'])
 def test_folded_statistics_match_the_statistics_launches(weights64, mode):
     """``ScoreNet(fold_stats=True)`` (optional): the full-resolution InstanceNorm++ statistics are formed from the tile moments
@@ -1024,14 +1079,14 @@ def test_persistent_grid_width_is_a_property_of_the_plan(weights64):
     assert np.array_equal(outs[32], want) and np.array_equal(outs[200], want)
 
 
-@pytest.fixture(scope='module')
-def trained_state(tmp_path_factory):
-    """The repository's own TRAINED checkpoint (tests/trained_weights.py: 300 optimiser steps of the package's trainer), re-created
-    here on the GPU -- a training step is bit-reproducible -- and checked against the digests in the golden."""
+@pytest.fixture(scope='module', params=[300, 4000])
+def trained_state(request, tmp_path_factory):
+    """The repository's own TRAINED checkpoints (tests/trained_weights.py: 300 and -- round 6 -- 4000 optimiser steps of the package's
+    trainer), re-created here on the GPU -- a training step is bit-reproducible -- and checked against the digests in the golden."""
     import warnings
     import trained_weights as TW
-    cfg, sd = TW.train_checkpoint(tmp_path_factory.mktemp('trained'))
-    g = load_golden('trained_300steps.npz')
+    cfg, sd = TW.train_checkpoint(tmp_path_factory.mktemp('trained%d' % request.param), request.param)
+    g = load_golden('trained_%dsteps.npz' % request.param)
     keys, dig, crc = TW.state_digest(sd)
     assert keys == [str(k) for k in g['weight_keys']]
     identical = bool(np.array_equal(crc, g['weight_crc']))
@@ -1069,3 +1124,13 @@ def test_trained_checkpoint_matches_reference_golden(trained_state, mode):
     assert rel_err(Y, g['Y']) < 1e-6
     assert np.max(np.abs(log / g['nmse_log'] - 1)) < NMSE_RTOL, np.max(np.abs(log / g['nmse_log'] - 1))
     assert rel_err(X, g['X_final']) < 1e-5
+    if mode == 'default':
+        # the calibrated activation scales of this checkpoint (first trailer word of every direct f16x2 form): how far training moved
+        # the window -- printed with -s, recorded in profiles/r06_trained_checkpoints.txt
+        sc = []
+        for k, off in net._woff.items():
+            if k.endswith('#split'):
+                w = sd[k[:-len('#split')]]
+                sc.append(float(net._wdev[off + w.shape[2] * w.shape[3] * w.shape[0] * w.shape[1]].item()))
+        lg = np.log2(np.asarray(sc))
+        print('f16x2 act_scale exponents over %d layers: min %d median %d max %d' % (len(sc), lg.min(), np.median(lg), lg.max()))

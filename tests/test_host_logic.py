@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     h = _lib.lib()
     for name in declared:
         assert hasattr(h, name), name
-    assert h.sbc_abi_version() == 13
+    assert h.sbc_abi_version() == 14
 
 
 def test_f16x2_calibration_input_is_fixed_and_trailers_carry_the_scale():

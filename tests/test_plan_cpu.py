@@ -193,3 +193,36 @@ def test_conv_down_plan_matches_reference_forward(weights64):
     x = np.ascontiguousarray(g['x'][:2].transpose(0, 2, 3, 1))
     out = run_plan(pl, sd, x, np.full((2,), 1155))
     assert rel_err(out.transpose(0, 3, 1, 2), g['out'][1][:2]) < 2e-5
+
+
+def test_skip_branches_on_lanes_keep_the_dataflow_and_never_share_live_storage():
+    """plan.hoist_skip_branches (round 6): the decoder's skip branches move behind their anchors onto launch lanes.  The list stays a
+    valid sequential order (every input is produced earlier), every wait names an event an EARLIER record signals, and no record
+    writes a slot that a concurrently running lane still reads or writes: for a lane record issued at i and joined at j, its input and
+    output slots are touched by no other record in (i, j)."""
+    kw = dict(fold_stats=True, fuse_pairs=P.PAIR_SHAPES, fuse_res=True, fuse_chain=True, fuse_down=True, fuse_end=True)
+    seq = P.build_score_plan(32, 64, 16, **kw)
+    pl = P.build_score_plan(32, 64, 16, skip_overlap=True, **kw)
+    assert sorted(o.name for o in seq.ops) == sorted(o.name for o in pl.ops)
+    assert P.count_conv_flops(pl) == 820772864
+    made, signalled = {id(pl.x)}, set()
+    for op in pl.ops:
+        assert all(id(t) in made for t in op.inputs()), op.name
+        assert all(e in signalled for e in op.wait), op.name
+        made.update(id(t) for t in op.outputs())
+        if op.signal:
+            signalled.add(op.signal)
+    lanes = [i for i, o in enumerate(pl.ops) if o.lane]
+    assert len(lanes) == 6 and max(o.lane for o in pl.ops) < P.MAX_LANES
+    for i in lanes:
+        op = pl.ops[i]
+        # the join: the first run-stream record waiting for an event this lane signals at or behind record i
+        j = min(m for k in range(i, len(pl.ops)) if pl.ops[k].lane == op.lane and pl.ops[k].signal
+                for m in range(k + 1, len(pl.ops)) if pl.ops[m].lane == 0 and pl.ops[k].signal in pl.ops[m].wait)
+        mine = {t.slot for t in op.inputs() + op.outputs()}
+        for m in range(i + 1, j):
+            other = pl.ops[m]
+            if other.lane == op.lane:
+                continue                      # same lane: list order
+            assert not mine & {t.slot for t in other.outputs()}, (op.name, other.name)
+            assert not {t.slot for t in op.outputs()} & {t.slot for t in other.inputs()}, (op.name, other.name)

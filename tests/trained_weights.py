@@ -10,14 +10,21 @@ import os
 import numpy as np
 
 TRAIN_ARGV = ['--synthetic', '--max_steps', '300', '--seed', '1', '--val_every', '1000']
+# round 6: a LONGER-trained checkpoint beside it -- 4000 optimiser steps, ~25 s of GPU -- to stress the f16x2
+# calibration window with weights that have moved further from their initial statistics (golden: trained_4000steps.npz)
+LONG_STEPS = 4000
 
 
-def train_checkpoint(out_dir):
+def train_argv(steps=300):
+    return ['--synthetic', '--max_steps', str(int(steps)), '--seed', '1', '--val_every', '1000' if steps == 300 else '1000000']
+
+
+def train_checkpoint(out_dir, steps=300):
     """Run the trainer CLI into ``out_dir`` (GPU only) and return the ``model_state`` as numpy arrays."""
     import torch
     from score_based_channels_amd import train_score
     from score_based_channels_amd.checkpoint import load_checkpoint
-    train_score.main(TRAIN_ARGV + ['--out_dir', str(out_dir)])
+    train_score.main(train_argv(steps) + ['--out_dir', str(out_dir)])
     torch.cuda.synchronize()
     ck = load_checkpoint(os.path.join(str(out_dir), 'final_model.pt'))
     return ck['config'], {k: np.asarray(v.detach().cpu().numpy() if hasattr(v, 'detach') else v) for k, v in ck['model_state'].items()}

@@ -9,7 +9,7 @@ per-step cost does not depend on the level: the network is unconditional and the
 ``torch.set_num_threads`` = every core.  Writes ``profiles/<round>_reference_cpu.json``; ``bench.py`` embeds that record as
 ``cpu_baseline.reference_build_container`` of its cdlc line.
 
-    python tools/time_reference_cpu.py [--steps 20] [--round r05] [--reps 7]
+    python tools/time_reference_cpu.py [--steps 20] [--round r06] [--reps 7]
 """
 import argparse
 import json
@@ -26,7 +26,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--batch', type=int, default=100)
-    ap.add_argument('--round', default='r05')
+    ap.add_argument('--round', default='r06')
     ap.add_argument('--reps', type=int, default=7)
     args = ap.parse_args()
     import numpy as np
