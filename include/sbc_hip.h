@@ -224,7 +224,8 @@ typedef struct sbc_op {
                                     scale into the trailer of EVERY form it is handed, so that a host which shares one weight buffer
                                     between array sizes -- fused at one, unfused Winograd at another -- finds the same scale in both */
     /* --- ABI 14: launch lanes of a plan (all zero: the record runs on the run stream in list order, as before) --- */
-    int32_t lane;                /* 0 = the stream handed to sbc_plan_run; 1 .. SBC_MAX_LANES-1 = a stream the plan owns.  Records of one
+    int32_t lane;                /* 0 = the stream handed to sbc_plan_run; 1 .. SBC_MAX_LANES-1 = a stream of the library that goes with that
+                                    run stream (probed once to sit on another hardware queue; shared by the plans run on it).  Records of one
                                     lane run in list order; records of different lanes are ordered ONLY by the events below (and by the
                                     start and the end of an sbc_plan_run call, which every lane is forked from / joined into) */
     int32_t signal;              /* 0, or an event id 1 .. SBC_MAX_EVENTS: recorded on this record's lane right behind it */
@@ -387,7 +388,7 @@ int sbc_op_launch(const sbc_op* op, void* stream);
 /* --- plans ---------------------------------------------------------------------------------------
  * sbc_plan_create copies `ops` (and their `ext` structs); the device buffers they point to must outlive the
  * plan.  sbc_plan_run executes the whole op list `n_iters` times in order on `stream` -- records with a `lane` (ABI 14) on the
- * plan's own streams: every lane is forked from `stream` at the start of the call and joined into it at its end (not between
+ * library's lane streams: every lane is forked from `stream` at the start of the call and joined into it at its end (not between
  * the iterations, where the records' own events order the lanes), so that a caller sees ONE asynchronous unit of work.  With
  * use_graph != 0 the op list is captured once into a hipGraph (on first use for that stream) and replayed;
  * this is legal because nothing in a plan depends on host state -- step-dependent scalars are read from

@@ -140,6 +140,59 @@ int balanced_sample_grid(int samples, int cus) {
     const int rounds = (samples + w - 1) / w;
     return (samples + rounds - 1) / rounds;
 }
+// The lane streams (sbc_op.lane, ABI 14) that go with a run stream: one per (device, run stream, lane), created on first use, never
+// destroyed.  A lane must not share a HARDWARE queue with its run stream: the runtime multiplexes its streams onto a few hardware queues
+// (least-referenced first), and in a process that has created many streams a new one lands on the run stream's queue as often as not --
+// the lane then runs strictly behind it (measured: the lanes' gain gone in the last segments of bench.py, present in a fresh process).
+// Streams of another PRIORITY come from another pool of queues, but measured far worse in a process with many live streams (3.0 against
+// 1.0 ms per step, high and low priority alike: profiles/r06_skip_lanes.txt).  So the library PROBES: a 200 us spin kernel on the run
+// stream with an event behind it, then a trivial launch on the candidate; if the candidate's launch completes while the run stream's
+// event is still pending, the two are on different hardware queues.  Up to eight fresh candidates (consecutive creations rotate over the
+// queues); rejected ones are destroyed.  Costs ~0.3 ms per candidate, once per run stream.
+__global__ void lane_probe_spin(long long ticks, int* sink) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) { }
+    if (ticks < 0) *sink = 1;
+}
+__global__ void lane_probe_touch(int* sink) { if (sink == nullptr) __builtin_trap(); }
+
+int lane_stream_for(hipStream_t run, int lane, hipStream_t* out) {
+    static std::mutex mu;
+    static std::map<std::pair<std::pair<int, hipStream_t>, int>, hipStream_t> streams;
+    int dev = 0;
+    SBC_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    hipStream_t& found = streams[std::make_pair(std::make_pair(dev, run), lane)];
+    if (!found) {
+        unsigned* w = nullptr;
+        { const int rc = range_flag_ptr(&w); if (rc) return rc; }
+        hipEvent_t e_run = nullptr, e_cand = nullptr;
+        SBC_CHECK_HIP(hipEventCreateWithFlags(&e_run, hipEventDisableTiming));
+        SBC_CHECK_HIP(hipEventCreateWithFlags(&e_cand, hipEventDisableTiming));
+        hipStream_t rejected[8];
+        int n_rej = 0;
+        for (int k = 0; k < 8 && !found; ++k) {
+            hipStream_t c = nullptr;
+            SBC_CHECK_HIP(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+            hipLaunchKernelGGL(lane_probe_spin, dim3(1), dim3(64), 0, run, (long long)20000, (int*)(w + 2));    // 100 MHz ticks: 200 us
+            SBC_CHECK_HIP(hipEventRecord(e_run, run));
+            hipLaunchKernelGGL(lane_probe_touch, dim3(1), dim3(64), 0, c, (int*)(w + 2));
+            SBC_CHECK_HIP(hipEventRecord(e_cand, c));
+            SBC_CHECK_HIP(hipEventSynchronize(e_cand));
+            const bool concurrent = hipEventQuery(e_run) == hipErrorNotReady;
+            (void)hipGetLastError();                                           // (hipErrorNotReady is not an error here)
+            SBC_CHECK_HIP(hipEventSynchronize(e_run));
+            if (concurrent || k == 7) found = c;                               // (the last candidate is taken whatever the probe says)
+            else rejected[n_rej++] = c;
+        }
+        for (int k = 0; k < n_rej; ++k) (void)hipStreamDestroy(rejected[k]);
+        (void)hipEventDestroy(e_run);
+        (void)hipEventDestroy(e_cand);
+    }
+    *out = found;
+    return SBC_OK;
+}
+
 struct PersistentCusScope {                              // RAII: a plan's width for the duration of its launches on this thread
     int saved;
     explicit PersistentCusScope(int n) : saved(tls_persistent_cus) { if (n > 0) tls_persistent_cus = n; }
@@ -156,11 +209,13 @@ struct sbc_plan {
     // side stream for ops flagged SBC_OP_SIDE (created on first use; forked from / joined into the run stream by events)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // launch lanes (sbc_op.lane / signal / wait, ABI 14): streams and events the plan owns, created by sbc_plan_create when a record asks
+    // launch lanes (sbc_op.lane / signal / wait, ABI 14): the lane streams that go with the run stream (lane_stream_for) and the plan's own events
     hipStream_t lanes[SBC_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t lane_evt[SBC_MAX_EVENTS + 1] = {};
     hipEvent_t ev_begin = nullptr, ev_lane_end[SBC_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
     bool uses_lanes = false;
+    hipStream_t lane_run = nullptr;      // the run stream `lanes` were resolved for
+    bool lanes_resolved = false;
     // per-tag timing
     int prof_tag = -1;
     std::vector<hipEvent_t> ev_pool;     // pairs
@@ -187,6 +242,19 @@ static int drain_events(sbc_plan* plan) {
 static int join_side(sbc_plan* plan, hipStream_t s) {
     SBC_CHECK_HIP(hipEventRecord(plan->ev_join, plan->side));
     SBC_CHECK_HIP(hipStreamWaitEvent(s, plan->ev_join, 0));
+    return SBC_OK;
+}
+
+// the lane streams that go with run stream `s` (lane_stream_for: probed once per run stream); not inside a stream capture
+static int resolve_lanes(sbc_plan* plan, hipStream_t s) {
+    if (!plan->uses_lanes || (plan->lanes_resolved && plan->lane_run == s)) return SBC_OK;
+    for (int l = 1; l < SBC_MAX_LANES; ++l)
+        if (plan->ev_lane_end[l]) {
+            const int rc = sbc::lane_stream_for(s, l, &plan->lanes[l]);
+            if (rc) return rc;
+        }
+    plan->lane_run = s;
+    plan->lanes_resolved = true;
     return SBC_OK;
 }
 
@@ -474,10 +542,7 @@ int sbc_plan_create(const sbc_op* ops, int32_t n_ops, sbc_plan** out_plan) {
             if (e != hipSuccess) return hip_fail(e);
             for (int i = 0; i < n_ops; ++i) {
                 const sbc_op& o = plan->ops[i].op;
-                if (o.lane > 0 && !plan->lanes[o.lane]) {
-                    // (stream priorities -1 / +1 for the lane and persistent-grid widths of 64 - 192 CUs for its launches were measured:
-                    // no effect on the step -- profiles/r06_skip_lanes.txt)
-                    if ((e = hipStreamCreateWithFlags(&plan->lanes[o.lane], hipStreamNonBlocking)) != hipSuccess) return hip_fail(e);
+                if (o.lane > 0 && !plan->ev_lane_end[o.lane]) {          // (the lane's stream itself: resolve_lanes, at the first run)
                     if ((e = hipEventCreateWithFlags(&plan->ev_lane_end[o.lane], evf)) != hipSuccess) return hip_fail(e);
                 }
                 if (o.signal > 0 && !plan->lane_evt[o.signal] && (e = hipEventCreateWithFlags(&plan->lane_evt[o.signal], evf)) != hipSuccess) return hip_fail(e);
@@ -492,6 +557,7 @@ int sbc_plan_run(sbc_plan* plan, void* stream, int32_t n_iters, int32_t use_grap
     SBC_REQUIRE(plan && n_iters >= 0, "sbc_plan_run: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     PersistentCusScope width(plan->persistent_cus);
+    if (n_iters > 0) { const int rc = resolve_lanes(plan, s); if (rc) return rc; }
     if (!use_graph || plan->prof_tag >= 0) {
         if (n_iters == 0) return SBC_OK;
         int rc = fork_lanes(plan, s);
@@ -536,10 +602,8 @@ void sbc_plan_destroy(sbc_plan* plan) {
     if (plan->ev_join) (void)hipEventDestroy(plan->ev_join);
     if (plan->side) (void)hipStreamDestroy(plan->side);
     if (plan->ev_begin) (void)hipEventDestroy(plan->ev_begin);
-    for (int l = 1; l < SBC_MAX_LANES; ++l) {
+    for (int l = 1; l < SBC_MAX_LANES; ++l)                   // (the lane streams belong to the run stream, not to the plan: lane_stream_for)
         if (plan->ev_lane_end[l]) (void)hipEventDestroy(plan->ev_lane_end[l]);
-        if (plan->lanes[l]) { (void)hipStreamSynchronize(plan->lanes[l]); (void)hipStreamDestroy(plan->lanes[l]); }
-    }
     for (hipEvent_t e : plan->lane_evt) if (e) (void)hipEventDestroy(e);
     delete plan;
 }

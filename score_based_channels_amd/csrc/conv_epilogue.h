@@ -168,6 +168,15 @@ __device__ __forceinline__ void conv_epilogue(const float* lds, const ConvParams
 #pragma unroll
         for (int i = 0; i < EC; ++i)
             if (ok[i]) st_stream(p.out + o[i], v[i]);
+        // SBC_EPI_MOMENTS_OUT (tile.h): 256 threads, 32 output channels -- a pass of four chunks per thread is one whole 128-pixel tile in
+        // the layout tile_moments_out32 takes (thread (tid >> 3, tid & 7): four pixels of channel quad tid & 7); scratch behind the tile
+        if constexpr (COUT == 32 && NTHREADS == 256 && EC == 4 && TM % 128 == 0) {
+            if (p.flags & SBC_EPI_MOMENTS_OUT) {
+                float* red = const_cast<float*>(lds) + TM * ES;
+                tile_moments_out32(v, red, p.pm_out + ((size_t)((g.p0 >> 7) + c0 / 4) * COUT) * 2, tid);
+                __syncthreads();                              // (the scratch is reused by the next pass)
+            }
+        }
     }
 }
 

@@ -260,7 +260,8 @@ int launch_conv(const sbc_op& op, hipStream_t stream, bool dry) {
     if (moments) {
         // tile moments of the output are written by the Winograd split kernels' 128-pixel variants with 32 / 64 output channels (tile.h):
         // whole 128-pixel tiles inside one sample, unpooled output
-        SBC_REQUIRE(op.weight_wino_split && op.ksize == 3 && op.dil == 1 && op.aux && (op.cout == 32 || op.cout == 64) && (op.H * op.W) % 128 == 0 &&
+        // (round 6: in conv_mode f16w the direct kernel writes them for 32 output channels, conv_epilogue.h)
+        SBC_REQUIRE((op.weight_wino_split || ((op.flags & SBC_CONV_F16W) && x3 && op.cout == 32)) && op.ksize == 3 && op.dil == 1 && op.aux && (op.cout == 32 || op.cout == 64) && (op.H * op.W) % 128 == 0 &&
                     128 % (2 * op.W) == 0 && !(op.flags & SBC_EPI_POOL),
                     "conv: EPI_MOMENTS_OUT needs the Winograd split kernel (weight_wino_split), aux, 32 / 64 output channels, whole 128-pixel "
                     "tiles per sample and an unpooled output");
@@ -279,7 +280,12 @@ int launch_conv(const sbc_op& op, hipStream_t stream, bool dry) {
         const int rc = launch_conv_dp(op, p.range_flag, stream, dry);
         if (rc <= 0) return rc;                                                    // launched (0) or failed (< 0)
     }
-    if (op.weight_wino_split && !f32_only && !no_wx3 && op.ksize == 3 && op.dil == 1) {
+    // conv_mode f16w (BASELINE config 5): ONE matrix instruction per product, so Winograd's 2.25 x fewer products buy nothing and its
+    // transforms cost vector time -- measured at 256 x 64, 1024 samples (profiles/r06_big_direct_vs_winograd.txt): 32 -> 32 917 against
+    // 1291 us, 64 -> 64 174 / 199, 128 -> 128 158 / 279, pooled 32 -> 64 1684 / 2143.  The direct kernel takes every f16w layer except
+    // the 64-channel producers of tile moments (its epilogue writes moments for 32 output channels only).
+    const bool f16w_direct = (op.flags & SBC_CONV_F16W) && x3 && !(moments && op.cout != 32);
+    if (op.weight_wino_split && !f32_only && !no_wx3 && !f16w_direct && op.ksize == 3 && op.dil == 1) {
         ConvParams pw = p;
         pw.wpk = (const float4*)op.weight_wino_split;
 #ifdef SBC_WITH_WP   // tools/experiments/conv_wp.hip (round 4: 64 -> 64 with the transformed filter resident in registers; measured slower)
@@ -291,7 +297,7 @@ int launch_conv(const sbc_op& op, hipStream_t stream, bool dry) {
         const int rc = launch_conv_wx3(pw, op.cin, op.cout, stream, dry);
         if (rc <= 0) return rc;                                                    // launched (0) or failed (< 0)
     }
-    if (moments) {
+    if (moments && !(f16w_direct && op.cout == 32)) {
         set_error("conv: tile moments requested but the Winograd split-bf16 kernel does not take this shape (%dx%d, %d -> %d)",
                   op.H, op.W, op.cin, op.cout);
         return SBC_ERR_UNSUPPORTED;

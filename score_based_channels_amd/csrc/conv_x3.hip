@@ -259,7 +259,8 @@ static size_t x3_lds_bytes(const ConvParams& p, int* plane_out) {
     const int plane = (TM + halo_px + 1) * (CIN + 8);
     if (plane_out) *plane_out = plane;
     const size_t staged = (size_t)TERMS * plane * sizeof(unsigned short);
-    const size_t epi = (size_t)TM * (COUT + 4) * sizeof(float);
+    // (+ 2 KB behind the epilogue tile: the reduction scratch of SBC_EPI_MOMENTS_OUT, conv_epilogue.h)
+    const size_t epi = (size_t)TM * (COUT + 4) * sizeof(float) + ((p.flags & SBC_EPI_MOMENTS_OUT) ? 2048 : 0);
     return staged > epi ? staged : epi;
 }
 
@@ -319,6 +320,11 @@ static int launch_sized(const ConvParams& p, hipStream_t stream, bool dry) {
     static const int force = getenv("SBC_TILE") ? atoi(getenv("SBC_TILE")) : 0;     // tuning aid
     int tm = 0;
     if (force && fits(force)) tm = force;
+    else if ((p.flags & SBC_EPI_MOMENTS_OUT) && !good(256)) {
+        // tile moments come out of the 256-thread variants (whole 128-pixel tiles per pass): never the 64-pixel tile
+        SBC_REQUIRE(COUT == 32 && fits(128), "conv: SBC_EPI_MOMENTS_OUT on the direct kernel needs 32 output channels and 128-pixel tiles (%dx%d)", p.H, p.W);
+        tm = 128;
+    }
     else if (good(256)) tm = 256;
     else if (good(128)) tm = 128;
     else if (fits(64)) tm = 64;

@@ -544,6 +544,46 @@ def test_conv_pool_matches_oracle(gpu, B, H, stage, mode):
                                  weight_split=_p(dw)))
 
 
+@pytest.mark.parametrize('B,H,W', [(1, 64, 16), (3, 256, 64), (300, 64, 16)])
+def test_direct_conv_writes_tile_moments_in_f16w(gpu, B, H, W):
+    """Round 6, conv_mode f16w (BASELINE config 5): ONE matrix instruction per product, so the direct kernel (csrc/conv_x3.hip) is faster
+    than Winograd for every layer and takes them all -- including the 32-channel producers of tile moments (SBC_EPI_MOMENTS_OUT), whose
+    (mean, M2) per 128-pixel tile now come out of its epilogue (conv_epilogue.h): both tile sizes (128 pixels at small batches, 256 at
+    large ones), with a residual operand, against numpy on the launch's own output; and the output against the oracle."""
+    torch, _lib = gpu
+    from score_based_channels_amd import plan as P
+    from score_based_channels_amd.weights import pack_conv_weight_f16, pack_conv_weight_winograd_f16, round_fp16
+    Cc = 32
+    rng = np.random.default_rng(B + H)
+    x = (rng.standard_normal((B, H, W, Cc)) * 1.5 + 0.3).astype(F32)
+    res = rng.standard_normal((B, H, W, Cc)).astype(F32)
+    w = (rng.standard_normal((Cc, Cc, 3, 3)) / np.sqrt(9 * Cc)).astype(F32)
+    bias = (0.3 * rng.standard_normal(Cc)).astype(F32)
+    d = {k: _dev(torch, a) for k, a in dict(x=x, res=res, w=pack_conv_weight_f16(w).view(np.float32), ww=pack_conv_weight_winograd_f16(w).view(np.float32),
+                                              b=bias).items()}
+    out = torch.full((B, H, W, Cc), float('nan'), dtype=torch.float32, device='cuda')
+    nt = H * W // 128
+    pm = torch.full((B, nt, Cc, 2), float('nan'), dtype=torch.float32, device='cuda')
+    # (the Winograd form rides along as the host binds it: the f16w dispatch must not take it)
+    op = _lib.sbc_op(kind=P.CONV, flags=P.CONV_F16W | P.PRO_ELU | P.EPI_MOMENTS_OUT, B=B, H=H, W=W, cin=Cc, cout=Cc, ksize=3, dil=1, in_=_p(d['x']),
+                     out=_p(out), bias=_p(d['b']), res1=_p(d['res']), weight_split=_p(d['w']), weight_wino_split=_p(d['ww']), aux=_p(pm))
+    _launch(gpu, op)
+    got = out.cpu().numpy()
+    nref = min(B, 4)
+    ref = O.conv2d(round_fp16(O.elu(x[:nref])).transpose(0, 3, 1, 2), round_fp16(w), bias, 1).transpose(0, 2, 3, 1) + res[:nref]
+    assert np.isfinite(got).all() and rel_err(got[:nref], ref) < 1e-4          # (the direct f16w tolerance of test_conv_matches_oracle)
+    tiles = got.astype(np.float64).reshape(B, nt, 128, Cc)
+    gm = pm.cpu().numpy()
+    assert np.isfinite(gm).all()
+    assert np.abs(gm[..., 0] - tiles.mean(2)).max() < 1e-5 * max(1.0, np.abs(tiles.mean(2)).max())
+    assert rel_err(gm[..., 1], ((tiles - tiles.mean(2, keepdims=True)) ** 2).sum(2)) < 1e-5
+    # the same launch without moments: the same output, bit for bit
+    out2 = torch.empty_like(out)
+    op.flags, op.aux, op.out = P.CONV_F16W | P.PRO_ELU, None, _p(out2)
+    _launch(gpu, op)
+    assert torch.equal(out, out2)
+
+
 @pytest.mark.parametrize('B', [1, 3, 300, 700])
 def test_res_block_matches_oracle(gpu, B):
     """SBC_OP_RES_BLOCK: one whole ResidualBlock without resampling (layers.py:443-456) in one launch -- a workgroup owns a sample and
