@@ -19,25 +19,11 @@
 // and every second unit, so with R = 8 at W = 16 the four waves run 5 + 4 units each: no idle wave in either convolution.
 #include <stdlib.h>
 #include <type_traits>
-#include "conv_common.h"
+#include "conv_pair.h"
 
 namespace sbc {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-
-struct PairParams {
-    const float* __restrict__ in;
-    float* __restrict__ out;
-    const uint4* __restrict__ w1;       // sbc_pack_conv_weight_f16x2 / _f16 layout of conv1 (32 -> 32, 3x3)
-    const uint4* __restrict__ w2;
-    unsigned* __restrict__ range_flag;
-    float* __restrict__ calib;          // sbc_f16x2_calibrate: two amax slots (conv1's input, the intermediate), else NULL
-    const float* __restrict__ res1;     // conv_pool_kernel: residual operands of the CONV epilogue (or NULL)
-    const float* __restrict__ res2;
-    int flags;                          // conv_pool_kernel: SBC_PRO_ELU, SBC_EPI_RES1_ELU
-    int B, H, ntiles, tiles_per_sample, wgs_per_xcd, tiles_per_xcd;
-    unsigned long long* dbg;            // SBC_PAIR_TIMING builds: per-phase cycle sums of wave 0 of every workgroup
-};
 
 #ifdef SBC_PAIR_TIMING
 #define PT_MARK(k) do { const unsigned long long _t = __builtin_readcyclecounter(); pt[k] += _t - pt_last; pt_last = _t; } while (0)
@@ -1300,6 +1286,9 @@ int launch_conv_pair(const sbc_op& op, hipStream_t stream, bool dry) {
         set_error("conv_pair: no 64-channel kernel for image %dx%d", op.H, op.W);
         return SBC_ERR_UNSUPPORTED;
     }
+#ifdef SBC_WITH_PAIR32   // tools/experiments/conv_pair32.hip (round 6: the 32-cycle matrix shape with the vector work inside the K loops; measured slower)
+    if (x2 && op.W == 16 && op.H % 8 == 0) return launch_pair32(p, stream, dry);
+#endif
     // many tiles per CU: the three-stage pipeline (identical results; below ~16 tiles per workgroup its fill and drain cost more
     // than it gains: 1040 tiles 21.8 us against 21.3, 6800 tiles 112 against 122, 13600 tiles 230 against 242)
     static const bool no_p3 = getenv("SBC_NO_PAIR_P3") != nullptr;           // A/B aid

@@ -81,6 +81,35 @@ __global__ __launch_bounds__(512) void two_kinds(float* out, int iters) {
     out[blockIdx.x * 512 + threadIdx.x] = r;
 }
 
+// dependent accumulator chains: every MFMA accumulates onto the one before it (DEP = 1), or two chains alternate (DEP = 2)
+template <int SHAPE, int DEP>
+__global__ __launch_bounds__(512) void dep_chain(float* out, int iters) {
+    f16x8 x = {1, 2, 3, 4, 5, 6, 7, 8}, w = {1, 1, 1, 1, 1, 1, 1, 1};
+    float r = 0.f;
+    if constexpr (SHAPE == 0) {
+        f32x4 a0 = {0, 0, 0, 0}, a1 = a0;
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (DEP == 1 || (k & 1) == 0) a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, x, a0, 0, 0, 0);
+                else a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, x, a1, 0, 0, 0);
+            }
+        }
+        r = a0[0] + a1[1];
+    } else {
+        f32x16 a0 = {0}, a1 = {0};
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (DEP == 1 || (k & 1) == 0) a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, a0, 0, 0, 0);
+                else a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, a1, 0, 0, 0);
+            }
+        }
+        r = a0[0] + a1[5];
+    }
+    out[blockIdx.x * 512 + threadIdx.x] = r;
+}
+
 template <class K> float timeit(K kern, int threads, float* out, int iters) {
     // minimum of 7 timed launches after two warm-up launches (the chip's clock moves with the power state: the minimum is the
     // launch that ran at the steadiest high clock)
@@ -115,6 +144,9 @@ int main() {
     printf("same-wave interleave { MFMA ; fillers } (v_fma_f32, independent), %d iterations per wave:\n", it);
     sweep<0>(out, it);
     sweep<1>(out, it);
+    printf("dependent accumulator chains, no fillers (us; 1 wave/SIMD, 2 waves/SIMD):\n");
+    printf("  16x16x32: one chain %8.1f %8.1f   two alternating chains %8.1f %8.1f\n", timeit(dep_chain<0, 1>, 256, out, it), timeit(dep_chain<0, 1>, 512, out, it), timeit(dep_chain<0, 2>, 256, out, it), timeit(dep_chain<0, 2>, 512, out, it));
+    printf("  32x32x16: one chain %8.1f %8.1f   two alternating chains %8.1f %8.1f\n", timeit(dep_chain<1, 1>, 256, out, it), timeit(dep_chain<1, 1>, 512, out, it), timeit(dep_chain<1, 2>, 256, out, it), timeit(dep_chain<1, 2>, 512, out, it));
     printf("separate matrix and vector waves on one SIMD (4 it x 16 matrix cycles / 16 it v_fma_f32 per wave):\n");
     printf("  16x16x32: matrix alone %8.1f  vector alone %8.1f  both %8.1f us\n", timeit(two_kinds<0, 1>, 512, out, it), timeit(two_kinds<0, 2>, 512, out, it), timeit(two_kinds<0, 3>, 512, out, it));
     printf("  32x32x16: matrix alone %8.1f  vector alone %8.1f  both %8.1f us\n", timeit(two_kinds<1, 1>, 512, out, it), timeit(two_kinds<1, 2>, 512, out, it), timeit(two_kinds<1, 3>, 512, out, it));
