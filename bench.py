@@ -163,6 +163,9 @@ def parse_args():
     ap.add_argument('--streams', type=int, default=None,
                     help='split the trajectories into this many concurrent sub-batch streams; default: what the CLIs default '
                          'to (config.DEFAULT_STREAMS)')
+    ap.add_argument('--pair-plan', type=int, default=0,
+                    help='experiment: run the two sub-batch streams as ONE plan with two launch lanes, this many Langevin steps per record list '
+                         '(ald.AldPair; with --graph 1: one captured graph with two branches); 0 = two host threads (driver.run_concurrently)')
     ap.add_argument('--skip-spec', default=None,
                     help='JSON list of [branch prefix, anchor record prefix, lane] (plan.hoist_skip_branches) for the small-batch plan; '
                          '"0" = no launch lanes; default: plan.DEFAULT_SKIP_SPEC for batches of at most scorenet.SKIP_OVERLAP_MAX_T trajectories')
@@ -327,7 +330,18 @@ def main():
             streams.append(torch.cuda.Stream(net.device) if n_streams > 1 else torch.cuda.current_stream(net.device))
         return alds, streams
 
+    pairs = {}
+
     def run_all(alds, streams, n, graph):
+        if args.pair_plan and len(alds) == 2 and n > 0:
+            # experiment: both sub-batches in ONE plan with two launch lanes -- one host thread, or one hipGraph with two branches
+            from score_based_channels_amd.ald import AldPair
+            key = id(alds[0])
+            if key not in pairs:
+                pairs[key] = AldPair(alds[0], alds[1], args.pair_plan)
+                pairs[key].set_persistent_cus(torch.cuda.get_device_properties(net.device).multi_processor_count // 2)
+            pairs[key].run(n, use_graph=graph)
+            return
         run_concurrently(alds, streams, n, graph)           # one host thread per stream when there are several
 
     logged = [0]                 # rows of the NMSE log the most recent timed() call wrote
@@ -606,22 +620,26 @@ def main():
             #   first stage also computes the 2 halo rows of its 8-row tile: (10 + 8) / (2 * 8)
             terms = {'bf16x3': 6.0, 'f16x2': 3.0, 'f16w': 1.0}.get(conv_mode)
             pair_roll = nr == 16 and T * (nt // 8) >= 1024 and conv_mode in ('f16x2', 'f16w')
-            names = {P.TAG_CONV_TOP: 'conv_wx3_kernel<32, 32, 1, true, %s, true, 1, 1, %d>' % ({'bf16x3': '3', 'f16x2': '4', 'f16w': '3'}.get(conv_mode, '3'),
-                                                                                              {'bf16x3': 0, 'f16w': 1, 'f16x2': 2}.get(conv_mode, 0)),
+            # (conv_mode f16w, round 6: one matrix instruction per product -- the direct kernel takes the layers Winograd used to, csrc/conv_mfma.hip)
+            names = {P.TAG_CONV_TOP: 'conv_x3_kernel<32, 32, 3, 2, 1, 4, 1, true, 1>' if conv_mode == 'f16w' else
+                                     'conv_wx3_kernel<32, 32, 1, true, %s, true, 1, 1, %d>' % ({'bf16x3': '3', 'f16x2': '4'}.get(conv_mode, '3'),
+                                                                                              {'bf16x3': 0, 'f16x2': 2}.get(conv_mode, 0)),
                      # (16-pixel rows, at least 1024 tiles in the launch: the three-role pipeline over row rings, csrc/conv_pair.hip)
                      P.TAG_PAIR_TOP: ('conv_pair_roll_kernel<%d>' % (2 if conv_mode == 'f16x2' else 1) if pair_roll else
                                       'conv_pair_kernel<%d, %d, %d, %d, 32>' % (nr, 4 if nr == 64 else 8, 2 if conv_mode == 'f16x2' else 1, 8 if nr == 64 else 4)),
                      P.TAG_POOL_TOP: 'conv_pool_kernel<%d, 8, %d, 4, 32>' % (nr, 2 if conv_mode == 'f16x2' else 1),
                      P.TAG_RES_TOP: 'conv_res_kernel',
-                     P.TAG_CONV_MID: 'conv_wx3_kernel<64, 64, 1, true, 2, false, 2, 1, %d>' % {'bf16x3': 0, 'f16w': 1, 'f16x2': 2}.get(conv_mode, 0),
+                     P.TAG_CONV_MID: 'conv_x3_kernel<64, 64, 3, 2, 2, 4, 1, true, 1> (conv_wx3_kernel<64, 64, 1, true, 2, false, 2, 1, 1> for the producers of tile moments)' if conv_mode == 'f16w' else
+                                     'conv_wx3_kernel<64, 64, 1, true, 2, false, 2, 1, %d>' % {'bf16x3': 0, 'f16x2': 2}.get(conv_mode, 0),
                      # (conv_mode f16x2 with 8-pixel rows: the direct persistent kernel, csrc/conv_dp.hip; else the Winograd kernel)
                      P.TAG_DIRECT_MID: ('conv_dp_kernel<64, 8, 8, 1, false, 4>' if conv_mode == 'f16x2' and nr == 16 else
-                                        'conv_wx3_kernel<64, 64, 1, true, 2, false, 2, 1, %d>' % {'bf16x3': 0, 'f16w': 1, 'f16x2': 2}.get(conv_mode, 0))}
+                                        'conv_x3_kernel<64, 64, 3, 2, 2, 4, 1, true, 1>' if conv_mode == 'f16w' else
+                                        'conv_wx3_kernel<64, 64, 1, true, 2, false, 2, 1, %d>' % {'bf16x3': 0, 'f16x2': 2}.get(conv_mode, 0))}
             direct_mid = names[P.TAG_DIRECT_MID].startswith('conv_dp')
             names[P.TAG_DOWN], names[P.TAG_DOWN + 1] = 'conv_down_kernel<32, 64, 16>', 'conv_down_kernel<64, 64, 8>'
             for k, (cc, cw) in enumerate(P.CHAIN_KERNELS):
                 names[P.TAG_CHAIN + k] = 'conv_chain_kernel<%d, %d, %d>' % (cc, cw, 8 if (cc, cw) in ((128, 2), (64, 8)) else 4)
-            what = {P.TAG_CONV_TOP: 'the unfused 3x3 32->32 convolutions at %dx%d (Winograd F(2x2,3x3))' % (nt, nr),
+            what = {P.TAG_CONV_TOP: 'the unfused 3x3 32->32 convolutions at %dx%d (%s)' % (nt, nr, 'direct, one matrix instruction per product' if conv_mode == 'f16w' else 'Winograd F(2x2,3x3)'),
                     P.TAG_PAIR_TOP: 'the fused RCU blocks at %dx%d: two direct 3x3 32->32 convolutions per launch, intermediate in LDS%s'
                                     % (nt, nr, '; a workgroup walks a contiguous run of 8-row tiles and keeps the rows adjacent tiles share in LDS rings '
                                                '(no halo recomputation: round 5)' if pair_roll else ''),
@@ -647,7 +665,7 @@ def main():
                 by = kc['bytes_per_step'] / kc['launches_per_step']
                 ratio = (((nt + 1.0) / nt if pair_roll else 18.0 / 16.0) if tag == P.TAG_PAIR_TOP else
                          1.0 if tag in (P.TAG_POOL_TOP, P.TAG_RES_TOP) or (tag == P.TAG_DIRECT_MID and direct_mid)
-                         else 0.5 if tag >= P.TAG_DOWN else kc['live_taps'] if tag >= P.TAG_CHAIN else 16.0 / 36.0) * (terms or 1.0)
+                         else 0.5 if tag >= P.TAG_DOWN else kc['live_taps'] if tag >= P.TAG_CHAIN else 1.0 if conv_mode == 'f16w' else 16.0 / 36.0) * (terms or 1.0)
                 ach = fl / t_launch / 1e12
                 e = {'kernel': names[tag], 'what': what[tag], 'launches_per_step': kc['launches_per_step'],
                      'us_per_launch': kc['us_per_launch'], 'share_of_one_stream_step': kc['us_per_launch'] * kc['launches_per_step'] / 1e3 / one_stream_ms,

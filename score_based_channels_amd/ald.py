@@ -277,3 +277,85 @@ class AldBatch:
     def nmse_log(self):
         """``[n_steps, T]`` float32 device tensor: row k = NMSE after Langevin step k (test_score.py:168-170)."""
         return self.d_nmse
+
+
+class AldPair:
+    """Two sub-batches of one lock-step chunk as ONE plan with two launch lanes ("one captured graph with two
+    branches"): sub-batch A on the run stream, sub-batch B on lane 1, ``k_steps`` Langevin steps unrolled into one record list in which B
+    starts behind the head of A's first step (the record ``driver.run_concurrently`` cuts at: A is in its issue-bound full-resolution
+    launches while B is in the small low-resolution ones) and keeps that lag for the whole list; the lanes join at the end of the list.
+    One host thread issues both lanes -- or one hipGraph holds both branches (``run(use_graph=True)``).  Every record is a record of A's
+    or B's own step plan with its own buffers: results are those of the two batches run alone, bit for bit."""
+
+    def __init__(self, a, b, k_steps=20):
+        if a.uses_lanes or b.uses_lanes or a.net is not b.net:
+            raise ValueError('AldPair takes two sequential-plan batches of one network')
+        self.a, self.b, self.k = a, b, int(k_steps)
+        names = [op.name for op in a.bound.plan.ops]
+        cut = next((i for i, nm in enumerate(names) if nm.startswith('refine31.')), len(names) // 2)
+        self.cut = cut
+        self._plans = {}
+        self._keep = []
+
+    def _plan(self, k):
+        if k not in self._plans:
+            import copy
+            A, B = self.a._step_ops, self.b._step_ops
+            n = len(A)
+            seq_a = [(s, i) for s in range(k) for i in range(n)]
+            seq_b = list(seq_a)
+            ops = []
+
+            def rec(src, lane, signal=0, wait=0):
+                o = _lib.sbc_op()
+                C.memmove(C.byref(o), C.byref(src), C.sizeof(o))
+                o.lane, o.signal = lane, signal
+                o.wait[0], o.wait[1] = wait, 0
+                self._keep.append(o)
+                return o
+            # A's head alone, then A and B record by record (B behind by the head), then B's tail
+            for j, (s, i) in enumerate(seq_a[:self.cut + 1]):
+                ops.append(rec(A[i], 0, signal=1 if j == self.cut else 0))
+            rest_a = seq_a[self.cut + 1:]
+            for j in range(max(len(rest_a), len(seq_b))):
+                if j < len(rest_a):
+                    ops.append(rec(A[rest_a[j][1]], 0))
+                if j < len(seq_b):
+                    ops.append(rec(B[seq_b[j][1]], 1, wait=1 if j == 0 else 0))
+            self._plans[k] = _lib.Plan(ops, keepalive=(self.a, self.b))
+        return self._plans[k]
+
+    def set_persistent_cus(self, n):
+        self._width = int(n)
+        for pl in self._plans.values():
+            pl.set_persistent_cus(n)
+
+    def run(self, n_steps, use_graph=False, stream=None):
+        """Advance both sub-batches by ``n_steps`` (whole lists of ``k_steps`` steps, then one shorter list)."""
+        for x in (self.a, self.b):
+            x._check_steps(n_steps)
+        cur = torch.cuda.current_stream(self.a.net.device)
+        if use_graph:                                  # (capture is not allowed on the legacy default stream: AldBatch.run)
+            if getattr(self, '_gstream', None) is None:
+                self._gstream = torch.cuda.Stream(self.a.net.device)
+            self._gstream.wait_stream(cur)
+            st = self._gstream.cuda_stream
+        else:
+            st = cur.cuda_stream if stream is None else stream
+        done = 0
+        while done < n_steps:
+            k = min(self.k, n_steps - done)
+            pl = self._plan(k)
+            pl.set_persistent_cus(getattr(self, '_width', 0))
+            pl.run(st, 1, use_graph)
+            done += k
+        if use_graph:
+            cur.wait_stream(self._gstream)
+        self.a._done += n_steps
+        self.b._done += n_steps
+
+    def close(self):
+        for pl in self._plans.values():
+            pl.close()
+            pl._keep = None
+        self._plans = {}

@@ -18,10 +18,27 @@ def dist_info():
             int(os.environ.get('LOCAL_RANK', '0')))
 
 
-def init_distributed(backend=None):
-    """Initialise ``torch.distributed`` when launched with WORLD_SIZE > 1; returns (rank, world, local_rank)."""
+# ``--force_dist`` of the CLIs: a ONE-rank process group is created and every agreement point / gather of this module goes through it
+# (world = 1 normally short-circuits them) -- the RCCL path end to end on a one-GPU box
+_force = [False]
+
+
+def _single(world):
+    """Is this a one-rank run whose collectives are skipped?"""
+    return world <= 1 and not _force[0]
+
+
+def init_distributed(backend=None, force=False):
+    """Initialise ``torch.distributed`` when launched with WORLD_SIZE > 1 (or ``force``: also for one rank); returns
+    (rank, world, local_rank)."""
     rank, world, local = dist_info()
-    if world > 1:
+    if force and world == 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+        _force[0] = True
+    if world > 1 or force:
         import torch
         import torch.distributed as dist
         if not dist.is_initialized():
@@ -67,7 +84,7 @@ def check_peers(world, where=''):
     here -- its handler (``report_failure``) sets the failure key instead -- and every healthy rank raises ``PeerFailure`` rather than
     entering a gather the failed rank will never join.  A peer that neither arrives nor reports within ``SBC_DIST_TIMEOUT_S``
     (default 300 s) counts as failed."""
-    if world <= 1:
+    if _single(world):
         return
     import time
     st = _store()
@@ -90,7 +107,7 @@ def report_failure(world):
     """The failing rank's half of ``check_peers``: sets the failure key its peers poll at their next agreement point.  Never blocks,
     so it is safe wherever the failure happened (also after the last collective).  Call once, from the handler of whatever
     exception ended this rank's work; never for a ``PeerFailure``."""
-    if world > 1:
+    if not _single(world):
         try:
             _store().set('sbc/failed', '1')
         except Exception:                                  # the store itself is gone: nothing more to tell anybody
@@ -109,7 +126,7 @@ def run_guarded(world, body):
         report_failure(world)
         raise
     finally:
-        if world > 1:
+        if not _single(world):
             import torch.distributed as dist
             if dist.is_initialized():
                 try:
@@ -120,7 +137,7 @@ def run_guarded(world, body):
 
 def gather_objects(obj, world):
     """Every rank's picklable ``obj`` as a list indexed by rank (``all_gather_object``; one rank: ``[obj]``)."""
-    if world == 1:
+    if _single(world):
         return [obj]
     import torch.distributed as dist
     out = [None] * world
@@ -162,7 +179,7 @@ def gather_trajectory_logs(local_log, n_items, rank, world):
     """All-gather per-rank NMSE logs ``[n_steps, T_local]`` into the full ``[n_steps, n_items]`` log (every rank
     gets it).  Blocks are padded to equal width because the collective needs equal shapes."""
     import torch
-    if world == 1:
+    if _single(world):
         return local_log
     import torch.distributed as dist
     b = block_bounds(n_items, world)
@@ -178,7 +195,7 @@ def gather_trajectory_logs(local_log, n_items, rank, world):
 def all_reduce_sum_(t, world):
     """In-place SUM all-reduce of a device tensor (the flat gradient buffer of data-parallel training, train.py).  RCCL
     reduces it where it lies; a gloo group (CPU tests, more ranks than GPUs) takes it through host memory."""
-    if world == 1:
+    if _single(world):
         return t
     import torch.distributed as dist
     if dist.get_backend() == 'nccl' or not t.is_cuda:

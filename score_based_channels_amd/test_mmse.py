@@ -80,6 +80,9 @@ def parse_args(argv=None):
                    help='[added] run each lock-step batch as this many concurrent sub-batches on their own HIP streams '
                         '(bit-identical results; +7 %% at 2 on MI355X for 1700 trajectories)')
     p.add_argument('--result_dir', type=str, default=None, help='[added] default TWC_rebuttal_MMSE_aug6_seed4321')
+    p.add_argument('--force_dist', action='store_true',
+                   help='[added] with ONE rank: still create the torch.distributed group (backend nccl = RCCL on a GPU box) and route the seed '
+                        'broadcast, the agreement points and the final gathers through it')
     return p.parse_args(argv)
 
 
@@ -135,7 +138,7 @@ def posterior_chains(diffuser, val_H, val_P, local_noise, step, noise_boost, n_r
 
 def main(argv=None):
     args = parse_args(argv)
-    rank, world, local = init_distributed()
+    rank, world, local = init_distributed(force=getattr(args, 'force_dist', False))
     # (a rank that fails tells the others at their next agreement point instead of leaving them in a collective: shard.run_guarded)
     return shard.run_guarded(world, lambda: _main(args, rank, world, local))
 
@@ -162,7 +165,7 @@ def _main(args, rank, world, local):
     diffuser = ScoreNet(config, device, conv_mode=args.conv_mode).load_state_dict(model_state).eval()
 
     seed = int.from_bytes(os.urandom(4), 'little') if args.seed is None else args.seed
-    if world > 1:
+    if world > 1 or getattr(args, 'force_dist', False):
         seed = shard.broadcast_int(seed, 0, device)
     np.random.seed(seed % (2 ** 32))
 

@@ -49,6 +49,9 @@ def parse_args(argv=None):
     p.add_argument('--streams', type=int, default=DEFAULT_STREAMS,
                    help='[added] run each lock-step batch as this many concurrent sub-batches on their own HIP streams '
                         '(bit-identical results; +7 %% at 2 on MI355X for 1700 trajectories)')
+    p.add_argument('--force_dist', action='store_true',
+                   help='[added] with ONE rank: still create the torch.distributed group (backend nccl = RCCL on a GPU box) and route the seed '
+                        'broadcast, the agreement points and the final gathers through it')
     return p.parse_args(argv)
 
 
@@ -66,7 +69,7 @@ def select_best(best_nmse, alpha_step_range, beta_noise_range):
 def main(argv=None):
     args = parse_args(argv)
     from . import shard
-    rank, world, local = shard.init_distributed()
+    rank, world, local = shard.init_distributed(force=getattr(args, 'force_dist', False))
     # (a rank that fails tells the others at their next agreement point instead of leaving them in a collective: shard.run_guarded)
     return shard.run_guarded(world, lambda: _main(args, rank, world, local))
 
@@ -96,7 +99,7 @@ def _main(args, rank, world, local):
     diffuser = ScoreNet(config, device, conv_mode=args.conv_mode).load_state_dict(model_state).eval()
 
     seed = int.from_bytes(os.urandom(4), 'little') if args.seed is None else args.seed
-    if world > 1:
+    if world > 1 or getattr(args, 'force_dist', False):
         seed = shard.broadcast_int(seed, 0, device)
     np.random.seed(seed % (2 ** 32))
 

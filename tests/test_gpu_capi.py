@@ -43,7 +43,9 @@ def test_c_built_score_network_equals_python_host(weights64, mode):
         ops_p, n = C.POINTER(_lib.sbc_op)(), C.c_int32()
         _lib.check(L.sbc_score_ops(h, C.byref(ops_p), C.byref(n)))
         net = ScoreNet(cfg, conv_mode=mode, fuse_pairs=pairs, fold_stats=fold, fuse_res=res, fuse_chain=chain, fuse_down=down, fuse_end=end).cuda().load_state_dict(sd)
-        bound = net.bind(B, nt, nr)
+        # (record for record against the SEQUENTIAL plan: the C builder does not move the skip branches onto launch lanes, which the Python host
+        # does for a batch this small -- the forward below runs the Python host's lane plan and must still agree bit for bit)
+        bound = net.bind(B, nt, nr, lanes=False)
         assert n.value == len(bound.ops)
         assert chain == any(o.kind == 24 for o in bound.ops) and down == any(o.kind == 25 for o in bound.ops)
         # identical records: every scalar field, and the same storage-sharing pattern (pointers renamed by first use)
@@ -58,6 +60,11 @@ def test_c_built_score_network_equals_python_host(weights64, mode):
                 if a is not None:
                     assert ids_c.setdefault(a, len(ids_c)) == ids_p.setdefault(b, len(ids_p)), (i, f)
             for f in ('weight', 'bias', 'weight_wino', 'weight_split', 'weight2_split', 'bias2', 'norm2'):
+                if ref.kind == 25 and f in ('weight', 'weight_wino'):
+                    # SBC_OP_CONV_DOWN: calibration-only pointers at the layers' UNPOOLED forms, which the Python host packs for other
+                    # array sizes and a C handle (one size, only the forms it runs) does not have (include/sbc_hip.h)
+                    assert getattr(got, f) is None
+                    continue
                 assert (getattr(got, f) is None) == (getattr(ref, f) is None), (i, f)
             if ref.kind == 24:                      # SBC_OP_CHAIN: the same blocks in the same order
                 cg, cr = C.cast(got.ext, C.POINTER(_lib.sbc_chain)).contents, C.cast(ref.ext, C.POINTER(_lib.sbc_chain)).contents

@@ -35,7 +35,7 @@ def test_forward_every_op_matches_cpu_interpretation(net64, weights64):
     g = load_golden('forward_64x16.npz')
     B = 3
     bound = net64.bind(B, 64, 16)
-    pl = net64.score_plan(64, 16)
+    pl = bound.plan                       # (a batch this small: the plan with the skip branches on a launch lane -- list order is a valid order)
     bound.x.copy_(torch.from_numpy(g['x'][:B]).permute(0, 2, 3, 1))
     labels = np.array([0, 1155, 2310])
     bound.labels.copy_(torch.from_numpy(labels))
@@ -511,7 +511,7 @@ def test_cli_tuner_matches_reference_pipeline(net64, tmp_path, monkeypatch, name
     assert np.array_equal(split, nmse_log)
 
 
-def test_concurrent_sub_batch_streams_do_not_change_results(net64):
+def test_concurrent_sub_batch_streams_do_not_change_results(net64, monkeypatch):
     """``run_trajectories(n_streams=2)``: two sub-batches on their own HIP streams, one host thread each
     (driver.run_concurrently).  Per-trajectory noise keys and per-sample normalisation make the split invisible -- and so
     must the hardware: with packed-fp32 instructions in the build, concurrently running kernels of different kinds corrupted
@@ -529,6 +529,9 @@ def test_concurrent_sub_batch_streams_do_not_change_results(net64):
     ln = np.repeat(snr_to_noise(snr, nt), nch)
     init = torch.randn(nch, nt, nr, dtype=torch.complex64, generator=torch.Generator().manual_seed(7))
     modes = [(1, False)] + [(2 + k % 2, bool(k & 2)) for k in range(8)]       # repeated: the hazard this guards is sporadic
+    # (a chunk this small would run as ONE batch with launch lanes whatever n_streams says, driver.stream_count: the lane plan is
+    # switched off here so that the sub-batch streams really run; tests/...::test_skip_overlap_plan_equals_sequential_plan has the lanes)
+    monkeypatch.setattr(net64, 'skip_overlap', False)
     out = [run_trajectories(net64, H, Pm, idx, idx, ln, 3e-11, 0.01, [0, 1155, 2310], 3, 11, init, n_streams=n,
                             use_graph=g, return_final=True) for n, g in modes]
     for (n, g), (log, est) in zip(modes[1:], out[1:]):
@@ -553,7 +556,8 @@ def test_lagging_second_stream_does_not_change_results(net64, monkeypatch):
     ln = np.repeat(snr_to_noise(snr, nt), nch)
     init = torch.randn(nch, nt, nr, dtype=torch.complex64, generator=torch.Generator().manual_seed(8))
     args = (net64, H, Pm, idx, idx, ln, 3e-11, 0.01, [0, 1155, 2310], 3, 13, init)
-    one = run_trajectories(*args, n_streams=1, return_final=True)
+    one = run_trajectories(*args, n_streams=1, return_final=True)            # (one batch, skip branches on a launch lane)
+    monkeypatch.setattr(net64, 'skip_overlap', False)                        # (... so that n_streams = 2 means two streams: driver.stream_count)
     monkeypatch.setenv('SBC_STREAM_LAG_MIN_STEPS', '1')
     for _ in range(3):
         two = run_trajectories(*args, n_streams=2, return_final=True)
@@ -580,6 +584,8 @@ def test_failing_leader_stream_does_not_hang_its_follower(net64, monkeypatch):
     def boom(self, *a, **k):
         raise RuntimeError('leader failed')
     monkeypatch.setattr(AldBatch, 'run_leading', boom)
+    # (a chunk this small would run as ONE batch with launch lanes, driver.stream_count: switch the lane plan off to get the two streams)
+    monkeypatch.setattr(net64, 'skip_overlap', False)
     with pytest.raises(RuntimeError, match='leader failed'):
         run_trajectories(net64, H, Pm, idx, idx, ln, 3e-11, 0.01, [0, 1155, 2310], 3, 13, init, n_streams=2)
 
@@ -804,6 +810,53 @@ def test_skip_overlap_plan_equals_sequential_plan(weights64):
         X1, L1, u1 = run(ovl, parts, graph)
         assert all(u1), (parts, graph)
         assert np.array_equal(X0, X1) and np.array_equal(L0, L1), (parts, graph)
+
+
+def test_two_sub_batches_in_one_plan_equal_two_runs(weights64):
+    """ald.AldPair: two sub-batches as ONE plan -- A on the run stream, B on a launch lane, several Langevin steps
+    unrolled, B lagging behind the head of A's first step -- issued by one host thread or replayed as ONE hipGraph with two branches.
+    Every record is a record of A's or B's own step plan: both equal the batches run alone, bit for bit."""
+    import torch
+    from score_based_channels_amd import synth
+    from score_based_channels_amd.ald import AldBatch, AldPair
+    from score_based_channels_amd.scorenet import ScoreNet
+    cfg, sd = weights64
+    net = ScoreNet(cfg).cuda().load_state_dict(sd)
+    T = 48
+    raw = synth.generate_channels('CDL-C', 16, 64, 16, 0.5, 5)
+    H = np.conj(np.transpose(raw / np.std(raw), (0, 2, 1))).astype(np.complex64)
+    Pm = np.conj(np.transpose(synth.qpsk_pilots(np.random.default_rng(2), 16, 64, 38), (0, 2, 1)))
+    idx = np.arange(T) % 16
+    ln = np.repeat(64.0 * 10 ** (-np.arange(-10, 20, 10) / 10.), 16)[:T]
+    init = torch.randn(16, 64, 16, dtype=torch.complex64, generator=torch.Generator().manual_seed(4))
+
+    def batches():
+        out = []
+        for part in np.array_split(np.arange(T), 2):
+            a = AldBatch(net, H, Pm, idx[part], idx[part], ln[part], levels=[0, 700, 2310], steps_each=3, seed=21, traj_id=part, lanes=False)
+            a.set_init(init[torch.from_numpy(idx[part])])
+            a.synthesize_measurements()
+            out.append(a)
+        return out
+
+    def result(alds):
+        torch.cuda.synchronize()
+        r = torch.cat([a.X for a in alds]).cpu().numpy(), torch.cat([a.nmse_log() for a in alds], dim=1).cpu().numpy()
+        for a in alds:
+            a.close()
+        return r
+    alone = batches()
+    for a in alone:
+        a.run(9)
+    X0, L0 = result(alone)
+    for graph in (False, True, False):
+        alds = batches()
+        pair = AldPair(alds[0], alds[1], k_steps=4)                 # 9 steps = two lists of four + one of one
+        pair.set_persistent_cus(128)
+        pair.run(9, use_graph=graph)
+        X1, L1 = result(alds)
+        pair.close()
+        assert np.array_equal(X0, X1) and np.array_equal(L0, L1), graph
 
 
 @pytest.mark.parametrize('mode', ['bf16x3', 'f16x2'])

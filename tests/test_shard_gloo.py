@@ -116,3 +116,33 @@ def test_a_rank_failing_after_the_last_collective_hangs_nobody():
     [p.join(60) for p in procs]
     assert res[0][1].startswith('own failure') and res[1][1] == 'done'
     assert max(r[2] for r in res) < 30
+
+
+def _forced_single_worker(port, q):
+    """``--force_dist``: ONE rank, but a real process group -- every agreement point and gather of shard.py goes
+    through it instead of being short-circuited."""
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        os.environ.pop(k, None)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from score_based_channels_amd import shard
+    r, w, _ = shard.init_distributed('gloo', force=True)
+    assert (r, w) == (0, 1) and dist.is_initialized() and dist.get_world_size() == 1
+
+    def body():
+        assert shard.broadcast_int(41, 0) == 41
+        shard.check_peers(w, 'the gather')
+        assert shard.gather_objects([{'rank': 0}], w) == [[{'rank': 0}]]
+        full = torch.arange(12, dtype=torch.float32).view(3, 4)
+        return bool(torch.equal(shard.gather_trajectory_logs(full.clone(), 4, r, w), full))
+    ok = shard.run_guarded(w, body)
+    q.put((ok, dist.is_initialized()))
+
+
+def test_forced_one_rank_group_routes_everything_through_the_collectives():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_single_worker, args=(28100 + os.getpid() % 500, q))
+    p.start()
+    ok, still = q.get(timeout=120)
+    p.join(60)
+    assert ok and not still

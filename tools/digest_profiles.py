@@ -3,17 +3,17 @@ usage: digest_profiles.py [cdlc|big] [round tag, default r03]"""
 import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 W = sys.argv[1] if len(sys.argv) > 1 else 'cdlc'
-TAG = sys.argv[2] if len(sys.argv) > 2 else 'r05'
+TAG = sys.argv[2] if len(sys.argv) > 2 else 'r06'
 R = os.path.join(ROOT, 'gpurun_out', 'profile_passes_' + W) + '/'
 P = os.path.join(ROOT, 'profiles') + '/'
 BIG = W == 'big'
 # the kernel classes bench.py tags; the dominant one = largest total time in the --stats pass
-CANDIDATES = (['conv_wx3_kernel<32, 32, 1, true, 3, true, 1, 1, 1>', 'conv_pair_kernel<64, 4, 1, 8, 32>',
-               'conv_wx3_kernel<64, 64, 1, true, 2, false, 2, 1, 1>'] if BIG else
+CANDIDATES = (['conv_x3_kernel<32, 32, 3, 2, 1, 4, 1, true, 1>', 'conv_wx3_kernel<32, 32, 1, true, 3, true, 1, 1, 1>', 'conv_pair_kernel<64, 4, 1, 8, 32>',
+               'conv_x3_kernel<64, 64, 3, 2, 2, 4, 1, true, 1>', 'conv_wx3_kernel<64, 64, 1, true, 2, false, 2, 1, 1>'] if BIG else
               ['conv_wx3_kernel<32, 32, 1, true, 4, true, 1, 1, 2>', 'conv_pair_roll_kernel<2>', 'conv_pair_p3_kernel<16, 8, 2, 4, 32>', 'conv_down_kernel<32, 64, 16>', 'conv_down_kernel<64, 64, 8>',
                'conv_pool_kernel<16, 8, 2, 4, 32>', 'conv_wx3_kernel<64, 64, 1, true, 2, false, 2, 1, 2>',
-               'conv_dp_kernel<64, 8, 8, 1, false, 4>', 'conv_res_kernel', 'conv_chain_kernel<128, 2, 8>', 'conv_chain_kernel<64, 2, 4>',
-               'conv_chain_kernel<64, 4, 4>', 'conv_chain_kernel<64, 8, 8>', 'conv_chain_kernel<32, 8, 4>'])
+               'conv_dp_kernel<64, 8, 8, 1, false, 4>', 'conv_res_kernel', 'conv_chain_kernel<128, 2, 8, 1>', 'conv_chain_kernel<64, 2, 4, 1>',
+               'conv_chain_kernel<64, 4, 4, 1>', 'conv_chain_kernel<64, 8, 8, 1>', 'conv_chain_kernel<32, 8, 4, 1>'])
 PX = (256 * 64) if BIG else (64 * 16)
 T = 1024 if BIG else 1700
 CMD = '--workload %s --streams 1 --no-cpu-baseline --no-strong --no-other-mode --no-exact-mode --sustained 0' % W
