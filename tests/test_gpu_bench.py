@@ -43,6 +43,9 @@ def test_bench_line_contract_single_gpu():
     assert d['exact_mode']['conv_mode'] == 'bf16x3' and d['exact_mode']['value'] > 0 and len(d['per_rank']['ms_per_step_by_rank']) == 1
     assert d['sustained_steps'] == 6 and d['sustained_ms_per_step'] > 0 and 'other_launch_mode' in d
     assert d['strong']['scaling'] == 'strong' and d['strong']['trajectories_total'] == 20400
+    # round 6: the small-batch numbers and the exact-mode rate as plain fields of `config`; blocks this small run as one batch with launch lanes
+    assert all(ss[w]['launch_lanes'] and ss[w]['streams'] == 1 for w in ss)
+    assert d['config']['rank_share_ms_per_step_T16'] > 0 and d['config']['exact_mode_bf16x3_channels_per_s'] > 0 and d['config']['sustained_channels_per_s'] > 0
 
 
 def test_bench_self_launches_its_ranks():
@@ -59,9 +62,16 @@ def test_bench_self_launches_its_ranks():
         assert bad.returncode != 0 and 'one rank per GPU' in (bad.stderr + bad.stdout)
         env_clean['SBC_DIST_BACKEND'] = 'gloo'
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
-                        '--channels', '8', '--snr-points', '4', '--sustained', '0', '--no-strong', '--no-other-mode'],
+                        '--channels', '8', '--snr-points', '4', '--sustained', '0', '--no-other-mode'],
                        capture_output=True, text=True, timeout=900, env=env_clean)
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')][-1])
     assert d['n_gpus'] == 2 and d['config']['trajectories_per_gpu'] == 32 and d['config']['world_size_seen_by_backend'] == 2
     assert abs(d['value'] - 2 * 32 / (6933 * d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+    # round 6: with N > 1 the line also MEASURES BASELINE configs[1] strong-sharded over the ranks of the job (here: this run's 32
+    # trajectories, 16 per rank), and repeats the numbers as plain fields of `config` (what the driver's record keeps)
+    sc = d['strong_cfg2']
+    assert sc['scaling'] == 'strong' and sc['trajectories_total'] == 32 and sc['trajectories_per_gpu'] == 16 and sc['value'] > 0
+    assert abs(sc['value'] - 32 / (6933 * sc['ms_per_step'] * 1e-3)) < 1e-6 * sc['value']
+    assert abs(d['config']['strong_cfg2_channels_per_s'] - sc['value']) < 1e-2 and d['config']['strong_cfg2_ms_per_step'] > 0
+    assert d['strong']['trajectories_total'] == 20400 and d['strong']['trajectories_per_gpu'] == 10200
