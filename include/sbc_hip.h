@@ -464,6 +464,9 @@ typedef struct sbc_score_desc {
 #define SBC_SCORE_FUSE_END  0x20 /* (ABI 13) the normalizer's statistics inside the SBC_OP_END_CONV launch (SBC_PRO_NORM_SELF on that record: 32 channels,
                                     1024 pixels; any conv_mode); what the Python host does by default next to SBC_SCORE_FUSE_PAIRS
                                     (scorenet.DEFAULT_FUSE_END) */
+#define SBC_SCORE_SKIP_LANES 0x40 /* (ABI 14) the decoder's skip branches (refineK.adapt_convs.0) behind their anchor records on launch lane 1 (sbc_op.lane /
+                                    signal / wait): for small batches, where the low-resolution launches are latency-bound -- what the Python host does for
+                                    batches of at most scorenet.SKIP_OVERLAP_MAX_T trajectories (plan.hoist_skip_branches; identical results) */
 typedef struct sbc_score sbc_score;
 int sbc_score_create(const sbc_score_desc* desc, const sbc_tensor_ref* tensors, int32_t n_tensors, sbc_score** out);
 int sbc_score_buffers(sbc_score* score, float** x, float** out, int64_t** labels);

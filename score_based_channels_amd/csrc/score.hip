@@ -32,6 +32,9 @@ struct POp {
         int dil = 1; std::string bias1, bias2, norm1, norm2, w3, bias3;
     };
     std::vector<Block> blocks;               // SBC_OP_CHAIN: the RCU / CRP blocks in execution order (plan.py: Op.blocks)
+    int lane = 0, signal = 0, wait0 = 0, wait1 = 0;   // launch lanes (sbc_op.lane / signal / wait; plan.hoist_skip_branches)
+    // the state_dict key that names the record's layer (plan.py: Op.name has the same prefix)
+    const std::string& label() const { return !blocks.empty() ? blocks[0].w1 : !weight.empty() ? weight : norm_key; }
 };
 
 // ---- wiring: a transcription of plan.py's _Builder (reference lines cited there) --------------------------------
@@ -259,9 +262,22 @@ namespace {
 void assign_slots(sbc_score& s) {       // plan.assign_slots: linear scan, outputs never alias inputs of their own op
     const int n_ops = (int)s.pops.size();
     std::vector<int> last_use(s.tensors.size(), -1);
+    // a record on a lane is known to be complete at the first run-stream record that waits for an event its lane signals at or behind it
+    // (plan.assign_slots); without one, at the end of the list
+    std::vector<int> done_at(n_ops);
+    for (int i = 0; i < n_ops; ++i) {
+        done_at[i] = i;
+        if (!s.pops[i].lane) continue;
+        done_at[i] = n_ops - 1;
+        for (int k = i; k < n_ops && done_at[i] == n_ops - 1; ++k) {
+            if (s.pops[k].lane != s.pops[i].lane || !s.pops[k].signal) continue;
+            for (int m = k + 1; m < n_ops; ++m)
+                if (!s.pops[m].lane && (s.pops[m].wait0 == s.pops[k].signal || s.pops[m].wait1 == s.pops[k].signal)) { done_at[i] = m; break; }
+        }
+    }
     for (int i = 0; i < n_ops; ++i)
         for (int id : {s.pops[i].src, s.pops[i].stats, s.pops[i].res1, s.pops[i].res2, s.pops[i].up})
-            if (id >= 0) last_use[id] = i;
+            if (id >= 0 && done_at[i] > last_use[id]) last_use[id] = done_at[i];
     std::map<size_t, std::vector<int>> free_slots;
     std::vector<int> live;
     auto elems = [&](int id) { return (size_t)s.tensors[id].h * s.tensors[id].w * s.tensors[id].c; };
@@ -366,6 +382,36 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
     }
     for (auto& o : b.ops)                   // plan.TAG_DIRECT_MID
         if (o.tag == 3 && !(o.flags & (SBC_PRO_NORM | SBC_EPI_UP | SBC_EPI_MOMENTS_OUT))) o.tag = 5;
+    if (d->flags & SBC_SCORE_SKIP_LANES) {
+        // plan.hoist_skip_branches with plan.DEFAULT_SKIP_SPEC: the decoder's skip branches behind their anchors, on lane 1
+        static const char* const spec[5][2] = {{"refine5.adapt_convs.0.", "res3.1."}, {"refine4.adapt_convs.0.", "res3.1."}, {"refine3.adapt_convs.0.", "res3.1."},
+                                               {"refine31.adapt_convs.0.", "res31.1."}, {"refine2.adapt_convs.0.", "res4.1."}};
+        auto starts = [](const std::string& v, const char* pre) { return v.compare(0, strlen(pre), pre) == 0; };
+        int next_evt = 1;
+        auto signal_of = [&](POp& o) { if (!o.signal) o.signal = next_evt++; return o.signal; };
+        for (const auto& e : spec) {
+            int i0 = -1, i1 = -1;
+            for (int i = 0; i < (int)b.ops.size(); ++i)
+                if (starts(b.ops[i].label(), e[0])) { if (i0 < 0) i0 = i; i1 = i; }
+            if (i0 < 0) continue;                                   // (a plan without this branch as records of its own)
+            for (int i = i0; i <= i1; ++i) SBC_REQUIRE(starts(b.ops[i].label(), e[0]) && !b.ops[i].lane, "sbc_score_create: skip branch %s is not one run of records", e[0]);
+            int a = -1;
+            for (int i = 0; i < i0; ++i) if (starts(b.ops[i].label(), e[1])) a = i;
+            SBC_REQUIRE(a >= 0, "sbc_score_create: anchor %s of skip branch %s not found", e[1], e[0]);
+            std::vector<POp> branch(b.ops.begin() + i0, b.ops.begin() + i1 + 1);
+            const int result = branch.back().dst;
+            b.ops.erase(b.ops.begin() + i0, b.ops.begin() + i1 + 1);
+            int consumer = -1;
+            for (int i = i0; i < (int)b.ops.size() && consumer < 0; ++i)
+                for (int id : {b.ops[i].src, b.ops[i].stats, b.ops[i].res1, b.ops[i].res2, b.ops[i].up}) if (id == result) consumer = i;
+            SBC_REQUIRE(consumer >= 0 && !b.ops[consumer].wait1, "sbc_score_create: skip branch %s has no consumer with a free wait slot", e[0]);
+            for (auto& o : branch) o.lane = 1;
+            branch.front().wait0 = signal_of(b.ops[a]);
+            const int done = signal_of(branch.back());
+            (b.ops[consumer].wait0 ? b.ops[consumer].wait1 : b.ops[consumer].wait0) = done;
+            b.ops.insert(b.ops.begin() + a + 1, branch.begin(), branch.end());
+        }
+    }
     s->tensors = b.t; s->pops = b.ops; s->x_t = x; s->out_t = o_t;
     assign_slots(*s);
 
@@ -509,6 +555,7 @@ int sbc_score_create(const sbc_score_desc* d, const sbc_tensor_ref* tensors, int
         const Tn& dst = s->tensors[o.dst];
         r.kind = o.kind; r.flags = o.flags; r.B = B; r.H = src.h; r.W = src.w;
         r.cin = src.c; r.cout = dst.c; r.ksize = o.ksize; r.dil = o.dil; r.tag = o.tag;
+        r.lane = o.lane; r.signal = o.signal; r.wait[0] = o.wait0; r.wait[1] = o.wait1;
         r.in = s->slots[s->tensors[o.src].slot]; r.out = s->slots[dst.slot];
         if (o.moments >= 0) r.aux = s->slots[s->tensors[o.moments].slot];
         auto wp = [&](const std::string& key) -> const void* { return off.count(key) ? s->wdev + off[key] : nullptr; };

@@ -13,14 +13,14 @@ pytestmark = pytest.mark.gpu
 MODES = {'bf16x3': 0, 'f32': 1, 'f16w': 2, 'f16x2': 3}
 
 
-def _create(sd, cfg, B, nt, nr, mode, pairs=False, fold=False, res=False, chain=False, down=False, end=False):
+def _create(sd, cfg, B, nt, nr, mode, pairs=False, fold=False, res=False, chain=False, down=False, end=False, lanes=False):
     from score_based_channels_amd import _lib
     keep = {k: np.ascontiguousarray(v, np.float32) for k, v in sd.items() if k != 'sigmas'}
     refs = (_lib.sbc_tensor_ref * len(keep))(*[
         _lib.sbc_tensor_ref(name=k.encode(), data=v.ctypes.data, numel=v.size) for k, v in keep.items()])
     sig = np.ascontiguousarray(sd['sigmas'], np.float32)
     desc = _lib.sbc_score_desc(ngf=32, channels=2, nt=nt, nr=nr, batch=B, conv_mode=MODES[mode], sigmas=sig.ctypes.data,
-                               num_classes=sig.size, flags=(1 if pairs else 0) | (2 if fold else 0) | (4 if res else 0) | (8 if chain else 0) | (16 if down else 0) | (32 if end else 0))
+                               num_classes=sig.size, flags=(1 if pairs else 0) | (2 if fold else 0) | (4 if res else 0) | (8 if chain else 0) | (16 if down else 0) | (32 if end else 0) | (64 if lanes else 0))
     h = C.c_void_p()
     _lib.check(_lib.lib().sbc_score_create(C.byref(desc), refs, len(keep), C.byref(h)))
     return h
@@ -28,7 +28,7 @@ def _create(sd, cfg, B, nt, nr, mode, pairs=False, fold=False, res=False, chain=
 
 @pytest.mark.parametrize('mode', ['bf16x3', 'f32', 'f16w', 'f16x2', 'f16x2+pairs', 'f16w+pairs', 'f16x2+pairs+fold', 'bf16x3+fold',
                                   'f16x2+pairs+fold+res', 'f16x2+pairs+fold+res+chain', 'f16x2+pairs+fold+res+chain+down', 'f16x2+pairs+fold+res+chain+down+end',
-                                  'bf16x3+end'])
+                                  'bf16x3+end', 'f16x2+pairs+fold+res+chain+down+end+lanes', 'bf16x3+lanes'])
 def test_c_built_score_network_equals_python_host(weights64, mode):
     import torch
     from score_based_channels_amd import _lib
@@ -38,22 +38,25 @@ def test_c_built_score_network_equals_python_host(weights64, mode):
     B, nt, nr = 3, 64, 16
     mode, *opts = mode.split('+')
     pairs, fold, res, chain, down, end = 'pairs' in opts, 'fold' in opts, 'res' in opts, 'chain' in opts, 'down' in opts, 'end' in opts
-    h = _create(sd, cfg, B, nt, nr, mode, pairs, fold, res, chain, down, end)
+    lanes = 'lanes' in opts                 # SBC_SCORE_SKIP_LANES: the skip branches on launch lane 1 (plan.hoist_skip_branches)
+    h = _create(sd, cfg, B, nt, nr, mode, pairs, fold, res, chain, down, end, lanes)
     try:
         ops_p, n = C.POINTER(_lib.sbc_op)(), C.c_int32()
         _lib.check(L.sbc_score_ops(h, C.byref(ops_p), C.byref(n)))
         net = ScoreNet(cfg, conv_mode=mode, fuse_pairs=pairs, fold_stats=fold, fuse_res=res, fuse_chain=chain, fuse_down=down, fuse_end=end).cuda().load_state_dict(sd)
-        # (record for record against the SEQUENTIAL plan: the C builder does not move the skip branches onto launch lanes, which the Python host
-        # does for a batch this small -- the forward below runs the Python host's lane plan and must still agree bit for bit)
-        bound = net.bind(B, nt, nr, lanes=False)
+        # (record for record against the plan the flags ask for: sequential, or -- SBC_SCORE_SKIP_LANES -- with the skip branches on a launch
+        # lane; the forward below runs whatever the Python host picks for a batch this small and must agree bit for bit either way)
+        bound = net.bind(B, nt, nr, lanes=lanes)
+        assert lanes == any(o.lane for o in bound.ops)
         assert n.value == len(bound.ops)
         assert chain == any(o.kind == 24 for o in bound.ops) and down == any(o.kind == 25 for o in bound.ops)
         # identical records: every scalar field, and the same storage-sharing pattern (pointers renamed by first use)
         ids_c, ids_p = {}, {}
         for i, ref in enumerate(bound.ops):
             got = ops_p[i]
-            for f in ('kind', 'flags', 'B', 'H', 'W', 'cin', 'cout', 'ksize', 'dil', 'up_h', 'up_w', 'tag'):
+            for f in ('kind', 'flags', 'B', 'H', 'W', 'cin', 'cout', 'ksize', 'dil', 'up_h', 'up_w', 'tag', 'lane', 'signal'):
                 assert getattr(got, f) == getattr(ref, f), (i, f)
+            assert list(got.wait) == list(ref.wait), (i, 'wait')
             for f in ('in_', 'out', 'stats', 'res1', 'res2', 'up', 'aux'):
                 a, b = getattr(got, f), getattr(ref, f)
                 assert (a is None) == (b is None), (i, f)
