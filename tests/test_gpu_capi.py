@@ -165,3 +165,27 @@ def test_score_create_reports_missing_tensors(weights64):
     bad = {k: v for k, v in sd.items() if k != 'refine3.msf.convs.1.bias'}
     with pytest.raises(_lib.SbcError, match='refine3.msf.convs.1.bias'):
         _create(bad, cfg, 2, 64, 16, 'bf16x3')
+
+
+def test_plan_refuses_inconsistent_lanes():
+    """sbc_plan_create validates the launch-lane fields of its records (ABI 14): a lane beyond SBC_MAX_LANES, an event id beyond
+    SBC_MAX_EVENTS, a wait for an event no EARLIER record signals, lanes mixed with the SBC_OP_SIDE / SBC_OP_JOIN flags -- all refused
+    with a message, none of them a hang at run time."""
+    import torch
+    from score_based_channels_amd import _lib, plan as P
+    x = torch.zeros(2, 8, 8, 2, device='cuda')
+    y = torch.zeros(1, dtype=torch.int32, device='cuda')
+
+    def inc(**kw):
+        return _lib.sbc_op(kind=P.STEP_INC, B=1, out=C.c_void_p(y.data_ptr()), **kw)
+    ok = _lib.Plan([inc(signal=1), inc(lane=1, wait=(C.c_int32 * 2)(1, 0), signal=2), inc(wait=(C.c_int32 * 2)(2, 0))])
+    ok.run(torch.cuda.current_stream().cuda_stream, 3)
+    torch.cuda.synchronize()
+    assert int(y.item()) == 9
+    ok.close()
+    for bad, what in (([inc(lane=4)], 'lane out of range'), ([inc(signal=65)], 'signal id out of range'),
+                      ([inc(wait=(C.c_int32 * 2)(1, 0)), inc(signal=1)], 'no earlier record signals'),
+                      ([inc(signal=1), inc(lane=1, flags=P.OP_SIDE, wait=(C.c_int32 * 2)(1, 0))], 'do not mix')):
+        with pytest.raises(_lib.SbcError, match=what):
+            _lib.Plan(bad)
+    del x
