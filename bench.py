@@ -629,13 +629,17 @@ def main():
                                       'conv_pair_kernel<%d, %d, %d, %d, 32>' % (nr, 4 if nr == 64 else 8, 2 if conv_mode == 'f16x2' else 1, 8 if nr == 64 else 4)),
                      P.TAG_POOL_TOP: 'conv_pool_kernel<%d, 8, %d, 4, 32>' % (nr, 2 if conv_mode == 'f16x2' else 1),
                      P.TAG_RES_TOP: 'conv_res_kernel',
+                     # (conv_mode f16x2 with 8-pixel rows, round 6: the direct persistent kernel also takes the layers with a norm prologue and a
+                     # tile-moment output -- its NM instantiation, csrc/conv_dp.hip)
                      P.TAG_CONV_MID: 'conv_x3_kernel<64, 64, 3, 2, 2, 4, 1, true, 1> (conv_wx3_kernel<64, 64, 1, true, 2, false, 2, 1, 1> for the producers of tile moments)' if conv_mode == 'f16w' else
+                                     'conv_dp_kernel<64, 8, 8, 1, false, 4, true>' if conv_mode == 'f16x2' and nr == 16 and not os.environ.get('SBC_NO_CONV_DP_NORM') else
                                      'conv_wx3_kernel<64, 64, 1, true, 2, false, 2, 1, %d>' % {'bf16x3': 0, 'f16x2': 2}.get(conv_mode, 0),
                      # (conv_mode f16x2 with 8-pixel rows: the direct persistent kernel, csrc/conv_dp.hip; else the Winograd kernel)
-                     P.TAG_DIRECT_MID: ('conv_dp_kernel<64, 8, 8, 1, false, 4>' if conv_mode == 'f16x2' and nr == 16 else
+                     P.TAG_DIRECT_MID: ('conv_dp_kernel<64, 8, 8, 1, false, 4, false>' if conv_mode == 'f16x2' and nr == 16 else
                                         'conv_x3_kernel<64, 64, 3, 2, 2, 4, 1, true, 1>' if conv_mode == 'f16w' else
                                         'conv_wx3_kernel<64, 64, 1, true, 2, false, 2, 1, %d>' % {'bf16x3': 0, 'f16x2': 2}.get(conv_mode, 0))}
             direct_mid = names[P.TAG_DIRECT_MID].startswith('conv_dp')
+            direct_norm_mid = names[P.TAG_CONV_MID].startswith('conv_dp')
             names[P.TAG_DOWN], names[P.TAG_DOWN + 1] = 'conv_down_kernel<32, 64, 16>', 'conv_down_kernel<64, 64, 8>'
             for k, (cc, cw) in enumerate(P.CHAIN_KERNELS):
                 # (fourth parameter: the group divisor launch_chain picks by batch size -- full groups at this size unless the batch is small)
@@ -651,7 +655,7 @@ def main():
                     P.TAG_RES_TOP: 'the fused ResidualBlocks at %dx%d: norm, ELU, direct 3x3 32->32 convolution, InstanceNorm++ statistics of the whole '
                                    'intermediate sample, norm, ELU, second convolution, + x per launch; one workgroup per sample' % (nt, nr),
                     P.TAG_CONV_MID: 'the undilated 3x3 64->64 convolutions of the %dx%d level with a norm prologue, a resized operand or '
-                                    'a tile-moment output (Winograd F(2x2,3x3))' % (nt // 2, nr // 2),
+                                    'a tile-moment output (%s)' % (nt // 2, nr // 2, 'direct, filter fragments in registers' if direct_norm_mid else 'Winograd F(2x2,3x3)'),
                     P.TAG_DIRECT_MID: 'the other undilated 3x3 64->64 convolutions of the %dx%d level (%s)'
                                       % (nt // 2, nr // 2, 'direct, filter fragments in registers' if direct_mid else 'Winograd F(2x2,3x3)')}
             for k, (cc, cw) in enumerate(P.CHAIN_KERNELS):
@@ -668,7 +672,7 @@ def main():
                 fl = kc['flops_per_step'] / kc['launches_per_step']           # algorithmic FLOPs of an average launch of the class
                 by = kc['bytes_per_step'] / kc['launches_per_step']
                 ratio = (((nt + 1.0) / nt if pair_roll else 18.0 / 16.0) if tag == P.TAG_PAIR_TOP else
-                         1.0 if tag in (P.TAG_POOL_TOP, P.TAG_RES_TOP) or (tag == P.TAG_DIRECT_MID and direct_mid)
+                         1.0 if tag in (P.TAG_POOL_TOP, P.TAG_RES_TOP) or (tag == P.TAG_DIRECT_MID and direct_mid) or (tag == P.TAG_CONV_MID and direct_norm_mid)
                          else 0.5 if tag >= P.TAG_DOWN else kc['live_taps'] if tag >= P.TAG_CHAIN else 1.0 if conv_mode == 'f16w' else 16.0 / 36.0) * (terms or 1.0)
                 ach = fl / t_launch / 1e12
                 e = {'kernel': names[tag], 'what': what[tag], 'launches_per_step': kc['launches_per_step'],

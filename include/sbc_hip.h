@@ -390,6 +390,8 @@ int sbc_op_launch(const sbc_op* op, void* stream);
  * plan.  sbc_plan_run executes the whole op list `n_iters` times in order on `stream` -- records with a `lane` (ABI 14) on the
  * library's lane streams: every lane is forked from `stream` at the start of the call and joined into it at its end (not between
  * the iterations, where the records' own events order the lanes), so that a caller sees ONE asynchronous unit of work.  With
+ * use_graph = 1 and lanes the captured graph is flat (lane records on the run stream in list order); use_graph = 2 keeps the lanes as
+ * parallel branches of the graph (experimental: the runtime's graph launch is not robust with them, see csrc/api.hip).  With
  * use_graph != 0 the op list is captured once into a hipGraph (on first use for that stream) and replayed;
  * this is legal because nothing in a plan depends on host state -- step-dependent scalars are read from
  * device tables through the device step counter. */
@@ -549,7 +551,7 @@ int64_t sbc_wgrad_scratch_floats(int32_t B, int32_t H, int32_t W, int32_t cin, i
  *   plan:       SBC_NO_CONV_DOWN, SBC_NO_CHAIN, SBC_NO_CHAIN4, SBC_NO_CHAIN8, SBC_NO_CHAIN8_CRP, SBC_CHAIN8_RES, SBC_NO_END_SELF,
  *               SBC_NO_RES_BLOCK, SBC_NO_CONV_POOL (plan.py: the unfused record sequence instead of the named fused record),
  *               SBC_NO_CALIB (scorenet.py: f16x2 activation scales stay 1)
- *   kernels:    SBC_NO_PAIR_P3, SBC_NO_PAIR_ROLL, SBC_PAIR_ROLL_MIN_TILES (conv_pair.hip), SBC_DP_WGS, SBC_NO_CONV_DP, SBC_NO_CONV_DP32
+ *   kernels:    SBC_NO_PAIR_P3, SBC_NO_PAIR_ROLL, SBC_PAIR_ROLL_MIN_TILES (conv_pair.hip), SBC_DP_WGS, SBC_NO_CONV_DP, SBC_NO_CONV_DP32, SBC_NO_CONV_DP_NORM
  *               (conv_dp.hip), SBC_TILE (conv_x3.hip, conv_mfma.hip), SBC_WX3_MB2 (conv_wx3.hip), SBC_WINO_MB1, SBC_NO_WINO (conv_wino.hip,
  *               conv_mfma.hip), SBC_CONV_MODE=f32, SBC_NO_WX3 (conv_mfma.hip), SBC_CHAIN_NW8, SBC_CHAIN_GD (conv_chain.hip)
  */

@@ -204,7 +204,8 @@ class Plan:
         self.n_ops = len(ops)
 
     def run(self, stream, n_iters=1, use_graph=False):
-        check(lib().sbc_plan_run(self._h, C.c_void_p(stream), int(n_iters), 1 if use_graph else 0))
+        # use_graph: False / True (a flat graph: lane records in list order on the run stream) / 2 (lanes as parallel branches of the graph)
+        check(lib().sbc_plan_run(self._h, C.c_void_p(stream), int(n_iters), 2 if use_graph == 2 else 1 if use_graph else 0))
 
     def set_persistent_cus(self, n):
         """Grid width (CUs) of this plan's persistent kernels; 0 = the process default (``sbc_plan_set_persistent_cus``)."""

@@ -347,7 +347,7 @@ class AldPair:
             k = min(self.k, n_steps - done)
             pl = self._plan(k)
             pl.set_persistent_cus(getattr(self, '_width', 0))
-            pl.run(st, 1, use_graph)
+            pl.run(st, 1, 2 if use_graph else False)         # (2: the lanes stay parallel branches of the captured graph)
             done += k
         if use_graph:
             cur.wait_stream(self._gstream)

@@ -206,6 +206,7 @@ struct sbc_plan {
     // hipGraph replay
     hipGraphExec_t exec = nullptr;
     hipStream_t graph_stream = nullptr;
+    bool graph_flat = true;              // the captured graph has the lane records on the run stream (use_graph = 1)
     // side stream for ops flagged SBC_OP_SIDE (created on first use; forked from / joined into the run stream by events)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -277,13 +278,14 @@ static int join_lanes(sbc_plan* plan, hipStream_t s) {
     return SBC_OK;
 }
 
-static int run_eager(sbc_plan* plan, hipStream_t s) {
+static int run_eager(sbc_plan* plan, hipStream_t s, bool flat = false) {
+    // flat: every record on `s` in list order, lanes and events ignored (a valid order: what a lane record waits for is an earlier record)
     bool side_busy = false;
     bool main_moved = true;          // the run stream has had work queued since the side stream last forked from it
     for (auto& po : plan->ops) {
         hipStream_t os = s;                              // the stream this op runs on
-        if (po.op.lane > 0) os = plan->lanes[po.op.lane];
-        for (int w = 0; w < 2; ++w)
+        if (po.op.lane > 0 && !flat) os = plan->lanes[po.op.lane];
+        for (int w = 0; w < 2 && !flat; ++w)
             if (po.op.wait[w] > 0) SBC_CHECK_HIP(hipStreamWaitEvent(os, plan->lane_evt[po.op.wait[w]], 0));
         if (po.op.flags & SBC_OP_SIDE) {
             if (!plan->side) {
@@ -331,7 +333,7 @@ static int run_eager(sbc_plan* plan, hipStream_t s) {
             SBC_CHECK_HIP(hipEventRecord(plan->ev_pool[plan->ev_used + 1], os));
             plan->ev_used += 2;
         }
-        if (po.op.signal > 0) SBC_CHECK_HIP(hipEventRecord(plan->lane_evt[po.op.signal], os));
+        if (po.op.signal > 0 && !flat) SBC_CHECK_HIP(hipEventRecord(plan->lane_evt[po.op.signal], os));
     }
     if (side_busy) return join_side(plan, s);            // never return with side work the run stream does not wait for
     return SBC_OK;
@@ -566,19 +568,25 @@ int sbc_plan_run(sbc_plan* plan, void* stream, int32_t n_iters, int32_t use_grap
         return rc ? rc : rj;
     }
     SBC_REQUIRE(s != nullptr, "sbc_plan_run: graph replay needs a non-default stream");
-    if (!plan->exec || plan->graph_stream != s) {
+    // use_graph = 1: the captured graph is FLAT -- lane records on the run stream in list order.  A graph with parallel branches replays
+    // correctly and side by side (ald.AldPair, use_graph = 2), but hipGraphLaunch of such a graph crashed inside the runtime
+    // (hip::Graph::UpdateStreams, ROCm 7.0.2) in a process that had created many streams -- reproducibly, depending on what ran before
+    // (tests/test_gpu_parity.py in one particular selection order) -- and graph replay is slower than eager launches anyway.
+    const bool flat = use_graph != 2;
+    if (!plan->exec || plan->graph_stream != s || plan->graph_flat != flat) {
         if (plan->exec) { (void)hipGraphExecDestroy(plan->exec); plan->exec = nullptr; }
         hipGraph_t graph = nullptr;
         SBC_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-        int rc = fork_lanes(plan, s);                    // (lanes join the capture through the events they wait for)
-        if (!rc) rc = run_eager(plan, s);
-        { const int rj = join_lanes(plan, s); if (!rc) rc = rj; }
+        int rc = flat ? SBC_OK : fork_lanes(plan, s);    // (lanes join the capture through the events they wait for)
+        if (!rc) rc = run_eager(plan, s, flat);
+        if (!flat) { const int rj = join_lanes(plan, s); if (!rc) rc = rj; }
         const hipError_t e = hipStreamEndCapture(s, &graph);
         if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
         SBC_CHECK_HIP(e);
         SBC_CHECK_HIP(hipGraphInstantiate(&plan->exec, graph, nullptr, nullptr, 0));
         SBC_CHECK_HIP(hipGraphDestroy(graph));
         plan->graph_stream = s;
+        plan->graph_flat = flat;
     }
     for (int it = 0; it < n_iters; ++it) SBC_CHECK_HIP(hipGraphLaunch(plan->exec, s));
     return SBC_OK;

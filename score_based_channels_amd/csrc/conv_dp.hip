@@ -13,6 +13,13 @@
 // operand planes, as in conv_pair.hip), one barrier, K loop, epilogue (x descale [+ bias] [+ (ELU) res1 [+ res2]]).  The two
 // workgroups of a CU drift apart, so one converts while the other multiplies.
 //
+// Round 6: the 64 -> 64 layers at 8-pixel rows WITH an InstanceNorm++ prologue and a tile-moment output (res2.1's two convolutions and
+// res3.0.conv1 of a 64 x 16 array: 115 us each as Winograd launches at 1700 samples, this kernel's plain form 79) run here too: the
+// lane's channel quad is the same for all its chunks of a tile, so the norm is three float4 of (mu, scale, shift) per tile; the output's
+// (mean, M2) per 128-pixel moment tile = two 64-pixel tiles of this kernel, which a workgroup then takes back to back, merging the two
+// partial moments in registers (sums over the 16 pixel lanes of a unit by DPP, over the four units in the lane; equal counts: a fixed
+// order that depends on the layer's shape only).
+//
 // The kernel lives on the LDS: three matrix instructions consume two ds_read_b128 (2 KB of operands), so four SIMDs ask for 64 LDS
 // cycles per 48 matrix cycles even without a bank conflict -- with the straightforward layout (a unit = adjacent rows, planes 256 B
 // aligned, thread = raw chunk) PMC counted 57 % of the LDS cycles as conflict cycles and the LDS 75 % busy.  Hence:
@@ -38,6 +45,15 @@ namespace sbc {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+// sum over the 16 lanes of a DPP row (= the 16 pixels of a unit for one k-quarter); every lane of the row gets the total
+__device__ __forceinline__ float dp_row_sum16(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124 /* row_ror:4 */, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122 /* row_ror:2 */, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121 /* row_ror:1 */, 0xf, 0xf, false));
+    return v;
+}
+
 struct DpParams {
     const float* __restrict__ in;
     float* __restrict__ out;
@@ -45,6 +61,8 @@ struct DpParams {
     const float* __restrict__ bias;
     const float* __restrict__ res1;
     const float* __restrict__ res2;
+    const float* __restrict__ stats;    // SBC_PRO_NORM: (mu, scale, shift) [B][3][C] of the InstanceNorm++ in front of the ELU (tiles of one sample only)
+    float* __restrict__ pm_out;         // SBC_EPI_MOMENTS_OUT: (mean, M2) of the output's 128-pixel tiles [B][HW / 128][C][2] (W = 8: two tiles of this kernel each)
     unsigned* __restrict__ range_flag;
     float* __restrict__ calib;          // sbc_f16x2_calibrate: amax slot of the input, else NULL
     int flags;                          // SBC_PRO_ELU, SBC_EPI_RES1_ELU
@@ -61,7 +79,9 @@ struct DpParams {
 // FULL: a tile is S whole samples (R = H): no halo rows are fetched, the plane rows above and below a sample stay zero.
 // C = 32: eight waves (two output-channel groups x four unit groups, 128 registers a wave: the fragments are 72), still two
 // workgroups per CU -- four waves per SIMD.
-template <int C, int W, int R, int S, bool FULL, int NW>
+// NM: the instantiation that knows the norm prologue and the tile-moment output (64 channels, 8-pixel rows; its own symbol so that the plain
+// one keeps its 248 registers: the extras spill there)
+template <int C, int W, int R, int S, bool FULL, int NW, bool NM = false>
 __global__ __launch_bounds__(64 * NW, (C == 32 ? 3 : 2) * NW / 4) void conv_dp_kernel(DpParams p) {
     constexpr int NTH = 64 * NW, KGS = C / 8, KH = C / 32, C4 = C / 4, NT = 2;
     constexpr int NHF = C / 16, NSUB = NW / NHF;      // 16-output-channel groups; unit groups (wave = (hf, sub))
@@ -82,6 +102,7 @@ __global__ __launch_bounds__(64 * NW, (C == 32 ? 3 : 2) * NW / 4) void conv_dp_k
     constexpr int RAW_BYTES = S * RR * W * C * 4;
     constexpr int NPIECE = RAW_BYTES / 1024;
     constexpr int X_OFF = RAW_BYTES;
+    constexpr int MOM_OFF = X_OFF + NT * KGS * XPS;     // NM: [wave][kq][(mean, M2) x 4 channels] floats
     constexpr int NCOMBO = S * RR * W / 8 * KGS;       // conversion work items: (8 pixels, k-group); 16 lanes each
     static_assert(NCOMBO % 4 == 0 && RAW_BYTES % 1024 == 0, "whole waves of conversion work, whole DMA pieces");
     constexpr int NIT = (NCOMBO + NTH / 16 - 1) / (NTH / 16);
@@ -147,16 +168,32 @@ __global__ __launch_bounds__(64 * NW, (C == 32 ? 3 : 2) * NW / 4) void conv_dp_k
                          : "=&s"(keep), "=&v"(l16) : "s"(dst), "s"(sbase) : "memory");
         }
     };
-    int tile = t_begin + jw;
+    // A workgroup walks groups of GS consecutive tiles, groups wgs_per_xcd apart (GS = 2 when tile moments are written: the two 64-pixel
+    // tiles of one 128-pixel moment tile; t_begin and the group bases are even then)
+    const int GS = (NM && p.pm_out) ? 2 : 1;
+    auto next_tile = [&](int t) {                                             // the tile this workgroup takes after tile t
+        const int g = (t - t_begin) % GS;
+        return g + 1 < GS ? t + 1 : t - g + p.wgs_per_xcd * GS;
+    };
+    int tile = t_begin + jw * GS;
     if (tile < t_end) issue_dma(tile);
 #ifdef SBC_PAIR_TIMING
     unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_last = __builtin_readcyclecounter();
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // first tile (and the filter fragments) landed
 
-    for (; tile < t_end; tile += p.wgs_per_xcd) {
+    for (; tile < t_end; tile = next_tile(tile)) {
         int n, r0;
         if (FULL) { n = tile * S; r0 = 0; } else { n = tile / p.tiles_per_sample; r0 = (tile - n * p.tiles_per_sample) * R; }
+        // SBC_PRO_NORM: the lane converts the same channel quad in every chunk of the tile: one (mu, scale, shift) per tile, requested here
+        float4 nmu = make_float4(0.f, 0.f, 0.f, 0.f), nsc = make_float4(1.f, 1.f, 1.f, 1.f), nsh = nmu;
+        const bool pro_norm = NM && p.stats != nullptr;
+        if (pro_norm) {
+            int tq = tid;
+            asm volatile("" : "+v"(tq));
+            const float* st = p.stats + (size_t)n * 3 * C + (2 * ((tq >> 4) % KGS) + (tq & 1)) * 4;
+            nmu = *reinterpret_cast<const float4*>(st); nsc = *reinterpret_cast<const float4*>(st + C); nsh = *reinterpret_cast<const float4*>(st + 2 * C);
+        }
         // (1) raw tile landed, for every wave; and every wave is through the previous tile's K loop (the planes are free)
         DP_MARK(0);
         asm volatile("s_barrier" ::: "memory");
@@ -195,6 +232,10 @@ __global__ __launch_bounds__(64 * NW, (C == 32 ? 3 : 2) * NW / 4) void conv_dp_k
                 if (FULL) inside = S == 1 || n + s < p.B;
                 else { const int grow = r0 - 1 + ri; inside = grow >= 0 && grow < H; }
                 float4 x = v[k];
+                if (pro_norm) {            // (uniform) the zero padding is the padding of the NORMALISED tensor: norm first, then the row mask
+                    x.x = fmaf(x.x - nmu.x, nsc.x, nsh.x); x.y = fmaf(x.y - nmu.y, nsc.y, nsh.y);
+                    x.z = fmaf(x.z - nmu.z, nsc.z, nsh.z); x.w = fmaf(x.w - nmu.w, nsc.w, nsh.w);
+                }
                 x.x = inside ? x.x : 0.f; x.y = inside ? x.y : 0.f; x.z = inside ? x.z : 0.f; x.w = inside ? x.w : 0.f;
                 if (ELU == 1) x = elu4(x);
                 if (ELU == 2) x = elu4_acc(x);
@@ -217,7 +258,7 @@ __global__ __launch_bounds__(64 * NW, (C == 32 ? 3 : 2) * NW / 4) void conv_dp_k
         lds_barrier();
         DP_MARK(3);
         // the raw copy is consumed: request the next tile of this workgroup; it flies during the K loop
-        if (tile + p.wgs_per_xcd < t_end) issue_dma(tile + p.wgs_per_xcd);
+        if (next_tile(tile) < t_end) issue_dma(next_tile(tile));
 
         // (3) residual operands: requested before the K loop, used after it.  Unit i of the tile, lane pixel c: image row (counted through
         // the tile's samples) UMR(i) + lrow, column lcol; the top-left tap of that pixel is plane row UPR(i) + lrow, slot lcol.
@@ -281,7 +322,7 @@ __global__ __launch_bounds__(64 * NW, (C == 32 ? 3 : 2) * NW / 4) void conv_dp_k
                 if (valid(i)) x1[i] = *reinterpret_cast<const float4*>(p.res1 + o0 + DO(i));
         }
         float4 x2[NU];
-        if (p.res2) {
+        if (!NM && p.res2) {                                                  // (the NM instantiation takes no second residual operand)
 #pragma unroll
             for (int i = 0; i < NU; ++i)
                 if (valid(i)) x2[i] = *reinterpret_cast<const float4*>(p.res2 + o0 + DO(i));
@@ -289,6 +330,7 @@ __global__ __launch_bounds__(64 * NW, (C == 32 ? 3 : 2) * NW / 4) void conv_dp_k
         // everything this wave has in flight -- the residuals, its pieces of the next tile's DMA -- has landed
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         DP_MARK(5);
+        float4 ysum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
             if (!valid(i)) continue;
@@ -297,14 +339,46 @@ __global__ __launch_bounds__(64 * NW, (C == 32 ? 3 : 2) * NW / 4) void conv_dp_k
             if (p.res1) {
                 // r = res1 [ELU];  if res2: r = res2 + r;  y = y + r     (include/sbc_hip.h: the CONV epilogue)
                 float4 rr = x1[i];
-                if (p.flags & SBC_EPI_RES1_ELU) rr = elu4_acc(rr);
-                if (p.res2) { rr.x = x2[i].x + rr.x; rr.y = x2[i].y + rr.y; rr.z = x2[i].z + rr.z; rr.w = x2[i].w + rr.w; }
+                if (!NM && (p.flags & SBC_EPI_RES1_ELU)) rr = elu4_acc(rr);
+                if (!NM && p.res2) { rr.x = x2[i].x + rr.x; rr.y = x2[i].y + rr.y; rr.z = x2[i].z + rr.z; rr.w = x2[i].w + rr.w; }
                 y.x += rr.x; y.y += rr.y; y.z += rr.z; y.w += rr.w;
             }
 #ifdef DP_PROBE_NOSTORE   // timing probe (wrong results): everything but the output stores
             if (y.x == 123456.f)
 #endif
             st_out(p.out + o0 + DO(i), y);
+            if (NM && p.pm_out) { acc[i] = f32x4v{y.x, y.y, y.z, y.w}; ysum.x += y.x; ysum.y += y.y; ysum.z += y.z; ysum.w += y.w; }
+        }
+        if constexpr (NM) {
+            static_assert(!NM || (W == 8 && C == 64 && !FULL && NSUB == 1), "the wave holds a whole 64-pixel tile of its channels");
+            if (p.pm_out) {
+                // (mean, M2) of the lane's four channels over this 64-pixel tile: the wave holds all of it (NSUB = 1) -- units in the lane, the
+                // 16 pixels of a unit across the DPP row; two tiles of a group merge into the 128-pixel moment tile (equal counts)
+                float4 mean = make_float4(dp_row_sum16(ysum.x) * (1.f / 64.f), dp_row_sum16(ysum.y) * (1.f / 64.f),
+                                          dp_row_sum16(ysum.z) * (1.f / 64.f), dp_row_sum16(ysum.w) * (1.f / 64.f));
+                float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < NU; ++i) {
+                    float d;
+                    d = acc[i][0] - mean.x; q.x = fmaf(d, d, q.x); d = acc[i][1] - mean.y; q.y = fmaf(d, d, q.y);
+                    d = acc[i][2] - mean.z; q.z = fmaf(d, d, q.z); d = acc[i][3] - mean.w; q.w = fmaf(d, d, q.w);
+                }
+                q = make_float4(dp_row_sum16(q.x), dp_row_sum16(q.y), dp_row_sum16(q.z), dp_row_sum16(q.w));
+                // (the first tile's moments wait in a corner of the LDS, not in eight registers across the next K loop)
+                float* keep = reinterpret_cast<float*>(smem + MOM_OFF) + (wave * 4 + kq) * 8;
+                if (((tile - t_begin) & 1) == 0) {
+                    if (c == 0) { *reinterpret_cast<float4*>(keep) = mean; *reinterpret_cast<float4*>(keep + 4) = q; }
+                } else if (c == 0) {
+                    const float4 mom_mean = *reinterpret_cast<const float4*>(keep), mom_m2 = *reinterpret_cast<const float4*>(keep + 4);
+                    const int jt = tile - n * p.tiles_per_sample;                 // (odd) tile of the sample: moment tile jt >> 1
+                    float* o = p.pm_out + (((size_t)n * (p.tiles_per_sample >> 1) + (jt >> 1)) * C + cq * 4) * 2;
+                    float d;
+                    d = mean.x - mom_mean.x; *reinterpret_cast<float2*>(o) = make_float2(mom_mean.x + 0.5f * d, mom_m2.x + q.x + d * d * 32.f);
+                    d = mean.y - mom_mean.y; *reinterpret_cast<float2*>(o + 2) = make_float2(mom_mean.y + 0.5f * d, mom_m2.y + q.y + d * d * 32.f);
+                    d = mean.z - mom_mean.z; *reinterpret_cast<float2*>(o + 4) = make_float2(mom_mean.z + 0.5f * d, mom_m2.z + q.z + d * d * 32.f);
+                    d = mean.w - mom_mean.w; *reinterpret_cast<float2*>(o + 6) = make_float2(mom_mean.w + 0.5f * d, mom_m2.w + q.w + d * d * 32.f);
+                }
+            }
         }
         DP_MARK(6);
     }
@@ -316,14 +390,14 @@ __global__ __launch_bounds__(64 * NW, (C == 32 ? 3 : 2) * NW / 4) void conv_dp_k
 #endif
 }
 
-template <int C, int W, int R, int S, bool FULL, int NW>
+template <int C, int W, int R, int S, bool FULL, int NW, bool NM = false>
 static int launch_dp(const DpParams& p0, hipStream_t stream, bool dry) {
     constexpr int NT = 2, RR = FULL ? R : R + 2, RP = R + 2, WP = W == 16 ? 18 : W == 8 ? 10 : 6;
     constexpr int XPS = (S * RP * WP * 16 + 255) / 256 * 256;
-    constexpr size_t lds = (size_t)S * RR * W * C * 4 + (size_t)NT * (C / 8) * XPS;
+    constexpr size_t lds = (size_t)S * RR * W * C * 4 + (size_t)NT * (C / 8) * XPS + (NM ? NW * 4 * 8 * 4 : 0);
     constexpr int WGPC = (C == 32 ? 3 : 2) * 4 / NW;                       // workgroups per CU (registers: 168 / 256 a wave)
     static_assert(lds * WGPC <= 160 * 1024, "LDS of the resident workgroups");
-    auto kern = conv_dp_kernel<C, W, R, S, FULL, NW>;
+    auto kern = conv_dp_kernel<C, W, R, S, FULL, NW, NM>;
     { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds); if (rc) return rc; }
     if (dry) return SBC_OK;
     DpParams p = p0;
@@ -332,8 +406,9 @@ static int launch_dp(const DpParams& p0, hipStream_t stream, bool dry) {
     int dev = 0, cus = 256;
     SBC_CHECK_HIP(hipGetDevice(&dev));
     SBC_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    p.tiles_per_xcd = (p.ntiles + 7) / 8;
-    p.wgs_per_xcd = max(1, min(WGPC * persistent_cus(cus) / 8, p.tiles_per_xcd));
+    const int gs = p.pm_out ? 2 : 1;                                       // tiles a workgroup takes back to back (conv_dp_kernel: GS)
+    p.tiles_per_xcd = ((p.ntiles + 8 * gs - 1) / (8 * gs)) * gs;
+    p.wgs_per_xcd = max(1, min(WGPC * persistent_cus(cus) / 8, (p.tiles_per_xcd + gs - 1) / gs));
 #ifdef SBC_PAIR_TIMING
     if (getenv("SBC_DP_WGS")) p.wgs_per_xcd = max(1, min(atoi(getenv("SBC_DP_WGS")), p.tiles_per_xcd));   // probe: workgroups per XCD
 #endif
@@ -348,8 +423,14 @@ int launch_conv_dp(const sbc_op& op, unsigned* range_flag, hipStream_t stream, b
     static const bool off32 = getenv("SBC_NO_CONV_DP32") != nullptr;         // A/B aid: 32-channel layers only
     if (off || !(op.flags & SBC_CONV_F16X2) || !op.weight_split || op.cin != op.cout || op.ksize != 3 || op.dil != 1) return 1;
     if (op.cin != 64 && (op.cin != 32 || off32)) return 1;
-    if (op.flags & (SBC_PRO_NORM | SBC_EPI_POOL | SBC_EPI_UP | SBC_EPI_ELUGRAD | SBC_EPI_MOMENTS_OUT)) return 1;
+    if (op.flags & (SBC_EPI_POOL | SBC_EPI_UP | SBC_EPI_ELUGRAD | SBC_PRO_NORM_SELF)) return 1;
     if (op.res2 && !op.res1) return 1;
+    // a norm prologue / a tile-moment output: the 64-channel kernel at 8-pixel rows only (round 6; moment tiles are 16 rows)
+    static const bool no_norm = getenv("SBC_NO_CONV_DP_NORM") != nullptr;    // A/B aid: those layers on the Winograd kernel
+    if (op.flags & (SBC_PRO_NORM | SBC_EPI_MOMENTS_OUT)) {
+        if (no_norm || op.cin != 64 || op.W != 8 || op.H % 16 != 0 || op.res2 || (op.flags & SBC_EPI_RES1_ELU)) return 1;
+        if (((op.flags & SBC_PRO_NORM) && !op.stats) || ((op.flags & SBC_EPI_MOMENTS_OUT) && !op.aux)) return 1;
+    }
     const bool w16 = op.W == 16 && op.H % 8 == 0 && op.cin == 32, w8 = op.W == 8 && op.H % 8 == 0;
     const bool w4 = op.W == 4 && op.H == 16 && op.cin == 64, w2 = op.W == 2 && op.H == 8 && op.cin == 64;
     if (!w16 && !w8 && !w4 && !w2) return 1;
@@ -357,9 +438,12 @@ int launch_conv_dp(const sbc_op& op, unsigned* range_flag, hipStream_t stream, b
     p.in = (const float*)op.in; p.out = (float*)op.out; p.w = (const uint4*)op.weight_split;
     p.bias = (const float*)op.bias; p.res1 = (const float*)op.res1; p.res2 = (const float*)op.res2;
     p.flags = op.flags; p.B = op.B; p.H = op.H;
+    p.stats = (op.flags & SBC_PRO_NORM) ? (const float*)op.stats : nullptr;
+    p.pm_out = (op.flags & SBC_EPI_MOMENTS_OUT) ? (float*)op.aux : nullptr;
     p.range_flag = range_flag; p.calib = (float*)op.calib;
     p.dbg = (op.flags & SBC_EPI_MOMENTS_OUT) ? nullptr : (unsigned long long*)op.aux;
     if (op.cin == 32) return w16 ? launch_dp<32, 16, 8, 1, false, 4>(p, stream, dry) : launch_dp<32, 8, 8, 1, false, 4>(p, stream, dry);
+    if (w8 && (p.stats || p.pm_out)) return launch_dp<64, 8, 8, 1, false, 4, true>(p, stream, dry);
     if (w8) return launch_dp<64, 8, 8, 1, false, 4>(p, stream, dry);
     if (w4) return launch_dp<64, 4, 16, 1, true, 4>(p, stream, dry);
     return launch_dp<64, 2, 8, 2, true, 4>(p, stream, dry);

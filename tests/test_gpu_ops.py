@@ -584,6 +584,54 @@ def test_direct_conv_writes_tile_moments_in_f16w(gpu, B, H, W):
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize('B', [1, 3, 700])
+def test_direct_conv_with_norm_prologue_and_tile_moments(gpu, B):
+    """Round 6: the 64 -> 64 layers at 8-pixel rows with an InstanceNorm++ prologue and a tile-moment output (res2.1's convolutions,
+    res3.0.conv1 of a 64 x 16 array) run on the direct persistent kernel (csrc/conv_dp.hip, its NM instantiation) instead of Winograd:
+    norm -> ELU -> conv + bias + res1 against the oracle, the (mean, M2) of the output's 128-pixel tiles -- two tiles of the kernel, merged
+    in registers / LDS by the workgroup that takes them back to back -- against numpy on the launch's own output, and batch independence
+    bit for bit (a piece of the batch alone: other run boundaries, other workgroups)."""
+    torch, _lib = gpu
+    from score_based_channels_amd import plan as P
+    from score_based_channels_amd.weights import pack_conv_weight_f16x2, pack_conv_weight_winograd_f16x2
+    H, W, Cc = 32, 8, 64
+    rng = np.random.default_rng(500 + B)
+    x = (rng.standard_normal((B, H, W, Cc)) * 1.5 + 0.3).astype(F32)
+    res = rng.standard_normal((B, H, W, Cc)).astype(F32)
+    w = (rng.standard_normal((Cc, Cc, 3, 3)) / np.sqrt(9 * Cc)).astype(F32)
+    bias = (0.3 * rng.standard_normal(Cc)).astype(F32)
+    agb = [(1 + 0.1 * rng.standard_normal(Cc)).astype(F32), (1 + 0.1 * rng.standard_normal(Cc)).astype(F32), (0.1 * rng.standard_normal(Cc)).astype(F32)]
+    st = inorm_stats(x, *agb)
+    v = O.elu((x - st[:, None, None, 0]) * st[:, None, None, 1] + st[:, None, None, 2])
+    nref = min(B, 4)
+    ref = O.conv2d(v[:nref].transpose(0, 3, 1, 2), w, bias, 1).transpose(0, 2, 3, 1) + res[:nref]
+    d = {k: _dev(torch, a) for k, a in dict(x=x, res=res, st=st, b=bias, w=pack_conv_weight_f16x2(w).view(np.float32),
+                                              ww=pack_conv_weight_winograd_f16x2(w).view(np.float32)).items()}
+    nt = H * W // 128
+
+    def run(lo, hi, moments=True):
+        out = torch.full((hi - lo, H, W, Cc), float('nan'), dtype=torch.float32, device='cuda')
+        pm = torch.full((hi - lo, nt, Cc, 2), float('nan'), dtype=torch.float32, device='cuda')
+        op = _lib.sbc_op(kind=P.CONV, flags=P.CONV_F16X2 | P.PRO_NORM | P.PRO_ELU | (P.EPI_MOMENTS_OUT if moments else 0), B=hi - lo, H=H, W=W, cin=Cc, cout=Cc,
+                         ksize=3, dil=1, in_=_p(d['x'][lo:hi]), out=_p(out), stats=_p(d['st'][lo:hi]), bias=_p(d['b']), res1=_p(d['res'][lo:hi]),
+                         weight_split=_p(d['w']), weight_wino_split=_p(d['ww']), aux=_p(pm) if moments else None)
+        _launch(gpu, op)
+        return out.cpu().numpy(), pm.cpu().numpy()
+    got, gm = run(0, B)
+    assert np.isfinite(got).all() and _lib.range_flag() == 0
+    assert rel_err(got[:nref] - res[:nref], ref - res[:nref]) < TOL
+    tiles = got.astype(np.float64).reshape(B, nt, 128, Cc)
+    assert np.isfinite(gm).all()
+    assert np.abs(gm[..., 0] - tiles.mean(2)).max() < 1e-5 * max(1.0, np.abs(tiles.mean(2)).max())
+    assert rel_err(gm[..., 1], ((tiles - tiles.mean(2, keepdims=True)) ** 2).sum(2)) < 1e-5
+    plain, _ = run(0, B, moments=False)                                  # without the moment output: the same numbers
+    assert np.array_equal(plain, got)
+    if B > 2:
+        lo, hi = B // 3, B // 3 + max(1, B // 5)
+        part, pmp = run(lo, hi)
+        assert np.array_equal(part, got[lo:hi]) and np.array_equal(pmp, gm[lo:hi])
+
+
 @pytest.mark.parametrize('B', [1, 3, 300, 700])
 def test_res_block_matches_oracle(gpu, B):
     """SBC_OP_RES_BLOCK: one whole ResidualBlock without resampling (layers.py:443-456) in one launch -- a workgroup owns a sample and

@@ -12,7 +12,7 @@ CANDIDATES = (['conv_x3_kernel<32, 32, 3, 2, 1, 4, 1, true, 1>', 'conv_wx3_kerne
                'conv_x3_kernel<64, 64, 3, 2, 2, 4, 1, true, 1>', 'conv_wx3_kernel<64, 64, 1, true, 2, false, 2, 1, 1>'] if BIG else
               ['conv_wx3_kernel<32, 32, 1, true, 4, true, 1, 1, 2>', 'conv_pair_roll_kernel<2>', 'conv_pair_p3_kernel<16, 8, 2, 4, 32>', 'conv_down_kernel<32, 64, 16>', 'conv_down_kernel<64, 64, 8>',
                'conv_pool_kernel<16, 8, 2, 4, 32>', 'conv_wx3_kernel<64, 64, 1, true, 2, false, 2, 1, 2>',
-               'conv_dp_kernel<64, 8, 8, 1, false, 4>', 'conv_res_kernel', 'conv_chain_kernel<128, 2, 8, 1>', 'conv_chain_kernel<64, 2, 4, 1>',
+               'conv_dp_kernel<64, 8, 8, 1, false, 4, false>', 'conv_dp_kernel<64, 8, 8, 1, false, 4, true>', 'conv_res_kernel', 'conv_chain_kernel<128, 2, 8, 1>', 'conv_chain_kernel<64, 2, 4, 1>',
                'conv_chain_kernel<64, 4, 4, 1>', 'conv_chain_kernel<64, 8, 8, 1>', 'conv_chain_kernel<32, 8, 4, 1>'])
 PX = (256 * 64) if BIG else (64 * 16)
 T = 1024 if BIG else 1700
