@@ -409,3 +409,24 @@ def test_documented_environment_variables():
                 read.update(re.findall(r'["\'](SBC_[A-Z0-9_]+)["\']', line))
     assert read == documented, (sorted(read - documented), sorted(documented - read))
     assert not [v for v in read if v.startswith(('SBC_EXP', 'SBC_TEST'))]
+
+
+def test_stream_count_keeps_small_chunks_as_one_batch():
+    """driver.stream_count (round 6): a chunk small enough for the plan with launch lanes (ScoreNet.skip_overlap_for: a rank's share of a
+    sharded run) is ONE batch whatever ``--streams`` says -- sub-batch streams and lanes exclude each other -- and larger chunks keep the
+    requested sub-batch streams.  Pure host logic (no device needed)."""
+    from score_based_channels_amd import driver
+    from score_based_channels_amd.config import DEFAULT_STREAMS, default_config
+    from score_based_channels_amd.scorenet import SKIP_OVERLAP_MAX_T, ScoreNet
+    net = ScoreNet(default_config(), 'cpu')            # (no weights, no device use: only the plan-selection predicates are called)
+    assert net.skip_overlap_for(213, 64, 16) and net.skip_overlap_for(SKIP_OVERLAP_MAX_T, 64, 16) and not net.skip_overlap_for(SKIP_OVERLAP_MAX_T + 1, 64, 16)
+    assert not net.skip_overlap_for(None, 64, 16) and not net.skip_overlap_for(64, 256, 64)            # (256 x 64: 16 x the pixels per trajectory)
+    assert driver.stream_count(net, 213, 64, 16) == 1 and driver.stream_count(net, 425, 64, 16, 2) == 1
+    assert driver.stream_count(net, 850, 64, 16) == DEFAULT_STREAMS and driver.stream_count(net, 1700, 64, 16, 3) == 3
+    assert driver.stream_count(net, 213, 64, 16, 1) == 1
+    off = ScoreNet(default_config(), 'cpu', skip_overlap=False)
+    assert not off.skip_overlap_for(213, 64, 16) and driver.stream_count(off, 213, 64, 16) == DEFAULT_STREAMS
+    # the two plans of one network: the same records, the lane plan with five branches on lane 1 (plan.DEFAULT_SKIP_SPEC)
+    seq, lanes = net.score_plan(64, 16, 1700), net.score_plan(64, 16, 213)
+    assert sorted(o.name for o in seq.ops) == sorted(o.name for o in lanes.ops)
+    assert not any(o.lane for o in seq.ops) and sum(1 for o in lanes.ops if o.lane) == 6 and {o.lane for o in lanes.ops} == {0, 1}
