@@ -645,7 +645,7 @@ def main():
                 # (fourth parameter: the group divisor launch_chain picks by batch size -- full groups at this size unless the batch is small)
                 gd = 1
                 if cw == 2:
-                    gd = (4 if (T + 1) // 2 <= 64 else 2 if 2 * ((T + 7) // 8) <= 128 else 1) if cc == 128 else (2 if 2 * ((T + 3) // 4) <= 256 else 1)
+                    gd = (4 if (T + 1) // 2 <= 128 else 2 if 2 * ((T + 7) // 8) <= 256 else 1) if cc == 128 else (2 if 2 * ((T + 3) // 4) <= 512 else 1)
                 names[P.TAG_CHAIN + k] = 'conv_chain_kernel<%d, %d, %d, %d>' % (cc, cw, 8 if (cc, cw) in ((128, 2), (64, 8)) else 4, gd)
             what = {P.TAG_CONV_TOP: 'the unfused 3x3 32->32 convolutions at %dx%d (%s)' % (nt, nr, 'direct, one matrix instruction per product' if conv_mode == 'f16w' else 'Winograd F(2x2,3x3)'),
                     P.TAG_PAIR_TOP: 'the fused RCU blocks at %dx%d: two direct 3x3 32->32 convolutions per launch, intermediate in LDS%s'

@@ -275,7 +275,16 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
 
             // ---- filter ring: K step s = (tap, 32-channel slice kh); the first three steps are requested behind the operand work, in
             // front of the two barriers of the plane update
-            constexpr int WD = 4;
+            // (ring depth: a K step is NU x 3 matrix instructions long -- with two or four units per wave (the half- and quarter-size
+            // groups of small batches, 64 channels at 8 x 2) four steps in flight do not cover the L2 round trip of a filter fragment,
+            // and those instantiations have the registers for more)
+#ifndef SBC_CHAIN_WD_SMALL
+#define SBC_CHAIN_WD_SMALL 8
+#endif
+#ifndef SBC_CHAIN_WD_MID
+#define SBC_CHAIN_WD_MID 6
+#endif
+            constexpr int WD = NU <= 2 ? SBC_CHAIN_WD_SMALL : NU <= 4 ? SBC_CHAIN_WD_MID : 4;
             uint4 wr[WD][2];
             auto ldw = [&](int tap, int kh, int slot) {                 // compile-time constants at every call
 #ifdef SBC_CHAIN_NO_WLOAD   // timing probe (tools/): every K step re-uses the first fragment's registers -- wrong results
@@ -397,8 +406,18 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
             }
 #endif
             pair_range_tile(ta, scale, rbits, p.calib ? p.calib + 3 * blk + wi : nullptr);
-            if (dx0) { ldw(1, 0, 0); ldw(KH > 1 ? 1 : 4, KH > 1 ? 1 : 0, 1); ldw(KH > 2 ? 1 : 4, KH > 2 ? 2 : 0, 2); }
-            else { ldw(0, 0, 0); ldw(1 / KH, 1 % KH, 1); ldw(2 / KH, 2 % KH, 2); }
+            // ring position r of the K loop's order: (tap r / KH, slice r % KH); dilated at a width of two: (tap 3 (r / KH) + 1, slice r % KH)
+            if (dx0) {
+                static_for<0, WD - 1>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    if constexpr (r < 3 * KH) ldw(3 * (r / KH) + 1, r % KH, r);
+                });
+            } else {
+                static_for<0, WD - 1>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    ldw(r / KH, r % KH, r);
+                });
+            }
             // every wave has left the previous K loop: the planes may be rewritten
             lds_barrier();
 #pragma unroll
