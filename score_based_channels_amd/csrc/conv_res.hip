@@ -28,8 +28,8 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "conv_common.h"
-#ifndef RES_NPRE
-#define RES_NPRE 16
+#ifndef RES_WD
+#define RES_WD 4
 #endif
 
 namespace sbc {
@@ -49,13 +49,14 @@ struct ResParams {
     unsigned* __restrict__ range_flag;
     float* __restrict__ calib;           // sbc_f16x2_calibrate: two amax slots (conv1's input, conv2's input), else NULL
     int B;
-    unsigned long long* dbg;             // SBC_PAIR_TIMING builds: per-phase cycle sums of wave 0 of every workgroup
+    unsigned long long* dbg;             // SBC_RES_TIMELINE builds: clock stamps of block 0 (tools/prof_res.py)
 };
 
-#ifdef SBC_PAIR_TIMING
-#define RS_MARK(k) do { const unsigned long long _t = __builtin_readcyclecounter(); pt[k] += _t - pt_last; pt_last = _t; } while (0)
+#ifdef SBC_RES_TIMELINE
+// block 0 only: every wave's clock at 12 points of every sample -> dbg[(iteration * 8 + wave) * 16 + k]
+#define RS_T(k) do { if (blockIdx.x == 0 && p.dbg) { const unsigned long long _t = __builtin_readcyclecounter(); if (lane == 0) p.dbg[((n / gridDim.x) * 8 + wave) * 16 + (k)] = _t; } } while (0)
 #else
-#define RS_MARK(k) do { } while (0)
+#define RS_T(k) do { } while (0)
 #endif
 
 // sum over the 16 lanes of a DPP row (= the 16 pixels of a unit for one k-quarter); every lane of the row gets the total
@@ -73,6 +74,7 @@ __global__ __launch_bounds__(512, 2) void conv_res_kernel(ResParams p) {
     constexpr int PS = (PR * WP * 16 + 255) / 256 * 256;   // bytes of one (term, k-group) plane
     constexpr int RED_OFF = NT * KGS * PS;             // [8 tiles][32 channels][(mean, M2)]
     constexpr int MV_OFF = RED_OFF + 8 * C * 2 * 4;    // mean_s[32], var_s[32]
+    constexpr int NRM_OFF = MV_OFF + 2 * C * 4;        // norm2 of this sample: mu[32], scale[32], shift[32]
     constexpr int NU = 16;                             // units (image rows) per wave
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
 
@@ -80,23 +82,26 @@ __global__ __launch_bounds__(512, 2) void conv_res_kernel(ResParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hf = wave & 1, sub = wave >> 1;          // 16-output-channel half; rows 16 sub .. + 15
     const int kq = lane >> 4, c = lane & 15;
-    const int cq = 4 * hf + kq;                        // channel quad of this lane's four outputs
+    const int cq = 4 * hf + kq;                        // channel quad of this lane's four outputs (and of the x it stages)
 
-    // ---- filter fragments: ONE convolution's at a time (72 registers), re-read from L2 for every sample -- both sets (144) beside 64
-    // accumulators and the operand ring spill.  The request for conv2's goes out when conv1's K loop ends and lands during the
-    // statistics; conv1's for the next sample when conv2's K loop ends.  (The lane index is made opaque per request: the loads are
-    // invariant in the sample loop and hipcc would hoist them out of it, back to 144 live registers.)
-    uint4 wf[9][NT];
+    // ---- filter fragments STREAM from L2 through a ring of WD taps (8 registers a tap), re-read for every sample.  (Round 5 kept one
+    // convolution's 72 registers resident; with x resident as well -- below -- that does not fit.)  The first WD - 1 taps are requested
+    // before the barrier in front of the convolution, tap + WD - 1 when tap starts: 2 x 768 matrix cycles ahead of its first use.
+    constexpr int WD = RES_WD;
+    static_assert(WD % 2 == 0, "an odd ring depth makes hipcc merge the two K loops into one loop over a scratch-resident ring");
+    uint4 wr[WD][NT];
+    const uint4* wb = nullptr;                          // this lane's fragment of tap 0, term 0 of the convolution in flight
+    auto ldw = [&](int tap) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) wr[tap % WD][t] = wb[(tap * (C / 16) * NT + t) * 64];
+    };
     auto load_w = [&](const uint4* __restrict__ w) {
         int lo = lane;
         asm volatile("" : "+v"(lo));                   // (per-lane offsets formed here: hoisted out of the sample loop they are spilled)
-        const int lsrc = (16 * hf + (lo & 15)) + 32 * ((lo >> 4) & 1);
+        wb = w + ((lo >> 5) * NT) * 64 + (16 * hf + (lo & 15)) + 32 * ((lo >> 4) & 1);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) wf[tap][t] = w[((tap * (C / 16) + (lo >> 5)) * NT + t) * 64 + lsrc];
+        for (int tap = 0; tap < WD - 1; ++tap) ldw(tap);
     };
-    load_w(p.w1);
     const float4 t1 = f16x2_trailer(reinterpret_cast<const float4*>(p.w1), 9 * (C / 16) * (C / 32) * NT);
     const float4 t2 = f16x2_trailer(reinterpret_cast<const float4*>(p.w2), 9 * (C / 16) * (C / 32) * NT);
     const float scale1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t1.x)));
@@ -104,8 +109,9 @@ __global__ __launch_bounds__(512, 2) void conv_res_kernel(ResParams p) {
     const float descale1 = t1.y, descale2 = t2.y;
     // sample-invariant parameters of the lane's four output channels (a global load inside a phase is a round trip nobody hides)
     const float4 b1 = *reinterpret_cast<const float4*>(p.bias1 + cq * 4), b2 = *reinterpret_cast<const float4*>(p.bias2 + cq * 4);
-    const float4 al = *reinterpret_cast<const float4*>(p.norm2 + cq * 4), ga = *reinterpret_cast<const float4*>(p.norm2 + C + cq * 4),
-                 be = *reinterpret_cast<const float4*>(p.norm2 + 2 * C + cq * 4);
+    // ... and, in the 32 threads that form norm2's parameters, alpha | gamma | beta of their channel
+    float al = 0.f, ga = 0.f, be = 0.f;
+    if (tid < C) { al = p.norm2[tid]; ga = p.norm2[C + tid]; be = p.norm2[2 * C + tid]; }
     unsigned rbits = 0;
     // the calibration found one of the two convolutions' inputs below 2^-4: this kernel has the exp(x) - 1 form of ELU only
     if (t1.w != 0.f || t2.w != 0.f) rbits |= 4u;
@@ -113,76 +119,69 @@ __global__ __launch_bounds__(512, 2) void conv_res_kernel(ResParams p) {
     // ---- zero the planes once: the padding columns and the rows above and below the image are never written again
     for (int i = tid; i < NT * KGS * PS / 16; i += 512) *reinterpret_cast<uint4*>(smem + i * 16) = make_uint4(0, 0, 0, 0);
 
-    // phase A's lane mapping: 16 adjacent lanes = (8 pixels pj, two halves) of k-group kgA; wave w takes the 8-pixel groups w, w + 8, ...
-    auto x_addr = [&](int n, int k, int tq) {          // element offset of chunk k (0 .. 15) of sample n for thread tq
-        const int G = k * 8 + wave, row = G >> 1, col = 8 * (G & 1) + ((tq >> 1) & 7);
-        return (unsigned)(((n * H + row) * W + col) * C + (2 * ((tq >> 4) & 3) + (tq & 1)) * 4);
-    };
-    // (NPRE of a sample's 16 chunks per lane are requested while the previous sample's epilogue runs, the rest at the start of phase A)
-    constexpr int NPRE = RES_NPRE;
-    float4 xv[NPRE], mu, sc, sh;                       // ... and norm1's (mu, scale, shift) of the lane's phase-A channel quad
-    auto st_addr = [&](int n, int tq) { return (size_t)n * 3 * C + (2 * ((tq >> 4) & 3) + (tq & 1)) * 4; };
-    int n = blockIdx.x;
-    if (n < p.B) {
+    // ---- x of the sample in flight stays in REGISTERS, in the accumulators' layout (lane (kq, c): pixel c of the wave's 16 rows, channel
+    // quad cq): phase A stages it, phase F adds it to conv2 -- no second read.  The next sample's x is requested into the same registers
+    // as soon as phase F has formed its sums.
+    float4 xr[NU], mu, sc, sh;                         // ... and norm1's (mu, scale, shift) of the lane's channel quad
+    auto request_x = [&](int n) {
+        int lo = lane;
+        asm volatile("" : "+v"(lo));
+        const float* src = p.in + (size_t)(((n * H + sub * NU) * W + (lo & 15)) * C + (4 * hf + (lo >> 4)) * 4);
 #pragma unroll
-        for (int k = 0; k < NPRE; ++k) xv[k] = *reinterpret_cast<const float4*>(p.in + x_addr(n, k, tid));
-        const float* st = p.stats1 + st_addr(n, tid);
+        for (int i = 0; i < NU; ++i) xr[i] = *reinterpret_cast<const float4*>(src + i * W * C);
+        const float* st = p.stats1 + (size_t)n * 3 * C + (4 * hf + (lo >> 4)) * 4;
         mu = *reinterpret_cast<const float4*>(st); sc = *reinterpret_cast<const float4*>(st + C); sh = *reinterpret_cast<const float4*>(st + 2 * C);
-    }
-#ifdef SBC_PAIR_TIMING
-    unsigned long long pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt_last = __builtin_readcyclecounter();
-#endif
+    };
+    int n = blockIdx.x;
+    if (n < p.B) request_x(n);
+    load_w(p.w1);
 
     for (; n < p.B; n += gridDim.x) {
         // every wave is through the previous sample's conv2 (first sample: the planes are zeroed)
-        RS_MARK(0);
+        RS_T(0);
         __syncthreads();
-        RS_MARK(1);
+        RS_T(1);
+        // this lane's slot in the operand planes (the same in phases A and D): pixel c of plane row 16 sub + 1, k-group cq >> 1, half cq & 1
+        int lq = lane;
+        asm volatile("" : "+v"(lq));                       // (formed per sample, see load_w)
+        unsigned char* const dst0 = smem + ((4 * hf + (lq >> 4)) >> 1) * PS + ((sub * NU + 1) * WP + (lq & 15) + 1) * 16 + ((lq >> 4) & 1) * 8;
         // ---- A: x -> norm1 -> ELU -> split -> planes
         float ta = 0.f, tb = 0.f;
-        int tq = tid;
-        asm volatile("" : "+v"(tq));                       // (the lane's plane addresses are formed per sample, see load_w)
-        {
-            const int half = tq & 1, pj = (tq >> 1) & 7, kgA = (tq >> 4) & 3;
-            auto convert_chunk = [&](int k, float4 v) {
-                const int G = k * 8 + wave, row = G >> 1, col = 8 * (G & 1) + pj;
-                v.x = fmaf(v.x - mu.x, sc.x, sh.x); v.y = fmaf(v.y - mu.y, sc.y, sh.y);
-                v.z = fmaf(v.z - mu.z, sc.z, sh.z); v.w = fmaf(v.w - mu.w, sc.w, sh.w);
-                v = elu4(v);
-                StageScale ss{scale1, ta};
-                scale_track(v, &ss);
-                ta = ss.amax;
-                uint2 h, l;
-                split_f16x2(v, scale1, h, l);
-                unsigned char* dst = smem + kgA * PS + ((row + 1) * WP + col + 1) * 16 + half * 8;
-                *reinterpret_cast<uint2*>(dst) = h;
-                *reinterpret_cast<uint2*>(dst + KGS * PS) = l;
-            };
-            float4 xw[16 - NPRE > 0 ? 16 - NPRE : 1];
 #pragma unroll
-            for (int k = NPRE; k < 16; ++k) xw[k - NPRE] = *reinterpret_cast<const float4*>(p.in + x_addr(n, k, tq));
-#pragma unroll
-            for (int k = 0; k < NPRE; ++k) convert_chunk(k, xv[k]);
-#pragma unroll
-            for (int k = NPRE; k < 16; ++k) convert_chunk(k, xw[k - NPRE]);
+        for (int i = 0; i < NU; ++i) {
+            float4 v = make_float4(fmaf(xr[i].x - mu.x, sc.x, sh.x), fmaf(xr[i].y - mu.y, sc.y, sh.y),
+                                   fmaf(xr[i].z - mu.z, sc.z, sh.z), fmaf(xr[i].w - mu.w, sc.w, sh.w));
+            v = elu4(v);
+            StageScale ss{scale1, ta};
+            scale_track(v, &ss);
+            ta = ss.amax;
+            uint2 h, l;
+            split_f16x2(v, scale1, h, l);
+            *reinterpret_cast<uint2*>(dst0 + i * WP * 16) = h;
+            *reinterpret_cast<uint2*>(dst0 + i * WP * 16 + KGS * PS) = l;
         }
         pair_range_tile(ta, scale1, rbits, p.calib);
-        RS_MARK(2);
+        RS_T(2);
         lds_barrier();
-        RS_MARK(3);
+        RS_T(3);
 
-        // one convolution over this wave's 16 rows: acc[i] (+)= D[16 couts][16 pixels of row 16 sub + i]
+        // one convolution over this wave's 16 rows: acc[i] = D[16 couts][16 pixels of row 16 sub + i]
         f32x4v acc[NU];
-        auto conv = [&](bool zero_init) {
-            // top-left tap of row u = 16 sub + i, pixel c: plane row u (image row u - 1), slot c (column c - 1)
-            const int ub0 = kq * PS + ((sub * NU) * WP + c) * 16;
+        auto conv = [&]() __attribute__((always_inline)) {
+            // top-left tap of row u = 16 sub + i, pixel c: plane row u (image row u - 1), slot c (column c - 1).  (One base per term
+            // plane, opaque: folded into the 144 read addresses the second plane's offset exceeds the 16-bit immediate and hipcc keeps
+            // ~50 precomputed addresses alive through the whole sample loop.)
+            int ub[NT];
+            ub[0] = kq * PS + ((sub * NU) * WP + c) * 16;
+#pragma unroll
+            for (int t = 1; t < NT; ++t) { ub[t] = ub[0] + t * KGS * PS; asm volatile("" : "+v"(ub[t])); }
             constexpr int NS = 9 * NU, D = 3;
             f16x8 ring[D][NT];
             auto ld = [&](int s) {                                            // s is a compile-time constant at every call
                 const int tap = s / NU, i = s % NU;
                 const int off = ((i + tap / 3) * WP + (tap % 3)) * 16;
 #pragma unroll
-                for (int t = 0; t < NT; ++t) ring[s % D][t] = *reinterpret_cast<const f16x8*>(smem + ub0 + (off + t * KGS * PS));
+                for (int t = 0; t < NT; ++t) ring[s % D][t] = *reinterpret_cast<const f16x8*>(smem + ub[t] + off);
             };
 #pragma unroll
             for (int s = 0; s < D - 1; ++s) ld(s);
@@ -191,9 +190,10 @@ __global__ __launch_bounds__(512, 2) void conv_res_kernel(ResParams p) {
             for (int s = 0; s < NS; ++s) {
                 const int tap = s / NU, i = s % NU;
                 if (s + D - 1 < NS) ld(s + D - 1);
+                if (i == 0 && tap + WD - 1 < 9) ldw(tap + WD - 1);
                 const f16x8 xh = ring[s % D][0], xl = ring[s % D][1];
-                const f16x8 wh = __builtin_bit_cast(f16x8, wf[tap][0]), wl = __builtin_bit_cast(f16x8, wf[tap][1]);
-                const f32x4v c0 = (tap == 0 && zero_init) ? f32x4v{0.f, 0.f, 0.f, 0.f} : acc[i];
+                const f16x8 wh = __builtin_bit_cast(f16x8, wr[tap % WD][0]), wl = __builtin_bit_cast(f16x8, wr[tap % WD][1]);
+                const f32x4v c0 = tap == 0 ? f32x4v{0.f, 0.f, 0.f, 0.f} : acc[i];
                 acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, c0, 0, 0, 0);
                 acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc[i], 0, 0, 0);
                 acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[i], 0, 0, 0);
@@ -217,9 +217,9 @@ __global__ __launch_bounds__(512, 2) void conv_res_kernel(ResParams p) {
         };
 
         // ---- B: conv1
-        conv(true);
+        conv();
         load_w(p.w2);
-        RS_MARK(4);
+        RS_T(4);
         // ---- C: t = conv1 + bias1 (in place), statistics of t over the whole sample
         {
 #pragma unroll
@@ -230,6 +230,7 @@ __global__ __launch_bounds__(512, 2) void conv_res_kernel(ResParams p) {
         }
         float* red = reinterpret_cast<float*>(smem + RED_OFF);
         float* mv = reinterpret_cast<float*>(smem + MV_OFF);
+        float* nrm = reinterpret_cast<float*>(smem + NRM_OFF);
 #pragma unroll
         for (int T = 0; T < 2; ++T) {
             float mean[4], m2[4];
@@ -240,86 +241,87 @@ __global__ __launch_bounds__(512, 2) void conv_res_kernel(ResParams p) {
                     *reinterpret_cast<float2*>(red + ((2 * sub + T) * C + cq * 4 + r) * 2) = make_float2(mean[r], m2[r]);
             }
         }
+        RS_T(5);
         lds_barrier();
-        if (tid < C) {                                                        // one channel each: the 8 tiles in order (ops.hip)
-            float mw[8], mu = 0.f, q = 0.f;
+        RS_T(6);
+        if (tid < C) {
+            // one channel each: the 8 tiles in order (ops.hip: inorm_from_moments_kernel), then -- the same 32 lanes of wave 0, through
+            // LDS, every lane summing all 32 channels in index order -- the cross-channel "++" term, and norm2's (mu, scale, shift)
+            float mw[8], m_c = 0.f, q = 0.f;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) { const float2 v = *reinterpret_cast<const float2*>(red + (t * C + tid) * 2); mw[t] = v.x; mu += v.x; q += v.y; }
-            mu *= 0.125f;
+            for (int t = 0; t < 8; ++t) { const float2 v = *reinterpret_cast<const float2*>(red + (t * C + tid) * 2); mw[t] = v.x; m_c += v.x; q += v.y; }
+            m_c *= 0.125f;
             float dd = 0.f;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) { const float d = mw[t] - mu; dd = fmaf(d, d, dd); }
-            mv[tid] = mu;
-            mv[C + tid] = fmaf(128.f, dd, q) * (1.f / (float)(H * W));
-        }
-        lds_barrier();
-        float4 nmu, nsc, nsh;                                                 // norm2 for the lane's four channels
-        {
+            for (int t = 0; t < 8; ++t) { const float d = mw[t] - m_c; dd = fmaf(d, d, dd); }
+            const float var_c = fmaf(128.f, dd, q) * (1.f / (float)(H * W));
+            mv[tid] = m_c;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // (one wave: its LDS operations complete in order)
             float m = 0.f;
-#pragma unroll 8
-            for (int k = 0; k < C; ++k) m += mv[k];
+#pragma unroll
+            for (int k = 0; k < C; k += 4) { const float4 v = *reinterpret_cast<const float4*>(mv + k); m += v.x; m += v.y; m += v.z; m += v.w; }
             m *= 1.f / (float)C;
             float v = 0.f;
-#pragma unroll 8
-            for (int k = 0; k < C; ++k) { const float d = mv[k] - m; v = fmaf(d, d, v); }
+#pragma unroll
+            for (int k = 0; k < C; k += 4) {
+                const float4 u = *reinterpret_cast<const float4*>(mv + k);
+                float d = u.x - m; v = fmaf(d, d, v);
+                d = u.y - m; v = fmaf(d, d, v);
+                d = u.z - m; v = fmaf(d, d, v);
+                d = u.w - m; v = fmaf(d, d, v);
+            }
             v *= 1.f / (float)(C - 1);
             const float rs = 1.f / sqrtf(v + 1e-5f);
-            const float4 mean = *reinterpret_cast<const float4*>(mv + cq * 4), var = *reinterpret_cast<const float4*>(mv + C + cq * 4);
-            nmu = mean;
-            nsc = make_float4(ga.x / sqrtf(fmaxf(var.x, 0.f) + 1e-5f), ga.y / sqrtf(fmaxf(var.y, 0.f) + 1e-5f),
-                              ga.z / sqrtf(fmaxf(var.z, 0.f) + 1e-5f), ga.w / sqrtf(fmaxf(var.w, 0.f) + 1e-5f));
-            nsh = make_float4(fmaf(ga.x, (mean.x - m) * rs * al.x, be.x), fmaf(ga.y, (mean.y - m) * rs * al.y, be.y),
-                              fmaf(ga.z, (mean.z - m) * rs * al.z, be.z), fmaf(ga.w, (mean.w - m) * rs * al.w, be.w));
+            nrm[tid] = m_c;
+            nrm[C + tid] = ga / sqrtf(fmaxf(var_c, 0.f) + 1e-5f);
+            nrm[2 * C + tid] = fmaf(ga, (m_c - m) * rs * al, be);
         }
-        RS_MARK(5);
-        // ---- D: t -> norm2 -> ELU -> split -> the same planes (conv2's operand); then request the residual operand x
-        const unsigned o0 = (unsigned)(((n * H + sub * NU) * W + c) * C + cq * 4);
-        {
-            int lq = lane;
-            asm volatile("" : "+v"(lq));                   // (the write addresses are formed per sample, see load_w)
-            const int cqd = 4 * hf + (lq >> 4);
-            unsigned char* dst0 = smem + (cqd >> 1) * PS + ((sub * NU + 1) * WP + (lq & 15) + 1) * 16 + (cqd & 1) * 8;
-#pragma unroll
-            for (int i = 0; i < NU; ++i) {
-                float4 v = make_float4(fmaf(acc[i][0] - nmu.x, nsc.x, nsh.x), fmaf(acc[i][1] - nmu.y, nsc.y, nsh.y),
-                                       fmaf(acc[i][2] - nmu.z, nsc.z, nsh.z), fmaf(acc[i][3] - nmu.w, nsc.w, nsh.w));
-                v = elu4(v);
-                StageScale ss{scale2, tb};
-                scale_track(v, &ss);
-                tb = ss.amax;
-                uint2 h, l;
-                split_f16x2(v, scale2, h, l);
-                *reinterpret_cast<uint2*>(dst0 + i * WP * 16) = h;
-                *reinterpret_cast<uint2*>(dst0 + i * WP * 16 + KGS * PS) = l;
-            }
-        }
-        pair_range_tile(tb, scale2, rbits, p.calib ? p.calib + 1 : nullptr);
-#pragma unroll
-        for (int i = 0; i < NU; ++i) {                                        // (lands while the workgroup meets at the barrier)
-            const float4 xr = *reinterpret_cast<const float4*>(p.in + o0 + i * W * C);
-            acc[i] = f32x4v{xr.x, xr.y, xr.z, xr.w};
-        }
-        RS_MARK(6);
         lds_barrier();
-        RS_MARK(7);
-        {
-            const float inv2 = 1.f / descale2;                                 // (a power of two)
-#pragma unroll
-            for (int i = 0; i < NU; ++i) {
-                acc[i][0] = (acc[i][0] + b2.x) * inv2; acc[i][1] = (acc[i][1] + b2.y) * inv2;
-                acc[i][2] = (acc[i][2] + b2.z) * inv2; acc[i][3] = (acc[i][3] + b2.w) * inv2;
-            }
-        }
-        // ---- E: conv2 onto (x + bias2) / descale2
-        conv(false);
-        if (n + (int)gridDim.x < p.B) load_w(p.w1);
-        RS_MARK(8);
-        // ---- F: out = acc x descale2; tile moments of the output; next sample's x
+        RS_T(7);
+        const float4 nmu = *reinterpret_cast<const float4*>(nrm + cq * 4), nsc = *reinterpret_cast<const float4*>(nrm + C + cq * 4),
+                     nsh = *reinterpret_cast<const float4*>(nrm + 2 * C + cq * 4);
+        // ---- D: t -> norm2 -> ELU -> split -> the same planes (conv2's operand)
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
-            acc[i][0] *= descale2; acc[i][1] *= descale2; acc[i][2] *= descale2; acc[i][3] *= descale2;
-            st_out(p.out + o0 + i * W * C, make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]));
+            float4 v = make_float4(fmaf(acc[i][0] - nmu.x, nsc.x, nsh.x), fmaf(acc[i][1] - nmu.y, nsc.y, nsh.y),
+                                   fmaf(acc[i][2] - nmu.z, nsc.z, nsh.z), fmaf(acc[i][3] - nmu.w, nsc.w, nsh.w));
+            v = elu4(v);
+            StageScale ss{scale2, tb};
+            scale_track(v, &ss);
+            tb = ss.amax;
+            uint2 h, l;
+            split_f16x2(v, scale2, h, l);
+            *reinterpret_cast<uint2*>(dst0 + i * WP * 16) = h;
+            *reinterpret_cast<uint2*>(dst0 + i * WP * 16 + KGS * PS) = l;
         }
+        pair_range_tile(tb, scale2, rbits, p.calib ? p.calib + 1 : nullptr);
+        RS_T(8);
+        lds_barrier();
+        RS_T(9);
+        // ---- E: conv2
+        conv();
+        load_w(p.w1);                                       // (conv1's first taps for the next sample; harmless behind the last one)
+        RS_T(10);
+        // ---- F: out = (conv2 x descale2 + bias2) + x -- the order of the unfused records: one rounding at the output's magnitude;
+        // then the next sample's x is requested (AHEAD of the stores: the memory counter is in order, behind 16 stores phase A would
+        // wait for every one of them to be acknowledged), the stores, the tile moments of the output
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            acc[i][0] = fmaf(acc[i][0], descale2, b2.x) + xr[i].x; acc[i][1] = fmaf(acc[i][1], descale2, b2.y) + xr[i].y;
+            acc[i][2] = fmaf(acc[i][2], descale2, b2.z) + xr[i].z; acc[i][3] = fmaf(acc[i][3], descale2, b2.w) + xr[i].w;
+        }
+        RS_T(12);
+        __builtin_amdgcn_sched_barrier(0);
+        request_x(min(n + (int)gridDim.x, p.B - 1));       // (unconditional: behind a branch the new x lands in other registers and is
+                                                            // COPIED at the end of the loop body -- after a wait for all of it)
+        RS_T(13);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            float* const o = p.out + (size_t)(((n * H + sub * NU) * W + (lq & 15)) * C + (4 * hf + (lq >> 4)) * 4);
+#pragma unroll
+            for (int i = 0; i < NU; ++i) st_out(o + i * W * C, make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]));
+        }
+        RS_T(14);
         if (p.pm_out) {
 #pragma unroll
             for (int T = 0; T < 2; ++T) {
@@ -332,20 +334,9 @@ __global__ __launch_bounds__(512, 2) void conv_res_kernel(ResParams p) {
                 }
             }
         }
-        if (n + (int)gridDim.x < p.B) {
-#pragma unroll
-            for (int k = 0; k < NPRE; ++k) xv[k] = *reinterpret_cast<const float4*>(p.in + x_addr(n + gridDim.x, k, tq));
-            const float* st = p.stats1 + st_addr(n + gridDim.x, tq);
-            mu = *reinterpret_cast<const float4*>(st); sc = *reinterpret_cast<const float4*>(st + C); sh = *reinterpret_cast<const float4*>(st + 2 * C);
-        }
-        RS_MARK(9);
+        RS_T(11);
     }
     if (rbits && lane == 0) atomicOr(p.range_flag, rbits);
-#ifdef SBC_PAIR_TIMING
-    // [wait, barrier, convert x, barrier, conv1, statistics, convert t + residual request, barrier, conv2, store + moments + prefetch]
-    if (tid == 0 && p.dbg)
-        for (int k = 0; k < 10; ++k) atomicAdd(p.dbg + k, pt[k]);
-#endif
 }
 
 int launch_res_block(const sbc_op& op, hipStream_t stream, bool dry) {
@@ -360,7 +351,7 @@ int launch_res_block(const sbc_op& op, hipStream_t stream, bool dry) {
     SBC_REQUIRE(!(op.flags & (SBC_EPI_POOL | SBC_EPI_UP | SBC_EPI_ELUGRAD | SBC_EPI_RES1_ELU)) && !op.res1 && !op.res2 && !op.up,
                 "res_block: the residual operand is the input itself; no other epilogue");
     SBC_REQUIRE((long)op.B * op.H * op.W * op.cin <= 0x7fffffffL, "res_block: tensor exceeds the 32-bit element index");
-    constexpr size_t lds = (size_t)2 * 4 * ((66 * 18 * 16 + 255) / 256 * 256) + 8 * 32 * 2 * 4 + 2 * 32 * 4;
+    constexpr size_t lds = (size_t)2 * 4 * ((66 * 18 * 16 + 255) / 256 * 256) + 8 * 32 * 2 * 4 + 2 * 32 * 4 + 3 * 32 * 4;
     static_assert(lds <= 160 * 1024, "LDS of the one resident workgroup");
     { const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(conv_res_kernel), lds); if (rc) return rc; }
     unsigned* word = nullptr;
@@ -373,7 +364,7 @@ int launch_res_block(const sbc_op& op, hipStream_t stream, bool dry) {
     p.stats1 = (const float*)op.stats; p.norm2 = (const float*)op.norm2;
     p.pm_out = (op.flags & SBC_EPI_MOMENTS_OUT) ? (float*)op.aux : nullptr;
     p.range_flag = word; p.calib = (float*)op.calib; p.B = op.B;
-#ifdef SBC_PAIR_TIMING
+#ifdef SBC_RES_TIMELINE
     p.dbg = (op.flags & SBC_EPI_MOMENTS_OUT) ? nullptr : (unsigned long long*)op.aux;
 #endif
     int dev = 0, cus = 256;

@@ -49,5 +49,25 @@ if 'pt' in os.environ.get('SBC_LIB_PATH', ''):
     v = dbg.tolist(); tot = sum(v) or 1
     names = ['wait', 'barrier', 'convert x', 'barrier', 'conv1', 'statistics', 'convert t', 'barrier', 'conv2', 'store + moments']
     print('wave 0, cycles per phase: ' + ', '.join('%s %.1f%%' % (names[i], 100.0 * v[i] / tot) for i in range(10)), '| per WG %.0f' % (tot / min(B, 256)))
+if 'tl' in os.path.basename(os.environ.get('SBC_LIB_PATH', '')):
+    # SBC_RES_TIMELINE build: block 0's eight waves stamp 12 points of every sample
+    nit = (B + 255) // 256 + 1
+    dbg = torch.zeros(nit * 8 * 16, dtype=torch.int64, device='cuda')
+    res.aux, res.flags = dbg.data_ptr(), P.CONV_F16X2
+    run([res], 1); torch.cuda.synchronize()
+    v = dbg.view(nit, 8, 16).cpu().numpy()
+    names = ['F end', 'top barrier', 'A end', 'A barrier', 'conv1 end', 'moments end', 'stats barrier 1', 'stats barrier 2', 'D end', 'D barrier', 'conv2 end', 'F end']
+    its = [i for i in range(1, nit) if v[i, :, 11].min() > 0]
+    for it in its[1:4]:
+        t0 = v[it, :, 1].min()
+        print('sample %d of block 0 (clock ticks since the top barrier opened; min .. max over the 8 waves)' % it)
+        for k in range(1, 12):
+            print('   %-16s %7d .. %7d' % (names[k], v[it, :, k].min() - t0, v[it, :, k].max() - t0))
+        if it == its[2]:
+            print('   per wave (hf, sub) = wave & 1, wave >> 1; clock ticks of every stamp (the last four: F sums formed, next x requested, stores issued, F end):')
+            for w in range(8):
+                print('     wave %d: ' % w + ' '.join('%6d' % (v[it, w, k] - t0) for k in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13, 14, 11)))
+        if it + 1 < nit and v[it + 1, :, 1].min() > 0:
+            print('   %-16s %7d' % ('next top barrier', v[it + 1, :, 1].min() - t0))
 err = float((out - out2).abs().max() / out2.abs().max())
 print('B = %d: fused ResidualBlock %.1f us; conv + statistics + conv %.1f us; max deviation %.2e' % (B, tr, t3, err))
