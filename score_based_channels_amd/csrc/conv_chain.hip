@@ -45,7 +45,17 @@ struct ChainParams {
     unsigned* __restrict__ range_flag;
     float* __restrict__ calib;          // sbc_f16x2_calibrate: 3 amax slots per block (inputs of conv 1, conv 2, shortcut conv), else NULL
     int B;
+    unsigned long long* dbg;            // SBC_CHAIN_TIMELINE builds (tools/prof_chain.py): clock stamps of the middle workgroup
 };
+
+#ifdef SBC_CHAIN_TIMELINE
+// the middle workgroup's waves stamp eight points of every phase -> dbg[wave][phase][8]:
+//   0 phase parameters read, 1 operand values formed (ELU / pool / norm), 2 split + filter prologue requested, 3 planes free (barrier),
+//   4 planes written (barrier), 5 K loop done, 6 result taken
+#define CH_T(k) do { if (p.dbg && blockIdx.x == gridDim.x / 2) { const unsigned long long _t = __builtin_readcyclecounter(); if (lane == 0) p.dbg[(wave * 16 + phase_no) * 8 + (k)] = _t; } } while (0)
+#else
+#define CH_T(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ float4 to_f4(f32x4v v) { return make_float4(v[0], v[1], v[2], v[3]); }
 __device__ __forceinline__ f32x4v to_v4(float4 v) { return f32x4v{v.x, v.y, v.z, v.w}; }
@@ -255,6 +265,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
 
     // phases of a block: every phase is one convolution; what feeds it and what happens to its result depends on the block type
     enum { PH_R1, PH_R2, PH_P1, PH_P2, PH_SC, PH_C1, PH_C2 };
+    int phase_no = -1;
+    (void)phase_no;
 #pragma unroll 1
     for (int blk = 0; blk < p.n_blocks; ++blk) {
         const int type = p.type[blk];
@@ -263,6 +275,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
         const int dil = p.dil[blk];
 #pragma unroll 1
         for (int ph = 0; ph < n_ph; ++ph) {
+            phase_no = min(phase_no + 1, 15);
             // phase kind and its filter: RCU (conv 1, conv 2), CRP (conv 1, conv 2), RES ([shortcut conv,] conv 1, conv 2)
             const int kind = type == SBC_CHAIN_RCU ? PH_R1 + ph : type == SBC_CHAIN_CRP ? PH_P1 + ph : (has_sc ? PH_SC + ph : PH_C1 + ph);
             const int wi = kind == PH_SC ? 2 : (kind == PH_R2 || kind == PH_P2 || kind == PH_C2) ? 1 : 0;
@@ -295,6 +308,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
                 wr[slot][1] = w[idx + 64];
             };
 
+            CH_T(0);
             // ---- the operand of this convolution, from registers
             f32x4v v[NU];
             if (kind == PH_R1 || kind == PH_R2) {
@@ -390,6 +404,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
                     }
                 }
             }
+            CH_T(1);
             float ta = 0.f;
             uint2 vh[NU], vl[NU];
 #ifdef SBC_CHAIN_NO_CONVERT   // timing probe: no ELU / pooling / norm / split (the values above are dead code then) -- wrong results
@@ -419,7 +434,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
                 });
             }
             // every wave has left the previous K loop: the planes may be rewritten
+            CH_T(2);
             lds_barrier();
+            CH_T(3);
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
                 unsigned char* dst = smem + wr_base + (((i / W) * SPU) * SP + (i % W) * CP) * 16;
@@ -427,6 +444,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
                 *reinterpret_cast<uint2*>(dst + TERM) = vl[i];
             }
             lds_barrier();
+            CH_T(4);
 
             // ---- K loop: D[16 couts][16 pixels] += W[16 couts][32 cin] X[32 cin][16 pixels] per (tap, slice), three fp16 products each.
             // Flat walk over micro-steps m = (K step, pair of units): the four X fragments of a micro-step are requested XD - 1
@@ -521,6 +539,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
 #ifdef SBC_CHAIN_PRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
+            CH_T(5);
 
             // ---- what the result is for
             if (kind == PH_R2 || kind == PH_P2) {
@@ -538,6 +557,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_chain_kernel(ChainParams p) {
                     for (int e = 0; e < 4; ++e) xs[i][e] = xs[i][e] + fmaf(acc[i][e], descale, b2[e]);
             }
             prev_descale = descale;
+            CH_T(6);
         }
     }
 #pragma unroll
@@ -592,6 +612,9 @@ int launch_chain(const sbc_op& op, const sbc_chain& c, hipStream_t stream, bool 
     }
     p.calib = (float*)op.calib;
     p.B = op.B;
+#ifdef SBC_CHAIN_TIMELINE
+    p.dbg = (unsigned long long*)op.aux;
+#endif
     unsigned* flag = nullptr;
     { const int rc = range_flag_ptr(&flag); if (rc) return rc; }
     p.range_flag = flag;

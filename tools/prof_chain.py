@@ -43,6 +43,20 @@ def main():
         us = e0.elapsed_time(e1) / reps * 1e3
         nconv = 2 * len(blocks)
         flops = nconv * 2.0 * B * H * W * 9 * Cc * Cc
+        if 'tl' in os.path.basename(os.environ.get('SBC_LIB_PATH', '')):
+            # SBC_CHAIN_TIMELINE build: the middle workgroup's waves stamp seven points of every phase (convolution)
+            dbg = torch.zeros(8 * 16 * 8, dtype=torch.int64, device='cuda')
+            op.aux = dbg.data_ptr()
+            _lib.check(_lib.lib().sbc_op_launch(C.byref(op), C.c_void_p(st)))
+            torch.cuda.synchronize()
+            op.aux = None
+            v = dbg.view(8, 16, 8).cpu().numpy()
+            nw = int((v[:, 0, 5] > 0).sum())
+            t0 = v[:nw, 0, 0].min()
+            print('   middle workgroup, %d waves; clock ticks since the first stamp; per phase and wave: parameters read, operand values formed, split + prologue, planes free, planes written, K loop done, result taken' % nw)
+            for ph in range(2 * len(blocks)):
+                for wv in (0, nw - 1):
+                    print('   phase %d wave %d: ' % (ph, wv) + ' '.join('%7d' % (v[wv, ph, k] - t0) for k in range(7)))
         print('%dx%d C=%d blocks=%s B=%d: %.1f us per launch, %.2f us per convolution, %.0f TFLOP/s algorithmic' % (H, W, Cc, blocks, B, us, us / nconv, flops / us / 1e6))
 
 
