@@ -7,24 +7,26 @@
 // registers across the two barriers that form the statistics.
 //
 // One 8-wave workgroup per CU walks samples.  Wave (hf, sub) owns output channels 16 hf .. + 15 of image rows 16 sub .. + 15 (16 units
-// of one row each) and holds the filter fragments of the convolution it is about to run in registers (72).  Per sample:
-//   A  x (requested from memory while the previous sample's epilogue ran: 16 float4 per lane) -> norm1 from the statistics table ->
-//      ELU -> x act_scale -> two fp16 terms -> operand planes [term][8-channel group][66 rows][18 slots][8 halves] (conv_dp.hip's lane
-//      mapping: 16 adjacent lanes write 8 pixels x the two halves of one k-group = 128 contiguous bytes, no bank conflict);
-//   B  conv1: direct implicit GEMM on v_mfma_f32_16x16x32_f16 (hh + hl + lh), K loop = LDS reads + matrix instructions only;
+// of one row each).  Round 6: the sample's x stays in REGISTERS in the accumulators' layout from phase A to phase F (64 a wave) -- it is
+// read from memory once, and the block's sum is formed behind the K loop as the unfused records form it -- and the filter fragments
+// stream from L2 through a four-tap register ring (32 registers; round 5 kept one convolution's 72 resident and read x twice).  Per sample:
+//   A  x (requested while the previous sample's epilogue ran) -> norm1 from the statistics table -> ELU -> x act_scale -> two fp16 terms
+//      -> operand planes [term][8-channel group][66 rows][18 slots][8 halves];
+//   B  conv1: direct implicit GEMM on v_mfma_f32_16x16x32_f16 (hh + hl + lh), K loop = LDS reads + filter requests + matrix instructions;
 //   C  t = conv1 + bias; per 128-pixel tile and channel (mean, M2) -- a wave holds two whole tiles of its 16 channels: in-lane sums
-//      over 8 rows, DPP sums over the 16 pixel lanes -- exchanged through LDS, merged per channel in a fixed order (the formulas of
-//      ops.hip: inorm_from_moments_kernel), then the cross-channel "++" term: (mu, scale, shift) of norm2 for the lane's 4 channels;
-//   D  t -> norm2 -> ELU -> x act_scale -> split -> the SAME planes (every wave is through conv1: phase C has two barriers); the
-//      residual operand x is requested into the registers that held t;
-//   E  conv2, accumulating onto (x + bias2) / descale2 (a power of two: exact).  (Adding x after the K loop instead -- one rounding at the
-//      output's magnitude, as the unfused records do -- was built and measured: the 16 float4 of x per lane do not fit beside the K loop's
-//      registers, and requested after it they cost a memory round trip per sample that nothing hides: 291-299 us against 264.
-//      Accumulating onto x rounds once per matrix instruction at the magnitude of x + conv2 instead of conv2: at most ~5 ulp of the
-//      OUTPUT when |x| >> |conv2| (tests/test_gpu_ops.py::test_res_block_is_calibrated_and_guarded), nothing measurable otherwise);
-//   F  out = acc x descale2, streamed out; with SBC_EPI_MOMENTS_OUT also the (mean, M2) of the output's 128-pixel tiles for the
-//      InstanceNorm++ that reads it next (tile.h) -- whole tiles per wave, no exchange; then the next sample's x is requested.
+//      over 8 rows, DPP sums over the 16 pixel lanes -- exchanged through LDS; 32 threads merge them per channel in a fixed order (the
+//      formulas of ops.hip: inorm_from_moments_kernel), form the cross-channel "++" term and leave norm2's (mu, scale, shift) per
+//      channel in LDS (round 5: every lane repeated the cross-channel sums, ~200 vector instructions of phase D);
+//   D  t -> norm2 -> ELU -> x act_scale -> split -> the SAME planes (every wave is through conv1: phase C has two barriers);
+//   E  conv2;
+//   F  out = (conv2 x descale2 + bias2) + x; the next sample's x is requested into the registers x just left, AHEAD of the 16 stores
+//      (the memory counter is in order); with SBC_EPI_MOMENTS_OUT also the (mean, M2) of the output's 128-pixel tiles for the
+//      InstanceNorm++ that reads it next (tile.h) -- whole tiles per wave, no exchange.
 // Five workgroup barriers per sample.  Everything is summed in an order that depends on the layer's shape only.
+// Timeline of a sample (-DSBC_RES_TIMELINE, tools/prof_res.py; profiles/r06_timeline_conv_res.txt): of 66 k clocks the two K loops take
+// 15 k and 22 k (the four waves that arrived first on their SIMDs finish each loop in 9 k, the other four get the matrix pipe afterwards --
+// and run conv2 beside the first four's epilogue), phases A and D 7 k each, the statistics 4 k, the epilogue of the late waves 9 k: a
+// CU moves its 256 KB per sample at ~50 GB/s whoever issues the requests.
 #include <stdlib.h>
 #include <type_traits>
 #include "conv_common.h"
