@@ -475,8 +475,8 @@ __global__ __launch_bounds__(NTH) void end_conv_self_kernel(const float* __restr
     constexpr int NQ = 1024 * C4 / NTH, NPX = 1024 / NTH;                       // chunks / output pixels per thread at HW = 1024
     static_assert(CIN == 32, "eight channel quads: a thread keeps one quad for all its chunks");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int HW = H * W;
-    const int nq = HW * C4 / NTH, npx = HW / NTH;                             // (<= NQ, <= NPX: checked by the launcher)
+    constexpr int HW = 1024;                                                  // (H W = 1024: checked by the launcher -- a compile-time count
+                                                                              // keeps the chunk loops free of branches and of full memory waits)
     float* const act = lds;                                                   // [HW + 1][S]: the activated sample + one zero pixel
     float* const red = lds + (HW + 1) * S;                                    // two buffers of [waves][CIN] partial sums
     float* const mean_s = red + 2 * NWV * CIN;                                // [CIN] channel means
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(NTH) void end_conv_self_kernel(const float* __restr
         const float* base = in + ((size_t)n * HW + j) * CIN + c4 * 4;
 #pragma unroll
         for (int k = 0; k < NQ; ++k)
-            if (k < nq) xv[k] = *reinterpret_cast<const float4*>(base + (size_t)k * PJ * CIN);
+            xv[k] = *reinterpret_cast<const float4*>(base + (size_t)k * PJ * CIN);
     };
     // sum over the threads that share a channel quad: lanes (bits 3..5), then the waves through `buf` -- every thread adds the
     // eight wave sums in the same order
@@ -514,17 +514,20 @@ __global__ __launch_bounds__(NTH) void end_conv_self_kernel(const float* __restr
     int n = blockIdx.x;
     if (n < B) request(n);
     for (; n < B; n += gridDim.x) {
+        // the sample's noise level, requested FIRST: read where it is used (behind the convolution) its two dependent round trips were
+        // exposed at the end of every sample, each behind a full memory wait that also covered the next sample's prefetch
+        const float sigma = e.labels ? e.sigmas[e.labels[n]] : e.sigma_of_step[*e.step];
         // ---- statistics of the sample in the registers
         float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int k = 0; k < NQ; ++k)
-            if (k < nq) { sum.x += xv[k].x; sum.y += xv[k].y; sum.z += xv[k].z; sum.w += xv[k].w; }
+            { sum.x += xv[k].x; sum.y += xv[k].y; sum.z += xv[k].z; sum.w += xv[k].w; }
         sum = quad_total(sum, red);
         const float4 mu = make_float4(sum.x * inv_hw, sum.y * inv_hw, sum.z * inv_hw, sum.w * inv_hw);
         float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int k = 0; k < NQ; ++k)
-            if (k < nq) {
+            {
                 float d;
                 d = xv[k].x - mu.x; q.x = fmaf(d, d, q.x); d = xv[k].y - mu.y; q.y = fmaf(d, d, q.y);
                 d = xv[k].z - mu.z; q.z = fmaf(d, d, q.z); d = xv[k].w - mu.w; q.w = fmaf(d, d, q.w);
@@ -547,7 +550,7 @@ __global__ __launch_bounds__(NTH) void end_conv_self_kernel(const float* __restr
         // ---- normalise, ELU, to LDS; then the registers take the next sample
 #pragma unroll
         for (int k = 0; k < NQ; ++k)
-            if (k < nq) {
+            {
                 float4 y;
                 y.x = (xv[k].x - mu.x) * sc.x + sh.x; y.y = (xv[k].y - mu.y) * sc.y + sh.y;
                 y.z = (xv[k].z - mu.z) * sc.z + sh.z; y.w = (xv[k].w - mu.w) * sc.w + sh.w;
@@ -596,10 +599,9 @@ __global__ __launch_bounds__(NTH) void end_conv_self_kernel(const float* __restr
                 }
             }
         }
-        const float sigma = e.labels ? e.sigmas[e.labels[n]] : e.sigma_of_step[*e.step];
 #pragma unroll
         for (int i = 0; i < NPX; ++i) {
-            if (i < npx) {
+            {
                 float2 o;
                 o.x = (a0[i] + b0) / sigma;
                 o.y = (a1[i] + b1) / sigma;

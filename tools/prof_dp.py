@@ -1,6 +1,6 @@
 """Performance triage helper (not part of the product): time one 64 -> 64 3x3 SBC_OP_CONV launch in conv_mode f16x2 -- the direct
 persistent kernel (csrc/conv_dp.hip), or with SBC_NO_CONV_DP=1 in the environment the Winograd kernel it replaces.
-usage: prof_dp.py [B H W] [--stage elu|elu_res|crp2|plain]"""
+usage: prof_dp.py [B H W] [--stage elu|elu_res|crp2|plain|norm]   (norm: InstanceNorm++ prologue + ELU + tile-moment output, the NM instantiation)"""
 import argparse, ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,9 +21,13 @@ r1, r2 = torch.randn_like(x), torch.randn_like(x)
 out = torch.empty_like(x)
 w1 = np.random.randn(CH, CH, 3, 3).astype(np.float32) / (3 * CH ** 0.5)
 d = [torch.from_numpy(f(w1).view(np.float32)).cuda() for f in (pack_conv_weight_f16x2, pack_conv_weight_winograd_f16x2)]
-fl = {'elu': P.PRO_ELU, 'elu_res': P.PRO_ELU, 'crp2': P.EPI_RES1_ELU, 'plain': 0}[a.stage]
+fl = {'elu': P.PRO_ELU, 'elu_res': P.PRO_ELU, 'crp2': P.EPI_RES1_ELU, 'plain': 0, 'norm': P.PRO_NORM | P.PRO_ELU | P.EPI_MOMENTS_OUT}[a.stage]
 cv = _lib.sbc_op(kind=P.CONV, flags=P.CONV_F16X2 | fl, B=B, H=H, W=W, cin=CH, cout=CH, ksize=3, dil=1, in_=x.data_ptr(),
                  out=out.data_ptr(), weight_split=d[0].data_ptr(), weight_wino_split=d[1].data_ptr())
+if a.stage == 'norm':
+    st = torch.stack([torch.zeros(B, CH), torch.ones(B, CH), torch.zeros(B, CH)], 1).cuda().contiguous()
+    pm = torch.empty(B, H * W // 128, CH, 2, device='cuda')
+    cv.stats, cv.aux = st.data_ptr(), pm.data_ptr()
 if a.stage in ('elu_res', 'crp2'):
     cv.res1 = r1.data_ptr()
 if a.stage == 'crp2':
