@@ -1,5 +1,7 @@
 """Performance triage helper (not part of the product): time one SBC_OP_RES_BLOCK launch (a whole ResidualBlock at 64x16) against the
-convolution -> statistics -> convolution launches it replaces.   usage: prof_res.py [B]"""
+convolution -> statistics -> convolution launches it replaces.   usage: prof_res.py [B]
+With a -DSBC_RES_TIMELINE build (tools/build_variant.sh res_tl conv_res.hip -DSBC_RES_TIMELINE; SBC_LIB_PATH=tools/var/libsbc_res_tl.so) it also
+prints the per-wave timeline of three samples of workgroup 0."""
 import argparse, ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -42,13 +44,6 @@ def timeit(ops):
     e0.record(); run(ops, a.iters); e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / a.iters * 1e3
 tr, t3 = timeit([res]), timeit([c1, st, c2])
-if 'pt' in os.environ.get('SBC_LIB_PATH', ''):
-    dbg = torch.zeros(10, dtype=torch.int64, device='cuda')
-    res.aux, res.flags = dbg.data_ptr(), P.CONV_F16X2
-    run([res], 1); torch.cuda.synchronize()
-    v = dbg.tolist(); tot = sum(v) or 1
-    names = ['wait', 'barrier', 'convert x', 'barrier', 'conv1', 'statistics', 'convert t', 'barrier', 'conv2', 'store + moments']
-    print('wave 0, cycles per phase: ' + ', '.join('%s %.1f%%' % (names[i], 100.0 * v[i] / tot) for i in range(10)), '| per WG %.0f' % (tot / min(B, 256)))
 if 'tl' in os.path.basename(os.environ.get('SBC_LIB_PATH', '')):
     # SBC_RES_TIMELINE build: block 0's eight waves stamp 12 points of every sample
     nit = (B + 255) // 256 + 1
